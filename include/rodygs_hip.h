@@ -1,0 +1,169 @@
+/*
+ * rodygs_hip.h -- C-ABI of librodygs_hip.so: the MI355X (gfx950) Gaussian-rasterizer hot path of RoDyGS.
+ *
+ * Drop-in boundary.  The reference (pure Python) reaches this arithmetic through three un-vendored native
+ * extensions; the entry points below are what a ctypes binding of those extensions' surfaces needs:
+ *
+ *   rdg_rasterize_forward / rdg_rasterize_backward
+ *       replace  diff_gauss_pose.GaussianRasterizer(raster_settings)(means3D, means2D, shs, colors_precomp,
+ *                opacities, scales, rotations, cov3Ds_precomp, viewmatrix)
+ *       called at /root/reference/src/trainer/renderer.py:65,87-101,
+ *                 /root/reference/src/model/rodygs_static.py:238,262-281,
+ *                 /root/reference/src/evaluator/eval.py:135,157-176   (settings built at renderer.py:50-63)
+ *   rdg_deform_forward / rdg_deform_backward
+ *       replace the per-Gaussian part of DynRoDyGS.get_gaussian_deformation
+ *                 /root/reference/src/model/rodygs_dynamic.py:122-138 (coeff @ (B(t) - B_table[birth]))
+ *   rdg_dist2_knn3
+ *       replaces simple_knn._C.distCUDA2 called at /root/reference/src/model/rodygs_static.py:130-133
+ *   rdg_sort_pairs, rdg_preprocess_forward, rdg_bin_forward
+ *       stage entry points (the same kernels rdg_rasterize_forward runs) exposed for the bit-exact
+ *       tile-key / sort-order parity tests.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; all float tensors are contiguous f32;
+ *   - the library never allocates or frees device memory: the caller (PyTorch caching allocator) owns every
+ *     buffer, including the three opaque workspaces whose sizes come from rdg_*_bytes();
+ *   - every launch goes to the hipStream_t passed as `stream` (void* here so the header is plain C);
+ *     no call synchronises the host except where stated;
+ *   - return value: 0 = ok, negative = error; rdg_last_error() gives a thread-local message;
+ *     no C++ exception crosses the ABI;
+ *   - matrices use the reference's "glm storage": viewmatrix = W2C^T, projmatrix = P^T (projection only),
+ *     i.e. flat[c*4+r] = M[r][c]  (renderer.py:57,97-99).
+ */
+#ifndef RODYGS_HIP_H
+#define RODYGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDG_ABI_VERSION 1
+
+/* Mirror of GaussianRasterizationSettings (renderer.py:50-63) + sizes. Host struct, passed by pointer. */
+typedef struct RdgRasterSettings {
+    int32_t P;               /* number of Gaussians                                         */
+    int32_t M;               /* SH coefficients stored per Gaussian (shs is [P,M,3]); 0 if colors_precomp */
+    int32_t sh_degree;       /* active degree 0..3                                           */
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t prefiltered;
+    int32_t debug;
+    int32_t enable_cov_grad; /* pose-gradient gates (SURVEY.md §7 open question 4)           */
+    int32_t enable_sh_grad;
+    int32_t render_normal;   /* 1: composite the normal channels (default); 0: leave them zero */
+    int32_t reserved[3];
+} RdgRasterSettings;
+
+/* stage ids for rdg_stage_time_ms() */
+enum {
+    RDG_STAGE_PREPROCESS = 0,
+    RDG_STAGE_SCAN_DUP = 1,
+    RDG_STAGE_SORT = 2,
+    RDG_STAGE_RANGES = 3,
+    RDG_STAGE_RENDER_FWD = 4,
+    RDG_STAGE_RENDER_BWD = 5,
+    RDG_STAGE_PREPROCESS_BWD = 6,
+    RDG_STAGE_DEFORM_FWD = 7,
+    RDG_STAGE_DEFORM_BWD = 8,
+    RDG_STAGE_ADAM = 9,
+    RDG_STAGE_COUNT = 10
+};
+
+int rdg_abi_version(void);
+const char* rdg_last_error(void);
+
+/* ---- workspace sizes (bytes) -------------------------------------------------------------------------- */
+size_t rdg_geom_bytes(int32_t P);                             /* per-Gaussian state kept for backward      */
+size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles);  /* keys/values (double-buffered) + sort tables */
+size_t rdg_image_bytes(int32_t H, int32_t W);                 /* final_T, n_contrib, tile ranges           */
+
+/* ---- rasterizer -------------------------------------------------------------------------------------------
+ * Forward.  Exactly one of shs / colors_precomp and one of (scales, rotations) / cov3D_precomp is non-NULL.
+ * `capacity` is the number of (tile, Gaussian) instances binning_ws was sized for.  num_rendered_dev receives
+ * the true instance count D; if D > capacity the binning and compositing stages are skipped on the device
+ * (outputs untouched) and the caller must call again with capacity >= D.  The call itself never syncs.
+ * Outputs: out_color[3,H,W], out_depth[1,H,W], out_normal[3,H,W], out_alpha[1,H,W], radii[P] (int32).       */
+int rdg_rasterize_forward(const RdgRasterSettings* s_host, const float* bg, const float* means3D,
+                          const float* shs, const float* colors_precomp, const float* opacities,
+                          const float* scales, const float* rotations, const float* cov3D_precomp,
+                          const float* viewmatrix, const float* projmatrix, void* geom_ws, void* binning_ws,
+                          int64_t capacity, void* image_ws, float* out_color, float* out_depth,
+                          float* out_normal, float* out_alpha, int32_t* radii, int32_t* num_rendered_dev,
+                          void* stream);
+
+/* Backward.  grad_out_* may be NULL (treated as zero).  All dL_* outputs must be zero-initialised by the
+ * caller EXCEPT none: the library zeroes what it accumulates into.  dL_dmeans2D is [P,3] (z unused = 0),
+ * dL_dviewmatrix is [16] in the same glm storage as viewmatrix.  grad_ws: rdg_grad_bytes(P) scratch.        */
+size_t rdg_grad_bytes(int32_t P);
+int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, const float* means3D,
+                           const float* shs, const float* colors_precomp, const float* opacities,
+                           const float* scales, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+                           const void* geom_ws, const void* binning_ws, int64_t capacity, const void* image_ws,
+                           const float* grad_out_color, const float* grad_out_depth,
+                           const float* grad_out_alpha, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
+                           float* dL_dshs, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
+                           float* dL_drotations, float* dL_dcov3D, float* dL_dviewmatrix, void* stream);
+
+/* ---- stage entry points (bit-exact parity tests) -------------------------------------------------------- */
+/* Runs only the per-Gaussian stage; fills geom_ws, radii, and *num_rendered_dev.                            */
+int rdg_preprocess_forward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                           const float* projmatrix, void* geom_ws, int32_t* radii, int32_t* num_rendered_dev,
+                           void* stream);
+/* Copies out per-Gaussian state for inspection: depth[P], xy[P,2], conic_opacity[P,4], rgb[P,3],
+ * tiles_touched[P] (uint32).  Any pointer may be NULL.                                                      */
+int rdg_geom_export(int32_t P, const void* geom_ws, float* depth, float* xy, float* conic_opacity, float* rgb,
+                    float* normal, uint32_t* tiles_touched, void* stream);
+/* duplicateWithKeys + sort + tile ranges.  keys_unsorted/vals_unsorted/keys_sorted/vals_sorted (capacity
+ * entries each) and ranges[n_tiles,2] are optional copies for the tests.                                    */
+int rdg_bin_forward(const RdgRasterSettings* s_host, const void* geom_ws, const int32_t* radii, void* binning_ws,
+                    int64_t capacity, void* image_ws, const int32_t* num_rendered_dev, uint64_t* keys_unsorted,
+                    uint32_t* vals_unsorted, uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
+                    void* stream);
+/* Stable LSD radix sort of n (key,value) pairs on key bits [0,end_bit).  n is read from *n_dev on the device
+ * (clamped to capacity).  tmp_ws: rdg_sort_tmp_bytes(capacity).  Result is written back into keys/vals.     */
+size_t rdg_sort_tmp_bytes(int64_t capacity);
+int rdg_sort_pairs(uint64_t* keys, uint32_t* vals, int64_t capacity, const int32_t* n_dev, int32_t end_bit,
+                   void* tmp_ws, void* stream);
+
+/* ---- time deformation ----------------------------------------------------------------------------------------
+ * delta[p,:] = sum_b coeff[p,b] * (basis_t[b,:] - table[time_ind[p], b, :]);  out_xyz = delta[:, :3]*spatial_scale,
+ * out_rot = delta[:, 3:7].  coeff [P,B] (B = 16), basis_t [B,7], table [Tu,B,7], time_ind [P] int64.
+ * table may be NULL (inverse_motion = False).                                                                */
+int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
+                       const float* basis_t, const float* table, float spatial_scale, float* out_xyz,
+                       float* out_rot, void* stream);
+/* d_coeff [P,B]; d_basis_t [B,7] and d_table [Tu,B,7] are zeroed then accumulated by the library.           */
+int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
+                        const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
+                        const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table, void* stream);
+
+/* ---- simple_knn ------------------------------------------------------------------------------------------ */
+size_t rdg_knn_tmp_bytes(int32_t P);
+/* out[p] = mean squared distance from points[p] to its 3 nearest other points.                              */
+int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream);
+
+/* ---- fused Adam over a flat f32 parameter (used by bench.py's train step) ---------- */
+int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* ---- measurement hooks -----------------------------------------------------------------------------------
+ * When enabled, every stage is bracketed by hipEvents recorded on the launch stream.  rdg_stage_time_ms()
+ * synchronises on the recorded events and returns accumulated milliseconds + launch count since the last
+ * reset.                                                                                                    */
+int rdg_timing_enable(int32_t on);
+int rdg_timing_reset(void);
+int rdg_stage_time_ms(int32_t stage, double* total_ms, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RODYGS_HIP_H */

@@ -1,0 +1,414 @@
+"""PyTorch-CPU differentiable Gaussian rasterizer -- the oracle (TEST INFRASTRUCTURE, never shipped).
+
+PARITY UNPINNED: the reference's rasterizer source (``diff_gauss_pose``; reference ``.gitmodules:1-4``) is an
+un-vendored submodule; no source, test or golden vector for it exists under ``/root/reference``.  This file
+restates the published 3DGS tile rasterizer at the boundary the reference calls
+(``/root/reference/src/trainer/renderer.py:50-101``) and is the normative spec of this build.  What it shares
+with importable reference code is pinned by ``tests/golden`` (SH basis ``src/utils/sh_utils.py:24-101``,
+projection ``src/utils/graphic_utils.py:43-63``, covariance ``src/model/rodygs_static.py:26-30`` +
+``src/utils/general_utils.py:92-127``).
+
+Numerical contract (mirrored 1:1 by ``rodygs_amd/csrc/rdg_preprocess.hip``):
+  * everything is float32, evaluated with separate (un-fused) multiplies and adds, left to right exactly as
+    written below -- torch CPU elementwise ops never contract to FMA, and the HIP preprocess kernel is built
+    with ``-ffp-contract=off`` -- so view-space depth bits, radii and tile rectangles (hence tile keys and the
+    sorted order) are BIT-EXACT between oracle and HIP;
+  * the compositing stage differs from the HIP kernel only by ``exp`` rounding and summation order
+    (tolerance 1e-4 relative, see tests).
+
+Backward is torch autograd of this forward, with the two places where the public 3DGS backward is known to
+deviate from the exact derivative reproduced explicitly (``_ste_min`` for the 0.99 alpha cap, and the
+detached frustum clamp of ``t`` in the EWA Jacobian).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+# ---- constants of the algorithm (SURVEY.md §7 "open questions" 6: 3DGS constants kept verbatim) -------------
+NEAR_CULL = 0.2
+FOV_CLAMP = 1.3
+DILATION = 0.3
+ALPHA_CAP = 0.99
+ALPHA_MIN = 1.0 / 255.0
+T_STOP = 1e-4
+LAMBDA_FLOOR = 0.1
+TILE = 16
+
+# SH constants -- same values as /root/reference/src/utils/sh_utils.py:24-41
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
+         -0.4570457994644658, 1.445305721320277, -0.5900435899266435]
+
+
+@dataclass
+class OracleSettings:
+    """Mirror of GaussianRasterizationSettings (reference call site src/trainer/renderer.py:50-63)."""
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    projmatrix: torch.Tensor
+    sh_degree: int
+    prefiltered: bool = False
+    debug: bool = False
+    enable_cov_grad: bool = True
+    enable_sh_grad: bool = True
+
+
+class _SteMin(torch.autograd.Function):
+    """min(x, cap) forward, identity backward: public 3DGS backward ignores the 0.99 alpha cap."""
+
+    @staticmethod
+    def forward(ctx, x, cap):
+        return torch.clamp(x, max=cap)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def _ste_min(x, cap):
+    return _SteMin.apply(x, cap)
+
+
+def eval_sh_rgb(deg: int, shs: torch.Tensor, d: torch.Tensor) -> torch.Tensor:
+    """SH -> RGB (before the +0.5 / clamp).  shs [P,K,3] (Gaussian, coeff, channel), d [P,3] unit dirs."""
+    x, y, z = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    res = SH_C0 * shs[:, 0]
+    if deg > 0:
+        res = res - SH_C1 * y * shs[:, 1] + SH_C1 * z * shs[:, 2] - SH_C1 * x * shs[:, 3]
+        if deg > 1:
+            xx, yy, zz = x * x, y * y, z * z
+            xy, yz, xz = x * y, y * z, x * z
+            res = (res + SH_C2[0] * xy * shs[:, 4] + SH_C2[1] * yz * shs[:, 5]
+                   + SH_C2[2] * (2.0 * zz - xx - yy) * shs[:, 6]
+                   + SH_C2[3] * xz * shs[:, 7] + SH_C2[4] * (xx - yy) * shs[:, 8])
+            if deg > 2:
+                res = (res + SH_C3[0] * y * (3.0 * xx - yy) * shs[:, 9]
+                       + SH_C3[1] * xy * z * shs[:, 10]
+                       + SH_C3[2] * y * (4.0 * zz - xx - yy) * shs[:, 11]
+                       + SH_C3[3] * z * (2.0 * zz - 3.0 * xx - 3.0 * yy) * shs[:, 12]
+                       + SH_C3[4] * x * (4.0 * zz - xx - yy) * shs[:, 13]
+                       + SH_C3[5] * z * (xx - yy) * shs[:, 14]
+                       + SH_C3[6] * x * (xx - 3.0 * yy) * shs[:, 15])
+    return res
+
+
+def rotation_from_raw_quat(q: torch.Tensor):
+    """R(q) WITHOUT normalisation.  Same polynomial as
+    /root/reference/src/utils/general_utils.py:92-113 minus the normalise.  Returns 9 tensors R00..R22."""
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R00 = 1.0 - 2.0 * (y * y + z * z)
+    R01 = 2.0 * (x * y - r * z)
+    R02 = 2.0 * (x * z + r * y)
+    R10 = 2.0 * (x * y + r * z)
+    R11 = 1.0 - 2.0 * (x * x + z * z)
+    R12 = 2.0 * (y * z - r * x)
+    R20 = 2.0 * (x * z - r * y)
+    R21 = 2.0 * (y * z + r * x)
+    R22 = 1.0 - 2.0 * (x * x + y * y)
+    return R00, R01, R02, R10, R11, R12, R20, R21, R22
+
+
+def covariance3d(scales: torch.Tensor, scale_modifier: float, rotations: torch.Tensor) -> torch.Tensor:
+    """Sigma = (R S)(R S)^T as the 6-vector xx,xy,xz,yy,yz,zz (order of general_utils.py:77-89)."""
+    s = scale_modifier * scales
+    R = rotation_from_raw_quat(rotations)
+    L = [[R[3 * i + j] * s[:, j] for j in range(3)] for i in range(3)]
+
+    def dot(a, b):
+        return (L[a][0] * L[b][0] + L[a][1] * L[b][1]) + L[a][2] * L[b][2]
+
+    return torch.stack([dot(0, 0), dot(0, 1), dot(0, 2), dot(1, 1), dot(1, 2), dot(2, 2)], dim=1)
+
+
+def f32(x: float) -> float:
+    """Round a python double to float32 (the value the C-ABI receives as a `float` argument)."""
+    return float(np.float32(x))
+
+
+def preprocess(means3D, means2D, opacities, viewmatrix, settings: OracleSettings, shs=None, colors_precomp=None,
+               scales=None, rotations=None, cov3Ds_precomp=None):
+    """Per-Gaussian stage.  All tensors float32 (or float64 for derivative studies)."""
+    dt = means3D.dtype
+    H, W = int(settings.image_height), int(settings.image_width)
+    P = means3D.shape[0]
+    cast = f32 if dt == torch.float32 else float
+    tanx, tany = cast(settings.tanfovx), cast(settings.tanfovy)
+    # the C-ABI receives tanfov as f32 and derives the focal lengths from that value in double
+    focal_x = cast(W / (2.0 * tanx))
+    focal_y = cast(H / (2.0 * tany))
+    V = viewmatrix.reshape(16)
+    Pm = settings.projmatrix.to(dt).reshape(16)
+    x, y, z = means3D[:, 0], means3D[:, 1], means3D[:, 2]
+
+    # view transform (glm/column-major storage: flat[c*4+r] = M[r][c])
+    vx = ((V[0] * x + V[4] * y) + V[8] * z) + V[12]
+    vy = ((V[1] * x + V[5] * y) + V[9] * z) + V[13]
+    vz = ((V[2] * x + V[6] * y) + V[10] * z) + V[14]
+    valid = vz > NEAR_CULL
+
+    hx = ((Pm[0] * vx + Pm[4] * vy) + Pm[8] * vz) + Pm[12]
+    hy = ((Pm[1] * vx + Pm[5] * vy) + Pm[9] * vz) + Pm[13]
+    hw = ((Pm[3] * vx + Pm[7] * vy) + Pm[11] * vz) + Pm[15]
+    pw = 1.0 / (hw + 1e-7)
+    # means2D is the zero "grad sink" of renderer.py:38-44; its gradient is dL/d(ndc) = dL/dpix * (W/2, H/2)
+    ndc_x = hx * pw + means2D[:, 0]
+    ndc_y = hy * pw + means2D[:, 1]
+
+    # 3-D covariance
+    if cov3Ds_precomp is not None:
+        cov3D = cov3Ds_precomp
+    else:
+        cov3D = covariance3d(scales, cast(settings.scale_modifier), rotations)
+    S00, S01, S02, S11, S12, S22 = [cov3D[:, i] for i in range(6)]
+
+    # EWA 2-D covariance.  enable_cov_grad gates the viewmatrix gradient through this block only.
+    Vc = V if settings.enable_cov_grad else V.detach()
+    if settings.enable_cov_grad:
+        cvx, cvy, cvz = vx, vy, vz
+    else:
+        xd, yd, zd = x, y, z
+        cvx = ((Vc[0] * xd + Vc[4] * yd) + Vc[8] * zd) + Vc[12]
+        cvy = ((Vc[1] * xd + Vc[5] * yd) + Vc[9] * zd) + Vc[13]
+        cvz = ((Vc[2] * xd + Vc[6] * yd) + Vc[10] * zd) + Vc[14]
+    limx = cast(np.float32(FOV_CLAMP) * np.float32(tanx)) if dt == torch.float32 else FOV_CLAMP * tanx
+    limy = cast(np.float32(FOV_CLAMP) * np.float32(tany)) if dt == torch.float32 else FOV_CLAMP * tany
+    txtz = cvx / cvz
+    tytz = cvy / cvz
+    cl_x = (txtz < -limx) | (txtz > limx)
+    cl_y = (tytz < -limy) | (tytz > limy)
+    tx_c = torch.clamp(txtz, min=-limx, max=limx) * cvz
+    ty_c = torch.clamp(tytz, min=-limy, max=limy) * cvz
+    # public 3DGS backward treats a clamped t.x / t.y as a constant
+    tx = torch.where(cl_x, tx_c.detach(), tx_c)
+    ty = torch.where(cl_y, ty_c.detach(), ty_c)
+    J00 = focal_x / cvz
+    J02 = -(focal_x * tx) / (cvz * cvz)
+    J11 = focal_y / cvz
+    J12 = -(focal_y * ty) / (cvz * cvz)
+    # W = rotation rows of W2C: W[i][j] = flat[j*4+i]
+    T0 = [J00 * Vc[4 * j + 0] + J02 * Vc[4 * j + 2] for j in range(3)]
+    T1 = [J11 * Vc[4 * j + 1] + J12 * Vc[4 * j + 2] for j in range(3)]
+    Sg = [[S00, S01, S02], [S01, S11, S12], [S02, S12, S22]]
+    u0 = [(T0[0] * Sg[0][j] + T0[1] * Sg[1][j]) + T0[2] * Sg[2][j] for j in range(3)]
+    u1 = [(T1[0] * Sg[0][j] + T1[1] * Sg[1][j]) + T1[2] * Sg[2][j] for j in range(3)]
+    ca = ((u0[0] * T0[0] + u0[1] * T0[1]) + u0[2] * T0[2]) + DILATION
+    cb = (u0[0] * T1[0] + u0[1] * T1[1]) + u0[2] * T1[2]
+    cc = ((u1[0] * T1[0] + u1[1] * T1[1]) + u1[2] * T1[2]) + DILATION
+    det = ca * cc - cb * cb
+    valid = valid & (det != 0)
+    det_safe = torch.where(det != 0, det, torch.ones_like(det))
+    det_inv = 1.0 / det_safe
+    conic_a = cc * det_inv
+    conic_b = -cb * det_inv
+    conic_c = ca * det_inv
+    with torch.no_grad():
+        mid = 0.5 * (ca + cc)
+        disc = torch.sqrt(torch.clamp(mid * mid - det, min=LAMBDA_FLOOR))
+        lam = torch.maximum(mid + disc, mid - disc)
+        radius_f = torch.ceil(3.0 * torch.sqrt(lam))
+    px = ((ndc_x + 1.0) * W - 1.0) * 0.5
+    py = ((ndc_y + 1.0) * H - 1.0) * 0.5
+    gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    with torch.no_grad():
+        rf = radius_f.to(dt)
+        pxd, pyd = px.detach(), py.detach()
+
+        def tr(v):  # (int) truncation toward zero, done in float64-safe int64
+            return torch.trunc(torch.nan_to_num(v, nan=0.0, posinf=2.0e9, neginf=-2.0e9)).to(torch.int64)
+
+        rminx = torch.clamp(tr((pxd - rf) / TILE), 0, gx)
+        rminy = torch.clamp(tr((pyd - rf) / TILE), 0, gy)
+        rmaxx = torch.clamp(tr((((pxd + rf) + TILE) - 1.0) / TILE), 0, gx)
+        rmaxy = torch.clamp(tr((((pyd + rf) + TILE) - 1.0) / TILE), 0, gy)
+        tiles = (rmaxx - rminx) * (rmaxy - rminy)
+        valid = valid & (tiles > 0)
+        tiles = torch.where(valid, tiles, torch.zeros_like(tiles))
+        radii = torch.where(valid, radius_f.to(torch.int64), torch.zeros_like(tiles)).to(torch.int32)
+
+    # colour
+    if colors_precomp is not None:
+        rgb = colors_precomp
+        clamped = torch.zeros(P, 3, dtype=torch.bool)
+    else:
+        Vs = V if settings.enable_sh_grad else V.detach()
+        camx = -((Vs[0] * Vs[12] + Vs[1] * Vs[13]) + Vs[2] * Vs[14])
+        camy = -((Vs[4] * Vs[12] + Vs[5] * Vs[13]) + Vs[6] * Vs[14])
+        camz = -((Vs[8] * Vs[12] + Vs[9] * Vs[13]) + Vs[10] * Vs[14])
+        dx, dy, dz = x - camx, y - camy, z - camz
+        ln = torch.sqrt((dx * dx + dy * dy) + dz * dz)
+        d = torch.stack([dx / ln, dy / ln, dz / ln], dim=1)
+        raw = eval_sh_rgb(int(settings.sh_degree), shs, d) + 0.5
+        clamped = raw < 0
+        rgb = torch.clamp(raw, min=0.0)
+
+    # normal (SURVEY.md §7 open question 2): shortest axis of R*diag(s) in view space, facing the camera.
+    if cov3Ds_precomp is None:
+        with torch.no_grad():
+            k = torch.argmin(scales, dim=1)
+        R = rotation_from_raw_quat(rotations)
+        Rm = torch.stack(R, dim=1).reshape(P, 3, 3)
+        n = torch.gather(Rm, 2, k.view(P, 1, 1).expand(P, 3, 1)).squeeze(2)
+        Vn = V.detach()
+        nv = [(Vn[0 + i] * n[:, 0] + Vn[4 + i] * n[:, 1]) + Vn[8 + i] * n[:, 2] for i in range(3)]
+        dotv = (nv[0] * vx.detach() + nv[1] * vy.detach()) + nv[2] * vz.detach()
+        sgn = torch.where(dotv > 0, -torch.ones_like(dotv), torch.ones_like(dotv))
+        normal = torch.stack([nv[0] * sgn, nv[1] * sgn, nv[2] * sgn], dim=1).detach()
+    else:
+        normal = torch.zeros(P, 3, dtype=dt)
+
+    return dict(valid=valid, depth=vz, px=px, py=py, conic=torch.stack([conic_a, conic_b, conic_c], dim=1),
+                opacity=opacities.reshape(P), rgb=rgb, clamped=clamped, normal=normal, radii=radii,
+                tiles_touched=tiles.to(torch.int32), rect=(rminx, rminy, rmaxx, rmaxy), cov3D=cov3D,
+                cov2D=torch.stack([ca, cb, cc], dim=1), grid=(gx, gy), vx=vx, vy=vy)
+
+
+def bin_and_sort(geom):
+    """Scan + duplicateWithKeys + stable sort + tile ranges -- integer, numpy."""
+    gx, gy = geom["grid"]
+    tiles = geom["tiles_touched"].numpy().astype(np.int64)
+    rminx, rminy, rmaxx, rmaxy = [r.numpy().astype(np.int64) for r in geom["rect"]]
+    depth_bits = geom["depth"].detach().to(torch.float32).numpy().view(np.uint32).astype(np.uint64)
+    offsets = np.cumsum(tiles)
+    D = int(offsets[-1]) if len(offsets) else 0
+    ids = np.repeat(np.arange(len(tiles), dtype=np.int64), tiles)
+    starts = offsets - tiles
+    j = np.arange(D, dtype=np.int64) - starts[ids]
+    w = (rmaxx - rminx)[ids]
+    ty = rminy[ids] + j // np.maximum(w, 1)
+    tx = rminx[ids] + j % np.maximum(w, 1)
+    tile_id = (ty * gx + tx).astype(np.uint64)
+    keys = (tile_id << np.uint64(32)) | depth_bits[ids]
+    vals = ids.astype(np.uint32)
+    order = np.argsort(keys, kind="stable")
+    keys_sorted = keys[order]
+    vals_sorted = vals[order]
+    tile_sorted = (keys_sorted >> np.uint64(32)).astype(np.int64)
+    ntiles = gx * gy
+    start = np.searchsorted(tile_sorted, np.arange(ntiles), side="left")
+    end = np.searchsorted(tile_sorted, np.arange(ntiles), side="right")
+    ranges = np.stack([start, end], axis=1).astype(np.uint32)
+    # tiles with no splats are left at (0,0) by the kernel (never written)
+    ranges[start == end] = 0
+    return dict(offsets=offsets.astype(np.uint32), num_rendered=D, keys_unsorted=keys, vals_unsorted=vals,
+                keys_sorted=keys_sorted, vals_sorted=vals_sorted, ranges=ranges)
+
+
+def render_tiles(geom, binning, bg, H, W, tile_subset=None):
+    """Per-tile front-to-back compositing, vectorised over [splats, 256 pixels]."""
+    dt = geom["px"].dtype
+    gx, gy = geom["grid"]
+    feats = torch.cat([geom["rgb"], geom["depth"].unsqueeze(1), geom["normal"]], dim=1)  # [P,7]
+    C = feats.shape[1]
+    out = torch.zeros(C, H, W, dtype=dt)
+    alpha_img = torch.zeros(1, H, W, dtype=dt)
+    final_T = torch.ones(H, W, dtype=dt)
+    n_contrib = torch.zeros(H, W, dtype=torch.int32)
+    vals = torch.from_numpy(binning["vals_sorted"].astype(np.int64))
+    ranges = binning["ranges"].astype(np.int64)
+    bgc = bg.to(dt).reshape(3)
+    ly, lx = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
+    tiles_iter = range(gx * gy) if tile_subset is None else tile_subset
+    for t in tiles_iter:
+        tyi, txi = divmod(t, gx)
+        x0, y0 = txi * TILE, tyi * TILE
+        x1, y1 = min(x0 + TILE, W), min(y0 + TILE, H)
+        tw, th = x1 - x0, y1 - y0
+        s, e = int(ranges[t, 0]), int(ranges[t, 1])
+        if e <= s:
+            out[0:3, y0:y1, x0:x1] = bgc.view(3, 1, 1).expand(3, th, tw)
+            continue
+        ids = vals[s:e]
+        pixx = (x0 + lx[:th, :tw]).reshape(-1).to(dt)
+        pixy = (y0 + ly[:th, :tw]).reshape(-1).to(dt)
+        dx = geom["px"][ids].unsqueeze(1) - pixx.unsqueeze(0)
+        dy = geom["py"][ids].unsqueeze(1) - pixy.unsqueeze(0)
+        con = geom["conic"][ids]
+        power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
+        ok = power <= 0
+        G = torch.exp(torch.where(ok, power, torch.zeros_like(power)))
+        alpha = _ste_min(geom["opacity"][ids].unsqueeze(1) * G, ALPHA_CAP)
+        ok = ok & (alpha >= ALPHA_MIN)
+        a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
+        cum = torch.cumprod(1.0 - a_eff, dim=0)
+        inc = ok & (cum >= T_STOP)
+        T_before = torch.cat([torch.ones(1, cum.shape[1], dtype=dt), cum[:-1]], dim=0)
+        wgt = torch.where(inc, a_eff * T_before, torch.zeros_like(a_eff))
+        acc = torch.einsum("np,nc->cp", wgt, feats[ids])
+        Tf = torch.prod(torch.where(inc, 1.0 - a_eff, torch.ones_like(a_eff)), dim=0)
+        acc = torch.cat([acc[0:3] + Tf.unsqueeze(0) * bgc.view(3, 1), acc[3:]], dim=0)
+        out[:, y0:y1, x0:x1] = acc.reshape(C, th, tw)
+        alpha_img[0, y0:y1, x0:x1] = (1.0 - Tf).reshape(th, tw)
+        with torch.no_grad():
+            final_T[y0:y1, x0:x1] = Tf.reshape(th, tw)
+            idx = torch.arange(1, inc.shape[0] + 1, dtype=torch.int32).unsqueeze(1)
+            n_contrib[y0:y1, x0:x1] = (inc.to(torch.int32) * idx).max(dim=0).values.reshape(th, tw)
+    return dict(color=out[0:3], depth=out[3:4], normal=out[4:7], alpha=alpha_img, final_T=final_T,
+                n_contrib=n_contrib)
+
+
+def rasterize(means3D, means2D, opacities, viewmatrix, settings: OracleSettings, shs=None, colors_precomp=None,
+              scales=None, rotations=None, cov3Ds_precomp=None, tile_subset=None):
+    """Full oracle forward.  Returns (color, depth, normal, alpha, radii, aux)."""
+    geom = preprocess(means3D, means2D, opacities, viewmatrix, settings, shs=shs, colors_precomp=colors_precomp,
+                      scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp)
+    binning = bin_and_sort(geom)
+    img = render_tiles(geom, binning, settings.bg, int(settings.image_height), int(settings.image_width),
+                       tile_subset=tile_subset)
+    aux = dict(geom=geom, binning=binning, final_T=img["final_T"], n_contrib=img["n_contrib"])
+    return img["color"], img["depth"], img["normal"], img["alpha"], geom["radii"], aux
+
+
+# ---- synthetic scene generator shared by tests / bench ---------------------------------------
+
+def projection_matrix(znear, zfar, fovx, fovy):
+    """Restatement of /root/reference/src/utils/graphic_utils.py:43-63 (pinned by tests/golden)."""
+    tx, ty = math.tan(fovx / 2), math.tan(fovy / 2)
+    top, right = ty * znear, tx * znear
+    Pm = torch.zeros(4, 4)
+    Pm[0, 0] = 2.0 * znear / (2 * right)
+    Pm[1, 1] = 2.0 * znear / (2 * top)
+    Pm[3, 2] = 1.0
+    Pm[2, 2] = zfar / (zfar - znear)
+    Pm[2, 3] = -(zfar * znear) / (zfar - znear)
+    return Pm
+
+
+def synthetic_scene(P: int, W: int, H: int, sh_degree_max: int = 3, seed: int = 777, fovx_deg: float = 50.0,
+                    device="cpu"):
+    """Seeded synthetic cloud + camera of SURVEY.md §8d (uniform in the frustum slab z in [2,20])."""
+    g = torch.Generator().manual_seed(seed)
+    fovx = math.radians(fovx_deg)
+    focal = W / (2 * math.tan(fovx / 2))
+    fovy = 2 * math.atan(H / (2 * focal))
+    tanx, tany = math.tan(fovx / 2), math.tan(fovy / 2)
+    z = 2.0 + 18.0 * torch.rand(P, generator=g)
+    x = (2 * torch.rand(P, generator=g) - 1) * 1.1 * z * tanx
+    y = (2 * torch.rand(P, generator=g) - 1) * 1.1 * z * tany
+    xyz = torch.stack([x, y, z], dim=1)
+    sigma_px = min(max(2.0 * (1e6 / P) ** (1.0 / 3.0) * (W / 1920.0), 0.7), 8.0)
+    scales = (sigma_px * z / focal).unsqueeze(1) * torch.exp(0.5 * torch.randn(P, 3, generator=g))
+    q = torch.randn(P, 4, generator=g)
+    q = q / q.norm(dim=1, keepdim=True)
+    opac = torch.sigmoid(2.0 * torch.randn(P, 1, generator=g))
+    K = (sh_degree_max + 1) ** 2
+    shs = torch.zeros(P, K, 3)
+    shs[:, 0] = (torch.rand(P, 3, generator=g) - 0.5) / SH_C0
+    if K > 1:
+        shs[:, 1:] = 0.05 * torch.randn(P, K - 1, 3, generator=g)
+    view = torch.eye(4)  # identity pose looking down +z
+    proj = projection_matrix(0.01, 100.0, fovx, fovy)
+    scene = dict(means3D=xyz, scales=scales, rotations=q, opacities=opac, shs=shs,
+                 viewmatrix=view.t().contiguous(), projmatrix=proj.t().contiguous(),
+                 tanfovx=tanx, tanfovy=tany, W=W, H=H, fovx=fovx, fovy=fovy)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in scene.items()}

@@ -1,0 +1,117 @@
+"""ctypes binding of librodygs_hip.so (the C-ABI in include/rodygs_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librodygs_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+_lock = threading.Lock()
+
+
+class RdgRasterSettings(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32), ("image_height", C.c_int32),
+        ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
+        ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("enable_cov_grad", C.c_int32), ("enable_sh_grad", C.c_int32), ("render_normal", C.c_int32),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
+STAGES = {
+    "preprocess": 0, "scan_dup": 1, "sort": 2, "ranges": 3, "render_fwd": 4, "render_bwd": 5,
+    "preprocess_bwd": 6, "deform_fwd": 7, "deform_bwd": 8, "adam": 9,
+}
+
+_vp = C.c_void_p
+_SIGS = {
+    "rdg_abi_version": (C.c_int, []),
+    "rdg_last_error": (C.c_char_p, []),
+    "rdg_geom_bytes": (C.c_size_t, [C.c_int32]),
+    "rdg_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "rdg_image_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "rdg_grad_bytes": (C.c_size_t, [C.c_int32]),
+    "rdg_sort_tmp_bytes": (C.c_size_t, [C.c_int64]),
+    "rdg_knn_tmp_bytes": (C.c_size_t, [C.c_int32]),
+    "rdg_rasterize_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 12 + [C.c_int64] + [_vp] * 8),
+    "rdg_rasterize_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13 + [C.c_int64] + [_vp] * 15),
+    "rdg_preprocess_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13),
+    "rdg_geom_export": (C.c_int, [C.c_int32] + [_vp] * 8),
+    "rdg_bin_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 8),
+    "rdg_sort_pairs": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int32, _vp, _vp]),
+    "rdg_deform_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
+    "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 6),
+    "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
+    "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int32, _vp]),
+    "rdg_timing_enable": (C.c_int, [C.c_int32]),
+    "rdg_timing_reset": (C.c_int, []),
+    "rdg_stage_time_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"rodygs_amd: HIP extension not built ({LIB_PATH} missing). Run `python -c 'import "
+                f"__graft_entry__ as g; g.build()'` or `make -C rodygs_amd/csrc`. There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)  # AttributeError if a declared symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if h.rdg_abi_version() != ABI_VERSION:
+            raise RuntimeError("rodygs_amd: librodygs_hip.so ABI version mismatch -- rebuild")
+        _lib = h
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().rdg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def timing_enable(on: bool = True):
+    lib().rdg_timing_enable(1 if on else 0)
+
+
+def timing_reset():
+    lib().rdg_timing_reset()
+
+
+def stage_times():
+    """{stage: (total_ms, launches)} accumulated since the last reset (synchronises on the recorded events)."""
+    out = {}
+    for name, sid in STAGES.items():
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        lib().rdg_stage_time_ms(sid, C.byref(ms), C.byref(n))
+        out[name] = (ms.value, n.value)
+    return out

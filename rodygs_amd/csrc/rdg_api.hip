@@ -1,0 +1,283 @@
+// rdg_api.hip -- the extern "C" surface of librodygs_hip.so (declared in include/rodygs_hip.h).
+// No torch headers, no exceptions across the ABI, no device allocation: plain pointers, sizes and a stream.
+#include "rdg_common.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+int rdg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+int rdg_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    return rdg_set_error("%s: %s", what, hipGetErrorString(e));
+}
+
+// ---- stage timing (hipEvents on the launch stream) -----------------------------------------------------------
+#define RDG_MAX_PENDING 4096
+struct RdgPending { hipEvent_t a, b; int stage; };
+static int g_timing = 0;
+static RdgPending g_pending[RDG_MAX_PENDING];
+static int g_npending = 0;
+static hipEvent_t g_open[RDG_STAGE_COUNT];
+static double g_total_ms[RDG_STAGE_COUNT];
+static int64_t g_count[RDG_STAGE_COUNT];
+
+static void rdg_timing_drain() {
+    for (int i = 0; i < g_npending; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_pending[i].b) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_pending[i].a, g_pending[i].b) == hipSuccess) {
+            g_total_ms[g_pending[i].stage] += ms;
+            g_count[g_pending[i].stage] += 1;
+        }
+        (void)hipEventDestroy(g_pending[i].a);
+        (void)hipEventDestroy(g_pending[i].b);
+    }
+    g_npending = 0;
+}
+void rdg_stage_begin(int stage, hipStream_t s) {
+    if (!g_timing) return;
+    if (g_npending >= RDG_MAX_PENDING) rdg_timing_drain();
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    g_open[stage] = e;
+}
+void rdg_stage_end(int stage, hipStream_t s) {
+    if (!g_timing || !g_open[stage]) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, s);
+    g_pending[g_npending].a = g_open[stage];
+    g_pending[g_npending].b = e;
+    g_pending[g_npending].stage = stage;
+    g_npending++;
+    g_open[stage] = nullptr;
+}
+
+static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
+    if (!s) return rdg_set_error("settings pointer is NULL");
+    if (s->P < 0 || s->image_height <= 0 || s->image_width <= 0) return rdg_set_error("bad sizes");
+    if (s->sh_degree < 0 || s->sh_degree > 3) return rdg_set_error("sh_degree must be 0..3");
+    d->P = s->P; d->M = s->M; d->deg = s->sh_degree; d->H = s->image_height; d->W = s->image_width;
+    d->gx = (d->W + RDG_TILE - 1) / RDG_TILE; d->gy = (d->H + RDG_TILE - 1) / RDG_TILE;
+    d->tanx = s->tanfovx; d->tany = s->tanfovy;
+    d->fx = (float)((double)d->W / (2.0 * (double)s->tanfovx));
+    d->fy = (float)((double)d->H / (2.0 * (double)s->tanfovy));
+    d->smod = s->scale_modifier;
+    d->prefiltered = s->prefiltered; d->cov_grad = s->enable_cov_grad; d->sh_grad = s->enable_sh_grad;
+    d->render_normal = s->render_normal;
+    return 0;
+}
+
+static int rdg_check_inputs(const RdgRasterSettings* s, const float* shs, const float* colors, const float* scales,
+                            const float* rots, const float* cov3D) {
+    if ((shs == nullptr) == (colors == nullptr))
+        return rdg_set_error("Please provide excatly one of either SHs or precomputed colors!");
+    if (((scales == nullptr || rots == nullptr) && cov3D == nullptr) ||
+        ((scales != nullptr || rots != nullptr) && cov3D != nullptr))
+        return rdg_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (shs && s->M < (s->sh_degree + 1) * (s->sh_degree + 1))
+        return rdg_set_error("shs holds %d coefficients, sh_degree %d needs %d", s->M, s->sh_degree,
+                             (s->sh_degree + 1) * (s->sh_degree + 1));
+    return 0;
+}
+
+extern "C" {
+
+int rdg_abi_version(void) { return RDG_ABI_VERSION; }
+const char* rdg_last_error(void) { return g_err; }
+
+size_t rdg_geom_bytes(int32_t P) { return rdg_geom_layout(P).total; }
+size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles) { (void)n_tiles; return rdg_bin_layout(capacity).total; }
+size_t rdg_image_bytes(int32_t H, int32_t W) { return rdg_image_layout(H, W).total; }
+size_t rdg_grad_bytes(int32_t P) { return rdg_align_up((size_t)(P > 0 ? P : 1) * RDG_GROW * 4, 256) + 256; }
+size_t rdg_sort_tmp_bytes(int64_t capacity) {
+    // alternate key/value buffers + tables
+    size_t cap = (size_t)(capacity > 0 ? capacity : 1);
+    return rdg_align_up(cap * 8, 256) + rdg_align_up(cap * 4, 256) + rdg_sort_layout(capacity).total;
+}
+
+int rdg_preprocess_forward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                           const float* projmatrix, void* geom_ws, int32_t* radii, int32_t* num_rendered_dev,
+                           void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    rdg_stage_begin(RDG_STAGE_PREPROCESS, st);
+    int rc = rdg_launch_preprocess_fwd(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                       viewmatrix, projmatrix, geom_ws, radii, num_rendered_dev, st);
+    rdg_stage_end(RDG_STAGE_PREPROCESS, st);
+    return rc;
+}
+
+int rdg_rasterize_forward(const RdgRasterSettings* s_host, const float* bg, const float* means3D, const float* shs,
+                          const float* colors_precomp, const float* opacities, const float* scales,
+                          const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                          const float* projmatrix, void* geom_ws, void* binning_ws, int64_t capacity, void* image_ws,
+                          float* out_color, float* out_depth, float* out_normal, float* out_alpha, int32_t* radii,
+                          int32_t* num_rendered_dev, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rdg_preprocess_forward(s_host, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                    viewmatrix, projmatrix, geom_ws, radii, num_rendered_dev, stream);
+    if (rc) return rc;
+    rc = rdg_launch_bin(d, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev, nullptr, nullptr, st);
+    if (rc) return rc;
+    rdg_stage_begin(RDG_STAGE_RENDER_FWD, st);
+    rc = rdg_launch_render_fwd(d, bg, geom_ws, binning_ws, capacity, image_ws, num_rendered_dev, out_color, out_depth,
+                               out_normal, out_alpha, st);
+    rdg_stage_end(RDG_STAGE_RENDER_FWD, st);
+    return rc;
+}
+
+int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                           const float* projmatrix, const int32_t* radii, const void* geom_ws, const void* binning_ws,
+                           int64_t capacity, const void* image_ws, const float* grad_out_color,
+                           const float* grad_out_depth, const float* grad_out_alpha, void* grad_ws,
+                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                           float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                           float* dL_dviewmatrix, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    float* grow = (float*)grad_ws;
+    const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
+    float* posebuf = (float*)((char*)grad_ws + grow_bytes);
+    rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
+    hipError_t e = hipMemsetAsync(grow, 0, grow_bytes, st);
+    if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
+    int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
+                                   grad_out_alpha, grow, st);
+    rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
+    if (rc) return rc;
+    rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
+    rc = rdg_launch_preprocess_bwd(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   viewmatrix, projmatrix, radii, geom_ws, grow, posebuf, dL_dmeans3D, dL_dmeans2D,
+                                   dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
+                                   dL_dviewmatrix, st);
+    rdg_stage_end(RDG_STAGE_PREPROCESS_BWD, st);
+    return rc;
+}
+
+// ---- geom export ---------------------------------------------------------------------------------------------
+__global__ void rdg_geom_export_kernel(int P, const RdgRec* __restrict__ rec, const uint32_t* __restrict__ tt,
+                                       float* depth, float* xy, float* conic_opacity, float* rgb, float* normal,
+                                       uint32_t* tiles_touched) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const RdgRec r = rec[i];
+    if (depth) depth[i] = r.q1.z;
+    if (xy) { xy[2 * i] = r.q0.x; xy[2 * i + 1] = r.q0.y; }
+    if (conic_opacity) {
+        conic_opacity[4 * i] = r.q0.z; conic_opacity[4 * i + 1] = r.q0.w; conic_opacity[4 * i + 2] = r.q1.x;
+        conic_opacity[4 * i + 3] = r.q1.y;
+    }
+    if (rgb) { rgb[3 * i] = r.q2.x; rgb[3 * i + 1] = r.q2.y; rgb[3 * i + 2] = r.q2.z; }
+    if (normal) { normal[3 * i] = r.q3.x; normal[3 * i + 1] = r.q3.y; normal[3 * i + 2] = r.q3.z; }
+    if (tiles_touched) tiles_touched[i] = tt[i];
+}
+
+int rdg_geom_export(int32_t P, const void* geom_ws, float* depth, float* xy, float* conic_opacity, float* rgb,
+                    float* normal, uint32_t* tiles_touched, void* stream) {
+    if (P <= 0) return 0;
+    const RdgGeomLayout G = rdg_geom_layout(P);
+    const char* g = (const char*)geom_ws;
+    hipLaunchKernelGGL(rdg_geom_export_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P,
+                       (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), depth, xy, conic_opacity,
+                       rgb, normal, tiles_touched);
+    return rdg_check_hip(hipGetLastError(), "geom_export launch");
+}
+
+__global__ void rdg_copy_u64_kernel(const uint64_t* __restrict__ a, uint64_t* __restrict__ b, long long cap,
+                                    const int32_t* __restrict__ n_dev) {
+    long long n = *n_dev; if (n > cap) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        b[i] = a[i];
+}
+__global__ void rdg_copy_u32_kernel(const uint32_t* __restrict__ a, uint32_t* __restrict__ b, long long cap,
+                                    const int32_t* __restrict__ n_dev) {
+    long long n = *n_dev; if (n > cap) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        b[i] = a[i];
+}
+
+int rdg_bin_forward(const RdgRasterSettings* s_host, const void* geom_ws, const int32_t* radii, void* binning_ws,
+                    int64_t capacity, void* image_ws, const int32_t* num_rendered_dev, uint64_t* keys_unsorted,
+                    uint32_t* vals_unsorted, uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
+                    void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rdg_launch_bin(d, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev, keys_unsorted,
+                            vals_unsorted, st);
+    if (rc) return rc;
+    const RdgBinLayout B = rdg_bin_layout(capacity);
+    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
+    const int n_tiles = d.gx * d.gy;
+    const int npass = (rdg_key_bits(n_tiles) + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
+    char* b = (char*)binning_ws;
+    if (keys_sorted)
+        hipLaunchKernelGGL(rdg_copy_u64_kernel, dim3(1024), dim3(256), 0, st,
+                           (const uint64_t*)(b + ((npass & 1) ? B.keys_b : B.keys_a)), keys_sorted, (long long)capacity,
+                           num_rendered_dev);
+    if (vals_sorted)
+        hipLaunchKernelGGL(rdg_copy_u32_kernel, dim3(1024), dim3(256), 0, st,
+                           (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a)), vals_sorted, (long long)capacity,
+                           num_rendered_dev);
+    if (ranges) {
+        hipError_t e = hipMemcpyAsync(ranges, (char*)image_ws + I.ranges, (size_t)n_tiles * 8, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return rdg_check_hip(e, "ranges copy");
+    }
+    return rdg_check_hip(hipGetLastError(), "bin_forward");
+}
+
+int rdg_sort_pairs(uint64_t* keys, uint32_t* vals, int64_t capacity, const int32_t* n_dev, int32_t end_bit,
+                   void* tmp_ws, void* stream) {
+    if (end_bit <= 0 || end_bit > 64) return rdg_set_error("end_bit must be 1..64");
+    hipStream_t st = (hipStream_t)stream;
+    size_t cap = (size_t)(capacity > 0 ? capacity : 1);
+    char* t = (char*)tmp_ws;
+    uint64_t* keys_b = (uint64_t*)t;
+    uint32_t* vals_b = (uint32_t*)(t + rdg_align_up(cap * 8, 256));
+    void* tables = t + rdg_align_up(cap * 8, 256) + rdg_align_up(cap * 4, 256);
+    int in_b = 0;
+    int rc = rdg_launch_sort(keys, keys_b, vals, vals_b, capacity, n_dev, end_bit, tables, &in_b, st);
+    if (rc) return rc;
+    if (in_b) {
+        hipLaunchKernelGGL(rdg_copy_u64_kernel, dim3(1024), dim3(256), 0, st, keys_b, keys, (long long)capacity, n_dev);
+        hipLaunchKernelGGL(rdg_copy_u32_kernel, dim3(1024), dim3(256), 0, st, vals_b, vals, (long long)capacity, n_dev);
+    }
+    return rdg_check_hip(hipGetLastError(), "sort_pairs");
+}
+
+int rdg_timing_enable(int32_t on) { g_timing = on ? 1 : 0; return 0; }
+int rdg_timing_reset(void) {
+    rdg_timing_drain();
+    memset(g_total_ms, 0, sizeof(g_total_ms));
+    memset(g_count, 0, sizeof(g_count));
+    return 0;
+}
+int rdg_stage_time_ms(int32_t stage, double* total_ms, int64_t* count) {
+    if (stage < 0 || stage >= RDG_STAGE_COUNT) return rdg_set_error("bad stage id");
+    rdg_timing_drain();
+    if (total_ms) *total_ms = g_total_ms[stage];
+    if (count) *count = g_count[stage];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+// rdg_binning.hip -- tile binning: duplicateWithKeys, stable LSD radix sort, tile ranges.
+//
+// Integer/byte work, HBM-bound.  Nothing here needs the host to know D (= num_rendered): every kernel is
+// launched with a D-independent grid and reads D from device memory, so the forward pass has no D2H stall.
+//
+// Radix sort design (wave64-native, no inter-workgroup communication => nothing to deadlock or go stale):
+//   the key array is cut into n_seg contiguous WAVE SEGMENTS; a wave owns one segment in every kernel.
+//   per 8-bit pass:  (1) hist    : each wave counts its segment's digits in wave-private LDS counters
+//                                  -> table[digit][segment]
+//                    (2) scan    : one 1024-thread block per digit row -> exclusive prefix over segments
+//                    (3) scatter : each wave re-reads its segment in order; ranks within a 64-key chunk come
+//                                  from a ballot "match" (8 ballots -> mask of equal-digit lanes ->
+//                                  popcount below me), so the order inside a segment, and therefore the
+//                                  whole sort, is stable.
+#include "rdg_common.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// duplicateWithKeys: load-balanced expansion.  A block owns 256 consecutive Gaussians; its output slots
+// [block_base, block_base + block_total) are dealt round-robin to the 256 threads, each of which finds its
+// Gaussian by binary search in the block's LDS offsets -> perfectly coalesced 8-B key / 4-B value stores
+// regardless of how skewed tiles_touched is.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rdg_rect_dup(float px, float py, int radius, int gx, int gy, int& x0, int& y0,
+                                             int& x1, int& y1) {
+    float r = (float)radius;
+    x0 = min(gx, max(0, (int)((px - r) / (float)RDG_TILE)));
+    y0 = min(gy, max(0, (int)((py - r) / (float)RDG_TILE)));
+    x1 = min(gx, max(0, (int)((((px + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+    y1 = min(gy, max(0, (int)((((py + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+}
+
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_duplicate_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
+                     const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
+                     const uint32_t* __restrict__ block_sums, uint64_t* __restrict__ keys,
+                     uint32_t* __restrict__ vals, long long capacity, const int32_t* __restrict__ num_rendered) {
+    if ((long long)(*num_rendered) > capacity) return;
+    __shared__ uint32_t sOff[RDG_PRE_BLOCK];
+    __shared__ uint32_t sDepth[RDG_PRE_BLOCK];
+    __shared__ uint16_t sX0[RDG_PRE_BLOCK], sY0[RDG_PRE_BLOCK], sW[RDG_PRE_BLOCK];
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * RDG_PRE_BLOCK + tid;
+    uint32_t t = 0;
+    if (i < P) {
+        t = tiles_touched[i];
+        if (t > 0) {
+            const float4 q0 = rec[i].q0;
+            const float4 q1 = rec[i].q1;
+            int x0, y0, x1, y1;
+            rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
+            sX0[tid] = (uint16_t)x0; sY0[tid] = (uint16_t)y0; sW[tid] = (uint16_t)(x1 - x0);
+            sDepth[tid] = __float_as_uint(q1.z);
+        }
+    }
+    const uint32_t inc = rdg_wave_scan_incl(t);
+    const uint32_t lane = tid & 63, w = tid >> 6;
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t k = 0; k < w; ++k) woff += wsum[k];
+    sOff[tid] = woff + inc - t;
+    __syncthreads();
+    const uint32_t base = block_sums[blockIdx.x];
+    const uint32_t total = block_sums[blockIdx.x + 1] - base;
+    for (uint32_t k = tid; k < total; k += RDG_PRE_BLOCK) {
+        // last g with sOff[g] <= k
+        int lo = 0, hi = RDG_PRE_BLOCK - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sOff[mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t j = k - sOff[lo];
+        const uint32_t wd = sW[lo];
+        const uint32_t ry = j / wd, rx = j - ry * wd;
+        const uint64_t tile = (uint64_t)(sY0[lo] + ry) * (uint64_t)gx + (uint64_t)(sX0[lo] + rx);
+        keys[base + k] = (tile << 32) | (uint64_t)sDepth[lo];
+        vals[base + k] = (uint32_t)(blockIdx.x * RDG_PRE_BLOCK + lo);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rdg_seg_bounds(long long n, int nseg, int seg, long long& b, long long& e) {
+    long long per = (n + nseg - 1) / nseg;
+    per = (per + 63) / 64 * 64;
+    b = (long long)seg * per;
+    e = b + per;
+    if (b > n) b = n;
+    if (e > n) e = n;
+}
+
+__global__ void __launch_bounds__(RDG_SORT_BLOCK)
+rdg_sort_hist_kernel(const uint64_t* __restrict__ keys, long long capacity, const int32_t* __restrict__ n_dev,
+                     int shift, int nseg, uint32_t* __restrict__ table) {
+    long long n = *n_dev;
+    if (n > capacity) return;
+    __shared__ uint32_t cnt[RDG_SORT_BLOCK / RDG_WAVE][RDG_SORT_RADIX];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg = blockIdx.x * (RDG_SORT_BLOCK / RDG_WAVE) + w;
+#pragma unroll
+    for (int k = 0; k < RDG_SORT_RADIX / RDG_WAVE; ++k) cnt[w][lane + 64 * k] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    long long b, e;
+    rdg_seg_bounds(n, nseg, seg, b, e);
+    for (long long i = b + lane; i < e; i += 64) {
+        const uint32_t dgt = (uint32_t)(keys[i] >> shift) & (RDG_SORT_RADIX - 1);
+        atomicAdd(&cnt[w][dgt], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int k = 0; k < RDG_SORT_RADIX / RDG_WAVE; ++k) {
+        const int dg = lane + 64 * k;
+        table[(size_t)dg * nseg + seg] = cnt[w][dg];
+    }
+}
+
+// one block per digit row: exclusive scan over segments (in place) + row total
+__global__ void __launch_bounds__(1024)
+rdg_sort_scan_kernel(uint32_t* __restrict__ table, int nseg, uint32_t* __restrict__ totals, long long capacity,
+                     const int32_t* __restrict__ n_dev) {
+    if ((long long)(*n_dev) > capacity) return;
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = table + (size_t)blockIdx.x * nseg;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nseg; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nseg ? row[i] : 0u;
+        const uint32_t inc = rdg_wave_scan_incl(v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < nseg) row[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+__global__ void __launch_bounds__(RDG_SORT_BLOCK)
+rdg_sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                        uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long long capacity,
+                        const int32_t* __restrict__ n_dev, int shift, int nseg,
+                        const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals) {
+    long long n = *n_dev;
+    if (n > capacity) return;
+    __shared__ uint32_t dbase[RDG_SORT_RADIX];
+    __shared__ uint32_t wtot[RDG_SORT_BLOCK / RDG_WAVE];
+    __shared__ uint32_t cursor_s[RDG_SORT_BLOCK / RDG_WAVE][RDG_SORT_RADIX];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // exclusive scan of the 256 digit totals (thread = digit)
+    {
+        const uint32_t v = totals[threadIdx.x];
+        const uint32_t inc = rdg_wave_scan_incl(v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
+        dbase[threadIdx.x] = woff + inc - v;
+        __syncthreads();
+    }
+    const int seg = blockIdx.x * (RDG_SORT_BLOCK / RDG_WAVE) + w;
+    volatile uint32_t* cursor = cursor_s[w];
+#pragma unroll
+    for (int k = 0; k < RDG_SORT_RADIX / RDG_WAVE; ++k) {
+        const int dg = lane + 64 * k;
+        cursor[dg] = dbase[dg] + table[(size_t)dg * nseg + seg];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    long long b, e;
+    rdg_seg_bounds(n, nseg, seg, b, e);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (long long i0 = b; i0 < e; i0 += 64) {
+        const long long i = i0 + lane;
+        const bool act = i < e;
+        uint64_t key = 0; uint32_t val = 0;
+        if (act) { key = keys_in[i]; val = vals_in[i]; }
+        const uint32_t dgt = (uint32_t)(key >> shift) & (RDG_SORT_RADIX - 1);
+        unsigned long long m = __ballot(act);
+#pragma unroll
+        for (int bit = 0; bit < RDG_SORT_BITS; ++bit) {
+            const bool bset = (dgt >> bit) & 1u;
+            const unsigned long long bal = __ballot(act && bset);
+            m &= bset ? bal : ~bal;
+        }
+        const uint32_t rank = __popcll(m & lt_mask);
+        uint32_t pos = 0;
+        if (act) pos = cursor[dgt] + rank;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (act && rank == 0) cursor[dgt] = pos + (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (act) { keys_out[pos] = key; vals_out[pos] = val; }
+    }
+}
+
+int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
+                    const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s) {
+    const RdgSortLayout L = rdg_sort_layout(capacity);
+    const int nseg = rdg_sort_nseg(capacity);
+    uint32_t* table = (uint32_t*)((char*)sort_tmp + L.table);
+    uint32_t* totals = (uint32_t*)((char*)sort_tmp + L.totals);
+    const int npass = (end_bit + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
+    uint64_t* kin = keys_a; uint64_t* kout = keys_b;
+    uint32_t* vin = vals_a; uint32_t* vout = vals_b;
+    const int nblk = nseg / (RDG_SORT_BLOCK / RDG_WAVE);
+    for (int p = 0; p < npass; ++p) {
+        const int shift = p * RDG_SORT_BITS;
+        hipLaunchKernelGGL(rdg_sort_hist_kernel, dim3(nblk), dim3(RDG_SORT_BLOCK), 0, s, kin, (long long)capacity,
+                           n_dev, shift, nseg, table);
+        hipLaunchKernelGGL(rdg_sort_scan_kernel, dim3(RDG_SORT_RADIX), dim3(1024), 0, s, table, nseg, totals,
+                           (long long)capacity, n_dev);
+        hipLaunchKernelGGL(rdg_sort_scatter_kernel, dim3(nblk), dim3(RDG_SORT_BLOCK), 0, s, kin, vin, kout, vout,
+                           (long long)capacity, n_dev, shift, nseg, table, totals);
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    if (result_in_b) *result_in_b = (npass & 1);
+    return rdg_check_hip(hipGetLastError(), "sort launch");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// identifyTileRanges
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rdg_tile_ranges_kernel(const uint64_t* __restrict__ keys, long long capacity, const int32_t* __restrict__ n_dev,
+                       uint2* __restrict__ ranges) {
+    const long long n = *n_dev;
+    if (n > capacity) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t tile = (uint32_t)(keys[i] >> 32);
+        if (i == 0) {
+            ranges[tile].x = 0;
+        } else {
+            const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+            if (prev != tile) {
+                ranges[prev].y = (uint32_t)i;
+                ranges[tile].x = (uint32_t)i;
+            }
+        }
+        if (i == n - 1) ranges[tile].y = (uint32_t)n;
+    }
+}
+
+__global__ void rdg_copy_pairs_kernel(const uint64_t* __restrict__ k, const uint32_t* __restrict__ v,
+                                      uint64_t* __restrict__ ko, uint32_t* __restrict__ vo, long long capacity,
+                                      const int32_t* __restrict__ n_dev) {
+    const long long n = *n_dev;
+    if (n > capacity) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        if (ko) ko[i] = k[i];
+        if (vo) vo[i] = v[i];
+    }
+}
+
+int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
+                   void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
+                   uint32_t* vals_unsorted_copy, hipStream_t s) {
+    const RdgGeomLayout G = rdg_geom_layout(d.P);
+    const RdgBinLayout B = rdg_bin_layout(capacity);
+    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
+    const char* g = (const char*)geom_ws;
+    char* b = (char*)bin_ws;
+    uint64_t* keys_a = (uint64_t*)(b + B.keys_a);
+    uint64_t* keys_b = (uint64_t*)(b + B.keys_b);
+    uint32_t* vals_a = (uint32_t*)(b + B.vals_a);
+    uint32_t* vals_b = (uint32_t*)(b + B.vals_b);
+    const int n_tiles = d.gx * d.gy;
+    uint2* ranges = (uint2*)((char*)image_ws + I.ranges);
+
+    rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
+    if (d.P > 0) {
+        const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+        hipLaunchKernelGGL(rdg_duplicate_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+                           (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                           (const uint32_t*)(g + G.block_sums), keys_a, vals_a, (long long)capacity, num_rendered);
+    }
+    rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
+    if (keys_unsorted_copy || vals_unsorted_copy) {
+        hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_a, vals_a, keys_unsorted_copy,
+                           vals_unsorted_copy, (long long)capacity, num_rendered);
+    }
+    rdg_stage_begin(RDG_STAGE_SORT, s);
+    int in_b = 0;
+    int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, capacity, num_rendered, rdg_key_bits(n_tiles),
+                             b + B.sort_tmp, &in_b, s);
+    rdg_stage_end(RDG_STAGE_SORT, s);
+    if (rc) return rc;
+    rdg_stage_begin(RDG_STAGE_RANGES, s);
+    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)n_tiles * sizeof(uint2), s);
+    if (e != hipSuccess) return rdg_check_hip(e, "ranges memset");
+    hipLaunchKernelGGL(rdg_tile_ranges_kernel, dim3(2048), dim3(256), 0, s, in_b ? keys_b : keys_a,
+                       (long long)capacity, num_rendered, ranges);
+    rdg_stage_end(RDG_STAGE_RANGES, s);
+    return rdg_check_hip(hipGetLastError(), "bin launch");
+}

@@ -1,0 +1,205 @@
+// rdg_common.h -- shared device/host definitions for librodygs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/rodygs_hip.h"
+
+#define RDG_TILE 16
+#define RDG_TILE_PIX 256
+#define RDG_WAVE 64
+
+// algorithm constants (SURVEY.md §7 open question 6: kept in one place)
+#define RDG_NEAR_CULL 0.2f
+#define RDG_FOV_CLAMP 1.3f
+#define RDG_DILATION 0.3f
+#define RDG_ALPHA_CAP 0.99f
+#define RDG_ALPHA_MIN (1.0f / 255.0f)
+#define RDG_T_STOP 0.0001f
+#define RDG_LAMBDA_FLOOR 0.1f
+
+// 64-byte per-Gaussian splat record: everything the compositing kernels gather, one L2 line-half per splat.
+//   q0 = (px, py, conic_a, conic_b)   q1 = (conic_c, opacity, depth, _)
+//   q2 = (r, g, b, _)                 q3 = (nx, ny, nz, _)
+struct __attribute__((aligned(64))) RdgRec {
+    float4 q0, q1, q2, q3;
+};
+
+// 64-byte per-Gaussian gradient accumulator row (one 64-B atomic request per (tile, splat)):
+//   [0] dL/dndc_x  [1] dL/dndc_y  [2..4] dL/dconic(a,b,c)  [5] dL/dopacity  [6..8] dL/drgb  [9] dL/ddepth
+#define RDG_GROW 16
+
+static inline size_t rdg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+#define RDG_PRE_BLOCK 256  // Gaussians per preprocess / duplicate block
+
+// ---- geom workspace layout -------------------------------------------------------------------------------
+struct RdgGeomLayout {
+    size_t rec;            // RdgRec[P]
+    size_t tiles_touched;  // uint32[P]
+    size_t clamped;        // uint8[P]  (bit c set = channel c clamped at 0)
+    size_t block_sums;     // uint32[nblk+1]  (exclusive-scanned in place; [nblk] = total)
+    size_t total;
+};
+static inline RdgGeomLayout rdg_geom_layout(int32_t P) {
+    RdgGeomLayout L;
+    size_t Pp = (size_t)(P > 0 ? P : 1);
+    size_t nblk = (Pp + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    size_t o = 0;
+    L.rec = o;            o = rdg_align_up(o + Pp * sizeof(RdgRec), 256);
+    L.tiles_touched = o;  o = rdg_align_up(o + Pp * 4, 256);
+    L.clamped = o;        o = rdg_align_up(o + Pp, 256);
+    L.block_sums = o;     o = rdg_align_up(o + (nblk + 1) * 4, 256);
+    L.total = o;
+    return L;
+}
+
+// ---- sort geometry ---------------------------------------------------------------------------------------
+#define RDG_SORT_BITS 8
+#define RDG_SORT_RADIX 256
+#define RDG_SORT_BLOCK 256                    // 4 independent waves per block
+#define RDG_SORT_MAX_WAVES 4096               // columns of the (digit, wave-segment) table
+
+struct RdgSortLayout {
+    size_t table;   // uint32[RADIX][n_seg]
+    size_t totals;  // uint32[RADIX]
+    size_t total;
+};
+static inline int32_t rdg_sort_nseg(int64_t capacity) {
+    int64_t n = (capacity + 1023) / 1024;  // >= 1024 keys per wave segment
+    if (n < 4) n = 4;
+    if (n > RDG_SORT_MAX_WAVES) n = RDG_SORT_MAX_WAVES;
+    n = (n + 3) / 4 * 4;
+    return (int32_t)n;
+}
+static inline RdgSortLayout rdg_sort_layout(int64_t capacity) {
+    RdgSortLayout L;
+    size_t o = 0;
+    L.table = o;   o = rdg_align_up(o + (size_t)RDG_SORT_RADIX * rdg_sort_nseg(capacity) * 4, 256);
+    L.totals = o;  o = rdg_align_up(o + RDG_SORT_RADIX * 4, 256);
+    L.total = o;
+    return L;
+}
+
+// ---- binning workspace layout ----------------------------------------------------------------------------
+struct RdgBinLayout {
+    size_t keys_a, keys_b;  // uint64[cap]
+    size_t vals_a, vals_b;  // uint32[cap]
+    size_t sort_tmp;        // RdgSortLayout
+    size_t total;
+};
+static inline RdgBinLayout rdg_bin_layout(int64_t capacity) {
+    RdgBinLayout L;
+    size_t cap = (size_t)(capacity > 0 ? capacity : 1);
+    size_t o = 0;
+    L.keys_a = o;  o = rdg_align_up(o + cap * 8, 256);
+    L.keys_b = o;  o = rdg_align_up(o + cap * 8, 256);
+    L.vals_a = o;  o = rdg_align_up(o + cap * 4, 256);
+    L.vals_b = o;  o = rdg_align_up(o + cap * 4, 256);
+    L.sort_tmp = o; o = rdg_align_up(o + rdg_sort_layout(capacity).total, 256);
+    L.total = o;
+    return L;
+}
+
+// ---- image workspace layout ------------------------------------------------------------------------------
+struct RdgImageLayout {
+    size_t final_T;    // float[H*W]
+    size_t n_contrib;  // uint32[H*W]
+    size_t ranges;     // uint2[n_tiles]
+    size_t total;
+};
+static inline RdgImageLayout rdg_image_layout(int32_t H, int32_t W) {
+    RdgImageLayout L;
+    size_t hw = (size_t)H * W;
+    size_t nt = (size_t)((W + RDG_TILE - 1) / RDG_TILE) * ((H + RDG_TILE - 1) / RDG_TILE);
+    size_t o = 0;
+    L.final_T = o;    o = rdg_align_up(o + hw * 4, 256);
+    L.n_contrib = o;  o = rdg_align_up(o + hw * 4, 256);
+    L.ranges = o;     o = rdg_align_up(o + nt * 8, 256);
+    L.total = o;
+    return L;
+}
+
+static inline int rdg_key_bits(int32_t n_tiles) {
+    int b = 0;
+    while ((1ll << b) < (long long)n_tiles) ++b;
+    return 32 + b;
+}
+
+// device-side view of the camera / settings handed to kernels by value
+
+struct RdgDev {
+    int32_t P, M, deg, H, W, gx, gy;
+    float tanx, tany, fx, fy, smod;
+    int32_t prefiltered, cov_grad, sh_grad, render_normal;
+};
+
+// ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------
+int rdg_set_error(const char* fmt, ...);
+int rdg_check_hip(hipError_t e, const char* what);
+void rdg_stage_begin(int stage, hipStream_t s);
+void rdg_stage_end(int stage, hipStream_t s);
+
+// ---- kernel launchers (one per .hip file) ----------------------------------------------------------------
+int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
+                              const float* opac, const float* scales, const float* rots, const float* cov3D,
+                              const float* view, const float* proj, void* geom_ws, int32_t* radii,
+                              int32_t* num_rendered, hipStream_t s);
+int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
+                   void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
+                   uint32_t* vals_unsorted_copy, hipStream_t s);
+int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
+                    const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s);
+int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
+                          int64_t capacity, void* image_ws, const int32_t* num_rendered, float* out_color,
+                          float* out_depth, float* out_normal, float* out_alpha, hipStream_t s);
+int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
+                          int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
+                          const float* g_alpha, float* grow, hipStream_t s);
+int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
+                              const float* opac, const float* scales, const float* rots, const float* cov3D,
+                              const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
+                              const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
+                              float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
+                              float* dview, hipStream_t s);
+
+// ---- small device helpers --------------------------------------------------------------------------------
+#ifdef __HIPCC__
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float rdg_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK,
+                                                                 BANK_MASK, BOUND));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ uint32_t rdg_dpp_u(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 (DPP only, no LDS traffic).
+__device__ __forceinline__ float rdg_wave_sum_to63(float x) {
+    x += rdg_dpp<0xB1>(x);         // quad_perm [1,0,3,2]
+    x += rdg_dpp<0x4E>(x);         // quad_perm [2,3,0,1]
+    x += rdg_dpp<0x141>(x);        // row_half_mirror
+    x += rdg_dpp<0x140>(x);        // row_mirror   -> every lane holds its 16-lane row total
+    x += rdg_dpp<0x142, 0xa>(x);   // row_bcast:15 into rows 1,3
+    x += rdg_dpp<0x143, 0xc>(x);   // row_bcast:31 into rows 2,3 -> lane 63 = total
+    return x;
+}
+__device__ __forceinline__ float rdg_wave_sum_all(float x) {
+    x = rdg_wave_sum_to63(x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+__device__ __forceinline__ uint32_t rdg_lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// inclusive prefix sum over the 64 lanes (uint32)
+__device__ __forceinline__ uint32_t rdg_wave_scan_incl(uint32_t x) {
+    uint32_t t;
+    t = rdg_dpp_u<0x111>(x); x += t;               // row_shr:1
+    t = rdg_dpp_u<0x112>(x); x += t;               // row_shr:2
+    t = rdg_dpp_u<0x114>(x); x += t;               // row_shr:4
+    t = rdg_dpp_u<0x118>(x); x += t;               // row_shr:8  -> row-inclusive
+    t = rdg_dpp_u<0x142, 0xa>(x); x += t;          // row_bcast:15 -> rows 1,3
+    t = rdg_dpp_u<0x143, 0xc>(x); x += t;          // row_bcast:31 -> rows 2,3
+    return x;
+}
+#endif

@@ -1,0 +1,217 @@
+// rdg_knn.hip -- simple_knn.distCUDA2 replacement: mean squared distance to the 3
+// nearest other points.  Call site: /root/reference/src/model/rodygs_static.py:130-133 (init only).
+//
+// Exact 3-NN: points are ordered along a 30-bit Morton curve with the library's own radix sort, cut into boxes
+// of 256 consecutive points with their AABBs; a thread (one point, in Morton order, so a wave's 64 points are
+// spatial neighbours and take the same branches) seeds its best-3 from its curve neighbours and then visits
+// only the boxes whose AABB is closer than its current 3rd-best distance.  Box AABBs are streamed through LDS.
+#include "rdg_common.h"
+#include <float.h>
+
+#define RDG_KNN_BOX 256
+
+struct RdgKnnLayout {
+    size_t minmax;      // float[8]
+    size_t n_dev;       // int32
+    size_t keys_a, keys_b, vals_a, vals_b, sort_tmp;
+    size_t sorted;      // float4[P]
+    size_t boxes;       // float4[2*nbox]
+    size_t total;
+};
+static RdgKnnLayout rdg_knn_layout(int32_t P) {
+    RdgKnnLayout L;
+    size_t Pp = (size_t)(P > 0 ? P : 1);
+    size_t nbox = (Pp + RDG_KNN_BOX - 1) / RDG_KNN_BOX;
+    size_t o = 0;
+    L.minmax = o;   o = rdg_align_up(o + 32, 256);
+    L.n_dev = o;    o = rdg_align_up(o + 4, 256);
+    L.keys_a = o;   o = rdg_align_up(o + Pp * 8, 256);
+    L.keys_b = o;   o = rdg_align_up(o + Pp * 8, 256);
+    L.vals_a = o;   o = rdg_align_up(o + Pp * 4, 256);
+    L.vals_b = o;   o = rdg_align_up(o + Pp * 4, 256);
+    L.sort_tmp = o; o = rdg_align_up(o + rdg_sort_layout((int64_t)Pp).total, 256);
+    L.sorted = o;   o = rdg_align_up(o + Pp * 16, 256);
+    L.boxes = o;    o = rdg_align_up(o + nbox * 32, 256);
+    L.total = o;
+    return L;
+}
+
+__global__ void __launch_bounds__(1024) rdg_knn_minmax_kernel(int P, const float* __restrict__ pts,
+                                                              float* __restrict__ minmax, int32_t* n_dev) {
+    __shared__ float s[6][16];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = threadIdx.x; i < P; i += 1024) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = pts[3 * i + c];
+            mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int c = 0; c < 3; ++c) { s[c][w] = mn[c]; s[3 + c][w] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < 3; ++c) {
+            float a = s[c][0], b = s[3 + c][0];
+            for (int k = 1; k < 16; ++k) { a = fminf(a, s[c][k]); b = fmaxf(b, s[3 + c][k]); }
+            minmax[c] = a; minmax[4 + c] = b;
+        }
+        *n_dev = P;
+    }
+}
+
+__device__ __forceinline__ uint32_t rdg_expand10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void rdg_knn_morton_kernel(int P, const float* __restrict__ pts, const float* __restrict__ minmax,
+                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lo = minmax[c], hi = minmax[4 + c];
+        const float ext = hi - lo;
+        float t = ext > 0.f ? (pts[3 * i + c] - lo) / ext : 0.f;
+        t = fminf(fmaxf(t * 1023.0f, 0.0f), 1023.0f);
+        code |= rdg_expand10((uint32_t)t) << (2 - c);
+    }
+    keys[i] = (uint64_t)code;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(RDG_KNN_BOX)
+rdg_knn_gather_box_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
+                          float4* __restrict__ sorted, float4* __restrict__ boxes) {
+    __shared__ float s[6][RDG_KNN_BOX / 64];
+    const int i = blockIdx.x * RDG_KNN_BOX + threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (i < P) {
+        const uint32_t src = order[i];
+        const float x = pts[3 * src], y = pts[3 * src + 1], z = pts[3 * src + 2];
+        sorted[i] = make_float4(x, y, z, __uint_as_float(src));
+        mn[0] = mx[0] = x; mn[1] = mx[1] = y; mn[2] = mx[2] = z;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+        }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { for (int c = 0; c < 3; ++c) { s[c][w] = mn[c]; s[3 + c][w] = mx[c]; } }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a[3], b[3];
+        for (int c = 0; c < 3; ++c) {
+            a[c] = s[c][0]; b[c] = s[3 + c][0];
+            for (int k = 1; k < RDG_KNN_BOX / 64; ++k) { a[c] = fminf(a[c], s[c][k]); b[c] = fmaxf(b[c], s[3 + c][k]); }
+        }
+        boxes[2 * blockIdx.x] = make_float4(a[0], a[1], a[2], 0.f);
+        boxes[2 * blockIdx.x + 1] = make_float4(b[0], b[1], b[2], 0.f);
+    }
+}
+
+__device__ __forceinline__ void rdg_knn_insert(float d, float& b0, float& b1, float& b2) {
+    if (d < b2) {
+        if (d < b1) {
+            b2 = b1;
+            if (d < b0) { b1 = b0; b0 = d; } else { b1 = d; }
+        } else {
+            b2 = d;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rdg_knn_search_kernel(int P, int nbox, const float4* __restrict__ sorted, const float4* __restrict__ boxes,
+                      float* __restrict__ out) {
+    __shared__ float4 sBox[2 * 256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool act = i < P;
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    if (act) {
+        me = sorted[i];
+        for (int j = max(0, i - 3); j <= min(P - 1, i + 3); ++j) {
+            if (j == i) continue;
+            const float4 o = sorted[j];
+            const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+            rdg_knn_insert(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+        }
+    }
+    for (int base = 0; base < nbox; base += 256) {
+        __syncthreads();
+        const int nb = min(256, nbox - base);
+        if ((int)threadIdx.x < nb) {
+            sBox[2 * threadIdx.x] = boxes[2 * (base + threadIdx.x)];
+            sBox[2 * threadIdx.x + 1] = boxes[2 * (base + threadIdx.x) + 1];
+        }
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            const float4 lo = sBox[2 * k], hi = sBox[2 * k + 1];
+            const float ex = fmaxf(fmaxf(lo.x - me.x, me.x - hi.x), 0.f);
+            const float ey = fmaxf(fmaxf(lo.y - me.y, me.y - hi.y), 0.f);
+            const float ez = fmaxf(fmaxf(lo.z - me.z, me.z - hi.z), 0.f);
+            const float dbox = ex * ex + ey * ey + ez * ez;
+            const bool visit = act && dbox <= b2;
+            if (!__any(visit)) continue;
+            if (visit) {
+                const int s0 = (base + k) * RDG_KNN_BOX, s1 = min(P, s0 + RDG_KNN_BOX);
+                for (int j = s0; j < s1; ++j) {
+                    if (j == i || (j >= i - 3 && j <= i + 3)) continue;  // seeds already counted
+                    const float4 o = sorted[j];
+                    const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+                    rdg_knn_insert(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+                }
+            }
+        }
+    }
+    if (act) out[__float_as_uint(me.w)] = (b0 + b1 + b2) / 3.0f;
+}
+
+extern "C" {
+
+size_t rdg_knn_tmp_bytes(int32_t P) { return rdg_knn_layout(P).total; }
+
+int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream) {
+    if (P <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const RdgKnnLayout L = rdg_knn_layout(P);
+    char* t = (char*)tmp_ws;
+    float* minmax = (float*)(t + L.minmax);
+    int32_t* n_dev = (int32_t*)(t + L.n_dev);
+    uint64_t* keys_a = (uint64_t*)(t + L.keys_a); uint64_t* keys_b = (uint64_t*)(t + L.keys_b);
+    uint32_t* vals_a = (uint32_t*)(t + L.vals_a); uint32_t* vals_b = (uint32_t*)(t + L.vals_b);
+    float4* sorted = (float4*)(t + L.sorted);
+    float4* boxes = (float4*)(t + L.boxes);
+    const int nbox = (P + RDG_KNN_BOX - 1) / RDG_KNN_BOX;
+    hipLaunchKernelGGL(rdg_knn_minmax_kernel, dim3(1), dim3(1024), 0, st, P, points, minmax, n_dev);
+    hipLaunchKernelGGL(rdg_knn_morton_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points, minmax, keys_a, vals_a);
+    int in_b = 0;
+    int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, (int64_t)P, n_dev, 30, t + L.sort_tmp, &in_b, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rdg_knn_gather_box_kernel, dim3(nbox), dim3(RDG_KNN_BOX), 0, st, P, points,
+                       in_b ? vals_b : vals_a, sorted, boxes);
+    hipLaunchKernelGGL(rdg_knn_search_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, nbox, sorted, boxes, out);
+    return rdg_check_hip(hipGetLastError(), "knn launch");
+}
+
+}  // extern "C"

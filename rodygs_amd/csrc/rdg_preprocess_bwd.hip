@@ -1,0 +1,346 @@
+// rdg_preprocess_bwd.hip -- per-Gaussian backward: conic -> Sigma2D -> (Sigma3D, mean),
+// projection -> mean3D, SH backward (clamp mask), Sigma3D -> (scale, raw quaternion), and the camera-pose
+// gradient dL/dviewmatrix (a reduction over all Gaussians: DPP wave sums -> 19 atomics per wave).
+//
+// One thread per Gaussian.  HBM-bound: reads the 64-B accumulator row + the forward inputs, writes 59 floats.
+// Pose-gradient gates (SURVEY.md §7 open question 4): enable_cov_grad switches the contribution through the
+// EWA block (t and W), enable_sh_grad the contribution through campos; Gaussian gradients are unaffected.
+#include "rdg_common.h"
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__device__ static const float BSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                           -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float BSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                           0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                           -0.5900435899266435f};
+
+// posebuf layout: [0..15] dL/dV (glm flat), [16..18] dL/dcampos
+#define RDG_POSE_N 19
+
+__global__ void __launch_bounds__(256)
+rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float* __restrict__ proj,
+                          const float* __restrict__ means3D, const float* __restrict__ shs,
+                          const float* __restrict__ colors, const float* __restrict__ opac,
+                          const float* __restrict__ scales, const float* __restrict__ rots,
+                          const float* __restrict__ cov3Dp, const int32_t* __restrict__ radii,
+                          const uint8_t* __restrict__ clampedm, const float* __restrict__ grow,
+                          float* __restrict__ posebuf, float* __restrict__ dmeans3D, float* __restrict__ dmeans2D,
+                          float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac,
+                          float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float V[16], Pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = view[k]; Pm[k] = proj[k]; }
+    float pose[RDG_POSE_N];
+#pragma unroll
+    for (int k = 0; k < RDG_POSE_N; ++k) pose[k] = 0.0f;
+
+    const bool live = i < d.P && radii[i] > 0;
+    if (i < d.P) {
+        float dmx = 0.f, dmy = 0.f, dmz = 0.f;
+        float gnx = 0.f, gny = 0.f, gop = 0.f;
+        float dsc0 = 0.f, dsc1 = 0.f, dsc2 = 0.f;
+        float dq0 = 0.f, dq1 = 0.f, dq2 = 0.f, dq3 = 0.f;
+        float dS[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float grgb[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            const float4* gr = reinterpret_cast<const float4*>(grow + (size_t)i * RDG_GROW);
+            const float4 ga = gr[0], gb = gr[1], gc = gr[2];
+            gnx = ga.x; gny = ga.y;
+            const float gca = ga.z, gcb = ga.w, gcc = gb.x;
+            gop = gb.y;
+            grgb[0] = gb.z; grgb[1] = gb.w; grgb[2] = gc.x;
+            const float gdepth = gc.y;
+
+            const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+            const float vx = V[0] * x + V[4] * y + V[8] * z + V[12];
+            const float vy = V[1] * x + V[5] * y + V[9] * z + V[13];
+            const float vz = V[2] * x + V[6] * y + V[10] * z + V[14];
+            // dL/dv: "all" feeds means3D; "pose" feeds the viewmatrix (may exclude the EWA path)
+            float dvx = 0.f, dvy = 0.f, dvz = 0.f;      // common part (projection + depth)
+            float evx = 0.f, evy = 0.f, evz = 0.f;      // EWA part (t in the Jacobian)
+
+            // (1) ndc path
+            {
+                const float hx = Pm[0] * vx + Pm[4] * vy + Pm[8] * vz + Pm[12];
+                const float hy = Pm[1] * vx + Pm[5] * vy + Pm[9] * vz + Pm[13];
+                const float hw = Pm[3] * vx + Pm[7] * vy + Pm[11] * vz + Pm[15];
+                const float pw = 1.0f / (hw + 1e-7f);
+                const float dhx = gnx * pw, dhy = gny * pw;
+                const float dhw = -(gnx * hx + gny * hy) * pw * pw;
+                dvx += Pm[0] * dhx + Pm[1] * dhy + Pm[3] * dhw;
+                dvy += Pm[4] * dhx + Pm[5] * dhy + Pm[7] * dhw;
+                dvz += Pm[8] * dhx + Pm[9] * dhy + Pm[11] * dhw;
+            }
+            // (2) depth
+            dvz += gdepth;
+
+            // recompute Sigma3D
+            float S00, S01, S02, S11, S12, S22;
+            float R00 = 0, R01 = 0, R02 = 0, R10 = 0, R11 = 0, R12 = 0, R20 = 0, R21 = 0, R22 = 0;
+            float s0 = 0, s1 = 0, s2 = 0, qr = 0, qx = 0, qy = 0, qz = 0;
+            if (cov3Dp) {
+                S00 = cov3Dp[6 * i + 0]; S01 = cov3Dp[6 * i + 1]; S02 = cov3Dp[6 * i + 2];
+                S11 = cov3Dp[6 * i + 3]; S12 = cov3Dp[6 * i + 4]; S22 = cov3Dp[6 * i + 5];
+            } else {
+                s0 = d.smod * scales[3 * i + 0]; s1 = d.smod * scales[3 * i + 1]; s2 = d.smod * scales[3 * i + 2];
+                const float4 q = reinterpret_cast<const float4*>(rots)[i];
+                qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+                R00 = 1.0f - 2.0f * (qy * qy + qz * qz); R01 = 2.0f * (qx * qy - qr * qz); R02 = 2.0f * (qx * qz + qr * qy);
+                R10 = 2.0f * (qx * qy + qr * qz); R11 = 1.0f - 2.0f * (qx * qx + qz * qz); R12 = 2.0f * (qy * qz - qr * qx);
+                R20 = 2.0f * (qx * qz - qr * qy); R21 = 2.0f * (qy * qz + qr * qx); R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+                const float L00 = R00 * s0, L01 = R01 * s1, L02 = R02 * s2;
+                const float L10 = R10 * s0, L11 = R11 * s1, L12 = R12 * s2;
+                const float L20 = R20 * s0, L21 = R21 * s1, L22 = R22 * s2;
+                S00 = L00 * L00 + L01 * L01 + L02 * L02; S01 = L00 * L10 + L01 * L11 + L02 * L12;
+                S02 = L00 * L20 + L01 * L21 + L02 * L22; S11 = L10 * L10 + L11 * L11 + L12 * L12;
+                S12 = L10 * L20 + L11 * L21 + L12 * L22; S22 = L20 * L20 + L21 * L21 + L22 * L22;
+            }
+            // recompute EWA
+            const float limx = RDG_FOV_CLAMP * d.tanx, limy = RDG_FOV_CLAMP * d.tany;
+            const float txtz = vx / vz, tytz = vy / vz;
+            const bool clx = txtz < -limx || txtz > limx, cly = tytz < -limy || tytz > limy;
+            const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+            const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+            const float iz = 1.0f / vz, iz2 = iz * iz, iz3 = iz2 * iz;
+            const float J00 = d.fx * iz, J02 = -d.fx * tx * iz2, J11 = d.fy * iz, J12 = -d.fy * ty * iz2;
+            const float W00 = V[0], W01 = V[4], W02 = V[8], W10 = V[1], W11 = V[5], W12 = V[9], W20 = V[2],
+                        W21 = V[6], W22 = V[10];
+            const float T00 = J00 * W00 + J02 * W20, T01 = J00 * W01 + J02 * W21, T02 = J00 * W02 + J02 * W22;
+            const float T10 = J11 * W10 + J12 * W20, T11 = J11 * W11 + J12 * W21, T12 = J11 * W12 + J12 * W22;
+            const float u00 = T00 * S00 + T01 * S01 + T02 * S02, u01 = T00 * S01 + T01 * S11 + T02 * S12,
+                        u02 = T00 * S02 + T01 * S12 + T02 * S22;
+            const float u10 = T10 * S00 + T11 * S01 + T12 * S02, u11 = T10 * S01 + T11 * S11 + T12 * S12,
+                        u12 = T10 * S02 + T11 * S12 + T12 * S22;
+            const float a = u00 * T00 + u01 * T01 + u02 * T02 + RDG_DILATION;
+            const float b = u00 * T10 + u01 * T11 + u02 * T12;
+            const float c = u10 * T10 + u11 * T11 + u12 * T12 + RDG_DILATION;
+            const float det = a * c - b * b;
+            // (3) conic -> cov2D
+            float da = 0.f, db = 0.f, dc = 0.f;
+            if (det != 0.0f) {
+                const float d2 = 1.0f / (det * det);
+                da = d2 * (-c * c * gca + b * c * gcb - b * b * gcc);
+                db = d2 * (2.0f * b * c * gca - (a * c + b * b) * gcb + 2.0f * a * b * gcc);
+                dc = d2 * (-b * b * gca + a * b * gcb - a * a * gcc);
+            }
+            // (4) cov2D -> Sigma3D (6-vector grads count both off-diagonal entries) and T
+            dS[0] = T00 * T00 * da + T00 * T10 * db + T10 * T10 * dc;
+            dS[3] = T01 * T01 * da + T01 * T11 * db + T11 * T11 * dc;
+            dS[5] = T02 * T02 * da + T02 * T12 * db + T12 * T12 * dc;
+            dS[1] = 2.0f * T00 * T01 * da + (T00 * T11 + T01 * T10) * db + 2.0f * T10 * T11 * dc;
+            dS[2] = 2.0f * T00 * T02 * da + (T00 * T12 + T02 * T10) * db + 2.0f * T10 * T12 * dc;
+            dS[4] = 2.0f * T01 * T02 * da + (T01 * T12 + T02 * T11) * db + 2.0f * T11 * T12 * dc;
+            const float dT00 = 2.0f * u00 * da + u10 * db, dT01 = 2.0f * u01 * da + u11 * db,
+                        dT02 = 2.0f * u02 * da + u12 * db;
+            const float dT10 = 2.0f * u10 * dc + u00 * db, dT11 = 2.0f * u11 * dc + u01 * db,
+                        dT12 = 2.0f * u12 * dc + u02 * db;
+            // (5) T = J W
+            const float dJ00 = W00 * dT00 + W01 * dT01 + W02 * dT02;
+            const float dJ02 = W20 * dT00 + W21 * dT01 + W22 * dT02;
+            const float dJ11 = W10 * dT10 + W11 * dT11 + W12 * dT12;
+            const float dJ12 = W20 * dT10 + W21 * dT11 + W22 * dT12;
+            if (d.cov_grad) {
+                // dL/dW[i][j] -> V[j*4+i]
+                pose[0] += J00 * dT00;  pose[4] += J00 * dT01;  pose[8] += J00 * dT02;
+                pose[1] += J11 * dT10;  pose[5] += J11 * dT11;  pose[9] += J11 * dT12;
+                pose[2] += J02 * dT00 + J12 * dT10;
+                pose[6] += J02 * dT01 + J12 * dT11;
+                pose[10] += J02 * dT02 + J12 * dT12;
+            }
+            // (6) J -> t (clamped t.x / t.y are constants, as in the public 3DGS backward)
+            evx = clx ? 0.0f : -d.fx * iz2 * dJ02;
+            evy = cly ? 0.0f : -d.fy * iz2 * dJ12;
+            evz = -d.fx * iz2 * dJ00 - d.fy * iz2 * dJ11 + 2.0f * d.fx * tx * iz3 * dJ02 + 2.0f * d.fy * ty * iz3 * dJ12;
+
+            // (9) colour
+            float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // dL/d(p - campos)
+            if (colors) {
+                // handled below (dcolors)
+            } else {
+                const uint8_t cl = clampedm[i];
+                const float gr0 = (cl & 1) ? 0.f : grgb[0], gr1 = (cl & 2) ? 0.f : grgb[1],
+                            gr2 = (cl & 4) ? 0.f : grgb[2];
+                const float gcol[3] = {gr0, gr1, gr2};
+                const float camx = -(V[0] * V[12] + V[1] * V[13] + V[2] * V[14]);
+                const float camy = -(V[4] * V[12] + V[5] * V[13] + V[6] * V[14]);
+                const float camz = -(V[8] * V[12] + V[9] * V[13] + V[10] * V[14]);
+                const float ox = x - camx, oy = y - camy, oz = z - camz;
+                const float ln = sqrtf(ox * ox + oy * oy + oz * oz);
+                const float il = 1.0f / ln;
+                const float ux = ox * il, uy = oy * il, uz = oz * il;
+                const float* sh = shs + (size_t)i * d.M * 3;
+                float* dsh = dshs + (size_t)i * d.M * 3;
+                float dRx = 0.f, dRy = 0.f, dRz = 0.f;  // dL/d(unit dir)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) dsh[ch] = SH_C0 * gcol[ch];
+                if (d.deg > 0) {
+                    const float b1 = -SH_C1 * uy, b2 = SH_C1 * uz, b3 = -SH_C1 * ux;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float g = gcol[ch];
+                        dsh[3 + ch] = b1 * g; dsh[6 + ch] = b2 * g; dsh[9 + ch] = b3 * g;
+                        dRx += -SH_C1 * sh[9 + ch] * g;
+                        dRy += -SH_C1 * sh[3 + ch] * g;
+                        dRz += SH_C1 * sh[6 + ch] * g;
+                    }
+                    if (d.deg > 1) {
+                        const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, yz = uy * uz, xz = ux * uz;
+                        const float b4 = BSH_C2[0] * xy, b5 = BSH_C2[1] * yz, b6 = BSH_C2[2] * (2.0f * zz - xx - yy),
+                                    b7 = BSH_C2[3] * xz, b8 = BSH_C2[4] * (xx - yy);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const float g = gcol[ch];
+                            dsh[12 + ch] = b4 * g; dsh[15 + ch] = b5 * g; dsh[18 + ch] = b6 * g;
+                            dsh[21 + ch] = b7 * g; dsh[24 + ch] = b8 * g;
+                            const float h4 = sh[12 + ch], h5 = sh[15 + ch], h6 = sh[18 + ch], h7 = sh[21 + ch],
+                                        h8 = sh[24 + ch];
+                            dRx += (BSH_C2[0] * uy * h4 + BSH_C2[2] * -2.0f * ux * h6 + BSH_C2[3] * uz * h7 +
+                                    BSH_C2[4] * 2.0f * ux * h8) * g;
+                            dRy += (BSH_C2[0] * ux * h4 + BSH_C2[1] * uz * h5 + BSH_C2[2] * -2.0f * uy * h6 +
+                                    BSH_C2[4] * -2.0f * uy * h8) * g;
+                            dRz += (BSH_C2[1] * uy * h5 + BSH_C2[2] * 4.0f * uz * h6 + BSH_C2[3] * ux * h7) * g;
+                        }
+                        if (d.deg > 2) {
+                            const float b9 = BSH_C3[0] * uy * (3.0f * xx - yy), b10 = BSH_C3[1] * xy * uz,
+                                        b11 = BSH_C3[2] * uy * (4.0f * zz - xx - yy),
+                                        b12 = BSH_C3[3] * uz * (2.0f * zz - 3.0f * xx - 3.0f * yy),
+                                        b13 = BSH_C3[4] * ux * (4.0f * zz - xx - yy), b14 = BSH_C3[5] * uz * (xx - yy),
+                                        b15 = BSH_C3[6] * ux * (xx - 3.0f * yy);
+#pragma unroll
+                            for (int ch = 0; ch < 3; ++ch) {
+                                const float g = gcol[ch];
+                                dsh[27 + ch] = b9 * g; dsh[30 + ch] = b10 * g; dsh[33 + ch] = b11 * g;
+                                dsh[36 + ch] = b12 * g; dsh[39 + ch] = b13 * g; dsh[42 + ch] = b14 * g;
+                                dsh[45 + ch] = b15 * g;
+                                const float h9 = sh[27 + ch], h10 = sh[30 + ch], h11 = sh[33 + ch], h12 = sh[36 + ch],
+                                            h13 = sh[39 + ch], h14 = sh[42 + ch], h15 = sh[45 + ch];
+                                dRx += (BSH_C3[0] * h9 * 3.0f * 2.0f * xy + BSH_C3[1] * h10 * yz +
+                                        BSH_C3[2] * h11 * -2.0f * xy + BSH_C3[3] * h12 * -3.0f * 2.0f * xz +
+                                        BSH_C3[4] * h13 * (-3.0f * xx + 4.0f * zz - yy) +
+                                        BSH_C3[5] * h14 * 2.0f * xz + BSH_C3[6] * h15 * 3.0f * (xx - yy)) * g;
+                                dRy += (BSH_C3[0] * h9 * 3.0f * (xx - yy) + BSH_C3[1] * h10 * xz +
+                                        BSH_C3[2] * h11 * (-3.0f * yy + 4.0f * zz - xx) +
+                                        BSH_C3[3] * h12 * -3.0f * 2.0f * yz + BSH_C3[4] * h13 * -2.0f * xy +
+                                        BSH_C3[5] * h14 * -2.0f * yz + BSH_C3[6] * h15 * -3.0f * 2.0f * xy) * g;
+                                dRz += (BSH_C3[1] * h10 * xy + BSH_C3[2] * h11 * 4.0f * 2.0f * yz +
+                                        BSH_C3[3] * h12 * 3.0f * (2.0f * zz - xx - yy) +
+                                        BSH_C3[4] * h13 * 4.0f * 2.0f * xz + BSH_C3[5] * h14 * (xx - yy)) * g;
+                            }
+                        }
+                    }
+                }
+                // zero the inactive-degree coefficients of this Gaussian
+                for (int k = (d.deg + 1) * (d.deg + 1); k < d.M; ++k) {
+                    dsh[3 * k + 0] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f;
+                }
+                // unit-vector normalisation backward
+                const float dotg = ux * dRx + uy * dRy + uz * dRz;
+                ddx = (dRx - ux * dotg) * il; ddy = (dRy - uy * dotg) * il; ddz = (dRz - uz * dotg) * il;
+                if (d.sh_grad) { pose[16] -= ddx; pose[17] -= ddy; pose[18] -= ddz; }
+            }
+
+            // (7) v = V p
+            const float avx = dvx + evx, avy = dvy + evy, avz = dvz + evz;  // for means3D
+            dmx = V[0] * avx + V[1] * avy + V[2] * avz + ddx;
+            dmy = V[4] * avx + V[5] * avy + V[6] * avz + ddy;
+            dmz = V[8] * avx + V[9] * avy + V[10] * avz + ddz;
+            const float pvx = d.cov_grad ? avx : dvx, pvy = d.cov_grad ? avy : dvy, pvz = d.cov_grad ? avz : dvz;
+            pose[0] += x * pvx;  pose[1] += x * pvy;  pose[2] += x * pvz;
+            pose[4] += y * pvx;  pose[5] += y * pvy;  pose[6] += y * pvz;
+            pose[8] += z * pvx;  pose[9] += z * pvy;  pose[10] += z * pvz;
+            pose[12] += pvx;     pose[13] += pvy;     pose[14] += pvz;
+
+            // (8) Sigma3D -> scale, raw quaternion
+            if (!cov3Dp) {
+                // dL/dL = 2 * dSigma_full * L, dSigma_full off-diagonals = half of the 6-vector entries
+                const float F00 = dS[0], F01 = 0.5f * dS[1], F02 = 0.5f * dS[2], F11 = dS[3], F12 = 0.5f * dS[4],
+                            F22 = dS[5];
+                const float L00 = R00 * s0, L01 = R01 * s1, L02 = R02 * s2;
+                const float L10 = R10 * s0, L11 = R11 * s1, L12 = R12 * s2;
+                const float L20 = R20 * s0, L21 = R21 * s1, L22 = R22 * s2;
+                const float dL00 = 2.0f * (F00 * L00 + F01 * L10 + F02 * L20), dL01 = 2.0f * (F00 * L01 + F01 * L11 + F02 * L21),
+                            dL02 = 2.0f * (F00 * L02 + F01 * L12 + F02 * L22);
+                const float dL10 = 2.0f * (F01 * L00 + F11 * L10 + F12 * L20), dL11 = 2.0f * (F01 * L01 + F11 * L11 + F12 * L21),
+                            dL12 = 2.0f * (F01 * L02 + F11 * L12 + F12 * L22);
+                const float dL20 = 2.0f * (F02 * L00 + F12 * L10 + F22 * L20), dL21 = 2.0f * (F02 * L01 + F12 * L11 + F22 * L21),
+                            dL22 = 2.0f * (F02 * L02 + F12 * L12 + F22 * L22);
+                dsc0 = d.smod * (R00 * dL00 + R10 * dL10 + R20 * dL20);
+                dsc1 = d.smod * (R01 * dL01 + R11 * dL11 + R21 * dL21);
+                dsc2 = d.smod * (R02 * dL02 + R12 * dL12 + R22 * dL22);
+                const float dR00 = s0 * dL00, dR01 = s1 * dL01, dR02 = s2 * dL02;
+                const float dR10 = s0 * dL10, dR11 = s1 * dL11, dR12 = s2 * dL12;
+                const float dR20 = s0 * dL20, dR21 = s1 * dL21, dR22 = s2 * dL22;
+                dq0 = 2.0f * (-qz * dR01 + qy * dR02 + qz * dR10 - qx * dR12 - qy * dR20 + qx * dR21);
+                dq1 = 2.0f * (qy * dR01 + qz * dR02 + qy * dR10 - 2.0f * qx * dR11 - qr * dR12 + qz * dR20 + qr * dR21 -
+                              2.0f * qx * dR22);
+                dq2 = 2.0f * (-2.0f * qy * dR00 + qx * dR01 + qr * dR02 + qx * dR10 + qz * dR12 - qr * dR20 + qz * dR21 -
+                              2.0f * qy * dR22);
+                dq3 = 2.0f * (-2.0f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.0f * qz * dR11 + qy * dR12 +
+                              qx * dR20 + qy * dR21);
+            }
+        } else if (shs) {
+            float* dsh = dshs + (size_t)i * d.M * 3;
+            for (int k = 0; k < d.M * 3; ++k) dsh[k] = 0.f;
+        }
+        dmeans3D[3 * i + 0] = dmx; dmeans3D[3 * i + 1] = dmy; dmeans3D[3 * i + 2] = dmz;
+        dmeans2D[3 * i + 0] = gnx; dmeans2D[3 * i + 1] = gny; dmeans2D[3 * i + 2] = 0.f;
+        dopac[i] = gop;
+        if (colors) {
+            dcolors[3 * i + 0] = grgb[0]; dcolors[3 * i + 1] = grgb[1]; dcolors[3 * i + 2] = grgb[2];
+        }
+        if (cov3Dp) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dcov3D[6 * i + k] = dS[k];
+        } else {
+            dscales[3 * i + 0] = dsc0; dscales[3 * i + 1] = dsc1; dscales[3 * i + 2] = dsc2;
+            reinterpret_cast<float4*>(drots)[i] = make_float4(dq0, dq1, dq2, dq3);
+        }
+    }
+    // pose-gradient reduction: wave DPP sums, then one atomic per value per wave
+    if (__any(live)) {
+#pragma unroll
+        for (int k = 0; k < RDG_POSE_N; ++k) {
+            if ((k & 3) == 3 && k < 16) continue;  // V[3],V[7],V[11],V[15] receive nothing
+            const float sm = rdg_wave_sum_to63(pose[k]);
+            if ((threadIdx.x & 63) == 63 && sm != 0.0f) atomicAdd(posebuf + k, sm);
+        }
+    }
+}
+
+// campos = -R^T t chain + copy into dL/dviewmatrix (glm flat)
+__global__ void rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict__ posebuf,
+                                         float* __restrict__ dview) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float V[16], g[16];
+    for (int k = 0; k < 16; ++k) { V[k] = view[k]; g[k] = posebuf[k]; }
+    const float gc[3] = {posebuf[16], posebuf[17], posebuf[18]};
+    // cam_j = -(V[4j+0]*V[12] + V[4j+1]*V[13] + V[4j+2]*V[14])
+    for (int j = 0; j < 3; ++j) {
+        for (int r = 0; r < 3; ++r) {
+            g[4 * j + r] += -V[12 + r] * gc[j];
+            g[12 + r] += -V[4 * j + r] * gc[j];
+        }
+    }
+    for (int k = 0; k < 16; ++k) dview[k] = g[k];
+}
+
+int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
+                              const float* opac, const float* scales, const float* rots, const float* cov3D,
+                              const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
+                              const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
+                              float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
+                              float* dview, hipStream_t s) {
+    const RdgGeomLayout G = rdg_geom_layout(d.P);
+    hipError_t e = hipMemsetAsync(posebuf, 0, RDG_POSE_N * sizeof(float), s);
+    if (e != hipSuccess) return rdg_check_hip(e, "posebuf memset");
+    if (d.P > 0) {
+        const int nblk = (d.P + 255) / 256;
+        hipLaunchKernelGGL(rdg_preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs, colors,
+                           opac, scales, rots, cov3D, radii, (const uint8_t*)((const char*)geom_ws + G.clamped),
+                           grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D);
+    }
+    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(64), 0, s, view, posebuf, dview);
+    return rdg_check_hip(hipGetLastError(), "preprocess_bwd launch");
+}

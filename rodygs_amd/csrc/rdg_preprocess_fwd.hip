@@ -1,0 +1,250 @@
+// rdg_preprocess_fwd.hip -- per-Gaussian forward stage.
+//
+// BUILT WITH -ffp-contract=off: the arithmetic below is evaluated left to right with separately rounded
+// multiplies and adds, exactly as oracle/rasterizer_oracle.py::preprocess writes it, so view-space depth bits,
+// radii and tile rectangles (=> tile keys, sort order) are bit-exact against the oracle.  The kernel is
+// HBM-bound (236 B read per Gaussian at SH-3), so giving up FMA contraction costs nothing.
+//
+// One thread per Gaussian, 256-thread blocks.  Besides the 64-B splat record the block leaves its
+// tiles_touched sum in block_sums[] so the scan needs no extra pass over P.
+#include "rdg_common.h"
+
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+__device__ static const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                          -1.0925484305920792f, 0.5462742152960396f};
+__device__ static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                          0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                          -0.5900435899266435f};
+
+__device__ __forceinline__ void rdg_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0,
+                                         int& x1, int& y1) {
+    float r = (float)radius;
+    x0 = min(gx, max(0, (int)((px - r) / (float)RDG_TILE)));
+    y0 = min(gy, max(0, (int)((py - r) / (float)RDG_TILE)));
+    x1 = min(gx, max(0, (int)((((px + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+    y1 = min(gy, max(0, (int)((((py + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+}
+
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float* __restrict__ proj,
+                          const float* __restrict__ means3D, const float* __restrict__ shs,
+                          const float* __restrict__ colors, const float* __restrict__ opac,
+                          const float* __restrict__ scales, const float* __restrict__ rots,
+                          const float* __restrict__ cov3Dp, RdgRec* __restrict__ rec,
+                          uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clampedm,
+                          uint32_t* __restrict__ block_sums, int32_t* __restrict__ radii) {
+    const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    // camera: uniform addresses -> scalar loads into SGPRs (the matrices live on the device because the
+    // viewmatrix is the output of autograd-tracked pose math; no host round trip)
+    float V[16], Pm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = view[k]; Pm[k] = proj[k]; }
+    uint32_t my_tiles = 0;
+    if (i < d.P) {
+        int radius_out = 0;
+        uint8_t cl = 0;
+        RdgRec R;
+        R.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        R.q1 = R.q0; R.q2 = R.q0; R.q3 = R.q0;
+        const float x = means3D[3 * i + 0], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+        const float vx = ((V[0] * x + V[4] * y) + V[8] * z) + V[12];
+        const float vy = ((V[1] * x + V[5] * y) + V[9] * z) + V[13];
+        const float vz = ((V[2] * x + V[6] * y) + V[10] * z) + V[14];
+        bool valid = vz > RDG_NEAR_CULL;
+        if (valid) {
+            const float hx = ((Pm[0] * vx + Pm[4] * vy) + Pm[8] * vz) + Pm[12];
+            const float hy = ((Pm[1] * vx + Pm[5] * vy) + Pm[9] * vz) + Pm[13];
+            const float hw = ((Pm[3] * vx + Pm[7] * vy) + Pm[11] * vz) + Pm[15];
+            const float pw = 1.0f / (hw + 1e-7f);
+            const float ndc_x = hx * pw, ndc_y = hy * pw;
+
+            float S00, S01, S02, S11, S12, S22;
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (cov3Dp) {
+                S00 = cov3Dp[6 * i + 0]; S01 = cov3Dp[6 * i + 1]; S02 = cov3Dp[6 * i + 2];
+                S11 = cov3Dp[6 * i + 3]; S12 = cov3Dp[6 * i + 4]; S22 = cov3Dp[6 * i + 5];
+            } else {
+                const float s0 = d.smod * scales[3 * i + 0], s1 = d.smod * scales[3 * i + 1],
+                            s2 = d.smod * scales[3 * i + 2];
+                const float4 q = reinterpret_cast<const float4*>(rots)[i];
+                const float r = q.x, qx = q.y, qy = q.z, qz = q.w;
+                const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz), R01 = 2.0f * (qx * qy - r * qz),
+                            R02 = 2.0f * (qx * qz + r * qy);
+                const float R10 = 2.0f * (qx * qy + r * qz), R11 = 1.0f - 2.0f * (qx * qx + qz * qz),
+                            R12 = 2.0f * (qy * qz - r * qx);
+                const float R20 = 2.0f * (qx * qz - r * qy), R21 = 2.0f * (qy * qz + r * qx),
+                            R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+                const float L00 = R00 * s0, L01 = R01 * s1, L02 = R02 * s2;
+                const float L10 = R10 * s0, L11 = R11 * s1, L12 = R12 * s2;
+                const float L20 = R20 * s0, L21 = R21 * s1, L22 = R22 * s2;
+                S00 = (L00 * L00 + L01 * L01) + L02 * L02;
+                S01 = (L00 * L10 + L01 * L11) + L02 * L12;
+                S02 = (L00 * L20 + L01 * L21) + L02 * L22;
+                S11 = (L10 * L10 + L11 * L11) + L12 * L12;
+                S12 = (L10 * L20 + L11 * L21) + L12 * L22;
+                S22 = (L20 * L20 + L21 * L21) + L22 * L22;
+                if (d.render_normal) {
+                    // shortest axis (first minimum) of R*diag(s), in view space, facing the camera
+                    const float sc0 = scales[3 * i + 0], sc1 = scales[3 * i + 1], sc2 = scales[3 * i + 2];
+                    int k = 0; float sm = sc0;
+                    if (sc1 < sm) { sm = sc1; k = 1; }
+                    if (sc2 < sm) { sm = sc2; k = 2; }
+                    const float n0 = k == 0 ? R00 : (k == 1 ? R01 : R02);
+                    const float n1 = k == 0 ? R10 : (k == 1 ? R11 : R12);
+                    const float n2 = k == 0 ? R20 : (k == 1 ? R21 : R22);
+                    float nvx = (V[0] * n0 + V[4] * n1) + V[8] * n2;
+                    float nvy = (V[1] * n0 + V[5] * n1) + V[9] * n2;
+                    float nvz = (V[2] * n0 + V[6] * n1) + V[10] * n2;
+                    const float dotv = (nvx * vx + nvy * vy) + nvz * vz;
+                    const float sg = dotv > 0.f ? -1.0f : 1.0f;
+                    nx = nvx * sg; ny = nvy * sg; nz = nvz * sg;
+                }
+            }
+            // EWA 2-D covariance
+            const float limx = RDG_FOV_CLAMP * d.tanx, limy = RDG_FOV_CLAMP * d.tany;
+            const float txtz = vx / vz, tytz = vy / vz;
+            const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+            const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+            const float J00 = d.fx / vz, J02 = -(d.fx * tx) / (vz * vz);
+            const float J11 = d.fy / vz, J12 = -(d.fy * ty) / (vz * vz);
+            const float T00 = J00 * V[0] + J02 * V[2], T01 = J00 * V[4] + J02 * V[6], T02 = J00 * V[8] + J02 * V[10];
+            const float T10 = J11 * V[1] + J12 * V[2], T11 = J11 * V[5] + J12 * V[6], T12 = J11 * V[9] + J12 * V[10];
+            const float u00 = (T00 * S00 + T01 * S01) + T02 * S02;
+            const float u01 = (T00 * S01 + T01 * S11) + T02 * S12;
+            const float u02 = (T00 * S02 + T01 * S12) + T02 * S22;
+            const float u10 = (T10 * S00 + T11 * S01) + T12 * S02;
+            const float u11 = (T10 * S01 + T11 * S11) + T12 * S12;
+            const float u12 = (T10 * S02 + T11 * S12) + T12 * S22;
+            const float ca = ((u00 * T00 + u01 * T01) + u02 * T02) + RDG_DILATION;
+            const float cb = (u00 * T10 + u01 * T11) + u02 * T12;
+            const float cc = ((u10 * T10 + u11 * T11) + u12 * T12) + RDG_DILATION;
+            const float det = ca * cc - cb * cb;
+            valid = det != 0.0f;
+            if (valid) {
+                const float det_inv = 1.0f / det;
+                const float mid = 0.5f * (ca + cc);
+                const float disc = sqrtf(fmaxf(RDG_LAMBDA_FLOOR, mid * mid - det));
+                const float lam = fmaxf(mid + disc, mid - disc);
+                const int radius = (int)ceilf(3.0f * sqrtf(lam));
+                const float px = ((ndc_x + 1.0f) * (float)d.W - 1.0f) * 0.5f;
+                const float py = ((ndc_y + 1.0f) * (float)d.H - 1.0f) * 0.5f;
+                int x0, y0, x1, y1;
+                rdg_rect(px, py, radius, d.gx, d.gy, x0, y0, x1, y1);
+                const int area = (x1 - x0) * (y1 - y0);
+                if (area > 0) {
+                    my_tiles = (uint32_t)area;
+                    radius_out = radius;
+                    float cr, cg, cbl;
+                    if (colors) {
+                        cr = colors[3 * i + 0]; cg = colors[3 * i + 1]; cbl = colors[3 * i + 2];
+                    } else {
+                        const float camx = -((V[0] * V[12] + V[1] * V[13]) + V[2] * V[14]);
+                        const float camy = -((V[4] * V[12] + V[5] * V[13]) + V[6] * V[14]);
+                        const float camz = -((V[8] * V[12] + V[9] * V[13]) + V[10] * V[14]);
+                        float dx = x - camx, dy = y - camy, dz = z - camz;
+                        const float ln = sqrtf((dx * dx + dy * dy) + dz * dz);
+                        dx = dx / ln; dy = dy / ln; dz = dz / ln;
+                        const float* sh = shs + (size_t)i * d.M * 3;
+                        float res[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) res[c] = SH_C0 * sh[c];
+                        if (d.deg > 0) {
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                res[c] = res[c] - SH_C1 * dy * sh[3 + c] + SH_C1 * dz * sh[6 + c] -
+                                         SH_C1 * dx * sh[9 + c];
+                            if (d.deg > 1) {
+                                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                                const float xy = dx * dy, yz = dy * dz, xz = dx * dz;
+#pragma unroll
+                                for (int c = 0; c < 3; ++c)
+                                    res[c] = res[c] + SH_C2[0] * xy * sh[12 + c] + SH_C2[1] * yz * sh[15 + c] +
+                                             SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] +
+                                             SH_C2[3] * xz * sh[21 + c] + SH_C2[4] * (xx - yy) * sh[24 + c];
+                                if (d.deg > 2) {
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c)
+                                        res[c] = res[c] + SH_C3[0] * dy * (3.0f * xx - yy) * sh[27 + c] +
+                                                 SH_C3[1] * xy * dz * sh[30 + c] +
+                                                 SH_C3[2] * dy * (4.0f * zz - xx - yy) * sh[33 + c] +
+                                                 SH_C3[3] * dz * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                                                 SH_C3[4] * dx * (4.0f * zz - xx - yy) * sh[39 + c] +
+                                                 SH_C3[5] * dz * (xx - yy) * sh[42 + c] +
+                                                 SH_C3[6] * dx * (xx - 3.0f * yy) * sh[45 + c];
+                                }
+                            }
+                        }
+                        res[0] += 0.5f; res[1] += 0.5f; res[2] += 0.5f;
+                        if (res[0] < 0.f) cl |= 1;
+                        if (res[1] < 0.f) cl |= 2;
+                        if (res[2] < 0.f) cl |= 4;
+                        cr = fmaxf(res[0], 0.f); cg = fmaxf(res[1], 0.f); cbl = fmaxf(res[2], 0.f);
+                    }
+                    R.q0 = make_float4(px, py, cc * det_inv, -cb * det_inv);
+                    R.q1 = make_float4(ca * det_inv, opac[i], vz, 0.f);
+                    R.q2 = make_float4(cr, cg, cbl, 0.f);
+                    R.q3 = make_float4(nx, ny, nz, 0.f);
+                }
+            }
+        }
+        rec[i] = R;
+        tiles_touched[i] = my_tiles;
+        clampedm[i] = cl;
+        radii[i] = radius_out;
+    }
+    // block sum of tiles_touched -> block_sums[blockIdx.x]
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    uint32_t inc = rdg_wave_scan_incl(my_tiles);
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Exclusive scan of block_sums[0..nblk) in place by ONE 1024-thread block; block_sums[nblk] and *num_rendered
+// receive the total (D).  nblk <= 16384 at P = 4 M, i.e. <= 16 sweeps.
+__global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblk,
+                                                                   int32_t* __restrict__ num_rendered) {
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nblk ? block_sums[i] : 0u;
+        uint32_t inc = rdg_wave_scan_incl(v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < nblk) block_sums[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        block_sums[nblk] = carry_s;
+        *num_rendered = (int32_t)carry_s;
+    }
+}
+
+int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
+                              const float* opac, const float* scales, const float* rots, const float* cov3D,
+                              const float* view, const float* proj, void* geom_ws, int32_t* radii,
+                              int32_t* num_rendered, hipStream_t s) {
+    const RdgGeomLayout L = rdg_geom_layout(d.P);
+    char* g = (char*)geom_ws;
+    const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    uint32_t* block_sums = (uint32_t*)(g + L.block_sums);
+    if (d.P > 0) {
+        hipLaunchKernelGGL(rdg_preprocess_fwd_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
+                           shs, colors, opac, scales, rots, cov3D, (RdgRec*)(g + L.rec),
+                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii);
+    }
+    hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
+                       num_rendered);
+    return rdg_check_hip(hipGetLastError(), "preprocess_fwd launch");
+}

@@ -1,0 +1,230 @@
+"""Time-deformation path of RoDyGS (reference: /root/reference/src/model/rodygs_dynamic.py).
+
+Host-side mirror of the reference interface, same names and argument meaning:
+  * ``TimestepEmbedder``      (rodygs_dynamic.py:190-220)
+  * ``MLPMotionBasis``        (:223-240)
+  * ``MLPBasisNetwork``       (:243-327)  -- state_dict-compatible with the reference class
+  * ``gaussian_deformation``  = the per-Gaussian part of ``DynRoDyGS.get_gaussian_deformation`` (:122-138)
+  * ``DeformationField``      = the bookkeeping of ``DynRoDyGS`` around it (birth-time table, cache)
+
+The tiny MLP (68 656 parameters, batch <= T rows) stays in torch, with the 16 heads batched into two bmm's
+instead of the reference's 16-iteration Python loop.  The per-Gaussian contraction -- the only part that scales
+with P -- is the HIP kernel ``rdg_deform_forward/backward`` (csrc/rdg_deform.hip): it never materialises the
+reference's ``table[gaussian_to_time_ind]`` ([P,16,7], 448 MB at P = 1 M).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class TimestepEmbedder(nn.Module):
+    """[t, sin(t f_i), cos(t f_i)]_i with f = pi * linspace(1, 2^(m-1), m) (or 2^linspace when log_sampling)."""
+
+    include_input: bool = True
+
+    def __init__(self, emb_multires, input_dims, log_sampling):
+        super().__init__()
+        self.num_freqs = emb_multires
+        self.max_freq_log2 = emb_multires - 1
+        self.input_dims = input_dims
+        self.log_sampling = log_sampling
+        if log_sampling:
+            freq = 2.0 ** torch.linspace(0.0, self.num_freqs - 1, self.num_freqs)
+        else:
+            freq = torch.linspace(1.0, 2.0 ** (self.num_freqs - 1), self.num_freqs)
+        # same float32 values as the reference computes on every call (freq_bands * np.pi)
+        self.register_buffer("freq_bands", freq * np.pi, persistent=False)
+
+    def forward(self, timestep):
+        t = torch.as_tensor(timestep, dtype=torch.float32, device=self.freq_bands.device)
+        # full-range sinf/cosf (arguments reach pi*2^25): torch's device sin/cos do proper range reduction
+        arg = t.unsqueeze(-1) * self.freq_bands            # [..., m]
+        sc = torch.stack([torch.sin(arg), torch.cos(arg)], dim=-1).flatten(-2)  # sin f0, cos f0, sin f1, ...
+        out = torch.cat([t.unsqueeze(-1), sc], dim=-1)     # [..., 2m+1]
+        # the reference stacks along dim 0: a [1]-shaped t gives [2m+1, 1]
+        if t.dim() >= 1:
+            return out.movedim(-1, 0)
+        return out
+
+
+class MLPMotionBasis(nn.Module):
+    def __init__(self, input_dim, output_dim, activation):
+        super().__init__()
+        self.basis = nn.Sequential(nn.Linear(input_dim, input_dim // 2), activation,
+                                   nn.Linear(input_dim // 2, output_dim))
+        for module in self.basis.modules():
+            if isinstance(module, nn.Linear):
+                nn.init.normal_(module.weight, mean=0, std=1e-2)
+                nn.init.constant_(module.bias, 0)
+
+    def forward(self, x):
+        return self.basis(x)
+
+
+class MLPBasisNetwork(nn.Module):
+    time_input_dim: int = 1
+    trans_dim: int = 3
+    rot_dim: int = 4
+
+    def __init__(self, netwidth, num_basis, t_emb_multires, t_log_sampling, activation="gelu"):
+        super().__init__()
+        self.netwidth = netwidth
+        self.num_basis = num_basis
+        self.t_embed_dim = t_emb_multires * self.time_input_dim * 2 + self.time_input_dim
+        self.t_embedder = TimestepEmbedder(t_emb_multires, self.time_input_dim, t_log_sampling)
+        self.activation = nn.GELU() if activation.lower() != "relu" else nn.ReLU(inplace=False)
+        self.timenet = nn.Sequential(
+            nn.Linear(self.t_embed_dim, netwidth), self.activation,
+            nn.Linear(netwidth, netwidth), self.activation,
+            nn.Linear(netwidth, netwidth // 2), self.activation,
+        )
+        for module in self.timenet.modules():
+            if isinstance(module, nn.Linear):
+                nn.init.normal_(module.weight, mean=0, std=1e-2)
+                nn.init.constant_(module.bias, 0)
+        self.basis_xyz = nn.ModuleList(
+            [MLPMotionBasis(netwidth // 2, self.trans_dim + self.rot_dim, self.activation) for _ in range(num_basis)])
+
+    # -- the 16 heads as two batched matmuls --------------------------------------------------------------------
+    def _heads(self, h: torch.Tensor) -> torch.Tensor:
+        """h [N, netwidth/2] -> [N, num_basis, 7]."""
+        W1 = torch.stack([m.basis[0].weight for m in self.basis_xyz])   # [B, 32, 64]
+        b1 = torch.stack([m.basis[0].bias for m in self.basis_xyz])     # [B, 32]
+        W2 = torch.stack([m.basis[2].weight for m in self.basis_xyz])   # [B, 7, 32]
+        b2 = torch.stack([m.basis[2].bias for m in self.basis_xyz])     # [B, 7]
+        u = torch.einsum("nk,bjk->bnj", h, W1) + b1.unsqueeze(1)
+        u = self.activation(u)
+        o = torch.einsum("bnj,boj->bno", u, W2) + b2.unsqueeze(1)       # [B, N, 7]
+        return o.transpose(0, 1)
+
+    def motion_basis(self, t_emb: torch.Tensor) -> torch.Tensor:
+        """t_emb [..., 53] -> motion basis [..., num_basis, 7]."""
+        lead = t_emb.shape[:-1]
+        h = self.timenet(t_emb.reshape(-1, t_emb.shape[-1]))
+        return self._heads(h).reshape(*lead, self.num_basis, self.trans_dim + self.rot_dim)
+
+    def batch_embedding(self, timesteps):
+        dev = self.t_embedder.freq_bands.device
+        return torch.stack([self.t_embedder(t) for t in timesteps]).to(dev).squeeze()
+
+    def batch_inference(self, t_embs):
+        """[T,53] -> [T,num_basis,7]  (rodygs_dynamic.py:296-306)."""
+        return self.motion_basis(t_embs)
+
+    def forward(self, coeff, timestep):
+        """Reference semantics (:308-327): (translation [P,3], rotation [P,4]) = squeeze(coeff) @ basis(t)."""
+        t_emb = self.t_embedder(timestep)
+        basis = self.motion_basis(t_emb.reshape(1, -1)).squeeze(0)      # [B,7]
+        c = coeff.reshape(coeff.shape[0], -1)
+        ind = torch.zeros(c.shape[0], dtype=torch.int64, device=c.device)
+        return gaussian_deformation(c, ind, basis, None, 1.0)
+
+
+class _DeformFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coeff, time_ind, basis_t, table, scale):
+        L = _lib.lib()
+        if not coeff.is_cuda:
+            raise RuntimeError("rodygs_amd.gaussian_deformation: tensors must be on the GPU (no CPU fallback exists)")
+        c = coeff.detach().to(torch.float32).contiguous()
+        P, B = c.shape
+        bt = basis_t.detach().to(torch.float32).contiguous()
+        tb = None if table is None else table.detach().to(torch.float32).contiguous()
+        ti = time_ind.detach().to(torch.int64).contiguous()
+        Tu = 0 if tb is None else tb.shape[0]
+        dxyz = torch.empty(P, 3, dtype=torch.float32, device=c.device)
+        drot = torch.empty(P, 4, dtype=torch.float32, device=c.device)
+        with torch.cuda.device(c.device):
+            _lib.check(L.rdg_deform_forward(P, B, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bt), _lib.ptr(tb),
+                                            float(scale), _lib.ptr(dxyz), _lib.ptr(drot), _lib.stream_ptr()),
+                       "rdg_deform_forward")
+        ctx.save_for_backward(c, ti, bt, tb)
+        ctx.scale = float(scale)
+        return dxyz, drot
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_rot):
+        L = _lib.lib()
+        c, ti, bt, tb = ctx.saved_tensors
+        P, B = c.shape
+        Tu = 0 if tb is None else tb.shape[0]
+        dev = c.device
+        g_xyz = (torch.zeros(P, 3, device=dev) if g_xyz is None else g_xyz).to(torch.float32).contiguous()
+        g_rot = (torch.zeros(P, 4, device=dev) if g_rot is None else g_rot).to(torch.float32).contiguous()
+        d_c = torch.empty_like(c)
+        d_bt = torch.empty_like(bt)
+        d_tb = None if tb is None else torch.empty_like(tb)
+        with torch.cuda.device(dev):
+            _lib.check(L.rdg_deform_backward(P, B, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bt), _lib.ptr(tb),
+                                             ctx.scale, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(d_c),
+                                             _lib.ptr(d_bt), _lib.ptr(d_tb), _lib.stream_ptr()),
+                       "rdg_deform_backward")
+        return d_c, None, d_bt, d_tb, None
+
+
+def gaussian_deformation(coeff: torch.Tensor, time_ind: torch.Tensor, basis_t: torch.Tensor,
+                         table: Optional[torch.Tensor], spatial_lr_scale: float):
+    """(scaled_translation [P,3], rotation_delta [P,4]) = coeff . (B(t) - B_table[time_ind]).
+
+    coeff [P,B] (or the reference's [P,1,B]); basis_t [B,7]; table [Tu,B,7] or None (inverse_motion=False);
+    translation is multiplied by ``spatial_lr_scale`` exactly as rodygs_dynamic.py:136."""
+    c = coeff.reshape(coeff.shape[0], -1)
+    return _DeformFn.apply(c, time_ind, basis_t, table, spatial_lr_scale)
+
+
+class DeformationField(nn.Module):
+    """The deformation bookkeeping of ``DynRoDyGS`` (rodygs_dynamic.py:56-147) around the HIP op.
+
+    gaussian_to_time: float birth time of every Gaussian; unique birth times are keyed by
+    ``int(trunc(float32(t) * 1000))`` exactly as ``timetokey`` (:44)."""
+
+    def __init__(self, num_gaussians: int, gaussian_to_time: torch.Tensor, netwidth=128, num_basis=16,
+                 t_emb_multires=26, t_log_sampling=False, inverse_motion=True, spatial_lr_scale=1.0,
+                 activation="gelu", device="cuda"):
+        super().__init__()
+        self.inverse_motion = inverse_motion
+        self.spatial_lr_scale = float(spatial_lr_scale)
+        self._deform_network = MLPBasisNetwork(netwidth, num_basis, t_emb_multires, t_log_sampling,
+                                               activation=activation).to(device)
+        self._motion_coeff = nn.Parameter(torch.zeros(num_gaussians, 1, num_basis, device=device))
+        self.gaussian_to_time = gaussian_to_time.to(torch.float32).to(device)
+        self.temporal_motion_table = None
+        self.sync_gaussian_to_time_ind()
+        self._time_batch_embeddings = self._deform_network.batch_embedding(self.real_times)
+
+    @staticmethod
+    def timetokey(time) -> int:
+        return int(torch.trunc(torch.tensor(time, dtype=torch.float32) * 1000).item())
+
+    def sync_gaussian_to_time_ind(self):
+        self.real_times, _ = torch.sort(torch.unique(self.gaussian_to_time))
+        keys = torch.trunc(self.gaussian_to_time * 1000).to(torch.int64)
+        uniq = torch.unique(keys)  # sorted
+        self.unique_times = uniq.tolist()
+        self.gaussian_to_time_ind = torch.searchsorted(uniq, keys)
+
+    def get_total_motion_table(self):
+        if self.temporal_motion_table is None:
+            self.temporal_motion_table = self._deform_network.batch_inference(self._time_batch_embeddings).squeeze()
+            if self.temporal_motion_table.dim() == 2:
+                self.temporal_motion_table = self.temporal_motion_table.unsqueeze(0)
+        return self.temporal_motion_table
+
+    def clean_motion_table(self):
+        self.temporal_motion_table = None
+
+    def get_gaussian_deformation(self, time):
+        net = self._deform_network
+        t_emb = net.t_embedder(torch.as_tensor(time, dtype=torch.float32).reshape(()))
+        basis_t = net.motion_basis(t_emb.reshape(1, -1)).squeeze(0)
+        table = self.get_total_motion_table() if self.inverse_motion else None
+        return gaussian_deformation(self._motion_coeff, self.gaussian_to_time_ind, basis_t, table,
+                                    self.spatial_lr_scale)
