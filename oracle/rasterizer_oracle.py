@@ -192,10 +192,12 @@ def preprocess(means3D, means2D, opacities, viewmatrix, settings: OracleSettings
     # public 3DGS backward treats a clamped t.x / t.y as a constant
     tx = torch.where(cl_x, tx_c.detach(), tx_c)
     ty = torch.where(cl_y, ty_c.detach(), ty_c)
-    J00 = focal_x / cvz
-    J02 = -(focal_x * tx) / (cvz * cvz)
-    J11 = focal_y / cvz
-    J12 = -(focal_y * ty) / (cvz * cvz)
+    # NB: python_scalar / tensor is reciprocal()*scalar in torch (two roundings) -- divide by a 0-dim tensor
+    fx_t, fy_t = torch.tensor(focal_x, dtype=dt), torch.tensor(focal_y, dtype=dt)
+    J00 = fx_t / cvz
+    J02 = -(fx_t * tx) / (cvz * cvz)
+    J11 = fy_t / cvz
+    J12 = -(fy_t * ty) / (cvz * cvz)
     # W = rotation rows of W2C: W[i][j] = flat[j*4+i]
     T0 = [J00 * Vc[4 * j + 0] + J02 * Vc[4 * j + 2] for j in range(3)]
     T1 = [J11 * Vc[4 * j + 1] + J12 * Vc[4 * j + 2] for j in range(3)]

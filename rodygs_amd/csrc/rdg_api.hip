@@ -98,7 +98,10 @@ const char* rdg_last_error(void) { return g_err; }
 size_t rdg_geom_bytes(int32_t P) { return rdg_geom_layout(P).total; }
 size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles) { (void)n_tiles; return rdg_bin_layout(capacity).total; }
 size_t rdg_image_bytes(int32_t H, int32_t W) { return rdg_image_layout(H, W).total; }
-size_t rdg_grad_bytes(int32_t P) { return rdg_align_up((size_t)(P > 0 ? P : 1) * RDG_GROW * 4, 256) + 256; }
+size_t rdg_grad_bytes(int32_t P) {
+    const size_t Pp = (size_t)(P > 0 ? P : 1);
+    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 255) / 256) * 19 * 4, 256);
+}
 size_t rdg_sort_tmp_bytes(int64_t capacity) {
     // alternate key/value buffers + tables
     size_t cap = (size_t)(capacity > 0 ? capacity : 1);

@@ -1,6 +1,7 @@
 // rdg_preprocess_bwd.hip -- per-Gaussian backward: conic -> Sigma2D -> (Sigma3D, mean),
 // projection -> mean3D, SH backward (clamp mask), Sigma3D -> (scale, raw quaternion), and the camera-pose
-// gradient dL/dviewmatrix (a reduction over all Gaussians: DPP wave sums -> 19 atomics per wave).
+// gradient dL/dviewmatrix (a reduction over all Gaussians: DPP wave sums -> per-workgroup partial rows ->
+// fixed-order finalize; deterministic, no atomics).
 //
 // One thread per Gaussian.  HBM-bound: reads the 64-B accumulator row + the forward inputs, writes 59 floats.
 // Pose-gradient gates (SURVEY.md §7 open question 4): enable_cov_grad switches the contribution through the
@@ -298,24 +299,41 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
             reinterpret_cast<float4*>(drots)[i] = make_float4(dq0, dq1, dq2, dq3);
         }
     }
-    // pose-gradient reduction: wave DPP sums, then one atomic per value per wave
-    if (__any(live)) {
+    // pose-gradient reduction: DPP wave sums -> LDS -> ONE partial row per workgroup (no atomics: 16 k waves
+    // hammering the same 19 addresses ran 20x slower than the rest of the kernel, and this form is deterministic)
+    __shared__ float sPose[4][RDG_POSE_N];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-        for (int k = 0; k < RDG_POSE_N; ++k) {
-            if ((k & 3) == 3 && k < 16) continue;  // V[3],V[7],V[11],V[15] receive nothing
-            const float sm = rdg_wave_sum_to63(pose[k]);
-            if ((threadIdx.x & 63) == 63 && sm != 0.0f) atomicAdd(posebuf + k, sm);
-        }
+    for (int k = 0; k < RDG_POSE_N; ++k) {
+        const float sm = rdg_wave_sum_to63(pose[k]);
+        if (lane == 63) sPose[wv][k] = sm;
     }
+    __syncthreads();
+    if (threadIdx.x < RDG_POSE_N)
+        posebuf[(size_t)blockIdx.x * RDG_POSE_N + threadIdx.x] =
+            (sPose[0][threadIdx.x] + sPose[1][threadIdx.x]) + (sPose[2][threadIdx.x] + sPose[3][threadIdx.x]);
 }
 
-// campos = -R^T t chain + copy into dL/dviewmatrix (glm flat)
-__global__ void rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict__ posebuf,
-                                         float* __restrict__ dview) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float V[16], g[16];
-    for (int k = 0; k < 16; ++k) { V[k] = view[k]; g[k] = posebuf[k]; }
-    const float gc[3] = {posebuf[16], posebuf[17], posebuf[18]};
+// Fixed-order reduction of the per-workgroup partial rows, then the campos = -R^T t chain, written into
+// dL/dviewmatrix (glm flat).  One 1024-thread block: 32 row-groups x 32 components.
+__global__ void __launch_bounds__(1024)
+rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict__ posebuf, int nblk,
+                         float* __restrict__ dview) {
+    __shared__ float sred[32][33];
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    float acc = 0.0f;
+    if (k < RDG_POSE_N)
+        for (int r = grp; r < nblk; r += 32) acc += posebuf[(size_t)r * RDG_POSE_N + k];
+    sred[grp][k] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float g[16], gc[3], V[16];
+    for (int c = 0; c < RDG_POSE_N; ++c) {
+        float t = 0.0f;
+        for (int r = 0; r < 32; ++r) t += sred[r][c];
+        if (c < 16) g[c] = t; else gc[c - 16] = t;
+    }
+    for (int c = 0; c < 16; ++c) V[c] = view[c];
     // cam_j = -(V[4j+0]*V[12] + V[4j+1]*V[13] + V[4j+2]*V[14])
     for (int j = 0; j < 3; ++j) {
         for (int r = 0; r < 3; ++r) {
@@ -323,7 +341,7 @@ __global__ void rdg_pose_finalize_kernel(const float* __restrict__ view, const f
             g[12 + r] += -V[4 * j + r] * gc[j];
         }
     }
-    for (int k = 0; k < 16; ++k) dview[k] = g[k];
+    for (int c = 0; c < 16; ++c) dview[c] = g[c];
 }
 
 int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
@@ -333,14 +351,12 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                               float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
                               float* dview, hipStream_t s) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
-    hipError_t e = hipMemsetAsync(posebuf, 0, RDG_POSE_N * sizeof(float), s);
-    if (e != hipSuccess) return rdg_check_hip(e, "posebuf memset");
+    const int nblk = (d.P + 255) / 256;
     if (d.P > 0) {
-        const int nblk = (d.P + 255) / 256;
         hipLaunchKernelGGL(rdg_preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs, colors,
                            opac, scales, rots, cov3D, radii, (const uint8_t*)((const char*)geom_ws + G.clamped),
                            grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D);
     }
-    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(64), 0, s, view, posebuf, dview);
+    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(1024), 0, s, view, posebuf, d.P > 0 ? nblk : 0, dview);
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd launch");
 }

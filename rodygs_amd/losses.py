@@ -1,0 +1,57 @@
+"""Image losses of the RoDyGS train step (callers of the hot path), restated for the bench
+loop: L1 and D-SSIM with the reference's definitions (/root/reference/src/utils/loss_utils.py:19-100 --
+11x11 Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2), pinned by tests/golden/loss_golden.npz.
+
+Own formulation: the 2-D window is an outer product, so the five filtered fields (x, y, x^2, y^2, xy) are
+produced by ONE batched separable pass (11 + 11 taps over a [5C,1,H,W] stack) instead of five 121-tap
+depth-wise convolutions.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+_WINDOW_CACHE = {}
+
+
+def _window1d(size: int, sigma: float, device, dtype):
+    key = (size, sigma, str(device), dtype)
+    w = _WINDOW_CACHE.get(key)
+    if w is None:
+        g = torch.tensor([math.exp(-((x - size // 2) ** 2) / float(2 * sigma ** 2)) for x in range(size)])
+        w = (g / g.sum()).to(device=device, dtype=dtype)
+        _WINDOW_CACHE[key] = w
+    return w
+
+
+def l1_loss(network_output: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    return torch.abs(network_output - gt).mean()
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11, size_average: bool = True) -> torch.Tensor:
+    """img [C,H,W] or [N,C,H,W] in [0,1]."""
+    squeeze = img1.dim() == 3
+    if squeeze:
+        img1, img2 = img1.unsqueeze(0), img2.unsqueeze(0)
+    N, C, H, W = img1.shape
+    w = _window1d(window_size, 1.5, img1.device, img1.dtype)
+    pad = window_size // 2
+    stack = torch.cat([img1, img2, img1 * img1, img2 * img2, img1 * img2], dim=1).reshape(N * 5 * C, 1, H, W)
+    f = F.conv2d(stack, w.view(1, 1, 1, -1), padding=(0, pad))
+    f = F.conv2d(f, w.view(1, 1, -1, 1), padding=(pad, 0)).reshape(N, 5, C, H, W)
+    mu1, mu2, e11, e22, e12 = f[:, 0], f[:, 1], f[:, 2], f[:, 3], f[:, 4]
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1, s2, s12 = e11 - mu1_sq, e22 - mu2_sq, e12 - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    if size_average:
+        return m.mean()
+    return m.mean(1).mean(1).mean(1)
+
+
+def photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """(1 - lambda) L1 + lambda (1 - SSIM): the 3DGS photometric loss RoDyGS uses for both sub-steps
+    (weights in /root/reference/configs/train/train_kubric_mrig.yaml)."""
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))

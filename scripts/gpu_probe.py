@@ -49,6 +49,10 @@ def probe_stages(P, W, H, deg, seed=1):
                                             torch.stack([g["px"], g["py"]], 1).numpy().view(np.uint32)[vis]))
     co = torch.cat([g["conic"], g["opacity"].unsqueeze(1)], 1).numpy()
     print("  conic bits equal:", np.array_equal(hs["conic_opacity"].view(np.uint32)[vis], co.view(np.uint32)[vis]))
+    ch, cor = hs["conic_opacity"].view(np.int32)[vis].astype(np.int64), co.view(np.int32)[vis].astype(np.int64)
+    for c in range(4):
+        dd = np.abs(ch[:, c] - cor[:, c])
+        print(f"   conic col {c}: mismatches {int((dd > 0).sum())} max ulp {int(dd.max())}")
     stats("rgb", hs["rgb"][vis], g["rgb"].numpy()[vis])
     stats("normal", hs["normal"][vis], g["normal"].numpy()[vis])
     if hs["D"] == b["num_rendered"]:

@@ -1,0 +1,145 @@
+"""Generates the golden vectors under tests/golden/ by IMPORTING the reference's own Python (only possible in the
+build container where /root/reference is mounted; the GPU box and CI read the committed .npz files).
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python -B tests/golden/make_golden.py
+
+What is pinned: the pieces of the hot path that exist as importable reference code --
+  G1 deformation : MLPBasisNetwork / TimestepEmbedder (src/model/rodygs_dynamic.py:190-327) + the inverse-motion
+                   arithmetic of DynRoDyGS.get_gaussian_deformation (:122-138), forward and autograd grads
+  G2 camera      : FixedCameraTorch.world_view_transform, getProjectionMatrix (src/data/utils.py:105-170,
+                   src/utils/graphic_utils.py:43-63)
+  G3 SH          : eval_sh degrees 0..3 (src/utils/sh_utils.py:44-118)
+  G4 covariance  : build_covariance_from_scaling_rotation (src/model/rodygs_static.py:26-30 +
+                   src/utils/general_utils.py:77-127; its hard-coded device="cuda" is neutralised by a
+                   torch.zeros wrapper for the duration of the call)
+  G6 losses      : l1_loss, ssim (src/utils/loss_utils.py) used by the bench train step
+Nothing from the reference is copied: only inputs and the outputs it produced are stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_modules():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("simple_knn")
+    mod("simple_knn._C", distCUDA2=None)
+    mod("diff_gauss_pose", GaussianRasterizationSettings=None, GaussianRasterizer=None)
+    mod("omegaconf", DictConfig=dict, OmegaConf=None)
+    mod("plyfile", PlyData=None, PlyElement=None)
+    mod("pytorch3d")
+    mod("pytorch3d.ops", knn_points=None, knn_gather=None)
+
+
+def main():
+    sys.dont_write_bytecode = True
+    _stub_modules()
+    sys.path.insert(0, REF)
+    torch.manual_seed(0)
+    np.random.seed(0)
+
+    # ---- G1 deformation --------------------------------------------------------------------------------------
+    from src.model.rodygs_dynamic import MLPBasisNetwork
+    net = MLPBasisNetwork(128, 16, 26, False, activation="gelu")
+    # non-trivial weights (reference init is N(0,1e-2) with zero bias: outputs ~1e-9; scale up for a useful test)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(torch.randn_like(p) * (0.3 if p.dim() > 1 else 0.1))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    P, T = 300, 9
+    coeff = (0.5 * torch.randn(P, 1, 16)).requires_grad_(True)
+    times = torch.sort(torch.rand(T))[0]
+    tind = torch.randint(0, T, (P,))
+    t_now = torch.tensor(0.37)
+    spatial = 2.3
+    emb_now = net.t_embedder(t_now)
+    embs = torch.stack([net.t_embedder(t) for t in times]).squeeze()
+    trans, rot = net(coeff, t_now)
+    table = net.batch_inference(embs).squeeze()
+    delta = (coeff @ table[tind]).squeeze()
+    trans2 = (trans - delta[..., :3]) * spatial
+    rot2 = rot - delta[..., 3:]
+    wx, wr = torch.randn(P, 3), torch.randn(P, 4)
+    loss = (trans2 * wx).sum() + (rot2 * wr).sum()
+    grads = torch.autograd.grad(loss, [coeff] + list(net.parameters()))
+    np.savez_compressed(
+        os.path.join(OUT, "deform_golden.npz"),
+        **{"sd." + k: v.numpy() for k, v in sd.items()},
+        coeff=coeff.detach().numpy(), times=times.numpy(), time_ind=tind.numpy(), t_now=t_now.numpy(),
+        spatial=np.float32(spatial), emb_now=emb_now.detach().numpy(), embs=embs.detach().numpy(),
+        trans_fwd=trans.detach().numpy(), rot_fwd=rot.detach().numpy(), table=table.detach().numpy(),
+        trans=trans2.detach().numpy(), rot=rot2.detach().numpy(), wx=wx.numpy(), wr=wr.numpy(),
+        d_coeff=grads[0].numpy(),
+        **{"dsd." + n: g.numpy() for (n, _), g in zip(net.named_parameters(), grads[1:])})
+
+    # ---- G2 camera -------------------------------------------------------------------------------------------
+    from src.data.utils import FixedCameraTorch
+    from src.utils.graphic_utils import getProjectionMatrix, focal2fov, fov2focal
+    cams = []
+    for i in range(4):
+        q = torch.randn(4)
+        t = torch.randn(3)
+        fovx = float(np.deg2rad(40 + 10 * i))
+        Wd, Hd = 320 + 64 * i, 200 + 40 * i
+        fovy = focal2fov(fov2focal(fovx, Wd), Hd)
+        cam = FixedCameraTorch(q, t, fovx, fovy, torch.zeros(3, Hd, Wd), "x", 0.1 * i, None, None, None, None, i)
+        cams.append(dict(q=q.numpy(), t=t.numpy(), fovx=fovx, fovy=fovy, W=Wd, H=Hd,
+                         w2c=cam.world_view_transform.numpy(), proj=cam.projection_matrix.numpy(),
+                         proj_fn=getProjectionMatrix(0.01, 100.0, fovx, fovy).numpy()))
+    np.savez_compressed(os.path.join(OUT, "camera_golden.npz"),
+                        **{f"{k}{i}": np.asarray(v) for i, c in enumerate(cams) for k, v in c.items()})
+
+    # ---- G3 SH -----------------------------------------------------------------------------------------------
+    from src.utils.sh_utils import eval_sh, RGB2SH, SH2RGB
+    n = 257
+    sh = torch.randn(n, 3, 16)          # reference layout [..., C, K]
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3), dim=1)
+    sh_out = {f"deg{d}": eval_sh(d, sh, dirs).numpy() for d in range(4)}
+    rgb = torch.rand(11, 3)
+    np.savez_compressed(os.path.join(OUT, "sh_golden.npz"), sh=sh.numpy(), dirs=dirs.numpy(), rgb=rgb.numpy(),
+                        rgb2sh=RGB2SH(rgb).numpy(), sh2rgb=SH2RGB(rgb).numpy(), **sh_out)
+
+    # ---- G4 covariance ---------------------------------------------------------------------------------------
+    import src.utils.general_utils as GU
+    real_zeros = torch.zeros
+
+    def cpu_zeros(*a, **k):
+        k.pop("device", None)
+        return real_zeros(*a, **k)
+
+    torch.zeros = cpu_zeros
+    try:
+        from src.model.rodygs_static import build_covariance_from_scaling_rotation
+        s = torch.exp(torch.randn(64, 3) * 0.5)
+        r = torch.randn(64, 4)
+        cov_norm = build_covariance_from_scaling_rotation(s, 1.3, r)                     # normalises r inside
+        rn = torch.nn.functional.normalize(r)
+        R = GU.build_rotation(r)
+    finally:
+        torch.zeros = real_zeros
+    np.savez_compressed(os.path.join(OUT, "cov_golden.npz"), scales=s.numpy(), rot_raw=r.numpy(),
+                        rot_unit=rn.numpy(), scale_modifier=np.float32(1.3), cov6=cov_norm.numpy(), R=R.numpy())
+
+    # ---- G6 losses -------------------------------------------------------------------------------------------
+    from src.utils.loss_utils import l1_loss, ssim
+    a = torch.rand(3, 48, 64)
+    b = (a + 0.1 * torch.randn(3, 48, 64)).clamp(0, 1)
+    np.savez_compressed(os.path.join(OUT, "loss_golden.npz"), a=a.numpy(), b=b.numpy(),
+                        l1=l1_loss(a, b).numpy(), ssim=ssim(a, b).numpy())
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
