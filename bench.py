@@ -1,0 +1,177 @@
+"""bench.py -- the driver's measurement contract for the rodygs_amd hot path.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 1 M dynamic Gaussians + time-deformation
+MLP, 1920x1080, SH degree 3, 100-frame synthetic video (SURVEY.md §8d generator, seed 777).  A "step" is one
+full train step on one camera per GPU: deformation -> rasterize forward -> 0.8 L1 + 0.2 D-SSIM -> backward ->
+(N > 1: one RCCL all-reduce of the flat gradient bucket) -> fused Adam over every parameter.  Inputs are resident
+in HBM before the timed region.  Weak scaling: every GPU renders its own frame of the replicated cloud, value =
+frames (train steps x GPUs) per second.
+
+The JSON line also carries
+  roofline     : the dominant kernel (render backward) -- ALGORITHMIC bytes per launch / its average duration,
+                 measured live with hipEvents recorded by the library on the launch stream;
+  cpu_baseline : the PyTorch-CPU oracle timed on this box's host cores on a bounded sample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(scene, sh_degree, sample_tiles=96, max_seconds=40.0):
+    """Oracle (kind "port") on a bounded sample: full per-Gaussian stage + binning for the frame, then forward +
+    backward compositing of `sample_tiles` evenly spaced tiles, extrapolated to the whole image."""
+    from oracle import rasterizer_oracle as O   # checker / baseline only -- never on the product path
+    P, H, W = scene["means3D"].shape[0], scene["H"], scene["W"]
+    st = O.OracleSettings(H, W, scene["tanfovx"], scene["tanfovy"], torch.zeros(3), 1.0, scene["projmatrix"], sh_degree)
+    names = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
+    ins = {k: scene[k].clone().requires_grad_(True) for k in names}
+    m2 = torch.zeros(P, 3, requires_grad=True)
+    t0 = time.perf_counter()
+    geom = O.preprocess(ins["means3D"], m2, ins["opacities"], ins["viewmatrix"], st, shs=ins["shs"],
+                        scales=ins["scales"], rotations=ins["rotations"])
+    binning = O.bin_and_sort(geom)
+    t_pre = time.perf_counter() - t0
+    gx, gy = geom["grid"]
+    n_tiles = gx * gy
+    stride = max(1, n_tiles // sample_tiles)
+    subset = list(range(stride // 2, n_tiles, stride))[:sample_tiles]
+    t1 = time.perf_counter()
+    img = O.render_tiles(geom, binning, st.bg, H, W, tile_subset=subset)
+    loss = img["color"].sum() + 0.1 * img["depth"].sum()
+    loss.backward()
+    t_tiles = time.perf_counter() - t1
+    pairs = int(sum((binning["ranges"][t, 1] - binning["ranges"][t, 0]) for t in subset))
+    total_pairs = int(binning["num_rendered"])
+    # tile time scales with the splat instances in the tile, not with the tile count
+    est = t_pre + t_tiles * (total_pairs / max(pairs, 1))
+    return {"value": 1.0 / est, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fwd+bwd of one frame: full preprocess+binning of {P} Gaussians ({t_pre:.1f}s) + "
+                      f"{len(subset)}/{n_tiles} tiles holding {pairs}/{total_pairs} splat instances ({t_tiles:.1f}s), "
+                      f"extrapolated by instances; rasterizer only (no MLP/loss/Adam)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=1000000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--gt-frames", type=int, default=16, help="distinct frames with ground truth resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rodygs_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from oracle import rasterizer_oracle as O          # synthetic-scene generator + cpu_baseline only
+    from rodygs_amd import _lib
+    from rodygs_amd.trainstep import DynamicScene
+    _lib.lib()
+
+    P, W, H = args.points, args.width, args.height
+    scene = O.synthetic_scene(P, W, H, 3, seed=777)
+    target = O.synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
+    ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777)
+    n_gt = min(args.gt_frames * world, args.frames)
+    gt_frames = [int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)]
+    gt_frames = sorted(set(gt_frames))
+    ds.make_ground_truth(target, gt_frames)
+    perm = gt_frames
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        ds.train_step(step, rank, world, perm)
+        step += 1
+    _lib.timing_enable(True)
+    _lib.timing_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ds.train_step(step, rank, world, perm)
+        step += 1
+    sync()
+    dt = time.perf_counter() - t0
+    stages = _lib.stage_times()
+    _lib.timing_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        from rodygs_amd import rasterizer
+        D = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
+        with torch.no_grad():
+            out, _ = ds.render(perm[0])
+            V = int((out[4] > 0).sum().item())
+        fps = args.steps * world / dt
+        per_stage = {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}
+        # dominant kernel: render backward.  Algorithmic bytes per launch (DESIGN.md §5 / SURVEY.md §8d):
+        #   D*44 (sorted id + 40-B splat features) + H*W*40 (5 upstream-gradient channels, final_T, n_contrib, +pad
+        #   as in the survey formula) + V*40 (10 accumulated floats per visible Gaussian)
+        dom = "render_bwd"
+        dom_ms = per_stage[dom]
+        alg_bytes = D * 44 + H * W * 40 + V * 40
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        res = {
+            "metric": "train-step fps at 1M dynamic Gaussians / 1080p (fwd+bwd+Adam, one camera per GPU per step)",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{P} dynamic Gaussians + deformation MLP, {W}x{H}, SH3, {args.frames}-frame "
+                                   f"synthetic video (BASELINE configs[2])", "points": P, "width": W, "height": H,
+                       "frames": args.frames, "parallelism": f"frame-dp{world}", "num_rendered_D": D, "visible_V": V},
+            "gaussians_per_s": fps * P,
+            "loss": float(loss.item()),
+            "stage_ms": per_stage,
+            "roofline": {"bound": "hbm", "kernel": "rdg_render_bwd_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": dom_ms,
+                         "note": "compositing kernels are VALU/exp/LDS-bound (SURVEY.md §8d); the HBM fraction is "
+                                 "reported because north_star asks for it"},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(scene, 3)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(),
+                                       "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,6 +195,11 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
         int blocks = (P + threads - 1) / threads;
         if (blocks > 256) blocks = 256;
         if (lds <= 128 * 1024) {
+            if (lds > 64 * 1024) {
+                hipError_t ea = hipFuncSetAttribute((const void*)rdg_deform_bwd_kernel<true>,
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (ea != hipSuccess) return rdg_check_hip(ea, "deform_bwd LDS attribute");
+            }
             hipLaunchKernelGGL(rdg_deform_bwd_kernel<true>, dim3(blocks), dim3(threads), lds, st, P, B, Tu, coeff,
                                (const long long*)time_ind, basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff,
                                d_basis_t, d_table);

@@ -1,0 +1,85 @@
+"""CPU multi-process tests (gloo, world_size 2) of the frame-data-parallel path: the flat-bucket gradient
+all-reduce used by bench.py / trainstep.py, with per-rank gradients produced by the oracle rasterizer for two
+different cameras -- the all-reduced bucket must equal the sum of the single-rank gradients (SURVEY.md §4 tier 4)."""
+import os
+import socket
+import tempfile
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_grads(rank):
+    from oracle import rasterizer_oracle as O
+    sc = O.synthetic_scene(300, 64, 48, 1, seed=21)
+    view = sc["viewmatrix"].clone()
+    view[3, 0] = 0.2 * (rank + 1)  # glm storage: row 3 is the translation; every rank = another camera/frame
+    st = O.OracleSettings(48, 64, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 1)
+    ins = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    out = O.rasterize(ins["means3D"], torch.zeros(300, 3), ins["opacities"], view, st, shs=ins["shs"],
+                      scales=ins["scales"], rotations=ins["rotations"])
+    out[0].sum().add(out[1].sum()).backward()
+    return {k: v.grad for k, v in ins.items()}
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rodygs_amd.dp import FlatParams, allreduce_sum_, frame_for
+    spec = {"means3D": ((300, 3), 1e-3), "shs": ((300, 4, 3), 1e-3), "opacities": ((300, 1), 1e-2),
+            "scales": ((300, 3), 1e-3), "rotations": ((300, 4), 1e-3)}
+    fp = FlatParams(spec, "cpu")
+    grads = _rank_grads(rank)
+    for k, g in grads.items():
+        fp[k].grad.copy_(g)
+    small = [torch.full((5,), float(rank + 1)), torch.full((2, 3), 10.0 * (rank + 1))]
+    allreduce_sum_(fp.flat_grad, small)
+    torch.save({"flat": fp.flat_grad.clone(), "small": small, "offsets": fp.offsets,
+                "frames": [frame_for(s, rank, world, list(range(7))) for s in range(7)]},
+               os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_equals_sum_of_single_rank_grads():
+    world = 2
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, d), nprocs=world, join=True)
+        r0 = torch.load(os.path.join(d, "r0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(d, "r1.pt"), weights_only=False)
+    assert torch.equal(r0["flat"], r1["flat"])                       # every rank holds the same summed bucket
+    g0, g1 = _rank_grads(0), _rank_grads(1)
+    for k, (o, n) in r0["offsets"].items():
+        want = (g0[k] + g1[k]).reshape(-1)
+        got = r0["flat"][o:o + n]
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), k
+    assert float(g0["means3D"].sub(g1["means3D"]).abs().max()) > 0  # the two frames really differ
+    assert torch.equal(r0["small"][0], torch.full((5,), 3.0)) and torch.equal(r1["small"][1], torch.full((2, 3), 30.0))
+    # strided frame assignment: the two ranks never render the same frame in a step and cover the permutation
+    assert all(a != b for a, b in zip(r0["frames"], r1["frames"]))
+    assert sorted(set(r0["frames"] + r1["frames"])) == list(range(7))
+
+
+def test_flat_params_views_and_single_process_noop():
+    from rodygs_amd.dp import FlatParams, allreduce_sum_
+    fp = FlatParams({"a": ((5, 3), 0.1), "b": ((7,), 0.2)}, "cpu")
+    assert fp["a"].is_leaf and fp["a"].requires_grad and fp["a"].grad.data_ptr() == fp.flat_grad.data_ptr()
+    (fp["a"].sum() * 2 + fp["b"].sum() * 3).backward()
+    o, n = fp.offsets["b"]
+    assert torch.equal(fp.flat_grad[o:o + n], torch.full((7,), 3.0)) and float(fp.flat_grad[:15].sum()) == 30.0
+    before = fp.flat_grad.clone()
+    allreduce_sum_(fp.flat_grad)            # not initialised -> no-op
+    assert torch.equal(before, fp.flat_grad)
+    fp.zero_grad()
+    assert float(fp["a"].grad.abs().sum()) == 0.0

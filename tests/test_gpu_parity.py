@@ -1,0 +1,405 @@
+"""-m gpu parity tests: the HIP path (through the C-ABI / the drop-in Python surface) against the CPU oracle on
+the same seeded inputs.  Bars (BASELINE.json north_star): tile keys, sort order, radii, tile ranges BIT-EXACT;
+rendered RGB / depth / alpha and all gradients within 1e-4 relative.
+
+"relative" = max|hip - oracle| <= TOL * max|oracle| per tensor (max-norm relative error).  A handful of pixels may
+sit exactly on a discontinuity of the algorithm itself (alpha vs 1/255, T vs 1e-4: an exp() ulp flips whether a
+splat is blended), so image tensors may have at most OUTLIER_FRAC of their entries above the bar.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import deform_oracle as DO
+from oracle import knn_oracle as KO
+from oracle import rasterizer_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+OUTLIER_FRAC = 2e-5
+DEV = "cuda"
+NAMES = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
+
+
+def rel_ok(a, b, tol=TOL, outliers=0.0, what=""):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert not torch.isnan(a).any(), what
+    d = (a - b).abs()
+    scale = b.abs().max().item() + 1e-30
+    bad = (d > tol * scale).double().mean().item()
+    assert bad <= outliers, f"{what}: max rel {d.max().item() / scale:.3e}, frac over bar {bad:.2e}"
+
+
+def orbit_view(deg_y=8.0, deg_x=-5.0, t=(0.4, -0.3, 0.8)):
+    """A non-identity W2C so every entry of the pose gradient is exercised; returns glm-flat [4,4]."""
+    ay, ax = math.radians(deg_y), math.radians(deg_x)
+    Ry = torch.tensor([[math.cos(ay), 0, math.sin(ay)], [0, 1, 0], [-math.sin(ay), 0, math.cos(ay)]])
+    Rx = torch.tensor([[1, 0, 0], [0, math.cos(ax), -math.sin(ax)], [0, math.sin(ax), math.cos(ax)]])
+    w2c = torch.eye(4)
+    w2c[:3, :3] = Rx @ Ry
+    w2c[:3, 3] = torch.tensor(t)
+    return w2c.t().contiguous()
+
+
+def run_pair(sc, deg, bg, cov_grad=True, sh_grad=True, use_colors=False, use_cov3d=False, scale_modifier=1.0, seed=3):
+    """Forward+backward through rodygs_amd (GPU) and through the oracle (CPU) with the same random loss weights."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    P, H, W = sc["means3D"].shape[0], sc["H"], sc["W"]
+    bgt = torch.tensor(bg)
+    gen = torch.Generator().manual_seed(seed)
+    wc, wd, wa = torch.rand(3, H, W, generator=gen), torch.rand(1, H, W, generator=gen), torch.rand(1, H, W, generator=gen)
+    extra = {}
+    if use_colors:
+        extra["colors_precomp"] = torch.rand(P, 3, generator=gen)
+    if use_cov3d:
+        with torch.no_grad():
+            extra["cov3Ds_precomp"] = O.covariance3d(sc["scales"], scale_modifier, sc["rotations"])
+
+    def inputs(dev):
+        d = {k: sc[k].clone().to(dev).requires_grad_(True) for k in NAMES}
+        for k, v in extra.items():
+            d[k] = v.clone().to(dev).requires_grad_(True)
+        return d
+
+    hi = inputs(DEV)
+    rs = HS.make_settings(sc, deg, bg=bgt, cov_grad=cov_grad, sh_grad=sh_grad, scale_modifier=scale_modifier)
+    hm2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    kw = dict(means3D=hi["means3D"], means2D=hm2, opacities=hi["opacities"], viewmatrix=hi["viewmatrix"])
+    kw.update(dict(colors_precomp=hi["colors_precomp"]) if use_colors else dict(shs=hi["shs"]))
+    kw.update(dict(cov3Ds_precomp=hi["cov3Ds_precomp"]) if use_cov3d else dict(scales=hi["scales"],
+                                                                               rotations=hi["rotations"]))
+    hout = GaussianRasterizer(rs)(**kw)
+    (hout[0] * wc.to(DEV)).sum().add((hout[1] * wd.to(DEV)).sum() * 0.1).add((hout[3] * wa.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+
+    oi = inputs("cpu")
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], bgt, scale_modifier, sc["projmatrix"], deg,
+                          enable_cov_grad=cov_grad, enable_sh_grad=sh_grad)
+    om2 = torch.zeros(P, 3, requires_grad=True)
+    okw = dict(shs=None if use_colors else oi["shs"], colors_precomp=oi.get("colors_precomp"),
+               scales=None if use_cov3d else oi["scales"], rotations=None if use_cov3d else oi["rotations"],
+               cov3Ds_precomp=oi.get("cov3Ds_precomp"))
+    oout = O.rasterize(oi["means3D"], om2, oi["opacities"], oi["viewmatrix"], st, **okw)
+    (oout[0] * wc).sum().add((oout[1] * wd).sum() * 0.1).add((oout[3] * wa).sum()).backward()
+    return hi, hm2, hout, oi, om2, oout
+
+
+def check_pair(res, grads):
+    hi, hm2, hout, oi, om2, oout = res
+    assert torch.equal(hout[4].cpu(), oout[4]), "radii"
+    assert hout[4].dtype == torch.int32 and hout[5].numel() == 0
+    for i, name in ((0, "color"), (1, "depth"), (2, "normal"), (3, "alpha")):
+        rel_ok(hout[i], oout[i], outliers=OUTLIER_FRAC, what=name)
+    for k in grads:
+        rel_ok(hi[k].grad, oi[k].grad, outliers=OUTLIER_FRAC, what="d_" + k)
+    rel_ok(hm2.grad, om2.grad, outliers=OUTLIER_FRAC, what="d_means2D")
+    assert float(hm2.grad[:, 2].abs().max()) == 0.0
+
+
+# ---- stage-level bit-exactness -------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("P,W,H,deg", [(1000, 256, 256, 0),        # BASELINE config 1
+                                       (20000, 640, 360, 3),
+                                       (7000, 333, 211, 2),          # ragged: W,H not multiples of 16
+                                       (100000, 1920, 1080, 3)])     # BASELINE config 2
+def test_preprocess_and_binning_bit_exact(P, W, H, deg):
+    import hip_stages as HS
+    sc = O.synthetic_scene(P, W, H, 3, seed=P % 97)
+    if P == 7000:
+        sc["viewmatrix"] = orbit_view()
+    hs = HS.run_stages(sc, deg)
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], deg)
+    with torch.no_grad():
+        g = O.preprocess(sc["means3D"], torch.zeros(P, 3), sc["opacities"], sc["viewmatrix"], st, shs=sc["shs"],
+                         scales=sc["scales"], rotations=sc["rotations"])
+    b = O.bin_and_sort(g)
+    vis = g["valid"].numpy()
+    assert hs["D"] == b["num_rendered"]
+    assert np.array_equal(hs["radii"], g["radii"].numpy())
+    assert np.array_equal(hs["tiles_touched"], g["tiles_touched"].numpy().astype(np.uint32))
+    assert np.array_equal(hs["depth"].view(np.uint32)[vis], g["depth"].numpy().view(np.uint32)[vis])
+    xy = torch.stack([g["px"], g["py"]], 1).numpy()
+    assert np.array_equal(hs["xy"].view(np.uint32)[vis], xy.view(np.uint32)[vis])
+    co = torch.cat([g["conic"], g["opacity"].unsqueeze(1)], 1).numpy()
+    assert np.array_equal(hs["conic_opacity"].view(np.uint32)[vis], co.view(np.uint32)[vis])
+    rel_ok(hs["rgb"][vis], g["rgb"].numpy()[vis], tol=1e-5, what="rgb")
+    rel_ok(hs["normal"][vis], g["normal"].numpy()[vis], tol=1e-6, what="normal")
+    assert np.array_equal(hs["keys_unsorted"], b["keys_unsorted"])
+    assert np.array_equal(hs["vals_unsorted"], b["vals_unsorted"])
+    assert np.array_equal(hs["keys_sorted"], b["keys_sorted"])
+    assert np.array_equal(hs["vals_sorted"], b["vals_sorted"])
+    assert np.array_equal(hs["ranges"], b["ranges"])
+
+
+@pytest.mark.parametrize("n,bits", [(0, 40), (1, 40), (63, 33), (64, 45), (1000, 40), (100000, 45), (3000000, 47),
+                                    (77, 64), (5000, 8)])
+def test_sort_pairs_stable_and_exact(n, bits):
+    from rodygs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(n + bits)
+    cap = max(n, 1)
+    keys = torch.randint(0, 2 ** 62, (cap,), generator=g, dtype=torch.int64) & ((1 << min(bits, 62)) - 1)
+    if n > 8:
+        keys[::7] = keys[0]            # many duplicates: stability decides the value order
+    vals = torch.arange(cap, dtype=torch.int32)
+    kd, vd = keys.to(DEV), vals.to(DEV)
+    nd = torch.tensor([n], dtype=torch.int32, device=DEV)
+    tmp = torch.empty(L.rdg_sort_tmp_bytes(cap), dtype=torch.uint8, device=DEV)
+    _lib.check(L.rdg_sort_pairs(kd.data_ptr(), vd.data_ptr(), cap, nd.data_ptr(), bits, tmp.data_ptr(),
+                                _lib.stream_ptr()), "sort")
+    torch.cuda.synchronize()
+    kn = keys.numpy()[:n].view(np.uint64)
+    order = np.argsort(kn, kind="stable")
+    assert np.array_equal(kd.cpu().numpy()[:n].view(np.uint64), kn[order])
+    assert np.array_equal(vd.cpu().numpy()[:n], vals.numpy()[:n][order])
+
+
+# ---- full forward + backward ----------------------------------------------------------------------------------
+
+def test_config1_forward_backward():
+    """BASELINE config 1 shape (1k Gaussians, 256x256, SH degree 0), here with gradients as well."""
+    sc = O.synthetic_scene(1000, 256, 256, 3, seed=2)
+    check_pair(run_pair(sc, 0, (0.0, 0.0, 0.0)), NAMES)
+
+
+def test_sh3_nonidentity_pose_background_ragged_image():
+    sc = O.synthetic_scene(6000, 333, 211, 3, seed=4)
+    sc["viewmatrix"] = orbit_view()
+    check_pair(run_pair(sc, 3, (0.1, 0.2, 0.3)), NAMES)
+
+
+@pytest.mark.parametrize("cov_grad,sh_grad", [(False, False), (True, False), (False, True)])
+def test_pose_gradient_gates(cov_grad, sh_grad):
+    sc = O.synthetic_scene(3000, 200, 152, 3, seed=6)
+    sc["viewmatrix"] = orbit_view(5.0, 3.0, (0.2, 0.1, 0.5))
+    check_pair(run_pair(sc, 2, (0.3, 0.3, 0.3), cov_grad=cov_grad, sh_grad=sh_grad), NAMES)
+
+
+def test_precomputed_colors_and_covariance_paths():
+    sc = O.synthetic_scene(3000, 208, 160, 3, seed=8)
+    sc["viewmatrix"] = orbit_view(-6.0, 4.0, (0.1, 0.2, 0.3))
+    res = run_pair(sc, 0, (0.0, 0.1, 0.0), use_colors=True, use_cov3d=True, scale_modifier=1.0)
+    check_pair(res, ("means3D", "opacities", "viewmatrix", "colors_precomp", "cov3Ds_precomp"))
+    res = run_pair(sc, 1, (0.0, 0.0, 0.0), scale_modifier=0.7)
+    check_pair(res, NAMES)
+
+
+def test_non_unit_quaternions_are_not_renormalised():
+    """RoDyGS feeds normalize(q) + dq: the kernel must use the raw quaternion."""
+    sc = O.synthetic_scene(2000, 160, 128, 3, seed=9)
+    sc["rotations"] = sc["rotations"] + 0.15 * torch.randn(2000, 4, generator=torch.Generator().manual_seed(1))
+    check_pair(run_pair(sc, 1, (0.0, 0.0, 0.0)), NAMES)
+
+
+def test_culled_and_degenerate_inputs():
+    from rodygs_amd import GaussianRasterizer
+    import hip_stages as HS
+    sc = O.synthetic_scene(1500, 128, 96, 3, seed=10)
+    sc["means3D"][:100, 2] = -2.0      # behind the camera
+    sc["means3D"][100:150, 2] = 0.15   # inside the near cull
+    sc["opacities"][150:200] = 0.0     # never reach 1/255
+    check_pair(run_pair(sc, 3, (0.2, 0.2, 0.2)), NAMES)
+    # everything culled -> background image, zero gradients, radii all zero
+    sc2 = O.synthetic_scene(300, 64, 48, 3, seed=1)
+    sc2["means3D"][:, 2] = -1.0
+    res = run_pair(sc2, 3, (0.5, 0.25, 0.125))
+    check_pair(res, ())
+    assert float(res[0]["means3D"].grad.abs().max()) == 0.0 and int(res[2][4].abs().sum()) == 0
+    # P = 0
+    rs = HS.make_settings(sc2, 3, bg=torch.tensor([0.5, 0.25, 0.125]))
+    z = torch.zeros(0, 3, device=DEV)
+    out = GaussianRasterizer(rs)(means3D=z, means2D=z, shs=torch.zeros(0, 16, 3, device=DEV),
+                                 opacities=torch.zeros(0, 1, device=DEV), scales=z, rotations=torch.zeros(0, 4, device=DEV),
+                                 viewmatrix=sc2["viewmatrix"].to(DEV))
+    assert torch.allclose(out[0][:, 0, 0].cpu(), torch.tensor([0.5, 0.25, 0.125])) and out[4].numel() == 0
+
+
+def test_capacity_overflow_retries_and_retain_graph():
+    """A too-small binning capacity must be detected on the device and retried, and backward must be repeatable
+    (loss.backward(retain_graph=True) at /root/reference/src/trainer/rodygs.py:310)."""
+    from rodygs_amd import GaussianRasterizer, rasterizer
+    import hip_stages as HS
+    sc = O.synthetic_scene(3000, 320, 240, 3, seed=12)
+    sc["scales"] = sc["scales"] * 6.0   # many tiles per Gaussian: D >> 4 P
+    rs = HS.make_settings(sc, 1)
+    ins = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+    rasterizer._CAPACITY_HINT.clear()
+    m2 = torch.zeros(3000, 3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                 scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+    D = rasterizer._CAPACITY_HINT[(3000, 240, 320)]
+    assert D > 4 * 3000 + 4096, "scene did not overflow the initial capacity; enlarge scales"
+    loss = out[0].sum()
+    loss.backward(retain_graph=True)
+    g1 = ins["means3D"].grad.clone()
+    ins["means3D"].grad = None
+    loss.backward()
+    rel_ok(ins["means3D"].grad, g1, tol=1e-5, what="repeat backward")
+    st = O.OracleSettings(240, 320, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 1)
+    with torch.no_grad():
+        oc = O.rasterize(sc["means3D"], torch.zeros(3000, 3), sc["opacities"], sc["viewmatrix"], st, shs=sc["shs"],
+                         scales=sc["scales"], rotations=sc["rotations"])
+    rel_ok(out[0], oc[0], outliers=OUTLIER_FRAC, what="color after retry")
+
+
+def test_render_wrapper_returns_reference_dict():
+    """render() mirror of /root/reference/src/trainer/renderer.py:17-114: keys, shapes, viewspace grad."""
+    from rodygs_amd import render
+    sc = O.synthetic_scene(2000, 160, 120, 3, seed=13)
+
+    class Cam:
+        FoVx, FoVy = sc["fovx"], sc["fovy"]
+        image_height, image_width = 120, 160
+        projection_matrix = sc["projmatrix"].t().contiguous().to(DEV)      # un-transposed P, as FixedCameraTorch
+        world_view_transform = sc["viewmatrix"].t().contiguous().to(DEV)
+
+    xyz = sc["means3D"].to(DEV).requires_grad_(True)
+    pkg = render(xyz, 3, sc["opacities"].to(DEV), sc["scales"].to(DEV), sc["rotations"].to(DEV), sc["shs"].to(DEV),
+                 Cam, torch.zeros(3, device=DEV), enable_sh_grad=True, enable_cov_grad=True)
+    assert set(pkg) == {"rendered_image", "rendered_depth", "rendered_normal", "rendered_alpha", "viewspace_points",
+                        "visibility_filter", "radii", "extra"}
+    assert pkg["rendered_image"].shape == (3, 120, 160) and pkg["rendered_depth"].shape == (1, 120, 160)
+    assert pkg["visibility_filter"].dtype == torch.bool and pkg["visibility_filter"].shape == (2000,)
+    pkg["rendered_image"].sum().backward()
+    assert pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].grad.shape == (2000, 3)
+    assert float(pkg["viewspace_points"].grad[:, :2].abs().sum()) > 0 and xyz.grad is not None
+
+
+# ---- full-size properties (BASELINE config 3 shape: 1 M Gaussians, 1080p) --------------------------------------
+
+def test_full_size_properties_1m_1080p():
+    """Too big for the oracle: size-independent properties instead -- sortedness of the key stream, a
+    partition-of-unity check of the tile ranges, determinism of the forward, linearity of the backward in the
+    upstream gradient, alpha/colour consistency."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    P, W, H = 1000000, 1920, 1080
+    sc = O.synthetic_scene(P, W, H, 3, seed=777)
+    hs = HS.run_stages(sc, 3)
+    ks = hs["keys_sorted"]
+    assert hs["D"] == int(hs["tiles_touched"].sum()) == len(ks)
+    assert np.all(ks[1:] >= ks[:-1])
+    eq = ks[1:] == ks[:-1]
+    assert np.all(hs["vals_sorted"][1:][eq] > hs["vals_sorted"][:-1][eq])                 # stable
+    assert np.array_equal(np.sort(hs["keys_unsorted"], kind="stable"), ks)                 # a permutation
+    assert int((hs["ranges"][:, 1].astype(np.int64) - hs["ranges"][:, 0]).sum()) == hs["D"]
+    tiles = (ks >> np.uint64(32)).astype(np.int64)
+    t_check = np.unique(tiles)[::97]
+    for t in t_check:
+        s, e = hs["ranges"][t]
+        assert tiles[s] == t and tiles[e - 1] == t and (e == len(ks) or tiles[e] != t)
+    rs = HS.make_settings(sc, 3, bg=torch.tensor([1.0, 1.0, 1.0]))
+    ins = {k: sc[k].to(DEV).requires_grad_(True) for k in NAMES}
+
+    def fwd():
+        m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        return GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                      scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+
+    a, b = fwd(), fwd()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])   # forward is deterministic
+    assert float(a[3].min()) >= 0.0 and float(a[3].max()) <= 1.0
+    # white background + colours in [0, inf): colour >= (1 - alpha) everywhere
+    assert bool((a[0] >= (1.0 - a[3]) - 1e-5).all())
+    gw = torch.rand(3, H, W, device=DEV)
+    g1 = torch.autograd.grad(a[0], ins["shs"], gw, retain_graph=True)[0]
+    g2 = torch.autograd.grad(a[0], ins["shs"], 2.5 * gw)[0]
+    rel_ok(g2, 2.5 * g1, tol=2e-5, what="backward linearity")      # float atomics: order-dependent rounding only
+
+
+# ---- deformation, knn, adam ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("P,Tu,inverse", [(5000, 37, True), (1, 1, True), (4097, 100, True), (3000, 0, False),
+                                          (2000, 200, True)])
+def test_deformation_forward_backward(P, Tu, inverse):
+    from rodygs_amd import gaussian_deformation
+    g = torch.Generator().manual_seed(P + Tu)
+    B = 16
+    coeff = (0.1 * torch.randn(P, 1, B, generator=g)).requires_grad_(True)
+    ind = torch.randint(0, max(Tu, 1), (P,), generator=g)
+    bt = torch.randn(B, 7, generator=g).requires_grad_(True)
+    tb = torch.randn(Tu, B, 7, generator=g).requires_grad_(True) if inverse else None
+    wx, wr = torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g)
+    if inverse:
+        ox, orr = DO.gaussian_deformation(coeff, ind, bt, tb, 1.7)
+    else:
+        d = coeff.reshape(P, B) @ bt
+        ox, orr = d[:, :3] * 1.7, d[:, 3:]
+    ((ox * wx).sum() + (orr * wr).sum()).backward()
+    c2 = coeff.detach().clone().to(DEV).requires_grad_(True)
+    bt2 = bt.detach().clone().to(DEV).requires_grad_(True)
+    tb2 = tb.detach().clone().to(DEV).requires_grad_(True) if inverse else None
+    hx, hr = gaussian_deformation(c2, ind.to(DEV), bt2, tb2, 1.7)
+    ((hx * wx.to(DEV)).sum() + (hr * wr.to(DEV)).sum()).backward()
+    rel_ok(hx, ox, tol=1e-5, what="dxyz"); rel_ok(hr, orr, tol=1e-5, what="drot")
+    rel_ok(c2.grad, coeff.grad, tol=1e-5, what="d_coeff")
+    rel_ok(bt2.grad, bt.grad, tol=2e-5, what="d_basis_t")
+    if inverse:
+        rel_ok(tb2.grad, tb.grad, tol=2e-5, what="d_table")
+
+
+def test_deformation_field_matches_reference_golden_on_gpu():
+    """End to end against the imported-reference golden (MLP in torch on the GPU + HIP per-Gaussian op)."""
+    from rodygs_amd.deform import MLPBasisNetwork, gaussian_deformation
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "deform_golden.npz"))
+    net = MLPBasisNetwork(128, 16, 26, False).to(DEV)
+    net.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    coeff = torch.from_numpy(g["coeff"]).to(DEV).requires_grad_(True)
+    emb = net.t_embedder(torch.tensor(float(g["t_now"]), device=DEV))
+    rel_ok(emb, g["emb_now"], tol=1e-5, what="time embedding on device (full-range sin/cos)")
+    basis_t = net.motion_basis(torch.from_numpy(g["emb_now"]).to(DEV).reshape(1, -1)).squeeze(0)
+    table = net.batch_inference(torch.from_numpy(g["embs"]).to(DEV))
+    tr, ro = gaussian_deformation(coeff, torch.from_numpy(g["time_ind"]).to(DEV), basis_t, table, float(g["spatial"]))
+    rel_ok(tr, g["trans"], tol=1e-4, what="translation"); rel_ok(ro, g["rot"], tol=1e-4, what="rotation")
+    ((tr * torch.from_numpy(g["wx"]).to(DEV)).sum() + (ro * torch.from_numpy(g["wr"]).to(DEV)).sum()).backward()
+    rel_ok(coeff.grad, g["d_coeff"], tol=1e-4, what="d_coeff")
+    gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("dsd."))
+    for n, p in net.named_parameters():
+        ref = g["dsd." + n]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 2e-6 * gmax, (n, err)
+    # reference forward(): coeff @ basis(t)
+    t2, r2 = net(torch.from_numpy(g["coeff"]).to(DEV), torch.tensor(float(g["t_now"]), device=DEV))
+    rel_ok(t2, g["trans_fwd"], tol=1e-4, what="forward translation"); rel_ok(r2, g["rot_fwd"], tol=1e-4, what="fwd rot")
+
+
+@pytest.mark.parametrize("P", [4, 5, 1000, 20000, 120000])
+def test_dist_cuda2(P):
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(P)
+    pts = torch.rand(P, 3, generator=g) * torch.tensor([3.0, 1.0, 0.2])
+    if P >= 1000:
+        pts[:50] = pts[50:100]          # exact duplicates -> zero distances
+    out = distCUDA2(pts.to(DEV))
+    rel_ok(out, KO.dist2_knn3(pts), tol=1e-5, what="dist2")
+
+
+def test_fused_adam_matches_torch():
+    from rodygs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(0)
+    n = 100003
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=1e-2, eps=1e-15)
+    pd, m, v = p.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 5):
+        pt.grad = gr * step
+        opt.step()
+        gd = (gr * step).to(DEV)
+        _lib.check(L.rdg_adam_step(n, pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 1e-2, 0.9, 0.999,
+                                   1e-15, step, _lib.stream_ptr()), "adam")
+    rel_ok(pd, pt.detach(), tol=1e-6, what="adam")
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
