@@ -107,6 +107,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             if shs.dim() != 3 or shs.shape[0] != P or shs.shape[2] != 3:
                 raise RuntimeError("shs must be [P,K,3]")
             M = shs.shape[1]
+        if P == 0:
+            # empty cloud: empty tensors have NULL data pointers, which the C-ABI reads as "not provided";
+            # hand it never-dereferenced placeholders so the normal path renders the background
+            ph = torch.zeros(16, 3, dtype=torch.float32, device=dev)
+            shs, col, cov, sc, ro, M = ph, None, None, ph, ph, 0
+            op = ph if op.numel() == 0 else op
+            m3 = ph
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
         cs = _c_settings(raster_settings, P, M)
         n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -139,6 +146,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     break
                 cap = int(n * 1.25) + 4096
         ctx.raster_settings = raster_settings
+        ctx.empty_cloud = (P == 0)
         ctx.cs = cs
         ctx.capacity = cap
         ctx.num_rendered = n
@@ -150,6 +158,8 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_normal, g_alpha, g_radii, g_extra):
+        if ctx.empty_cloud:
+            return (None,) * 10
         L = _lib.lib()
         m3, shs, col, op, sc, ro, cov, vm, pm, bg, radii, geom, binning, image = ctx.saved_tensors
         dev = m3.device

@@ -88,7 +88,12 @@ def run_pair(sc, deg, bg, cov_grad=True, sh_grad=True, use_colors=False, use_cov
                scales=None if use_cov3d else oi["scales"], rotations=None if use_cov3d else oi["rotations"],
                cov3Ds_precomp=oi.get("cov3Ds_precomp"))
     oout = O.rasterize(oi["means3D"], om2, oi["opacities"], oi["viewmatrix"], st, **okw)
-    (oout[0] * wc).sum().add((oout[1] * wd).sum() * 0.1).add((oout[3] * wa).sum()).backward()
+    ol = (oout[0] * wc).sum().add((oout[1] * wd).sum() * 0.1).add((oout[3] * wa).sum())
+    if ol.requires_grad:          # nothing visible -> the oracle image has no graph at all
+        ol.backward()
+    for t in list(oi.values()) + [om2]:
+        if t.grad is None:
+            t.grad = torch.zeros_like(t)
     return hi, hm2, hout, oi, om2, oout
 
 
