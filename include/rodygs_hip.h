@@ -72,7 +72,9 @@ enum {
     RDG_STAGE_DEFORM_FWD = 7,
     RDG_STAGE_DEFORM_BWD = 8,
     RDG_STAGE_ADAM = 9,
-    RDG_STAGE_COUNT = 10
+    RDG_STAGE_LOSS_FWD = 10,
+    RDG_STAGE_LOSS_BWD = 11,
+    RDG_STAGE_COUNT = 12
 };
 
 int rdg_abi_version(void);
@@ -154,6 +156,18 @@ int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, voi
 /* ---- fused Adam over a flat f32 parameter (used by bench.py's train step) ---------- */
 int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, int32_t step, void* stream);
+
+/* ---- fused photometric loss -------------------------------------------------------------
+ * loss = (1-lambda) mean|img-gt| + lambda (1 - mean SSIM(img, gt)), SSIM as in
+ * /root/reference/src/utils/loss_utils.py:19-100 (11x11 Gaussian window, sigma 1.5, zero padding), the combination
+ * the reference builds from L1Loss + SSIMLoss (/root/reference/src/trainer/losses.py:78-107, weights in
+ * configs/train/train_kubric_mrig.yaml:134-146).  img, gt: [C,H,W] f32.  ws: rdg_loss_ws_bytes() scratch that
+ * must survive until backward.  loss3 receives {loss, l1_mean, ssim_mean}.  grad_loss: device scalar (NULL = 1). */
+size_t rdg_loss_ws_bytes(int32_t C, int32_t H, int32_t W);
+int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float lambda,
+                                 void* ws, float* loss3, void* stream);
+int rdg_photometric_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float lambda,
+                                  const void* ws, const float* grad_loss, float* d_img, void* stream);
 
 /* ---- measurement hooks -----------------------------------------------------------------------------------
  * When enabled, every stage is bracketed by hipEvents recorded on the launch stream.  rdg_stage_time_ms()

@@ -28,7 +28,7 @@ class RdgRasterSettings(C.Structure):
 
 STAGES = {
     "preprocess": 0, "scan_dup": 1, "sort": 2, "ranges": 3, "render_fwd": 4, "render_bwd": 5,
-    "preprocess_bwd": 6, "deform_fwd": 7, "deform_bwd": 8, "adam": 9,
+    "preprocess_bwd": 6, "deform_fwd": 7, "deform_bwd": 8, "adam": 9, "loss_fwd": 10, "loss_bwd": 11,
 }
 
 _vp = C.c_void_p
@@ -52,6 +52,10 @@ _SIGS = {
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int32, _vp]),
+    "rdg_loss_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rdg_photometric_loss_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
+    "rdg_photometric_loss_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp,
+                                                _vp]),
     "rdg_timing_enable": (C.c_int, [C.c_int32]),
     "rdg_timing_reset": (C.c_int, []),
     "rdg_stage_time_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -266,7 +266,8 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f,
                       g9 = 0.f;
                 if (hit) {
-                    T = T / (1.0f - alpha);
+                    const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+                    T = T * inv1ma;
                     const float dch = alpha * T;
                     float dL_dalpha = 0.0f;
                     acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0; lc0 = q2.x;
@@ -279,7 +280,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     dL_dalpha += (q1.z - accd) * dLd; g9 = dch * dLd;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (T_final / (1.0f - alpha)) * tail;
+                    dL_dalpha += (T_final * inv1ma) * tail;
                     const float dL_dG = q1.y * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
@@ -291,15 +292,29 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     g4 = -0.5f * gdy * dy * dL_dG;
                     g5 = G * dL_dalpha;
                 }
-                g0 = rdg_wave_sum_to63(g0); g1 = rdg_wave_sum_to63(g1); g2 = rdg_wave_sum_to63(g2);
-                g3 = rdg_wave_sum_to63(g3); g4 = rdg_wave_sum_to63(g4); g5 = rdg_wave_sum_to63(g5);
-                g6 = rdg_wave_sum_to63(g6); g7 = rdg_wave_sum_to63(g7); g8 = rdg_wave_sum_to63(g8);
-                g9 = rdg_wave_sum_to63(g9);
-                if (lane == 63) {
-                    float* gr = sGrad[j];
-                    atomicAdd(gr + 0, g0); atomicAdd(gr + 1, g1); atomicAdd(gr + 2, g2); atomicAdd(gr + 3, g3);
-                    atomicAdd(gr + 4, g4); atomicAdd(gr + 5, g5); atomicAdd(gr + 6, g6); atomicAdd(gr + 7, g7);
-                    atomicAdd(gr + 8, g8); atomicAdd(gr + 9, g9);
+                // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds, everything ending in
+                // lane 63), fold the VALUE index into the lane index while reducing: xor-1 and xor-2 exchanges halve
+                // the number of live values each (lane&3 then selects the component), two row rotations finish the
+                // 16-lane rows, and the 4 rows are combined by the LDS atomic itself (lanes 0-3 of every row add
+                // their row total to the component they hold).  28 VALU + 3 ds_add instead of 60 DPP + 10 ds_add.
+                {
+                    const bool b0 = lane & 1, b1 = lane & 2;
+                    const float a0 = (b0 ? g1 : g0) + rdg_dpp<0xB1>(b0 ? g0 : g1);   // comp 0 + b0
+                    const float a1 = (b0 ? g3 : g2) + rdg_dpp<0xB1>(b0 ? g2 : g3);   // comp 2 + b0
+                    const float a2 = (b0 ? g5 : g4) + rdg_dpp<0xB1>(b0 ? g4 : g5);   // comp 4 + b0
+                    const float a3 = (b0 ? g7 : g6) + rdg_dpp<0xB1>(b0 ? g6 : g7);   // comp 6 + b0
+                    const float a4 = (b0 ? g9 : g8) + rdg_dpp<0xB1>(b0 ? g8 : g9);   // comp 8 + b0
+                    float s0 = (b1 ? a1 : a0) + rdg_dpp<0x4E>(b1 ? a0 : a1);         // comp (lane & 3)
+                    float s1 = (b1 ? a3 : a2) + rdg_dpp<0x4E>(b1 ? a2 : a3);         // comp 4 + (lane & 3)
+                    float s2 = a4 + rdg_dpp<0x4E>(a4);                               // comp 8 + b0
+                    s0 += rdg_dpp<0x124>(s0); s1 += rdg_dpp<0x124>(s1); s2 += rdg_dpp<0x124>(s2);   // row_ror:4
+                    s0 += rdg_dpp<0x128>(s0); s1 += rdg_dpp<0x128>(s1); s2 += rdg_dpp<0x128>(s2);   // row_ror:8
+                    if ((lane & 12) == 0) {
+                        float* gr = sGrad[j] + (lane & 3);
+                        atomicAdd(gr, s0);
+                        atomicAdd(gr + 4, s1);
+                        if (!b1) atomicAdd(gr + 8, s2);
+                    }
                 }
             }
         }

@@ -7,20 +7,23 @@ Host-side mirror of the reference interface, same names and argument meaning:
   * ``gaussian_deformation``  = the per-Gaussian part of ``DynRoDyGS.get_gaussian_deformation`` (:122-138)
   * ``DeformationField``      = the bookkeeping of ``DynRoDyGS`` around it (birth-time table, cache)
 
-The tiny MLP (68 656 parameters, batch <= T rows) stays in torch, with the 16 heads batched into two bmm's
-instead of the reference's 16-iteration Python loop.  The per-Gaussian contraction -- the only part that scales
-with P -- is the HIP kernel ``rdg_deform_forward/backward`` (csrc/rdg_deform.hip): it never materialises the
-reference's ``table[gaussian_to_time_ind]`` ([P,16,7], 448 MB at P = 1 M).
+The tiny MLP (68 656 parameters, batch <= T+1 rows) stays in torch.  The reference runs its 16 heads as a
+16-iteration Python loop over separate nn.Linear modules (~40 launches forward, ~550 tiny kernels per train step
+with backward and per-parameter optimiser work); here the head weights ARE four stacked parameters
+([16,32,64], [16,32], [16,7,32], [16,7]) driven by two batched matmuls, and state_dict()/load_state_dict()
+translate to and from the reference's per-head key names, so checkpoints interchange.
+The per-Gaussian contraction -- the only part that scales with P -- is the HIP kernel
+``rdg_deform_forward/backward`` (csrc/rdg_deform.hip): it never materialises the reference's
+``table[gaussian_to_time_ind]`` ([P,16,7], 448 MB at P = 1 M).
 """
 from __future__ import annotations
 
-import math
+import re
 from typing import Optional
 
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib
 
@@ -56,6 +59,9 @@ class TimestepEmbedder(nn.Module):
 
 
 class MLPMotionBasis(nn.Module):
+    """One reference head (rodygs_dynamic.py:223-240).  Kept for API parity; MLPBasisNetwork stores its heads
+    stacked and does not instantiate this class."""
+
     def __init__(self, input_dim, output_dim, activation):
         super().__init__()
         self.basis = nn.Sequential(nn.Linear(input_dim, input_dim // 2), activation,
@@ -67,6 +73,10 @@ class MLPMotionBasis(nn.Module):
 
     def forward(self, x):
         return self.basis(x)
+
+
+_HEAD_KEY = re.compile(r"^(.*)basis_xyz\.(\d+)\.basis\.(0|2)\.(weight|bias)$")
+_STACKED = {("0", "weight"): "head_w1", ("0", "bias"): "head_b1", ("2", "weight"): "head_w2", ("2", "bias"): "head_b2"}
 
 
 class MLPBasisNetwork(nn.Module):
@@ -90,19 +100,43 @@ class MLPBasisNetwork(nn.Module):
             if isinstance(module, nn.Linear):
                 nn.init.normal_(module.weight, mean=0, std=1e-2)
                 nn.init.constant_(module.bias, 0)
-        self.basis_xyz = nn.ModuleList(
-            [MLPMotionBasis(netwidth // 2, self.trans_dim + self.rot_dim, self.activation) for _ in range(num_basis)])
+        hin, hmid, hout = netwidth // 2, netwidth // 4, self.trans_dim + self.rot_dim
+        # the 16 heads, stacked: reference init N(0, 1e-2) weights, zero biases (rodygs_dynamic.py:234-237)
+        self.head_w1 = nn.Parameter(torch.randn(num_basis, hmid, hin) * 1e-2)
+        self.head_b1 = nn.Parameter(torch.zeros(num_basis, hmid))
+        self.head_w2 = nn.Parameter(torch.randn(num_basis, hout, hmid) * 1e-2)
+        self.head_b2 = nn.Parameter(torch.zeros(num_basis, hout))
+        self._register_state_dict_hook(MLPBasisNetwork._to_reference_keys)
+        self._register_load_state_dict_pre_hook(self._from_reference_keys)
 
-    # -- the 16 heads as two batched matmuls --------------------------------------------------------------------
+    # -- checkpoint interchange with the reference's per-head modules ---------------------------------------------
+    @staticmethod
+    def _to_reference_keys(module, state_dict, prefix, local_metadata):
+        for (layer, kind), name in _STACKED.items():
+            t = state_dict.pop(prefix + name)
+            for b in range(t.shape[0]):
+                state_dict[f"{prefix}basis_xyz.{b}.basis.{layer}.{kind}"] = t[b]
+        return state_dict
+
+    def _from_reference_keys(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                             error_msgs):
+        found = {}
+        for k in list(state_dict.keys()):
+            m = _HEAD_KEY.match(k)
+            if m and m.group(1) == prefix:
+                found.setdefault(_STACKED[(m.group(3), m.group(4))], {})[int(m.group(2))] = state_dict.pop(k)
+        for name, parts in found.items():
+            if sorted(parts) != list(range(self.num_basis)):
+                error_msgs.append(f"{prefix}{name}: expected {self.num_basis} heads, found {sorted(parts)}")
+                continue
+            state_dict[prefix + name] = torch.stack([parts[b] for b in range(self.num_basis)])
+
+    # -- forward ---------------------------------------------------------------------------------------------------
     def _heads(self, h: torch.Tensor) -> torch.Tensor:
-        """h [N, netwidth/2] -> [N, num_basis, 7]."""
-        W1 = torch.stack([m.basis[0].weight for m in self.basis_xyz])   # [B, 32, 64]
-        b1 = torch.stack([m.basis[0].bias for m in self.basis_xyz])     # [B, 32]
-        W2 = torch.stack([m.basis[2].weight for m in self.basis_xyz])   # [B, 7, 32]
-        b2 = torch.stack([m.basis[2].bias for m in self.basis_xyz])     # [B, 7]
-        u = torch.einsum("nk,bjk->bnj", h, W1) + b1.unsqueeze(1)
-        u = self.activation(u)
-        o = torch.einsum("bnj,boj->bno", u, W2) + b2.unsqueeze(1)       # [B, N, 7]
+        """h [N, netwidth/2] -> [N, num_basis, 7] with two batched matmuls."""
+        hb = h.unsqueeze(0).expand(self.num_basis, -1, -1)
+        u = self.activation(torch.baddbmm(self.head_b1.unsqueeze(1), hb, self.head_w1.transpose(1, 2)))
+        o = torch.baddbmm(self.head_b2.unsqueeze(1), u, self.head_w2.transpose(1, 2))   # [B, N, 7]
         return o.transpose(0, 1)
 
     def motion_basis(self, t_emb: torch.Tensor) -> torch.Tensor:
@@ -199,6 +233,8 @@ class DeformationField(nn.Module):
         self.temporal_motion_table = None
         self.sync_gaussian_to_time_ind()
         self._time_batch_embeddings = self._deform_network.batch_embedding(self.real_times)
+        if self._time_batch_embeddings.dim() == 1:
+            self._time_batch_embeddings = self._time_batch_embeddings.unsqueeze(0)
 
     @staticmethod
     def timetokey(time) -> int:
@@ -213,18 +249,25 @@ class DeformationField(nn.Module):
 
     def get_total_motion_table(self):
         if self.temporal_motion_table is None:
-            self.temporal_motion_table = self._deform_network.batch_inference(self._time_batch_embeddings).squeeze()
-            if self.temporal_motion_table.dim() == 2:
-                self.temporal_motion_table = self.temporal_motion_table.unsqueeze(0)
+            self.temporal_motion_table = self._deform_network.batch_inference(self._time_batch_embeddings)
         return self.temporal_motion_table
 
     def clean_motion_table(self):
         self.temporal_motion_table = None
 
-    def get_gaussian_deformation(self, time):
+    def motion_at(self, time):
+        """(basis_t [B,7], table [Tu,B,7] or None) from ONE pass of the MLP over the Tu+1 time rows."""
         net = self._deform_network
-        t_emb = net.t_embedder(torch.as_tensor(time, dtype=torch.float32).reshape(()))
-        basis_t = net.motion_basis(t_emb.reshape(1, -1)).squeeze(0)
-        table = self.get_total_motion_table() if self.inverse_motion else None
+        t_emb = net.t_embedder(torch.as_tensor(time, dtype=torch.float32).reshape(())).reshape(1, -1)
+        if not self.inverse_motion:
+            return net.motion_basis(t_emb).squeeze(0), None
+        if self.temporal_motion_table is not None:
+            return net.motion_basis(t_emb).squeeze(0), self.temporal_motion_table
+        allb = net.motion_basis(torch.cat([self._time_batch_embeddings, t_emb], dim=0))
+        self.temporal_motion_table = allb[:-1]
+        return allb[-1], self.temporal_motion_table
+
+    def get_gaussian_deformation(self, time):
+        basis_t, table = self.motion_at(time)
         return gaussian_deformation(self._motion_coeff, self.gaussian_to_time_ind, basis_t, table,
                                     self.spatial_lr_scale)

@@ -55,3 +55,47 @@ def photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float 
     """(1 - lambda) L1 + lambda (1 - SSIM): the 3DGS photometric loss RoDyGS uses for both sub-steps
     (weights in /root/reference/configs/train/train_kubric_mrig.yaml)."""
     return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+class _FusedPhotometric(torch.autograd.Function):
+    """HIP fused (1-lambda) L1 + lambda (1-SSIM): csrc/rdg_loss.hip (rdg_photometric_loss_forward/backward)."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        from . import _lib
+        L = _lib.lib()
+        if not image.is_cuda:
+            raise RuntimeError("rodygs_amd.fused_photometric_loss: tensors must be on the GPU (no CPU fallback exists)")
+        img = image.detach().to(torch.float32).contiguous()
+        g = gt.detach().to(torch.float32).contiguous()
+        if img.dim() != 3 or img.shape != g.shape:
+            raise RuntimeError("fused_photometric_loss expects image and gt of the same [C,H,W] shape")
+        C_, H, W = img.shape
+        with torch.cuda.device(img.device):
+            ws = torch.empty(L.rdg_loss_ws_bytes(C_, H, W), dtype=torch.uint8, device=img.device)
+            out = torch.empty(3, dtype=torch.float32, device=img.device)
+            _lib.check(L.rdg_photometric_loss_forward(C_, H, W, img.data_ptr(), g.data_ptr(), float(lambda_dssim),
+                                                      ws.data_ptr(), out.data_ptr(), _lib.stream_ptr()),
+                       "rdg_photometric_loss_forward")
+        ctx.save_for_backward(img, g, ws)
+        ctx.lam = float(lambda_dssim)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        from . import _lib
+        L = _lib.lib()
+        img, g, ws = ctx.saved_tensors
+        C_, H, W = img.shape
+        d_img = torch.empty_like(img)
+        gl = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(img.device):
+            _lib.check(L.rdg_photometric_loss_backward(C_, H, W, img.data_ptr(), g.data_ptr(), ctx.lam, ws.data_ptr(),
+                                                       gl.data_ptr(), d_img.data_ptr(), _lib.stream_ptr()),
+                       "rdg_photometric_loss_backward")
+        return d_img, None, None
+
+
+def fused_photometric_loss(image: torch.Tensor, gt: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+    """Same value and image-gradient as ``photometric_loss`` (torch), computed by two HIP kernels."""
+    return _FusedPhotometric.apply(image, gt, lambda_dssim)

@@ -111,7 +111,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # empty cloud: empty tensors have NULL data pointers, which the C-ABI reads as "not provided";
             # hand it never-dereferenced placeholders so the normal path renders the background
             ph = torch.zeros(16, 3, dtype=torch.float32, device=dev)
-            shs, col, cov, sc, ro, M = ph, None, None, ph, ph, 0
+            shs, col, cov, sc, ro, M = ph, None, None, ph, ph, 16
             op = ph if op.numel() == 0 else op
             m3 = ph
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import _lib
 from .deform import MLPBasisNetwork, gaussian_deformation
 from .dp import FlatParams, allreduce_sum_, frame_for
-from .losses import photometric_loss
+from .losses import fused_photometric_loss
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -96,6 +96,7 @@ class DynamicScene:
         self.net = MLPBasisNetwork(128, 16, 26, False).to(dev)
         self.times = torch.arange(num_frames, dtype=torch.float32) / num_frames
         self.time_batch_embeddings = self.net.batch_embedding(self.times.to(dev))
+        self.frame_embeddings = self.time_batch_embeddings  # frame i is rendered at time i/T (same rows)
         # cameras: orbit of +-orbit_deg about the scene centroid (z = 11 on the optical axis)
         cz = 11.0
         qs, ts = [], []
@@ -113,7 +114,7 @@ class DynamicScene:
         self.small_opt = torch.optim.Adam([
             {"params": list(self.net.parameters()), "lr": 0.0016},
             {"params": [self.cam_q], "lr": 1e-5},
-            {"params": [self.cam_t], "lr": 1e-6}], eps=1e-15)
+            {"params": [self.cam_t], "lr": 1e-6}], eps=1e-15, fused=True)
         self.gt = {}
 
     # ---- pieces of the step ------------------------------------------------------------------------------------
@@ -124,9 +125,9 @@ class DynamicScene:
     def gaussians_at(self, frame: int):
         """DynRoDyGS.get_gaussian_deformation + activations for the frame's time."""
         fp, net = self.fp, self.net
-        t = self.times[frame].to(self.device)
-        basis_t = net.motion_basis(net.t_embedder(t).reshape(1, -1)).squeeze(0)
-        table = net.batch_inference(self.time_batch_embeddings)
+        # ONE pass of the MLP over the T birth-time rows + the frame's own time (row T)
+        allb = net.motion_basis(torch.cat([self.time_batch_embeddings, self.frame_embeddings[frame:frame + 1]], dim=0))
+        table, basis_t = allb[:-1], allb[-1]
         dxyz, drot = gaussian_deformation(fp["motion_coeff"], self.time_ind, basis_t, table, self.spatial_lr_scale)
         xyz = fp["xyz"] + dxyz
         rot = F.normalize(fp["rotation"]) + drot
@@ -158,9 +159,9 @@ class DynamicScene:
         perm = perm if perm is not None else list(self.gt.keys())
         frame = frame_for(step, rank, world, perm)
         self.fp.zero_grad()
-        self.small_opt.zero_grad(set_to_none=False)
+        self.small_opt.zero_grad(set_to_none=True)
         out, _ = self.render(frame)
-        loss = photometric_loss(out[0], self.gt[frame], 0.2)
+        loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
         if world > 1:
             small = [p.grad for p in self.net.parameters() if p.grad is not None]
