@@ -367,8 +367,13 @@ def test_deformation_field_matches_reference_golden_on_gpu():
     ((tr * torch.from_numpy(g["wx"]).to(DEV)).sum() + (ro * torch.from_numpy(g["wr"]).to(DEV)).sum()).backward()
     rel_ok(coeff.grad, g["d_coeff"], tol=1e-4, what="d_coeff")
     gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("dsd."))
+    stacked = {"head_w1": ("0", "weight"), "head_b1": ("0", "bias"), "head_w2": ("2", "weight"), "head_b2": ("2", "bias")}
     for n, p in net.named_parameters():
-        ref = g["dsd." + n]
+        if n in stacked:   # our heads are stacked parameters; the reference golden is keyed per head
+            layer, kind = stacked[n]
+            ref = np.stack([g[f"dsd.basis_xyz.{b}.basis.{layer}.{kind}"] for b in range(16)])
+        else:
+            ref = g["dsd." + n]
         err = np.abs(p.grad.cpu().numpy() - ref).max()
         assert err <= 2e-4 * np.abs(ref).max() + 2e-6 * gmax, (n, err)
     # reference forward(): coeff @ basis(t)
