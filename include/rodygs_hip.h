@@ -143,10 +143,14 @@ int rdg_sort_pairs(uint64_t* keys, uint32_t* vals, int64_t capacity, const int32
 int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                        const float* basis_t, const float* table, float spatial_scale, float* out_xyz,
                        float* out_rot, void* stream);
-/* d_coeff [P,B]; d_basis_t [B,7] and d_table [Tu,B,7] are zeroed then accumulated by the library.           */
+/* d_coeff [P,B]; d_basis_t [B,7] and d_table [Tu,B,7] are zeroed then accumulated by the library.
+ * order: optional int32 [P] permutation that sorts the Gaussians by time_ind (it changes only when time_ind
+ * does, so the caller caches it).  With it (and B == 16) the two dB reductions run on the matrix cores
+ * (v_mfma_f32_16x16x4_f32, one per 4 Gaussians); NULL selects the order-free LDS-atomic form.              */
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
-                        const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table, void* stream);
+                        const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table,
+                        const int32_t* order, void* stream);
 
 /* ---- simple_knn ------------------------------------------------------------------------------------------ */
 size_t rdg_knn_tmp_bytes(int32_t P);
@@ -168,6 +172,30 @@ int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* i
                                  void* ws, float* loss3, void* stream);
 int rdg_photometric_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float lambda,
                                   const void* ws, const float* grad_loss, float* d_img, void* stream);
+
+/* ---- parameter activations and pose -> viewmatrix ---------------------------------
+ * rdg_activate_*: StaticRoDyGS.get_xyz/get_scaling/get_rotation/get_opacity/get_features
+ * (/root/reference/src/model/rodygs_static.py:82-105) + the deformation add and concat of get_GS_properties
+ * (/root/reference/src/trainer/rodygs.py:68-113):
+ *   means3D = xyz + dxyz, scales = exp(scaling), rots = normalize(rotation) + drot, opac = sigmoid(opacity),
+ *   shs[P,K,3] = cat(f_dc[P,1,3], f_rest[P,K-1,3]).   dxyz / drot may be NULL.
+ * Backward OVERWRITES d_* (so they can point straight into a flat gradient bucket); g_* may be NULL (= zero).
+ * d(dxyz) = g_means3D and d(drot) = g_rots are identities and are not produced.                               */
+int rdg_activate_forward(int32_t P, int32_t K, const float* xyz, const float* dxyz, const float* scaling,
+                         const float* rotation, const float* drot, const float* opacity, const float* f_dc,
+                         const float* f_rest, float* out_means3D, float* out_scales, float* out_rots, float* out_opac,
+                         float* out_shs, void* stream);
+int rdg_activate_backward(int32_t P, int32_t K, const float* scaling, const float* rotation, const float* opacity,
+                          const float* g_means3D, const float* g_scales, const float* g_rots, const float* g_opac,
+                          const float* g_shs, float* d_xyz, float* d_scaling, float* d_rotation, float* d_opacity,
+                          float* d_fdc, float* d_frest, void* stream);
+/* FixedCameraTorch.world_view_transform (/root/reference/src/data/utils.py:161-170) for row `frame` of the
+ * learnable cam_q[T,4] (r,i,j,k; normalised by 2/|q|^2 as graphic_utils.py:76-102) and cam_t[T,3] tables;
+ * out_view16 = W2C^T (glm storage).  Backward writes full [T,4] / [T,3] gradients (zero outside `frame`).     */
+int rdg_pose_view_forward(int32_t T, int32_t frame, const float* cam_q, const float* cam_t, float* out_view16,
+                          void* stream);
+int rdg_pose_view_backward(int32_t T, int32_t frame, const float* cam_q, const float* cam_t, const float* g_view16,
+                           float* d_q, float* d_t, void* stream);
 
 /* ---- measurement hooks -----------------------------------------------------------------------------------
  * When enabled, every stage is bracketed by hipEvents recorded on the launch stream.  rdg_stage_time_ms()

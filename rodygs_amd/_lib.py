@@ -48,7 +48,7 @@ _SIGS = {
     "rdg_bin_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 8),
     "rdg_sort_pairs": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int32, _vp, _vp]),
     "rdg_deform_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
-    "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 6),
+    "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 7),
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int32, _vp]),
@@ -56,6 +56,10 @@ _SIGS = {
     "rdg_photometric_loss_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "rdg_photometric_loss_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp,
                                                 _vp]),
+    "rdg_activate_forward": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 14),
+    "rdg_activate_backward": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 15),
+    "rdg_pose_view_forward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    "rdg_pose_view_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdg_timing_enable": (C.c_int, [C.c_int32]),
     "rdg_timing_reset": (C.c_int, []),
     "rdg_stage_time_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

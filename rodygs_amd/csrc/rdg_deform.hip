@@ -56,7 +56,7 @@ rdg_deform_fwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
     }
 }
 
-template <bool USE_LDS>
+template <bool USE_LDS, bool ACC>
 __global__ void __launch_bounds__(1024)
 rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, const long long* __restrict__ time_ind,
                       const float* __restrict__ basis_t, const float* __restrict__ table, float scale,
@@ -67,13 +67,13 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
     const int stride = row + 1;
     const int Tu_eff = table ? Tu : 1;
     float* sDiff = smem;                                  // [Tu_eff][stride]      (LDS path)
-    float* sAcc = smem + (size_t)Tu_eff * stride;         // [Tu_eff][stride]      (LDS path)
+    float* sAcc = smem + (size_t)Tu_eff * stride;         // [Tu_eff][stride]      (LDS path, ACC only)
     float* sBt = smem;                                    // [row]                 (global path)
     if (USE_LDS) {
         for (int k = threadIdx.x; k < Tu_eff * row; k += blockDim.x) {
             const int u = k / row, c = k - u * row;
             sDiff[u * stride + c] = basis_t[c] - (table ? table[(size_t)u * row + c] : 0.0f);
-            sAcc[u * stride + c] = 0.0f;
+            if (ACC) sAcc[u * stride + c] = 0.0f;
         }
     } else {
         for (int k = threadIdx.x; k < row; k += blockDim.x) sBt[k] = basis_t[k];
@@ -96,7 +96,8 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
                 else dv = sBt[b * RDG_DEF_K + k] - (table ? table[(size_t)u * row + b * RDG_DEF_K + k] : 0.0f);
                 s += g[k] * dv;
                 const float v = cb * g[k];
-                if (USE_LDS) {
+                if (!ACC) {
+                } else if (USE_LDS) {
                     atomicAdd(&sAcc[u * stride + b * RDG_DEF_K + k], v);
                 } else {
                     atomicAdd(&d_basis_t[b * RDG_DEF_K + k], v);
@@ -106,7 +107,7 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
             dc[b] = s;
         }
     }
-    if (USE_LDS) {
+    if (USE_LDS && ACC) {
         __syncthreads();
         // dB_table[u] -= acc[u];  dB(t) += sum_u acc[u]
         for (int k = threadIdx.x; k < Tu_eff * row; k += blockDim.x) {
@@ -120,6 +121,94 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
             if (s != 0.0f) atomicAdd(&d_basis_t[c], s);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dB accumulation on the matrix cores (the one GEMM-shaped piece of this path: K = number of Gaussians).
+// acc[u] = sum_{birth(p)=u} c_p^T g_p  is a [16 x n_u] x [n_u x 7] product per birth index u.  Gaussians are
+// visited in BIRTH-SORTED order (`order`, a permutation the host caches: birth indices only change at
+// densification), so a wave's run of Gaussians shares one u and the wave keeps a 16x16 f32 accumulator in
+// registers: one v_mfma_f32_16x16x4_f32 per 4 Gaussians (A = coefficients [16 x 4], B = gradients [4 x 16],
+// columns 7..15 zero), flushed with 112 float atomics only when u changes (about once per wave).
+// f32-input MFMA is bit-for-bit a k-ordered fmaf chain, so numerics equal the VALU form.
+// ---------------------------------------------------------------------------------------------------------
+typedef float rdg_f32x4 __attribute__((ext_vector_type(4)));
+#define RDG_DEF_G 8  // groups of 4 Gaussians gathered per loop iteration
+
+__device__ __forceinline__ void rdg_deform_flush(rdg_f32x4 acc, int u, int lane, bool has_table,
+                                                 float* __restrict__ d_basis_t, float* __restrict__ d_table) {
+    const int k = lane & 15;
+    if (u < 0 || k >= RDG_DEF_K) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = (lane >> 4) * 4 + r;
+        const float v = acc[r];
+        if (v != 0.0f) {
+            atomicAdd(&d_basis_t[b * RDG_DEF_K + k], v);
+            if (has_table) atomicAdd(&d_table[(size_t)u * (16 * RDG_DEF_K) + b * RDG_DEF_K + k], -v);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const long long* __restrict__ time_ind,
+                               const int* __restrict__ order, const float* __restrict__ g_xyz,
+                               const float* __restrict__ g_rot, float scale, int has_table,
+                               float* __restrict__ d_basis_t, float* __restrict__ d_table) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    int per = (P + nwaves - 1) / nwaves;
+    per = (per + 4 * RDG_DEF_G - 1) / (4 * RDG_DEF_G) * (4 * RDG_DEF_G);
+    const int beg = min(P, wave * per), end = min(P, beg + per);
+    const int slot = lane >> 4, j = lane & 15;
+    rdg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int cur_u = -1;
+    const int jx = min(j, 2), jr = min(max(j - 3, 0), 3);
+    const float wx = j < 3 ? scale : 0.0f, wr = (j >= 3 && j < RDG_DEF_K) ? 1.0f : 0.0f;
+    for (int base = beg; base < end; base += 4 * RDG_DEF_G) {
+        // RDG_DEF_G groups of 4 Gaussians.  Branch-free gathers (indices clamped, values masked afterwards) so
+        // that all first-level loads (order[]) and then all second-level loads are in flight together.
+        int p4[RDG_DEF_G], u4[RDG_DEF_G]; float a4[RDG_DEF_G], g4[RDG_DEF_G]; bool v4[RDG_DEF_G];
+#pragma unroll
+        for (int q = 0; q < RDG_DEF_G; ++q) {
+            const int idx = base + 4 * q + slot;
+            v4[q] = idx < end;
+            p4[q] = order[min(idx, end - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < RDG_DEF_G; ++q) {
+            const size_t p = (size_t)p4[q];
+            const long long tu = time_ind[p];
+            const float av = coeff[p * 16 + j];
+            const float gx = g_xyz[p * 3 + jx], gr = g_rot[p * 4 + jr];
+            u4[q] = v4[q] ? (has_table ? (int)tu : 0) : -1;
+            a4[q] = v4[q] ? av : 0.0f;
+            g4[q] = v4[q] ? (gx * wx + gr * wr) : 0.0f;   // arithmetic blend: keeps both loads unconditional
+        }
+#pragma unroll
+        for (int q = 0; q < RDG_DEF_G; ++q) {
+            const int u = u4[q];
+            const float a = a4[q], gv = g4[q];
+            if (__ballot(v4[q] && u != cur_u) == 0ull) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gv, acc, 0, 0, 0);
+            } else {
+                // a birth-index boundary inside this group of 4 (or the first group): one slot at a time
+#pragma unroll 1
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int us = __builtin_amdgcn_readlane(u, sl * 16);
+                    if (us < 0) continue;
+                    if (us != cur_u) {
+                        rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table);
+                        acc = rdg_f32x4{0.f, 0.f, 0.f, 0.f};
+                        cur_u = us;
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, slot == sl ? gv : 0.0f, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table);
 }
 
 __global__ void __launch_bounds__(256)
@@ -180,7 +269,8 @@ int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, con
 
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
-                        const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table, void* stream) {
+                        const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table, const int32_t* order,
+                        void* stream) {
     if (B <= 0 || B > RDG_DEF_MAXB * 4) return rdg_set_error("deform: bad basis count %d", B);
     hipStream_t st = (hipStream_t)stream;
     const int row = B * RDG_DEF_K;
@@ -190,23 +280,31 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
     if (e != hipSuccess) return rdg_check_hip(e, "deform_bwd memset");
     if (P > 0) {
         const int Tu_eff = table ? Tu : 1;
-        const size_t lds = 2 * (size_t)Tu_eff * (row + 1) * sizeof(float);
+        const bool mfma = order != nullptr && B == 16;   // birth-sorted order given: dB on the matrix cores
+        const size_t lds = (mfma ? 1 : 2) * (size_t)Tu_eff * (row + 1) * sizeof(float);
         const int threads = 1024;
         int blocks = (P + threads - 1) / threads;
-        if (blocks > 256) blocks = 256;
+        if (blocks > (mfma ? 512 : 256)) blocks = mfma ? 512 : 256;
+#define RDG_DEF_BWD(USE, ACC, LDSB)                                                                              \
+        hipLaunchKernelGGL((rdg_deform_bwd_kernel<USE, ACC>), dim3(blocks), dim3(threads), LDSB, st, P, B, Tu, coeff, \
+                           (const long long*)time_ind, basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff,      \
+                           d_basis_t, d_table)
         if (lds <= 128 * 1024) {
             if (lds > 64 * 1024) {
-                hipError_t ea = hipFuncSetAttribute((const void*)rdg_deform_bwd_kernel<true>,
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t ea = mfma ? hipFuncSetAttribute((const void*)rdg_deform_bwd_kernel<true, false>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                     : hipFuncSetAttribute((const void*)rdg_deform_bwd_kernel<true, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (ea != hipSuccess) return rdg_check_hip(ea, "deform_bwd LDS attribute");
             }
-            hipLaunchKernelGGL(rdg_deform_bwd_kernel<true>, dim3(blocks), dim3(threads), lds, st, P, B, Tu, coeff,
-                               (const long long*)time_ind, basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff,
-                               d_basis_t, d_table);
+            if (mfma) RDG_DEF_BWD(true, false, lds); else RDG_DEF_BWD(true, true, lds);
         } else {
-            hipLaunchKernelGGL(rdg_deform_bwd_kernel<false>, dim3(blocks), dim3(threads), (size_t)row * 4, st, P, B, Tu,
-                               coeff, (const long long*)time_ind, basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff,
-                               d_basis_t, d_table);
+            if (mfma) RDG_DEF_BWD(false, false, (size_t)row * 4); else RDG_DEF_BWD(false, true, (size_t)row * 4);
+        }
+        if (mfma) {
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(2048), dim3(256), 0, st, P, coeff,
+                               (const long long*)time_ind, (const int*)order, g_xyz, g_rot, spatial_scale,
+                               table ? 1 : 0, d_basis_t, d_table);
         }
     }
     rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);

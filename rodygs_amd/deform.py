@@ -162,6 +162,31 @@ class MLPBasisNetwork(nn.Module):
         return gaussian_deformation(c, ind, basis, None, 1.0)
 
 
+_ORDER_CACHE = {}
+
+
+def _birth_order(time_ind: torch.Tensor) -> torch.Tensor:
+    """int32 permutation sorting the Gaussians by birth index; cached until time_ind changes (it only does at
+    densification), so the sort is not part of the step."""
+    key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device))
+    o = _ORDER_CACHE.get(key)
+    if o is None:
+        if len(_ORDER_CACHE) > 8:
+            _ORDER_CACHE.clear()
+        o = torch.argsort(time_ind, stable=True).to(torch.int32).contiguous()
+        _ORDER_CACHE[key] = o
+    return o
+
+
+def _identity_order(P: int, dev) -> torch.Tensor:
+    key = ("id", P, str(dev))
+    o = _ORDER_CACHE.get(key)
+    if o is None:
+        o = torch.arange(P, dtype=torch.int32, device=dev)
+        _ORDER_CACHE[key] = o
+    return o
+
+
 class _DeformFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, coeff, time_ind, basis_t, table, scale):
@@ -199,7 +224,9 @@ class _DeformFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.rdg_deform_backward(P, B, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bt), _lib.ptr(tb),
                                              ctx.scale, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(d_c),
-                                             _lib.ptr(d_bt), _lib.ptr(d_tb), _lib.stream_ptr()),
+                                             _lib.ptr(d_bt), _lib.ptr(d_tb), _lib.ptr(_birth_order(ti) if tb is not None
+                                                                                      else _identity_order(P, dev)),
+                                             _lib.stream_ptr()),
                        "rdg_deform_backward")
         return d_c, None, d_bt, d_tb, None
 

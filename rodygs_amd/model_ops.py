@@ -1,0 +1,118 @@
+"""Fused per-Gaussian glue between raw parameters and the rasterizer (csrc/rdg_model.hip).
+
+* ``activate_gaussians`` = the reference's model getters + the deformation add + the feature concat
+  (/root/reference/src/model/rodygs_static.py:82-105, /root/reference/src/trainer/rodygs.py:68-113) in two HIP
+  launches forward and two backward, instead of ~25 elementwise framework kernels and a cat.
+* ``pose_view_matrix`` = ``FixedCameraTorch.world_view_transform(...).transpose(0, 1)``
+  (/root/reference/src/data/utils.py:161-170; the transpose is the "glm storage" of renderer.py:97-99) for one
+  frame of the learnable pose tables, one launch each way instead of ~130 scalar-tensor kernels.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+
+
+class _Activate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest, sinks):
+        L = _lib.lib()
+        if not xyz.is_cuda:
+            raise RuntimeError("rodygs_amd.activate_gaussians: tensors must be on the GPU (no CPU fallback exists)")
+        dev = xyz.device
+        P = xyz.shape[0]
+        K = 1 + f_rest.shape[1]
+        c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()   # noqa: E731
+        xyz_, dxyz_, sc_, ro_, drot_, op_, dc_, fr_ = map(c, (xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest))
+        f32 = dict(dtype=torch.float32, device=dev)
+        means3D = torch.empty(P, 3, **f32)
+        scales = torch.empty(P, 3, **f32)
+        rots = torch.empty(P, 4, **f32)
+        opac = torch.empty(P, 1, **f32)
+        shs = torch.empty(P, K, 3, **f32)
+        with torch.cuda.device(dev):
+            _lib.check(L.rdg_activate_forward(P, K, _lib.ptr(xyz_), _lib.ptr(dxyz_), _lib.ptr(sc_), _lib.ptr(ro_),
+                                              _lib.ptr(drot_), _lib.ptr(op_), _lib.ptr(dc_), _lib.ptr(fr_),
+                                              _lib.ptr(means3D), _lib.ptr(scales), _lib.ptr(rots), _lib.ptr(opac),
+                                              _lib.ptr(shs), _lib.stream_ptr()), "rdg_activate_forward")
+        ctx.save_for_backward(sc_, ro_, op_)
+        ctx.sinks = sinks
+        ctx.shapes = (xyz.shape, scaling.shape, rotation.shape, opacity.shape, f_dc.shape, f_rest.shape)
+        ctx.has_d = (dxyz is not None, drot is not None)
+        ctx.K = K
+        return means3D, scales, rots, opac, shs
+
+    @staticmethod
+    def backward(ctx, g_m, g_s, g_r, g_o, g_sh):
+        L = _lib.lib()
+        sc_, ro_, op_ = ctx.saved_tensors
+        dev = sc_.device
+        P = sc_.shape[0]
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()   # noqa: E731
+        g_m, g_s, g_r, g_o, g_sh = map(c, (g_m, g_s, g_r, g_o, g_sh))
+        sinks = ctx.sinks
+        names = ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")
+        if sinks is None:
+            outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
+        else:
+            outs = [sinks[n] for n in names]
+        with torch.cuda.device(dev):
+            _lib.check(L.rdg_activate_backward(P, ctx.K, _lib.ptr(sc_), _lib.ptr(ro_), _lib.ptr(op_), _lib.ptr(g_m),
+                                               _lib.ptr(g_s), _lib.ptr(g_r), _lib.ptr(g_o), _lib.ptr(g_sh),
+                                               *[_lib.ptr(o) for o in outs], _lib.stream_ptr()),
+                       "rdg_activate_backward")
+        d_dxyz = g_m if ctx.has_d[0] else None
+        d_drot = g_r if ctx.has_d[1] else None
+        if sinks is None:
+            return outs[0], d_dxyz, outs[1], outs[2], d_drot, outs[3], outs[4], outs[5], None
+        return None, d_dxyz, None, None, d_drot, None, None, None, None
+
+
+def activate_gaussians(xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest,
+                       grad_sinks: Optional[Dict[str, torch.Tensor]] = None):
+    """(means3D, scales, rotations, opacities, shs) ready for the rasterizer.
+
+    With ``grad_sinks`` (name -> tensor for xyz, scaling, rotation, opacity, f_dc, f_rest) the backward pass
+    OVERWRITES those tensors with the parameter gradients instead of returning them through autograd -- used to
+    write straight into the flat gradient bucket of ``rodygs_amd.dp.FlatParams`` (no AccumulateGrad copies)."""
+    return _Activate.apply(xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest, grad_sinks)
+
+
+class _PoseView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cam_q, cam_t, frame):
+        L = _lib.lib()
+        if not cam_q.is_cuda:
+            raise RuntimeError("rodygs_amd.pose_view_matrix: tensors must be on the GPU (no CPU fallback exists)")
+        q = cam_q.detach().to(torch.float32).contiguous()
+        t = cam_t.detach().to(torch.float32).contiguous()
+        T = q.shape[0]
+        view = torch.empty(4, 4, dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(L.rdg_pose_view_forward(T, int(frame), _lib.ptr(q), _lib.ptr(t), _lib.ptr(view),
+                                               _lib.stream_ptr()), "rdg_pose_view_forward")
+        ctx.save_for_backward(q, t)
+        ctx.frame = int(frame)
+        return view
+
+    @staticmethod
+    def backward(ctx, g_view):
+        L = _lib.lib()
+        q, t = ctx.saved_tensors
+        T = q.shape[0]
+        g = g_view.to(torch.float32).contiguous()
+        d_q = torch.empty_like(q)
+        d_t = torch.empty_like(t)
+        with torch.cuda.device(q.device):
+            _lib.check(L.rdg_pose_view_backward(T, ctx.frame, _lib.ptr(q), _lib.ptr(t), _lib.ptr(g), _lib.ptr(d_q),
+                                                _lib.ptr(d_t), _lib.stream_ptr()), "rdg_pose_view_backward")
+        return d_q, d_t, None
+
+
+def pose_view_matrix(cam_q: torch.Tensor, cam_t: torch.Tensor, frame: int) -> torch.Tensor:
+    """W2C^T (glm storage, what the rasterizer takes as ``viewmatrix``) of frame ``frame`` from the learnable
+    camera-to-world quaternions cam_q[T,4] (r,i,j,k) and translations cam_t[T,3]."""
+    return _PoseView.apply(cam_q, cam_t, frame)

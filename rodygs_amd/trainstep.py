@@ -20,6 +20,7 @@ from . import _lib
 from .deform import MLPBasisNetwork, gaussian_deformation
 from .dp import FlatParams, allreduce_sum_, frame_for
 from .losses import fused_photometric_loss
+from .model_ops import activate_gaussians, pose_view_matrix
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -129,14 +130,16 @@ class DynamicScene:
         allb = net.motion_basis(torch.cat([self.time_batch_embeddings, self.frame_embeddings[frame:frame + 1]], dim=0))
         table, basis_t = allb[:-1], allb[-1]
         dxyz, drot = gaussian_deformation(fp["motion_coeff"], self.time_ind, basis_t, table, self.spatial_lr_scale)
-        xyz = fp["xyz"] + dxyz
-        rot = F.normalize(fp["rotation"]) + drot
-        return (xyz, torch.sigmoid(fp["opacity"]), torch.exp(fp["scaling"]), rot,
-                torch.cat((fp["f_dc"], fp["f_rest"]), dim=1))
+        # activations + deformation add + feature concat: 2 HIP launches; the parameter gradients are written by
+        # the backward kernel straight into the flat gradient bucket (no AccumulateGrad copies)
+        sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")}
+        xyz, scaling, rot, opacity, feats = activate_gaussians(fp["xyz"], dxyz, fp["scaling"], fp["rotation"], drot,
+                                                               fp["opacity"], fp["f_dc"], fp["f_rest"], grad_sinks=sinks)
+        return xyz, opacity, scaling, rot, feats
 
     def render(self, frame: int):
         xyz, opacity, scaling, rot, feats = self.gaussians_at(frame)
-        vm = world_view_transform(self.cam_q[frame], self.cam_t[frame]).transpose(0, 1)
+        vm = pose_view_matrix(self.cam_q, self.cam_t, frame)
         m2 = torch.zeros_like(xyz, requires_grad=True)
         out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
                                                   rotations=rot, viewmatrix=vm)
@@ -147,7 +150,7 @@ class DynamicScene:
         dev = self.device
         with torch.no_grad():
             for f in frames:
-                vm = world_view_transform(self.cam_q[f], self.cam_t[f]).transpose(0, 1).contiguous()
+                vm = pose_view_matrix(self.cam_q, self.cam_t, int(f))
                 z = torch.zeros_like(target_scene["means3D"])
                 out = GaussianRasterizer(self.settings())(
                     means3D=target_scene["means3D"].to(dev), means2D=z.to(dev), shs=target_scene["shs"].to(dev),
@@ -158,7 +161,9 @@ class DynamicScene:
     def train_step(self, step: int, rank: int = 0, world: int = 1, perm=None) -> torch.Tensor:
         perm = perm if perm is not None else list(self.gt.keys())
         frame = frame_for(step, rank, world, perm)
-        self.fp.zero_grad()
+        # only the motion coefficients still arrive through autograd accumulation; every other segment of the
+        # flat bucket is overwritten by the activation backward kernel
+        self.fp.segment(self.fp.flat_grad, "motion_coeff").zero_()
         self.small_opt.zero_grad(set_to_none=True)
         out, _ = self.render(frame)
         loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)

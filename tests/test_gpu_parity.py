@@ -445,6 +445,66 @@ def test_train_step_runs_and_reduces_loss():
     assert float(ds.cam_q.grad.abs().sum()) > 0 and ds.net.head_w1.grad is not None
 
 
+@pytest.mark.parametrize("use_sinks", [False, True])
+def test_fused_activations_match_reference_getters(use_sinks):
+    """activate_gaussians vs the torch formulas of the reference getters (rodygs_static.py:82-105) + deformation add."""
+    import torch.nn.functional as F
+    from rodygs_amd.model_ops import activate_gaussians
+    g = torch.Generator().manual_seed(11)
+    P, K = 3001, 16
+    raw = dict(xyz=torch.randn(P, 3, generator=g), scaling=torch.randn(P, 3, generator=g) - 2,
+               rotation=torch.randn(P, 4, generator=g), opacity=torch.randn(P, 1, generator=g),
+               f_dc=torch.randn(P, 1, 3, generator=g), f_rest=torch.randn(P, K - 1, 3, generator=g))
+    dxyz, drot = 0.1 * torch.randn(P, 3, generator=g), 0.1 * torch.randn(P, 4, generator=g)
+    ws = [torch.randn(P, 3, generator=g), torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g),
+          torch.randn(P, 1, generator=g), torch.randn(P, K, 3, generator=g)]
+
+    def torch_ref(r, dx, dr):
+        return (r["xyz"] + dx, torch.exp(r["scaling"]), F.normalize(r["rotation"]) + dr, torch.sigmoid(r["opacity"]),
+                torch.cat((r["f_dc"], r["f_rest"]), dim=1))
+
+    rc = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+    dxc, drc = dxyz.clone().requires_grad_(True), drot.clone().requires_grad_(True)
+    outs_c = torch_ref(rc, dxc, drc)
+    sum((o * w).sum() for o, w in zip(outs_c, ws)).backward()
+    rg = {k: v.clone().to(DEV).requires_grad_(True) for k, v in raw.items()}
+    dxg, drg = dxyz.clone().to(DEV).requires_grad_(True), drot.clone().to(DEV).requires_grad_(True)
+    sinks = {k: torch.full_like(v, 7.0) for k, v in rg.items()} if use_sinks else None
+    outs_g = activate_gaussians(rg["xyz"], dxg, rg["scaling"], rg["rotation"], drg, rg["opacity"], rg["f_dc"],
+                                rg["f_rest"], grad_sinks=sinks)
+    sum((o * w.to(DEV)).sum() for o, w in zip(outs_g, ws)).backward()
+    for o_g, o_c, n in zip(outs_g, outs_c, ("means3D", "scales", "rots", "opac", "shs")):
+        rel_ok(o_g, o_c, tol=2e-6, what=n)
+    for k in raw:
+        got = sinks[k] if use_sinks else rg[k].grad
+        rel_ok(got, rc[k].grad, tol=5e-6, what="d_" + k)
+        if use_sinks:
+            assert rg[k].grad is None
+    rel_ok(dxg.grad, dxc.grad, tol=1e-6, what="d_dxyz"); rel_ok(drg.grad, drc.grad, tol=1e-6, what="d_drot")
+
+
+def test_pose_view_matrix_matches_reference_camera():
+    """pose_view_matrix vs the torch restatement of FixedCameraTorch.world_view_transform (pinned to the reference by
+    tests/golden/camera_golden.npz), forward and gradients, including non-unit quaternions."""
+    from rodygs_amd.model_ops import pose_view_matrix
+    from rodygs_amd.trainstep import world_view_transform
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera_golden.npz"))
+    q = torch.stack([torch.from_numpy(gold[f"q{i}"]) for i in range(4)]).float()
+    t = torch.stack([torch.from_numpy(gold[f"t{i}"]) for i in range(4)]).float()
+    for f in range(4):
+        ref = torch.from_numpy(gold[f"w2c{f}"])
+        qc, tc = q.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        vc = world_view_transform(qc[f], tc[f])
+        rel_ok(vc, ref, tol=1e-6, what="torch restatement vs reference golden")
+        w = torch.randn(4, 4, generator=torch.Generator().manual_seed(f))
+        (vc.transpose(0, 1) * w).sum().backward()
+        qg, tg = q.clone().to(DEV).requires_grad_(True), t.clone().to(DEV).requires_grad_(True)
+        vg = pose_view_matrix(qg, tg, f)
+        rel_ok(vg, ref.t(), tol=1e-6, what="view (glm storage)")
+        (vg * w.to(DEV)).sum().backward()
+        rel_ok(qg.grad, qc.grad, tol=1e-5, what="d_quat"); rel_ok(tg.grad, tc.grad, tol=1e-5, what="d_trans")
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
