@@ -160,6 +160,12 @@ int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, voi
 /* ---- fused Adam over a flat f32 parameter (used by bench.py's train step) ---------- */
 int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, int32_t step, void* stream);
+/* Same, for a segment made of rows of row_len floats whose first head_len floats use lr_head and the rest lr_tail
+ * (the SH features [P,16,3] kept as ONE tensor: DC at feature_lr, the rest at feature_lr/20, as the parameter
+ * groups f_dc / f_rest of /root/reference/src/trainer/rodygs_static.py:106-141).                               */
+int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                       int32_t row_len, int32_t head_len, float lr_head, float lr_tail, float beta1, float beta2,
+                       float eps, int32_t step, void* stream);
 
 /* ---- fused photometric loss -------------------------------------------------------------
  * loss = (1-lambda) mean|img-gt| + lambda (1 - mean SSIM(img, gt)), SSIM as in

@@ -52,6 +52,8 @@ _SIGS = {
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int32, _vp]),
+    "rdg_adam_step_rows": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                     C.c_float, C.c_float, C.c_float, C.c_int32, _vp]),
     "rdg_loss_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rdg_photometric_loss_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "rdg_photometric_loss_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp,

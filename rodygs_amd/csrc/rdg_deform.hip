@@ -144,8 +144,10 @@ __device__ __forceinline__ void rdg_deform_flush(rdg_f32x4 acc, int u, int lane,
         const int b = (lane >> 4) * 4 + r;
         const float v = acc[r];
         if (v != 0.0f) {
-            atomicAdd(&d_basis_t[b * RDG_DEF_K + k], v);
+            // with a table, dB(t) = -sum_u dB_table[u] is formed afterwards by rdg_deform_dbt_kernel: thousands of
+            // waves adding into the SAME 112 floats ran at the contended-atomic rate (0.64 ms at P = 1 M)
             if (has_table) atomicAdd(&d_table[(size_t)u * (16 * RDG_DEF_K) + b * RDG_DEF_K + k], -v);
+            else atomicAdd(&d_basis_t[b * RDG_DEF_K + k], v);
         }
     }
 }
@@ -211,21 +213,43 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
     rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table);
 }
 
+// dB(t)[c] = -sum_u dB_table[u][c]   (fixed order: deterministic given dB_table)
+__global__ void rdg_deform_dbt_kernel(int Tu, int row, const float* __restrict__ d_table, float* __restrict__ d_basis_t) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= row) return;
+    float s = 0.0f;
+    for (int u = 0; u < Tu; ++u) s += d_table[(size_t)u * row + c];
+    d_basis_t[c] = -s;
+}
+
+// Fused Adam over a flat f32 segment.  row_len > 1 gives the segment a row structure whose first head_len floats
+// take step_head and the rest step_tail: the SH features [P,16,3] are ONE tensor whose DC coefficient trains 20x
+// faster than the rest (feature_lr vs feature_lr/20), so no cat/split of f_dc/f_rest is ever needed.
 __global__ void __launch_bounds__(256)
 rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                float* __restrict__ v, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+                float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
+                float eps, float bc2_sqrt) {
     const long long n4 = n >> 2;
-    const float step = lr / bc1;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         const float4 gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
-#define RDG_ADAM1(c)                                                   \
+        float s0 = step_tail, s1 = step_tail, s2 = step_tail, s3 = step_tail;
+        if (row_len > 1) {
+            const unsigned r = (unsigned)((i * 4) % row_len);   // row_len is a multiple of 4 or handled per lane below
+            s0 = (int)(r % row_len) < head_len ? step_head : step_tail;
+            s1 = (int)((r + 1) % row_len) < head_len ? step_head : step_tail;
+            s2 = (int)((r + 2) % row_len) < head_len ? step_head : step_tail;
+            s3 = (int)((r + 3) % row_len) < head_len ? step_head : step_tail;
+        } else {
+            s0 = s1 = s2 = s3 = step_head;
+        }
+#define RDG_ADAM1(c, st)                                               \
         mm.c = b1 * mm.c + (1.0f - b1) * gg.c;                         \
         vv.c = b2 * vv.c + (1.0f - b2) * gg.c * gg.c;                  \
-        pp.c -= step * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
-        RDG_ADAM1(x) RDG_ADAM1(y) RDG_ADAM1(z) RDG_ADAM1(w)
+        pp.c -= st * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
+        RDG_ADAM1(x, s0) RDG_ADAM1(y, s1) RDG_ADAM1(z, s2) RDG_ADAM1(w, s3)
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
@@ -234,11 +258,12 @@ rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g,
     const long long t0 = n4 << 2;
     const long long i = t0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
+        const float st = (row_len > 1) ? ((int)(i % row_len) < head_len ? step_head : step_tail) : step_head;
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] -= step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] -= st * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
 }
 
@@ -302,17 +327,22 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
             if (mfma) RDG_DEF_BWD(false, false, (size_t)row * 4); else RDG_DEF_BWD(false, true, (size_t)row * 4);
         }
         if (mfma) {
-            hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(2048), dim3(256), 0, st, P, coeff,
+            // without a table every wave flushes into the same 112 floats: keep the wave count low there
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? 2048 : 64), dim3(256), 0, st, P, coeff,
                                (const long long*)time_ind, (const int*)order, g_xyz, g_rot, spatial_scale,
                                table ? 1 : 0, d_basis_t, d_table);
+            if (table)
+                hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3((row + 127) / 128), dim3(128), 0, st, Tu, row, d_table,
+                                   d_basis_t);
         }
     }
     rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);
     return rdg_check_hip(hipGetLastError(), "deform_bwd launch");
 }
 
-int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                  float beta2, float eps, int32_t step, void* stream) {
+static int rdg_adam_launch(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int row_len,
+                           int head_len, float lr_head, float lr_tail, float beta1, float beta2, float eps, int32_t step,
+                           void* stream) {
     if (n <= 0) return 0;
     if (step < 1) return rdg_set_error("adam: step must be >= 1");
     hipStream_t st = (hipStream_t)stream;
@@ -323,9 +353,23 @@ int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
     if (blocks > 4096) blocks = 4096;
     rdg_stage_begin(RDG_STAGE_ADAM, st);
     hipLaunchKernelGGL(rdg_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n, param, grad, exp_avg,
-                       exp_avg_sq, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                       exp_avg_sq, (float)(lr_head / bc1), (float)(lr_tail / bc1), row_len, head_len, beta1, beta2, eps,
+                       (float)sqrt(bc2));
     rdg_stage_end(RDG_STAGE_ADAM, st);
     return rdg_check_hip(hipGetLastError(), "adam launch");
+}
+
+int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, int32_t step, void* stream) {
+    return rdg_adam_launch(n, param, grad, exp_avg, exp_avg_sq, 1, 1, lr, lr, beta1, beta2, eps, step, stream);
+}
+
+int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t row_len,
+                       int32_t head_len, float lr_head, float lr_tail, float beta1, float beta2, float eps, int32_t step,
+                       void* stream) {
+    if (row_len < 1 || head_len < 0 || head_len > row_len) return rdg_set_error("adam: bad row structure");
+    return rdg_adam_launch(n, param, grad, exp_avg, exp_avg_sq, row_len, head_len, lr_head, lr_tail, beta1, beta2, eps,
+                           step, stream);
 }
 
 }  // extern "C"

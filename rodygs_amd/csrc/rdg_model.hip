@@ -165,7 +165,8 @@ int rdg_activate_forward(int32_t P, int32_t K, const float* xyz, const float* dx
     hipLaunchKernelGGL(rdg_activate_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, xyz, dxyz, scaling,
                        rotation, drot, opacity, out_means3D, out_scales, out_rots, out_opac);
     const long long n = (long long)P * K * 3;
-    hipLaunchKernelGGL(rdg_sh_concat_kernel, dim3(4096), dim3(256), 0, st, n, K * 3, f_dc, f_rest, out_shs);
+    if (f_dc && out_shs)   // features kept as one [P,K,3] tensor by the caller: nothing to concatenate
+        hipLaunchKernelGGL(rdg_sh_concat_kernel, dim3(4096), dim3(256), 0, st, n, K * 3, f_dc, f_rest, out_shs);
     return rdg_check_hip(hipGetLastError(), "activate_fwd launch");
 }
 
@@ -178,7 +179,8 @@ int rdg_activate_backward(int32_t P, int32_t K, const float* scaling, const floa
     hipLaunchKernelGGL(rdg_activate_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, scaling, rotation, opacity,
                        g_means3D, g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity);
     const long long n = (long long)P * K * 3;
-    if (g_shs) {
+    if (!d_fdc) {
+    } else if (g_shs) {
         hipLaunchKernelGGL(rdg_sh_split_kernel, dim3(4096), dim3(256), 0, st, n, K * 3, g_shs, d_fdc, d_frest);
     } else {
         hipError_t e = hipMemsetAsync(d_fdc, 0, (size_t)P * 3 * 4, st);

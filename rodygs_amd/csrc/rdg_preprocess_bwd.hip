@@ -326,12 +326,18 @@ rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict
         for (int r = grp; r < nblk; r += 32) acc += posebuf[(size_t)r * RDG_POSE_N + k];
     sred[grp][k] = acc;
     __syncthreads();
+    // second level: 19 threads each fold their 32 partials (fixed order), thread 0 finishes
+    __shared__ float stot[32];
+    if (threadIdx.x < RDG_POSE_N) {
+        float t = 0.0f;
+        for (int r = 0; r < 32; ++r) t += sred[r][threadIdx.x];
+        stot[threadIdx.x] = t;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     float g[16], gc[3], V[16];
     for (int c = 0; c < RDG_POSE_N; ++c) {
-        float t = 0.0f;
-        for (int r = 0; r < 32; ++r) t += sred[r][c];
-        if (c < 16) g[c] = t; else gc[c - 16] = t;
+        if (c < 16) g[c] = stot[c]; else gc[c - 16] = stot[c];
     }
     for (int c = 0; c < 16; ++c) V[c] = view[c];
     // cam_j = -(V[4j+0]*V[12] + V[4j+1]*V[13] + V[4j+2]*V[14])

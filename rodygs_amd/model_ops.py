@@ -24,7 +24,7 @@ class _Activate(torch.autograd.Function):
             raise RuntimeError("rodygs_amd.activate_gaussians: tensors must be on the GPU (no CPU fallback exists)")
         dev = xyz.device
         P = xyz.shape[0]
-        K = 1 + f_rest.shape[1]
+        K = 1 if f_dc is None else 1 + f_rest.shape[1]
         c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()   # noqa: E731
         xyz_, dxyz_, sc_, ro_, drot_, op_, dc_, fr_ = map(c, (xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest))
         f32 = dict(dtype=torch.float32, device=dev)
@@ -32,7 +32,7 @@ class _Activate(torch.autograd.Function):
         scales = torch.empty(P, 3, **f32)
         rots = torch.empty(P, 4, **f32)
         opac = torch.empty(P, 1, **f32)
-        shs = torch.empty(P, K, 3, **f32)
+        shs = torch.empty(P, K, 3, **f32) if f_dc is not None else None
         with torch.cuda.device(dev):
             _lib.check(L.rdg_activate_forward(P, K, _lib.ptr(xyz_), _lib.ptr(dxyz_), _lib.ptr(sc_), _lib.ptr(ro_),
                                               _lib.ptr(drot_), _lib.ptr(op_), _lib.ptr(dc_), _lib.ptr(fr_),
@@ -40,9 +40,14 @@ class _Activate(torch.autograd.Function):
                                               _lib.ptr(shs), _lib.stream_ptr()), "rdg_activate_forward")
         ctx.save_for_backward(sc_, ro_, op_)
         ctx.sinks = sinks
-        ctx.shapes = (xyz.shape, scaling.shape, rotation.shape, opacity.shape, f_dc.shape, f_rest.shape)
+        ctx.split = f_dc is not None
+        ctx.shapes = (xyz.shape, scaling.shape, rotation.shape, opacity.shape) + (
+            (f_dc.shape, f_rest.shape) if f_dc is not None else ())
         ctx.has_d = (dxyz is not None, drot is not None)
         ctx.K = K
+        if shs is None:
+            shs = torch.empty(0, **f32)
+            ctx.mark_non_differentiable(shs)
         return means3D, scales, rots, opac, shs
 
     @staticmethod
@@ -54,11 +59,14 @@ class _Activate(torch.autograd.Function):
         c = lambda t: None if t is None else t.to(torch.float32).contiguous()   # noqa: E731
         g_m, g_s, g_r, g_o, g_sh = map(c, (g_m, g_s, g_r, g_o, g_sh))
         sinks = ctx.sinks
-        names = ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")
+        names = ("xyz", "scaling", "rotation", "opacity") + (("f_dc", "f_rest") if ctx.split else ())
         if sinks is None:
             outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.shapes]
         else:
             outs = [sinks[n] for n in names]
+        if not ctx.split:
+            outs = outs + [None, None]
+            g_sh = None
         with torch.cuda.device(dev):
             _lib.check(L.rdg_activate_backward(P, ctx.K, _lib.ptr(sc_), _lib.ptr(ro_), _lib.ptr(op_), _lib.ptr(g_m),
                                                _lib.ptr(g_s), _lib.ptr(g_r), _lib.ptr(g_o), _lib.ptr(g_sh),

@@ -80,8 +80,9 @@ def _empty(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
-                raster_settings):
+                raster_settings, grad_sinks=None):
         L = _lib.lib()
+        ctx.grad_sinks = grad_sinks
         dev = means3D.device
         sh, colors_precomp = _empty(sh), _empty(colors_precomp)
         scales, rotations, cov3Ds_precomp = _empty(scales), _empty(rotations), _empty(cov3Ds_precomp)
@@ -159,7 +160,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_color, g_depth, g_normal, g_alpha, g_radii, g_extra):
         if ctx.empty_cloud:
-            return (None,) * 10
+            return (None,) * 11
         L = _lib.lib()
         m3, shs, col, op, sc, ro, cov, vm, pm, bg, radii, geom, binning, image = ctx.saved_tensors
         dev = m3.device
@@ -176,6 +177,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_m2 = torch.empty(P, 3, **f32)
             d_op = torch.empty_like(op)
             d_sh = torch.empty_like(shs) if shs is not None else None
+            sink_sh = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs")
+            if sink_sh is not None and shs is not None:
+                # the kernel overwrites every element of dL/dshs: let it write straight into the caller's buffer
+                # (e.g. a flat gradient bucket) and return nothing through autograd for that input
+                if sink_sh.shape != shs.shape or not sink_sh.is_contiguous() or sink_sh.dtype != torch.float32:
+                    raise RuntimeError("grad_sinks['shs'] must be a contiguous float32 tensor shaped like shs")
+                d_sh = sink_sh
             d_col = torch.empty_like(col) if col is not None else None
             d_sc = torch.empty_like(sc) if sc is not None else None
             d_ro = torch.empty_like(ro) if ro is not None else None
@@ -189,13 +197,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                                           _lib.ptr(d_sh), _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_sc),
                                           _lib.ptr(d_ro), _lib.ptr(d_cov), _lib.ptr(d_vm), _lib.stream_ptr())
             _lib.check(rc, "rdg_rasterize_backward")
-        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_ro, d_cov, d_vm, None
+        if sink_sh is not None:
+            d_sh = None
+        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_ro, d_cov, d_vm, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
-                        raster_settings):
+                        raster_settings, grad_sinks=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, viewmatrix, raster_settings)
+                                     cov3Ds_precomp, viewmatrix, raster_settings, grad_sinks)
 
 
 class GaussianRasterizer(nn.Module):
@@ -211,7 +221,9 @@ class GaussianRasterizer(nn.Module):
             return z > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3Ds_precomp=None, viewmatrix=None, extra_attrs=None):
+                cov3Ds_precomp=None, viewmatrix=None, extra_attrs=None, grad_sinks=None):
+        """Reference call signature (renderer.py:87-101).  ``grad_sinks`` is an extension outside the reference
+        surface: {"shs": tensor} makes backward write dL/dshs into that tensor instead of returning it."""
         if extra_attrs is not None:
             raise NotImplementedError("extra_attrs is not used by RoDyGS and is not implemented")
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
@@ -222,4 +234,4 @@ class GaussianRasterizer(nn.Module):
         if viewmatrix is None:
             raise Exception("viewmatrix must be given (it is a differentiable forward argument in the pose branch)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                   viewmatrix, self.raster_settings)
+                                   viewmatrix, self.raster_settings, grad_sinks)

@@ -43,17 +43,24 @@ def world_view_transform(q_c2w: torch.Tensor, t_c2w: torch.Tensor) -> torch.Tens
     return torch.cat([top, bottom], dim=0)
 
 
-def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15) -> None:
-    """One fused HIP launch per parameter group over the flat buffers (rdg_adam_step)."""
+def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None) -> None:
+    """One fused HIP launch per parameter group over the flat buffers (rdg_adam_step / rdg_adam_step_rows).
+    row_lr: {name: (row_len, head_len, lr_tail)} for segments whose rows mix two learning rates."""
     L = _lib.lib()
     fp.step_count += 1
     st = _lib.stream_ptr()
     for k in fp.names:
         o, n = fp.offsets[k]
         esz = 4
-        _lib.check(L.rdg_adam_step(n, fp.flat.data_ptr() + o * esz, fp.flat_grad.data_ptr() + o * esz,
-                                   fp.exp_avg.data_ptr() + o * esz, fp.exp_avg_sq.data_ptr() + o * esz,
-                                   fp.lr[k] * lr_scale, betas[0], betas[1], eps, fp.step_count, st), "rdg_adam_step")
+        ptrs = (fp.flat.data_ptr() + o * esz, fp.flat_grad.data_ptr() + o * esz, fp.exp_avg.data_ptr() + o * esz,
+                fp.exp_avg_sq.data_ptr() + o * esz)
+        if row_lr and k in row_lr:
+            row_len, head_len, lr_tail = row_lr[k]
+            _lib.check(L.rdg_adam_step_rows(n, *ptrs, row_len, head_len, fp.lr[k] * lr_scale, lr_tail * lr_scale,
+                                            betas[0], betas[1], eps, fp.step_count, st), "rdg_adam_step_rows")
+        else:
+            _lib.check(L.rdg_adam_step(n, *ptrs, fp.lr[k] * lr_scale, betas[0], betas[1], eps, fp.step_count, st),
+                       "rdg_adam_step")
 
 
 class DynamicScene:
@@ -75,8 +82,9 @@ class DynamicScene:
         K = scene["shs"].shape[1]
         spec = {
             "xyz": ((P, 3), 0.00016 * spatial_lr_scale),
-            "f_dc": ((P, 1, 3), 0.0025),
-            "f_rest": ((P, K - 1, 3), 0.0025 / 20.0),
+            # SH features as ONE [P,K,3] tensor (what the rasterizer consumes): no cat forward, no split backward.
+            # Row-structured Adam keeps the reference's two groups: f_dc at feature_lr, f_rest at feature_lr/20.
+            "features": ((P, K, 3), 0.0025),
             "scaling": ((P, 3), 0.001),
             "rotation": ((P, 4), 0.001),
             "opacity": ((P, 1), 0.05),
@@ -85,14 +93,14 @@ class DynamicScene:
         fp = FlatParams(spec, dev)
         with torch.no_grad():
             fp["xyz"].copy_(scene["means3D"])
-            fp["f_dc"].copy_(scene["shs"][:, :1])
-            fp["f_rest"].copy_(scene["shs"][:, 1:])
+            fp["features"].copy_(scene["shs"])
             fp["scaling"].copy_(torch.log(scene["scales"]))
             fp["rotation"].copy_(scene["rotations"])
             op = scene["opacities"].clamp(1e-4, 1 - 1e-4)
             fp["opacity"].copy_(torch.log(op / (1 - op)))
             fp["motion_coeff"].copy_(0.1 * torch.randn(P, 1, 16, generator=g))
         self.fp = fp
+        self.row_lr = {"features": (K * 3, 3, 0.0025 / 20.0)}
         self.time_ind = torch.randint(0, num_frames, (P,), generator=g).to(dev)
         self.net = MLPBasisNetwork(128, 16, 26, False).to(dev)
         self.times = torch.arange(num_frames, dtype=torch.float32) / num_frames
@@ -132,17 +140,18 @@ class DynamicScene:
         dxyz, drot = gaussian_deformation(fp["motion_coeff"], self.time_ind, basis_t, table, self.spatial_lr_scale)
         # activations + deformation add + feature concat: 2 HIP launches; the parameter gradients are written by
         # the backward kernel straight into the flat gradient bucket (no AccumulateGrad copies)
-        sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")}
-        xyz, scaling, rot, opacity, feats = activate_gaussians(fp["xyz"], dxyz, fp["scaling"], fp["rotation"], drot,
-                                                               fp["opacity"], fp["f_dc"], fp["f_rest"], grad_sinks=sinks)
-        return xyz, opacity, scaling, rot, feats
+        sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
+        xyz, scaling, rot, opacity, _ = activate_gaussians(fp["xyz"], dxyz, fp["scaling"], fp["rotation"], drot,
+                                                           fp["opacity"], None, None, grad_sinks=sinks)
+        return xyz, opacity, scaling, rot, fp["features"]
 
     def render(self, frame: int):
         xyz, opacity, scaling, rot, feats = self.gaussians_at(frame)
         vm = pose_view_matrix(self.cam_q, self.cam_t, frame)
         m2 = torch.zeros_like(xyz, requires_grad=True)
         out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
-                                                  rotations=rot, viewmatrix=vm)
+                                                  rotations=rot, viewmatrix=vm,
+                                                  grad_sinks={"shs": self.fp["features"].grad})
         return out, m2
 
     def make_ground_truth(self, target_scene: dict, frames):
@@ -174,6 +183,6 @@ class DynamicScene:
                 if t.grad is not None:
                     small.append(t.grad)
             allreduce_sum_(self.fp.flat_grad, small)
-        fused_adam_(self.fp)
+        fused_adam_(self.fp, row_lr=self.row_lr)
         self.small_opt.step()
         return loss.detach()

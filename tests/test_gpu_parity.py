@@ -505,6 +505,28 @@ def test_pose_view_matrix_matches_reference_camera():
         rel_ok(qg.grad, qc.grad, tol=1e-5, what="d_quat"); rel_ok(tg.grad, tc.grad, tol=1e-5, what="d_trans")
 
 
+def test_fused_adam_rows_matches_two_torch_groups():
+    """Row-structured Adam (features [P,16,3]: DC at lr, rest at lr/20) == torch Adam with two parameter groups."""
+    from rodygs_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    P, K = 1237, 16
+    feats, gr = torch.randn(P, K, 3, generator=g), torch.randn(P, K, 3, generator=g)
+    dc = feats[:, :1].clone().requires_grad_(True)
+    rest = feats[:, 1:].clone().requires_grad_(True)
+    opt = torch.optim.Adam([{"params": [dc], "lr": 2.5e-3}, {"params": [rest], "lr": 2.5e-3 / 20}], eps=1e-15)
+    pd = feats.clone().to(DEV)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step in range(1, 4):
+        dc.grad, rest.grad = (gr[:, :1] * step).clone(), (gr[:, 1:] * step).clone()
+        opt.step()
+        gd = (gr * step).to(DEV)
+        _lib.check(L.rdg_adam_step_rows(pd.numel(), pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), K * 3, 3,
+                                        2.5e-3, 2.5e-3 / 20, 0.9, 0.999, 1e-15, step, _lib.stream_ptr()), "adam rows")
+    want = torch.cat([dc.detach(), rest.detach()], dim=1)
+    rel_ok(pd - feats.to(DEV), want - feats, tol=1e-5, what="adam rows update")
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
