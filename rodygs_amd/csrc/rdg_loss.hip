@@ -97,12 +97,27 @@ rdg_loss_fwd_kernel(int H, int Wd, RdgWin win, const float* __restrict__ img, co
     ms = rdg_wave_sum_to63(ms);
     if ((tid & 63) == 63) { sred[0][tid >> 6] = l1; sred[1][tid >> 6] = ms; }
     __syncthreads();
-    if (tid < 2) atomicAdd(&sums[tid], (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]));
+    // one partial pair per workgroup, summed in fixed order by the finalize kernel: 24 k workgroups adding into the
+    // same two floats ran at the contended-atomic rate (0.3 ms of a 0.33 ms kernel) and were not deterministic
+    if (tid < 2) {
+        const size_t bid = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        sums[2 * bid + tid] = (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]);
+    }
 }
 
-__global__ void rdg_loss_finalize_kernel(const float* __restrict__ sums, float inv_n, float lambda, float* __restrict__ loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float l1 = sums[0] * inv_n, ss = sums[1] * inv_n;
+__global__ void __launch_bounds__(1024)
+rdg_loss_finalize_kernel(const float* __restrict__ sums, int nblk, float inv_n, float lambda, float* __restrict__ loss) {
+    __shared__ float s0[16], s1[16];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 1024) { a += sums[2 * i]; b += sums[2 * i + 1]; }
+    a = rdg_wave_sum_to63(a);
+    b = rdg_wave_sum_to63(b);
+    if ((threadIdx.x & 63) == 63) { s0[threadIdx.x >> 6] = a; s1[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float l1 = 0.f, ss = 0.f;
+        for (int k = 0; k < 16; ++k) { l1 += s0[k]; ss += s1[k]; }
+        l1 *= inv_n; ss *= inv_n;
         loss[0] = (1.0f - lambda) * l1 + lambda * (1.0f - ss);
         loss[1] = l1;
         loss[2] = ss;
@@ -163,7 +178,10 @@ rdg_loss_bwd_kernel(int H, int Wd, RdgWin win, const float* __restrict__ img, co
 
 extern "C" {
 
-size_t rdg_loss_ws_bytes(int32_t C, int32_t H, int32_t W) { return (size_t)3 * C * H * W * 4 + 256; }
+size_t rdg_loss_ws_bytes(int32_t C, int32_t H, int32_t W) {
+    const size_t nblk = (size_t)((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C;
+    return (size_t)3 * C * H * W * 4 + nblk * 8 + 256;
+}
 
 int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float lambda,
                                  void* ws, float* loss3, void* stream) {
@@ -172,12 +190,11 @@ int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* i
     float* maps = (float*)ws;
     float* sums = (float*)((char*)ws + (size_t)3 * C * H * W * 4);
     rdg_stage_begin(RDG_STAGE_LOSS_FWD, st);
-    hipError_t e = hipMemsetAsync(sums, 0, 8, st);
-    if (e != hipSuccess) return rdg_check_hip(e, "loss memset");
     const RdgWin win = rdg_make_window();
     dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, C);
     hipLaunchKernelGGL(rdg_loss_fwd_kernel, grid, dim3(256), 0, st, H, W, win, img, gt, maps, sums);
-    hipLaunchKernelGGL(rdg_loss_finalize_kernel, dim3(1), dim3(64), 0, st, sums, 1.0f / ((float)C * H * W), lambda, loss3);
+    hipLaunchKernelGGL(rdg_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, (int)(grid.x * grid.y * grid.z),
+                       1.0f / ((float)C * H * W), lambda, loss3);
     rdg_stage_end(RDG_STAGE_LOSS_FWD, st);
     return rdg_check_hip(hipGetLastError(), "loss_fwd launch");
 }

@@ -220,7 +220,6 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     const int rounds = (kmax + RDG_BATCH - 1) / RDG_BATCH;
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;
     const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
 
     for (int r = 0; r < rounds; ++r) {
@@ -263,35 +262,31 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const bool hit = (k < last_contributor) && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
                 if (!__any(hit)) continue;
                 const float4 q2 = sQ2[j];
-                float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f,
-                      g9 = 0.f;
-                if (hit) {
-                    const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
-                    T = T * inv1ma;
-                    const float dch = alpha * T;
-                    float dL_dalpha = 0.0f;
-                    acc0 = last_alpha * lc0 + (1.0f - last_alpha) * acc0; lc0 = q2.x;
-                    dL_dalpha += (q2.x - acc0) * dLp0; g6 = dch * dLp0;
-                    acc1 = last_alpha * lc1 + (1.0f - last_alpha) * acc1; lc1 = q2.y;
-                    dL_dalpha += (q2.y - acc1) * dLp1; g7 = dch * dLp1;
-                    acc2 = last_alpha * lc2 + (1.0f - last_alpha) * acc2; lc2 = q2.z;
-                    dL_dalpha += (q2.z - acc2) * dLp2; g8 = dch * dLp2;
-                    accd = last_alpha * ld + (1.0f - last_alpha) * accd; ld = q1.z;
-                    dL_dalpha += (q1.z - accd) * dLd; g9 = dch * dLd;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (T_final * inv1ma) * tail;
-                    const float dL_dG = q1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-                    const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-                    g0 = dL_dG * dG_ddelx * half_w;
-                    g1 = dL_dG * dG_ddely * half_h;
-                    g2 = -0.5f * gdx * dx * dL_dG;
-                    g3 = -gdx * dy * dL_dG;
-                    g4 = -0.5f * gdy * dy * dL_dG;
-                    g5 = G * dL_dalpha;
-                }
+                // Branch-free per-pixel derivatives.  A lane that does not blend this splat runs the same instructions
+                // with alpha_eff = 0, which leaves every piece of its state unchanged (T/(1-0) = T, B += 0*(c - B)) and
+                // zeroes its contributions, so no per-variable selects are needed.  B* is the colour accumulated
+                // BEHIND the current splat (back-to-front recurrence B <- alpha c + (1 - alpha) B), i.e. upstream's
+                // accum_rec evaluated eagerly instead of through last_alpha / last_color.
+                const float aeff = hit ? alpha : 0.0f;
+                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - aeff);
+                T = T * inv1ma;
+                const float dch = aeff * T;
+                const float e0 = q2.x - acc0, e1 = q2.y - acc1, e2 = q2.z - acc2, ed = q1.z - accd;
+                float dL_dalpha = e0 * dLp0 + e1 * dLp1 + e2 * dLp2 + ed * dLd;
+                acc0 += aeff * e0; acc1 += aeff * e1; acc2 += aeff * e2; accd += aeff * ed;
+                dL_dalpha = dL_dalpha * T + (T_final * inv1ma) * tail;
+                dL_dalpha = hit ? dL_dalpha : 0.0f;
+                const float dL_dG = q1.y * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
+                const float dG_ddely = -gdy * q1.x - gdx * q0.w;
+                const float g0 = dL_dG * dG_ddelx * half_w;
+                const float g1 = dL_dG * dG_ddely * half_h;
+                const float g2 = -0.5f * gdx * dx * dL_dG;
+                const float g3 = -gdx * dy * dL_dG;
+                const float g4 = -0.5f * gdy * dy * dL_dG;
+                const float g5 = G * dL_dalpha;
+                const float g6 = dch * dLp0, g7 = dch * dLp1, g8 = dch * dLp2, g9 = dch * dLd;
                 // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds, everything ending in
                 // lane 63), fold the VALUE index into the lane index while reducing: xor-1 and xor-2 exchanges halve
                 // the number of live values each (lane&3 then selects the component), two row rotations finish the
