@@ -104,9 +104,33 @@ rdg_sort_hist_kernel(const uint64_t* __restrict__ keys, long long capacity, cons
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     long long b, e;
     rdg_seg_bounds(n, nseg, seg, b, e);
-    for (long long i = b + lane; i < e; i += 64) {
-        const uint32_t dgt = (uint32_t)(keys[i] >> shift) & (RDG_SORT_RADIX - 1);
-        atomicAdd(&cnt[w][dgt], 1u);
+    // 4 chunks of 64 keys in flight per wave (the kernel is latency-bound otherwise), counted with the same ballot
+    // "match" as the scatter: the lowest lane of every equal-digit group adds the group size with a plain LDS
+    // read-modify-write (LDS atomics measured several times slower than plain LDS traffic on this part).
+    volatile uint32_t* cw = cnt[w];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (long long i0 = b; i0 < e; i0 += 4 * 64) {
+        uint64_t k4[4]; bool a4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long i = i0 + 64 * c + lane;
+            a4[c] = i < e;
+            k4[c] = a4[c] ? keys[i] : 0ull;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t dgt = (uint32_t)(k4[c] >> shift) & (RDG_SORT_RADIX - 1);
+            unsigned long long m = __ballot(a4[c]);
+            if (m == 0ull) break;
+#pragma unroll
+            for (int bit = 0; bit < RDG_SORT_BITS; ++bit) {
+                const bool bset = (dgt >> bit) & 1u;
+                const unsigned long long bal = __ballot(a4[c] && bset);
+                m &= bset ? bal : ~bal;
+            }
+            if (a4[c] && (m & lt_mask) == 0ull) cw[dgt] = cw[dgt] + (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -177,26 +201,39 @@ rdg_sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __
     long long b, e;
     rdg_seg_bounds(n, nseg, seg, b, e);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (long long i0 = b; i0 < e; i0 += 64) {
-        const long long i = i0 + lane;
-        const bool act = i < e;
-        uint64_t key = 0; uint32_t val = 0;
-        if (act) { key = keys_in[i]; val = vals_in[i]; }
-        const uint32_t dgt = (uint32_t)(key >> shift) & (RDG_SORT_RADIX - 1);
-        unsigned long long m = __ballot(act);
+    for (long long i0 = b; i0 < e; i0 += 4 * 64) {
+        // prefetch 4 chunks (keys + values) before ranking them IN ORDER: the ranking is serial per segment, the
+        // global loads need not be
+        uint64_t k4[4]; uint32_t v4[4]; bool a4[4];
 #pragma unroll
-        for (int bit = 0; bit < RDG_SORT_BITS; ++bit) {
-            const bool bset = (dgt >> bit) & 1u;
-            const unsigned long long bal = __ballot(act && bset);
-            m &= bset ? bal : ~bal;
+        for (int c = 0; c < 4; ++c) {
+            const long long i = i0 + 64 * c + lane;
+            a4[c] = i < e;
+            k4[c] = 0; v4[c] = 0;
+            if (a4[c]) { k4[c] = keys_in[i]; v4[c] = vals_in[i]; }
         }
-        const uint32_t rank = __popcll(m & lt_mask);
-        uint32_t pos = 0;
-        if (act) pos = cursor[dgt] + rank;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (act && rank == 0) cursor[dgt] = pos + (uint32_t)__popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (act) { keys_out[pos] = key; vals_out[pos] = val; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool act = a4[c];
+            const uint64_t key = k4[c];
+            const uint32_t val = v4[c];
+            const uint32_t dgt = (uint32_t)(key >> shift) & (RDG_SORT_RADIX - 1);
+            unsigned long long m = __ballot(act);
+            if (m == 0ull) break;
+#pragma unroll
+            for (int bit = 0; bit < RDG_SORT_BITS; ++bit) {
+                const bool bset = (dgt >> bit) & 1u;
+                const unsigned long long bal = __ballot(act && bset);
+                m &= bset ? bal : ~bal;
+            }
+            const uint32_t rank = __popcll(m & lt_mask);
+            uint32_t pos = 0;
+            if (act) pos = cursor[dgt] + rank;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (act && rank == 0) cursor[dgt] = pos + (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (act) { keys_out[pos] = key; vals_out[pos] = val; }
+        }
     }
 }
 

@@ -264,7 +264,6 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             if (lane == 0) sMask[q][wv] = m;
         }
         __syncthreads();
-        const int nb = min(RDG_BATCH, kbase + 1);
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
