@@ -227,7 +227,7 @@ int rdg_bin_forward(const RdgRasterSettings* s_host, const void* geom_ws, const 
     if (rdg_make_dev(s_host, &d)) return -1;
     hipStream_t st = (hipStream_t)stream;
     int rc = rdg_launch_bin(d, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev, keys_unsorted,
-                            vals_unsorted, st);
+                            vals_unsorted, st, keys_sorted != nullptr);
     if (rc) return rc;
     const RdgBinLayout B = rdg_bin_layout(capacity);
     const RdgImageLayout I = rdg_image_layout(d.H, d.W);

@@ -13,6 +13,7 @@
 //                                  popcount below me), so the order inside a segment, and therefore the
 //                                  whole sort, is stable.
 #include "rdg_common.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------------------
 // duplicateWithKeys: load-balanced expansion.  A block owns 256 consecutive Gaussians; its output slots
@@ -298,9 +299,171 @@ __global__ void rdg_copy_pairs_kernel(const uint64_t* __restrict__ k, const uint
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Bucket binning (default): the 45-47-bit LSD radix sort moves every (key, value) pair 6 times through HBM with
+// a random scatter each time.  The key is (tile | depth), so the same order is reached with far less traffic:
+//   1. count   : per-tile instance counts (load-balanced expansion + integer atomics)
+//   2. scan    : exclusive scan over tiles  ->  the tile ranges themselves (no identifyTileRanges pass)
+//   3. scatter : every instance goes to a slot of its tile (atomic cursor) as the 64-bit composite
+//                (depth_bits << 32 | gaussian_id); arrival order inside a tile is arbitrary ...
+//   4. sort    : ... and is fixed by a per-tile bitonic sort of the composites in LDS.  Composites are unique,
+//                so the result is deterministic and identical to the stable sort on (tile | depth): equal depths
+//                come out in increasing Gaussian index = emission order.  Bit-exact against the oracle.
+// Tiles with more than RDG_TSORT_LDS instances are sorted in place in global memory by the same network.
+// ---------------------------------------------------------------------------------------------------------
+#define RDG_TSORT_SMALL 1024
+#define RDG_TSORT_LDS 8192
+
+template <int MODE>  // 0 = count, 1 = scatter
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
+                       const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
+                       const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_cnt,
+                       const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill,
+                       uint64_t* __restrict__ comp, long long capacity, const int32_t* __restrict__ num_rendered) {
+    if ((long long)(*num_rendered) > capacity) return;
+    __shared__ uint32_t sOff[RDG_PRE_BLOCK];
+    __shared__ uint32_t sDepth[RDG_PRE_BLOCK];
+    __shared__ uint16_t sX0[RDG_PRE_BLOCK], sY0[RDG_PRE_BLOCK], sW[RDG_PRE_BLOCK];
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * RDG_PRE_BLOCK + tid;
+    uint32_t t = 0;
+    if (i < P) {
+        t = tiles_touched[i];
+        if (t > 0) {
+            const float4 q0 = rec[i].q0;
+            const float4 q1 = rec[i].q1;
+            int x0, y0, x1, y1;
+            rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
+            sX0[tid] = (uint16_t)x0; sY0[tid] = (uint16_t)y0; sW[tid] = (uint16_t)(x1 - x0);
+            sDepth[tid] = __float_as_uint(q1.z);
+        }
+    }
+    const uint32_t inc = rdg_wave_scan_incl(t);
+    const uint32_t lane = tid & 63, w = tid >> 6;
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t k = 0; k < w; ++k) woff += wsum[k];
+    sOff[tid] = woff + inc - t;
+    __syncthreads();
+    const uint32_t total = block_sums[blockIdx.x + 1] - block_sums[blockIdx.x];
+    for (uint32_t k = tid; k < total; k += RDG_PRE_BLOCK) {
+        int lo = 0, hi = RDG_PRE_BLOCK - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sOff[mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t j = k - sOff[lo];
+        const uint32_t wd = sW[lo];
+        const uint32_t ry = j / wd, rx = j - ry * wd;
+        const uint32_t tile = (uint32_t)(sY0[lo] + ry) * (uint32_t)gx + (uint32_t)(sX0[lo] + rx);
+        if (MODE == 0) {
+            atomicAdd(&tile_cnt[tile], 1u);
+        } else {
+            const uint32_t pos = ranges[tile].x + atomicAdd(&tile_fill[tile], 1u);
+            comp[pos] = ((uint64_t)sDepth[lo] << 32) | (uint64_t)(blockIdx.x * RDG_PRE_BLOCK + lo);
+        }
+    }
+}
+
+// exclusive scan of tile_cnt -> ranges (untouched tiles stay (0,0), as identifyTileRanges leaves them); clears cursors
+__global__ void __launch_bounds__(1024)
+rdg_tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
+                     uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered) {
+    if ((long long)(*num_rendered) > capacity) return;
+    __shared__ uint32_t wtot[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n_tiles ? tile_cnt[i] : 0u;
+        const uint32_t inc = rdg_wave_scan_incl(v);
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
+        const uint32_t carry = carry_s;
+        if (i < n_tiles) {
+            const uint32_t st = carry + woff + inc - v;
+            ranges[i] = v ? make_uint2(st, st + v) : make_uint2(0u, 0u);
+            tile_fill[i] = 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+}
+
+// ascending compare-exchange network without directions (virtual +inf padding: partners >= n are skipped)
+template <typename ARR>
+__device__ __forceinline__ void rdg_bitonic_sort(ARR a, uint32_t n, uint32_t N2, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t k = 2; k <= N2; k <<= 1) {
+        const uint32_t hk = k >> 1;
+        for (uint32_t idx = tid; idx < (N2 >> 1); idx += nthreads) {
+            const uint32_t base = (idx / hk) * k, off = idx & (hk - 1);
+            const uint32_t i = base + off, p = base + k - 1 - off;
+            if (p < n) {
+                const uint64_t x = a[i], y = a[p];
+                if (x > y) { a[i] = y; a[p] = x; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t idx = tid; idx < (N2 >> 1); idx += nthreads) {
+                const uint32_t i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), p = i + j;
+                if (p < n) {
+                    const uint64_t x = a[i], y = a[p];
+                    if (x > y) { a[i] = y; a[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int LDS_N, bool LARGE>
+__global__ void __launch_bounds__(256)
+rdg_tile_sort_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __restrict__ comp,
+                     uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out, long long capacity,
+                     const int32_t* __restrict__ num_rendered) {
+    if ((long long)(*num_rendered) > capacity) return;
+    const int tile = blockIdx.x;
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (LARGE ? (n <= RDG_TSORT_SMALL) : (n == 0 || n > RDG_TSORT_SMALL)) return;
+    __shared__ uint64_t sK[LDS_N];
+    uint32_t N2 = 2;
+    while (N2 < n) N2 <<= 1;
+    uint64_t* g = comp + rg.x;
+    const uint32_t tid = threadIdx.x;
+    if (n <= (uint32_t)LDS_N) {
+        for (uint32_t i = tid; i < n; i += 256) sK[i] = g[i];
+        __syncthreads();
+        if (n > 1) rdg_bitonic_sort(sK, n, N2, tid, 256u);
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t k = sK[i];
+            g[i] = k;
+            vals_out[rg.x + i] = (uint32_t)k;
+            if (keys_full_out) keys_full_out[rg.x + i] = ((uint64_t)tile << 32) | (k >> 32);
+        }
+    } else {
+        // oversized tile: same network, in place in global memory (workgroup-scope visibility via the barriers)
+        rdg_bitonic_sort(g, n, N2, tid, 256u);
+        for (uint32_t i = tid; i < n; i += 256) {
+            const uint64_t k = g[i];
+            vals_out[rg.x + i] = (uint32_t)k;
+            if (keys_full_out) keys_full_out[rg.x + i] = ((uint64_t)tile << 32) | (k >> 32);
+        }
+    }
+}
+
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
                    void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
-                   uint32_t* vals_unsorted_copy, hipStream_t s) {
+                   uint32_t* vals_unsorted_copy, hipStream_t s, bool radix_export_keys) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const RdgBinLayout B = rdg_bin_layout(capacity);
     const RdgImageLayout I = rdg_image_layout(d.H, d.W);
@@ -312,6 +475,52 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     uint32_t* vals_b = (uint32_t*)(b + B.vals_b);
     const int n_tiles = d.gx * d.gy;
     uint2* ranges = (uint2*)((char*)image_ws + I.ranges);
+
+    static int radix_mode = -1;   // RDG_BIN_MODE=radix selects the LSD radix path (kept for A/B runs)
+    if (radix_mode < 0) { const char* ev = getenv("RDG_BIN_MODE"); radix_mode = (ev && ev[0] == 'r') ? 1 : 0; }
+    if (!radix_mode) {
+        const int npass = (rdg_key_bits(n_tiles) + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
+        uint32_t* vals_out = (npass & 1) ? vals_b : vals_a;      // where the compositing kernels look
+        uint64_t* keys_out = (npass & 1) ? keys_b : keys_a;      // full (tile | depth) keys, tests only
+        uint64_t* comp = (npass & 1) ? keys_a : keys_b;          // composites live in the other key buffer
+        uint32_t* tile_cnt = (uint32_t*)((char*)image_ws + I.tile_cnt);
+        uint32_t* tile_fill = (uint32_t*)((char*)image_ws + I.tile_fill);
+        const bool want_keys = keys_unsorted_copy != nullptr || vals_unsorted_copy != nullptr || radix_export_keys;
+        const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+        if (want_keys && d.P > 0 && (keys_unsorted_copy || vals_unsorted_copy)) {
+            // emission-order (key, value) stream for the parity tests: the radix path's duplicate kernel
+            uint32_t* vscr = (npass & 1) ? vals_a : vals_b;
+            hipLaunchKernelGGL(rdg_duplicate_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                               (const uint32_t*)(g + G.block_sums), keys_out, vscr, (long long)capacity, num_rendered);
+            hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_out, vscr, keys_unsorted_copy,
+                               vals_unsorted_copy, (long long)capacity, num_rendered);
+        }
+        rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
+        hipError_t em = hipMemsetAsync(tile_cnt, 0, (size_t)n_tiles * 4, s);
+        if (em != hipSuccess) return rdg_check_hip(em, "tile_cnt memset");
+        if (d.P > 0)
+            hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                               (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, tile_fill, comp,
+                               (long long)capacity, num_rendered);
+        hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_cnt, ranges, tile_fill,
+                           (long long)capacity, num_rendered);
+        if (d.P > 0)
+            hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                               (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, tile_fill, comp,
+                               (long long)capacity, num_rendered);
+        rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
+        rdg_stage_begin(RDG_STAGE_SORT, s);
+        uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
+        hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_SMALL, false>), dim3(n_tiles), dim3(256), 0, s, n_tiles, ranges,
+                           comp, vals_out, kfull, (long long)capacity, num_rendered);
+        hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_LDS, true>), dim3(n_tiles), dim3(256), 0, s, n_tiles, ranges,
+                           comp, vals_out, kfull, (long long)capacity, num_rendered);
+        rdg_stage_end(RDG_STAGE_SORT, s);
+        return rdg_check_hip(hipGetLastError(), "bucket bin launch");
+    }
 
     rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
     if (d.P > 0) {

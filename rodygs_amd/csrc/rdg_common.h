@@ -106,6 +106,8 @@ struct RdgImageLayout {
     size_t final_T;    // float[H*W]
     size_t n_contrib;  // uint32[H*W]
     size_t ranges;     // uint2[n_tiles]
+    size_t tile_cnt;   // uint32[n_tiles]  instances per tile (bucket binning)
+    size_t tile_fill;  // uint32[n_tiles]  scatter cursors
     size_t total;
 };
 static inline RdgImageLayout rdg_image_layout(int32_t H, int32_t W) {
@@ -116,6 +118,8 @@ static inline RdgImageLayout rdg_image_layout(int32_t H, int32_t W) {
     L.final_T = o;    o = rdg_align_up(o + hw * 4, 256);
     L.n_contrib = o;  o = rdg_align_up(o + hw * 4, 256);
     L.ranges = o;     o = rdg_align_up(o + nt * 8, 256);
+    L.tile_cnt = o;   o = rdg_align_up(o + nt * 4, 256);
+    L.tile_fill = o;  o = rdg_align_up(o + nt * 4, 256);
     L.total = o;
     return L;
 }
@@ -147,7 +151,7 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
                               int32_t* num_rendered, hipStream_t s);
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
                    void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
-                   uint32_t* vals_unsorted_copy, hipStream_t s);
+                   uint32_t* vals_unsorted_copy, hipStream_t s, bool export_sorted_keys = false);
 int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
                     const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s);
 int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
