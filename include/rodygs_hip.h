@@ -74,7 +74,9 @@ enum {
     RDG_STAGE_ADAM = 9,
     RDG_STAGE_LOSS_FWD = 10,
     RDG_STAGE_LOSS_BWD = 11,
-    RDG_STAGE_COUNT = 12
+    RDG_STAGE_MLP_FWD = 12,
+    RDG_STAGE_MLP_BWD = 13,
+    RDG_STAGE_COUNT = 14
 };
 
 int rdg_abi_version(void);
@@ -151,6 +153,22 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
                         const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table,
                         const int32_t* order, void* stream);
+
+/* ---- time-deformation MLP on the matrix cores (csrc/rdg_mlp.hip) --------------------------------------------
+ * MLPBasisNetwork.batch_inference / the basis part of forward (/root/reference/src/model/rodygs_dynamic.py:296-327):
+ * x [NR,D0] time embeddings -> timenet (D0-H-H-H/2, GELU) -> NB heads (H/2-H/4-OUT, GELU) -> out [NR,NB,OUT].
+ * Weights in nn.Linear layout ([out,in]); heads stacked: hw1 [NB,H/4,H/2], hb1 [NB,H/4], hw2 [NB,OUT,H/4],
+ * hb2 [NB,OUT].  ws: rdg_mlp_ws_bytes() scratch holding the activations; it must survive until backward.
+ * Every product runs on v_mfma_f32_16x16x4_f32 (exact f32).  Backward overwrites all d* outputs.            */
+size_t rdg_mlp_ws_bytes(int32_t NR, int32_t H, int32_t NB);
+int rdg_mlp_forward(int32_t NR, int32_t D0, int32_t H, int32_t NB, int32_t OUT, const float* x, const float* W0,
+                    const float* b0, const float* W1, const float* b1, const float* W2, const float* b2,
+                    const float* hw1, const float* hb1, const float* hw2, const float* hb2, void* ws, float* out,
+                    void* stream);
+int rdg_mlp_backward(int32_t NR, int32_t D0, int32_t H, int32_t NB, int32_t OUT, const float* x, const float* W1,
+                     const float* W2, const float* hw1, const float* hw2, void* ws, const float* g_out, float* dW0,
+                     float* db0, float* dW1, float* db1, float* dW2, float* db2, float* dhw1, float* dhb1, float* dhw2,
+                     float* dhb2, void* stream);
 
 /* ---- simple_knn ------------------------------------------------------------------------------------------ */
 size_t rdg_knn_tmp_bytes(int32_t P);

@@ -28,7 +28,7 @@ class RdgRasterSettings(C.Structure):
 
 STAGES = {
     "preprocess": 0, "scan_dup": 1, "sort": 2, "ranges": 3, "render_fwd": 4, "render_bwd": 5,
-    "preprocess_bwd": 6, "deform_fwd": 7, "deform_bwd": 8, "adam": 9, "loss_fwd": 10, "loss_bwd": 11,
+    "preprocess_bwd": 6, "deform_fwd": 7, "deform_bwd": 8, "adam": 9, "loss_fwd": 10, "loss_bwd": 11, "mlp_fwd": 12, "mlp_bwd": 13,
 }
 
 _vp = C.c_void_p
@@ -62,6 +62,9 @@ _SIGS = {
     "rdg_activate_backward": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 15),
     "rdg_pose_view_forward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_pose_view_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdg_mlp_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "rdg_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_vp] * 14),
+    "rdg_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_vp] * 18),
     "rdg_timing_enable": (C.c_int, [C.c_int32]),
     "rdg_timing_reset": (C.c_int, []),
     "rdg_stage_time_ms": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -75,6 +75,47 @@ class MLPMotionBasis(nn.Module):
         return self.basis(x)
 
 
+FUSED_MLP = True   # GPU tensors: run MLPBasisNetwork through the HIP MFMA kernels (csrc/rdg_mlp.hip)
+
+
+class _FusedMLP(torch.autograd.Function):
+    """timenet + 16 heads on v_mfma_f32_16x16x4_f32: rdg_mlp_forward / rdg_mlp_backward."""
+
+    @staticmethod
+    def forward(ctx, x, W0, b0, W1, b1, W2, b2, hw1, hb1, hw2, hb2):
+        L = _lib.lib()
+        ps = [t.detach().to(torch.float32).contiguous() for t in (x, W0, b0, W1, b1, W2, b2, hw1, hb1, hw2, hb2)]
+        x_, W0_, _, W1_, _, W2_, _, hw1_, _, hw2_, _ = ps
+        NR, D0 = x_.shape
+        H, NB, OUT = W0_.shape[0], hw1_.shape[0], hw2_.shape[1]
+        if W1_.shape != (H, H) or W2_.shape != (H // 2, H) or hw1_.shape[1:] != (H // 4, H // 2) or \
+                hw2_.shape[2] != H // 4:
+            raise RuntimeError("rodygs_amd fused MLP: unexpected layer shapes")
+        dev = x_.device
+        with torch.cuda.device(dev):
+            ws = torch.empty(L.rdg_mlp_ws_bytes(NR, H, NB), dtype=torch.uint8, device=dev)
+            out = torch.empty(NR, NB, OUT, dtype=torch.float32, device=dev)
+            _lib.check(L.rdg_mlp_forward(NR, D0, H, NB, OUT, *[_lib.ptr(t) for t in ps], _lib.ptr(ws), _lib.ptr(out),
+                                         _lib.stream_ptr()), "rdg_mlp_forward")
+        ctx.save_for_backward(x_, W1_, W2_, hw1_, hw2_, ws)
+        ctx.dims = (NR, D0, H, NB, OUT)
+        ctx.shapes = [t.shape for t in ps[1:]]
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L = _lib.lib()
+        x_, W1_, W2_, hw1_, hw2_, ws = ctx.saved_tensors
+        NR, D0, H, NB, OUT = ctx.dims
+        g = g_out.to(torch.float32).contiguous()
+        grads = [torch.empty(s, dtype=torch.float32, device=x_.device) for s in ctx.shapes]
+        with torch.cuda.device(x_.device):
+            _lib.check(L.rdg_mlp_backward(NR, D0, H, NB, OUT, _lib.ptr(x_), _lib.ptr(W1_), _lib.ptr(W2_), _lib.ptr(hw1_),
+                                          _lib.ptr(hw2_), _lib.ptr(ws), _lib.ptr(g), *[_lib.ptr(t) for t in grads],
+                                          _lib.stream_ptr()), "rdg_mlp_backward")
+        return (None, *grads)
+
+
 _HEAD_KEY = re.compile(r"^(.*)basis_xyz\.(\d+)\.basis\.(0|2)\.(weight|bias)$")
 _STACKED = {("0", "weight"): "head_w1", ("0", "bias"): "head_b1", ("2", "weight"): "head_w2", ("2", "bias"): "head_b2"}
 
@@ -140,9 +181,19 @@ class MLPBasisNetwork(nn.Module):
         return o.transpose(0, 1)
 
     def motion_basis(self, t_emb: torch.Tensor) -> torch.Tensor:
-        """t_emb [..., 53] -> motion basis [..., num_basis, 7]."""
+        """t_emb [..., 53] -> motion basis [..., num_basis, 7].
+
+        GPU tensors with the default GELU run the whole network as 5 MFMA launches forward / 16 backward
+        (csrc/rdg_mlp.hip); the torch expression below is the same arithmetic and serves CPU tensors (checkpoint
+        tooling, golden tests) and the ReLU variant."""
         lead = t_emb.shape[:-1]
-        h = self.timenet(t_emb.reshape(-1, t_emb.shape[-1]))
+        x = t_emb.reshape(-1, t_emb.shape[-1])
+        if x.is_cuda and FUSED_MLP and isinstance(self.activation, nn.GELU):
+            tn = self.timenet
+            out = _FusedMLP.apply(x, tn[0].weight, tn[0].bias, tn[2].weight, tn[2].bias, tn[4].weight, tn[4].bias,
+                                  self.head_w1, self.head_b1, self.head_w2, self.head_b2)
+            return out.reshape(*lead, self.num_basis, self.trans_dim + self.rot_dim)
+        h = self.timenet(x)
         return self._heads(h).reshape(*lead, self.num_basis, self.trans_dim + self.rot_dim)
 
     def batch_embedding(self, timesteps):

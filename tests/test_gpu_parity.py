@@ -505,6 +505,32 @@ def test_pose_view_matrix_matches_reference_camera():
         rel_ok(qg.grad, qc.grad, tol=1e-5, what="d_quat"); rel_ok(tg.grad, tc.grad, tol=1e-5, what="d_trans")
 
 
+@pytest.mark.parametrize("NR", [1, 37, 101, 300])
+def test_mfma_mlp_matches_torch(NR):
+    """rdg_mlp_forward/backward (v_mfma_f32_16x16x4_f32) vs the torch expression of the same network."""
+    from rodygs_amd import deform
+    g = torch.Generator().manual_seed(NR)
+    net = deform.MLPBasisNetwork(128, 16, 26, False).to(DEV)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1)).to(DEV))
+    x = torch.randn(NR, 53, generator=g).to(DEV)
+    w = torch.randn(NR, 16, 7, generator=g).to(DEV)
+    res = {}
+    for fused in (True, False):
+        deform.FUSED_MLP = fused
+        try:
+            net.zero_grad(set_to_none=True)
+            out = net.motion_basis(x)
+            (out * w).sum().backward()
+            res[fused] = (out.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()})
+        finally:
+            deform.FUSED_MLP = True
+    rel_ok(res[True][0], res[False][0], tol=1e-5, what="mlp out")
+    for n in res[False][1]:
+        rel_ok(res[True][1][n], res[False][1][n], tol=2e-5, what="d_" + n)
+
+
 def test_fused_adam_rows_matches_two_torch_groups():
     """Row-structured Adam (features [P,16,3]: DC at lr, rest at lr/20) == torch Adam with two parameter groups."""
     from rodygs_amd import _lib
