@@ -185,6 +185,20 @@ int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_av
                        int32_t row_len, int32_t head_len, float lr_head, float lr_tail, float beta1, float beta2,
                        float eps, int32_t step, void* stream);
 
+/* All parameter groups in ONE launch (the reference steps ~8 groups per sub-step, rodygs_static.py:106-141).     */
+#define RDG_ADAM_MAX_SEGS 12
+typedef struct RdgAdamSeg {
+    int64_t n;              /* floats in this segment                                   */
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float lr_head, lr_tail; /* lr of the first head_len floats of every row / of the rest */
+    int32_t row_len, head_len;   /* row_len <= 1: uniform lr_head                          */
+} RdgAdamSeg;
+int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, float beta2, float eps, int32_t step,
+                        void* stream);
+
 /* ---- fused photometric loss -------------------------------------------------------------
  * loss = (1-lambda) mean|img-gt| + lambda (1 - mean SSIM(img, gt)), SSIM as in
  * /root/reference/src/utils/loss_utils.py:19-100 (11x11 Gaussian window, sigma 1.5, zero padding), the combination
@@ -226,6 +240,7 @@ int rdg_pose_view_backward(int32_t T, int32_t frame, const float* cam_q, const f
  * synchronises on the recorded events and returns accumulated milliseconds + launch count since the last
  * reset.                                                                                                    */
 int rdg_timing_enable(int32_t on);
+int rdg_timing_select(uint32_t stage_mask);   /* bit i = time stage i (default all); events cost ~5 us of stream gap each */
 int rdg_timing_reset(void);
 int rdg_stage_time_ms(int32_t stage, double* total_ms, int64_t* count);
 

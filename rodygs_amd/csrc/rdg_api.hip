@@ -23,6 +23,7 @@ int rdg_check_hip(hipError_t e, const char* what) {
 #define RDG_MAX_PENDING 4096
 struct RdgPending { hipEvent_t a, b; int stage; };
 static int g_timing = 0;
+static uint32_t g_timing_mask = 0xFFFFFFFFu;
 static RdgPending g_pending[RDG_MAX_PENDING];
 static int g_npending = 0;
 static hipEvent_t g_open[RDG_STAGE_COUNT];
@@ -43,7 +44,7 @@ static void rdg_timing_drain() {
     g_npending = 0;
 }
 void rdg_stage_begin(int stage, hipStream_t s) {
-    if (!g_timing) return;
+    if (!g_timing || !((g_timing_mask >> stage) & 1u)) return;
     if (g_npending >= RDG_MAX_PENDING) rdg_timing_drain();
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -269,6 +270,7 @@ int rdg_sort_pairs(uint64_t* keys, uint32_t* vals, int64_t capacity, const int32
 }
 
 int rdg_timing_enable(int32_t on) { g_timing = on ? 1 : 0; return 0; }
+int rdg_timing_select(uint32_t stage_mask) { g_timing_mask = stage_mask; return 0; }
 int rdg_timing_reset(void) {
     rdg_timing_drain();
     memset(g_total_ms, 0, sizeof(g_total_ms));

@@ -372,7 +372,12 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
 __global__ void __launch_bounds__(1024)
 rdg_tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
                      uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered) {
-    if ((long long)(*num_rendered) > capacity) return;
+    if ((long long)(*num_rendered) > capacity) {
+        // capacity overflow: leave EVERY tile empty, so the compositing kernels (forward and backward) see a valid,
+        // empty scene (background image, zero gradients) instead of stale ranges; the host detects D > capacity
+        for (int i = threadIdx.x; i < n_tiles; i += 1024) { ranges[i] = make_uint2(0u, 0u); tile_fill[i] = 0u; }
+        return;
+    }
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;

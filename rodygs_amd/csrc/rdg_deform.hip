@@ -225,10 +225,10 @@ __global__ void rdg_deform_dbt_kernel(int Tu, int row, const float* __restrict__
 // Fused Adam over a flat f32 segment.  row_len > 1 gives the segment a row structure whose first head_len floats
 // take step_head and the rest step_tail: the SH features [P,16,3] are ONE tensor whose DC coefficient trains 20x
 // faster than the rest (feature_lr vs feature_lr/20), so no cat/split of f_dc/f_rest is ever needed.
-__global__ void __launch_bounds__(256)
-rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
-                float eps, float bc2_sqrt) {
+__device__ __forceinline__ void
+rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
+                 float eps, float bc2_sqrt) {
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -265,6 +265,22 @@ rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g,
         m[i] = mi; v[i] = vi;
         p[i] -= st * (mi / (sqrtf(vi) / bc2_sqrt + eps));
     }
+}
+
+__global__ void __launch_bounds__(256)
+rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
+                float eps, float bc2_sqrt) {
+    rdg_adam_segment(n, p, g, m, v, step_head, step_tail, row_len, head_len, b1, b2, eps, bc2_sqrt);
+}
+
+// all parameter groups of a model in ONE launch: blockIdx.y selects the segment
+struct RdgAdamSegs { RdgAdamSeg s[RDG_ADAM_MAX_SEGS]; };
+__global__ void __launch_bounds__(256)
+rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+    const RdgAdamSeg sg = segs.s[blockIdx.y];
+    rdg_adam_segment(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, sg.lr_head * inv_bc1, sg.lr_tail * inv_bc1,
+                     sg.row_len, sg.head_len, b1, b2, eps, bc2_sqrt);
 }
 
 extern "C" {
@@ -362,6 +378,31 @@ static int rdg_adam_launch(int64_t n, float* param, const float* grad, float* ex
 int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, int32_t step, void* stream) {
     return rdg_adam_launch(n, param, grad, exp_avg, exp_avg_sq, 1, 1, lr, lr, beta1, beta2, eps, step, stream);
+}
+
+int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, float beta2, float eps, int32_t step,
+                        void* stream) {
+    if (nseg <= 0) return 0;
+    if (nseg > RDG_ADAM_MAX_SEGS) return rdg_set_error("adam: at most %d segments per launch", RDG_ADAM_MAX_SEGS);
+    if (step < 1) return rdg_set_error("adam: step must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    RdgAdamSegs segs;
+    long long nmax = 0;
+    for (int i = 0; i < nseg; ++i) {
+        segs.s[i] = segs_host[i];
+        if (segs.s[i].row_len < 1) segs.s[i].row_len = 1;
+        if (segs.s[i].n > nmax) nmax = segs.s[i].n;
+    }
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    long long blocks = ((nmax >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    rdg_stage_begin(RDG_STAGE_ADAM, st);
+    hipLaunchKernelGGL(rdg_adam_multi_kernel, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs, (float)(1.0 / bc1),
+                       beta1, beta2, eps, (float)sqrt(bc2));
+    rdg_stage_end(RDG_STAGE_ADAM, st);
+    return rdg_check_hip(hipGetLastError(), "adam multi launch");
 }
 
 int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t row_len,

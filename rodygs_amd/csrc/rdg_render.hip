@@ -66,7 +66,7 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                       const RdgRec* __restrict__ rec, long long capacity, const int32_t* __restrict__ num_rendered,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_normal, float* __restrict__ out_alpha) {
-    if ((long long)(*num_rendered) > capacity) return;
+    // on capacity overflow the binning stage has emptied every tile range: this kernel then renders the background
     const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH], sQ3[RDG_BATCH];

@@ -28,6 +28,39 @@ RENDER_NORMAL = True          # composite the (unused-by-RoDyGS) normal channels
 _CAPACITY_HINT = {}           # (P, H, W) -> last num_rendered, to size the binning workspace without a sync
 
 
+DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
+_PENDING = []                     # (event, pinned int32[1], key, capacity) of forwards not yet checked
+_PINNED_FREE = []
+
+
+class RasterizerCapacityOverflow(RuntimeError):
+    """Raised (deferred mode only) when an earlier forward produced more (tile, Gaussian) instances than its binning
+    workspace could hold.  That frame was rendered as an EMPTY scene (background, zero gradients); the capacity hint
+    has been raised, so re-running the frame succeeds."""
+
+
+def _pinned_slot() -> torch.Tensor:
+    return _PINNED_FREE.pop() if _PINNED_FREE else torch.empty(1, dtype=torch.int32).pin_memory()
+
+
+def poll_overflow(block: bool = False) -> None:
+    """Deferred mode: check the instance counts of forwards whose copy has landed (all of them if ``block``)."""
+    while _PENDING:
+        ev, host, key, cap = _PENDING[0]
+        if not block and not ev.query():
+            return
+        ev.synchronize()
+        n = int(host[0])
+        _PENDING.pop(0)
+        _PINNED_FREE.append(host)
+        _CAPACITY_HINT[key] = max(n, int(_CAPACITY_HINT.get(key, 0) * 0.9))
+        if n > cap:
+            _CAPACITY_HINT[key] = n
+            raise RasterizerCapacityOverflow(
+                f"rasterizer forward for (P,H,W)={key} needed {n} instances, workspace held {cap}: that frame was "
+                f"rendered empty; re-run it (the capacity hint is now {n})")
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -132,6 +165,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             key = (P, H, W)
             cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
             stream = _lib.stream_ptr()
+            deferred = DEFERRED_OVERFLOW_CHECK and key in _CAPACITY_HINT
+            if deferred:
+                poll_overflow(block=False)
             while True:
                 binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), **u8)
                 rc = L.rdg_rasterize_forward(C.byref(cs), _lib.ptr(bg), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col),
@@ -140,6 +176,17 @@ class _RasterizeGaussians(torch.autograd.Function):
                                              _lib.ptr(color), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha),
                                              _lib.ptr(radii), _lib.ptr(nren), stream)
                 _lib.check(rc, "rdg_rasterize_forward")
+                if deferred:
+                    # opt-in: no host wait at all.  D goes to pinned memory asynchronously and is checked by
+                    # poll_overflow() at the next forward / on demand; on overflow the device has rendered an
+                    # empty scene (every tile range zero) and RasterizerCapacityOverflow is raised then.
+                    host = _pinned_slot()
+                    host.copy_(nren, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _PENDING.append((ev, host, key, cap))
+                    n = -1
+                    break
                 # one host read AFTER the whole forward is queued (upstream stalls mid-pipeline instead)
                 n = int(nren.item())
                 _CAPACITY_HINT[key] = n

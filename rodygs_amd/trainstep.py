@@ -44,23 +44,26 @@ def world_view_transform(q_c2w: torch.Tensor, t_c2w: torch.Tensor) -> torch.Tens
 
 
 def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None) -> None:
-    """One fused HIP launch per parameter group over the flat buffers (rdg_adam_step / rdg_adam_step_rows).
+    """ONE fused HIP launch for all parameter groups of the flat buffers (rdg_adam_step_multi).
     row_lr: {name: (row_len, head_len, lr_tail)} for segments whose rows mix two learning rates."""
     L = _lib.lib()
     fp.step_count += 1
-    st = _lib.stream_ptr()
-    for k in fp.names:
+    segs = (_lib.RdgAdamSeg * len(fp.names))()
+    for i, k in enumerate(fp.names):
         o, n = fp.offsets[k]
-        esz = 4
-        ptrs = (fp.flat.data_ptr() + o * esz, fp.flat_grad.data_ptr() + o * esz, fp.exp_avg.data_ptr() + o * esz,
-                fp.exp_avg_sq.data_ptr() + o * esz)
-        if row_lr and k in row_lr:
-            row_len, head_len, lr_tail = row_lr[k]
-            _lib.check(L.rdg_adam_step_rows(n, *ptrs, row_len, head_len, fp.lr[k] * lr_scale, lr_tail * lr_scale,
-                                            betas[0], betas[1], eps, fp.step_count, st), "rdg_adam_step_rows")
-        else:
-            _lib.check(L.rdg_adam_step(n, *ptrs, fp.lr[k] * lr_scale, betas[0], betas[1], eps, fp.step_count, st),
-                       "rdg_adam_step")
+        b = o * 4
+        row_len, head_len, lr_tail = (row_lr or {}).get(k, (1, 1, fp.lr[k]))
+        segs[i].n = n
+        segs[i].param = fp.flat.data_ptr() + b
+        segs[i].grad = fp.flat_grad.data_ptr() + b
+        segs[i].exp_avg = fp.exp_avg.data_ptr() + b
+        segs[i].exp_avg_sq = fp.exp_avg_sq.data_ptr() + b
+        segs[i].lr_head = fp.lr[k] * lr_scale
+        segs[i].lr_tail = lr_tail * lr_scale
+        segs[i].row_len = row_len
+        segs[i].head_len = head_len
+    _lib.check(L.rdg_adam_step_multi(len(fp.names), segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
+               "rdg_adam_step_multi")
 
 
 class DynamicScene:
