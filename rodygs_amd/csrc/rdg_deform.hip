@@ -217,9 +217,14 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
 __global__ void rdg_deform_dbt_kernel(int Tu, int row, const float* __restrict__ d_table, float* __restrict__ d_basis_t) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= row) return;
-    float s = 0.0f;
-    for (int u = 0; u < Tu; ++u) s += d_table[(size_t)u * row + c];
-    d_basis_t[c] = -s;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int u = 0;
+    for (; u + 7 < Tu; u += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] += d_table[(size_t)(u + q) * row + c];
+    }
+    for (; u < Tu; ++u) a[0] += d_table[(size_t)u * row + c];
+    d_basis_t[c] = -(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
 }
 
 // Fused Adam over a flat f32 segment.  row_len > 1 gives the segment a row structure whose first head_len floats

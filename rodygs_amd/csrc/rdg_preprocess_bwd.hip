@@ -322,8 +322,17 @@ rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict
     __shared__ float sred[32][33];
     const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
     float acc = 0.0f;
-    if (k < RDG_POSE_N)
-        for (int r = grp; r < nblk; r += 32) acc += posebuf[(size_t)r * RDG_POSE_N + k];
+    if (k < RDG_POSE_N) {
+        // 8 independent loads in flight per thread (a single dependent chain of 122 L2 reads took 40 us)
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = grp;
+        for (; r + 7 * 32 < nblk; r += 8 * 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += posebuf[(size_t)(r + 32 * u) * RDG_POSE_N + k];
+        }
+        for (; r < nblk; r += 32) a[0] += posebuf[(size_t)r * RDG_POSE_N + k];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     sred[grp][k] = acc;
     __syncthreads();
     // second level: 19 threads each fold their 32 partials (fixed order), thread 0 finishes
