@@ -160,6 +160,16 @@ def main():
         dom = "render_bwd"
         dom_ms = per_stage[dom]
         alg_bytes = D * 44 + H * W * 40 + V * 40
+        # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE in separate runs, gfx950 correction applied); only valid for the workload it was taken on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            wl = pmc["workload"]
+            if (wl["points"], wl["width"], wl["height"]) == (P, W, H):
+                traffic = pmc["kernels"]["rdg_render_bwd_kernel"]["hbm_bytes_corrected"]
+        except Exception:
+            traffic = None
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         res = {
             "metric": "train-step fps at 1M dynamic Gaussians / 1080p (fwd+bwd+Adam, one camera per GPU per step)",
@@ -174,7 +184,7 @@ def main():
             "stage_ms": per_stage,
             "roofline": {"bound": "hbm", "kernel": "rdg_render_bwd_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": dom_ms,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": dom_ms,
                          "note": "compositing kernels are VALU/exp/LDS-bound (SURVEY.md §8d); the HBM fraction is "
                                  "reported because north_star asks for it"},
         }
