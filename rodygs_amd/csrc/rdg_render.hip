@@ -12,11 +12,13 @@
 // (wave, splat) pairs are never touched.  The test is conservative (power margin 0.01 + inflated box), so the
 // result is identical to visiting every splat; order inside the list is preserved.
 //
-// Backward: per (wave, splat) the 10 partial derivatives are summed across the 64 lanes with DPP (no LDS
-// traffic), lane 63 folds them into a per-batch LDS accumulator shared by the 4 waves (ds_add_f32), and at the
-// end of each 256-splat batch the block flushes with ONE 64-B-row atomic per (tile, splat): 16 consecutive
-// lanes cover the 16 floats of a Gaussian's accumulator row, which is the access shape the global float-atomic
-// unit runs at full rate for (MI355X_MICROARCH.md "Global float atomics").
+// Backward: per (wave, splat) the 10 partial derivatives are reduced with a TRANSPOSED DPP reduction (the value
+// index is folded into the lane index: 14 DPP adds instead of 60) down to one total per 16-lane row; the row totals
+// are parked with plain LDS stores in a ring PRIVATE to the wave (no LDS atomics -- ds_add_f32 into a table shared
+// by the 4 waves was a third of the kernel), and every 16 splats the wave flushes its ring with 64-B-row global
+// float atomics: 16 consecutive lanes cover the 16 floats of a Gaussian's accumulator row, 4 Gaussians per
+// instruction, which is the access shape the global float-atomic unit runs at full rate for (MI355X_MICROARCH.md
+// "Global float atomics").  Atomics are therefore per (wave, splat) that a pixel actually blended.
 //
 // The kernels are VALU/transcendental bound, not HBM bound.
 #include "rdg_common.h"
@@ -308,8 +310,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds, everything ending in
                 // lane 63), fold the VALUE index into the lane index while reducing: xor-1 and xor-2 exchanges halve
                 // the number of live values each (lane&3 then selects the component), two row rotations finish the
-                // 16-lane rows, and the 4 rows are combined by the LDS atomic itself (lanes 0-3 of every row add
-                // their row total to the component they hold).  28 VALU + 3 ds_add instead of 60 DPP + 10 ds_add.
+                // 16-lane rows, and the 4 row totals are summed when the ring is flushed.
                 {
                     const bool b0 = lane & 1, b1 = lane & 2;
                     const float a0 = (b0 ? g1 : g0) + rdg_dpp<0xB1>(b0 ? g0 : g1);   // comp 0 + b0
