@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: FP32 vector peak
 
 
 def cpu_baseline(scene, sh_degree, sample_tiles=96, max_seconds=40.0):
@@ -171,6 +172,31 @@ def main():
         except Exception:
             traffic = None
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # whole-step and per-stage algorithmic bytes (the survey's own formula, radix-sort term and
+        # all, so the number is comparable across builds) and the FP32-VALU fraction of the two compositing kernels
+        with torch.no_grad():
+            _, n_contrib = rasterizer.last_compositing_state()
+            S = int(n_contrib.sum(dtype=torch.int64).item())
+        K, tiles = 16, ((W + 15) // 16) * ((H + 15) // 16)
+        n_pass = (32 + max(tiles - 1, 1).bit_length() + 7) // 8
+        sb = {
+            "preprocess": P * (44 + 12 * K) + V * 48 + P * 8,
+            "binning": D * 12 + D * 24 * n_pass + D * 8 + tiles * 8,
+            "render_fwd": D * 44 + H * W * 40,
+            "render_bwd": alg_bytes,
+            "preprocess_bwd": P * (44 + 12 * K) * 2 + V * 48,
+            "deform_fwd": P * 96, "deform_bwd": P * 96,
+            "adam": 28 * (59 + 16) * P,
+        }
+        sms = dict(per_stage)
+        sms["binning"] = per_stage["scan_dup"] + per_stage["sort"] + per_stage["ranges"]
+        stage_roofline = {k: {"algorithmic_bytes": b, "ms": sms[k],
+                              "hbm_frac": (b / (sms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if sms[k] > 0 else None}
+                          for k, b in sb.items()}
+        b_step = sum(sb.values())
+        valu = {k: {"flops": S * f, "tflops": S * f / (per_stage[k] * 1e-3) / 1e12,
+                    "frac_of_fp32_vector_peak": S * f / (per_stage[k] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
+                for k, f in (("render_fwd", 22), ("render_bwd", 60)) if per_stage[k] > 0}
         res = {
             "metric": "train-step fps at 1M dynamic Gaussians / 1080p (fwd+bwd+Adam, one camera per GPU per step)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,6 +208,12 @@ def main():
             "gaussians_per_s": fps * P,
             "loss": float(loss.item()),
             "stage_ms": per_stage,
+            "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": b_step * fps / world / 1e9,
+                              "frac_of_8TBps": b_step * fps / world / 1e9 / HBM_PEAK_GBPS,
+                              "frac_of_6.3TBps_achievable": b_step * fps / world / 1e9 / 6300.0,
+                              "pixel_splat_pairs_S": S},
+            "stage_roofline": stage_roofline,
+            "render_valu": valu,
             "roofline": {"bound": "hbm", "kernel": "rdg_render_bwd_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": dom_ms,

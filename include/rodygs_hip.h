@@ -126,6 +126,10 @@ int rdg_preprocess_forward(const RdgRasterSettings* s_host, const float* means3D
  * tiles_touched[P] (uint32).  Any pointer may be NULL.                                                      */
 int rdg_geom_export(int32_t P, const void* geom_ws, float* depth, float* xy, float* conic_opacity, float* rgb,
                     float* normal, uint32_t* tiles_touched, void* stream);
+/* Copies out the per-pixel compositing state the backward replays from: final_T[H*W] (transmittance left after
+ * the last blended splat) and n_contrib[H*W] (1 + list position of the last blended splat; their sum is S, the
+ * number of pixel-splat pairs the forward walked).  Either pointer may be NULL.                               */
+int rdg_image_export(int32_t H, int32_t W, const void* image_ws, float* final_T, uint32_t* n_contrib, void* stream);
 /* duplicateWithKeys + sort + tile ranges.  keys_unsorted/vals_unsorted/keys_sorted/vals_sorted (capacity
  * entries each) and ranges[n_tiles,2] are optional copies for the tests.                                    */
 int rdg_bin_forward(const RdgRasterSettings* s_host, const void* geom_ws, const int32_t* radii, void* binning_ws,

@@ -51,6 +51,7 @@ _SIGS = {
     "rdg_rasterize_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13 + [C.c_int64] + [_vp] * 15),
     "rdg_preprocess_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13),
     "rdg_geom_export": (C.c_int, [C.c_int32] + [_vp] * 8),
+    "rdg_image_export": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 4),
     "rdg_bin_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 8),
     "rdg_sort_pairs": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int32, _vp, _vp]),
     "rdg_deform_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),

@@ -207,6 +207,22 @@ int rdg_geom_export(int32_t P, const void* geom_ws, float* depth, float* xy, flo
     return rdg_check_hip(hipGetLastError(), "geom_export launch");
 }
 
+int rdg_image_export(int32_t H, int32_t W, const void* image_ws, float* final_T, uint32_t* n_contrib, void* stream) {
+    if (H <= 0 || W <= 0 || !image_ws) return rdg_set_error("rdg_image_export: bad arguments");
+    const RdgImageLayout I = rdg_image_layout(H, W);
+    const size_t bytes = (size_t)H * W * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (final_T) {
+        hipError_t e = hipMemcpyAsync(final_T, (const char*)image_ws + I.final_T, bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return rdg_check_hip(e, "image_export final_T");
+    }
+    if (n_contrib) {
+        hipError_t e = hipMemcpyAsync(n_contrib, (const char*)image_ws + I.n_contrib, bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return rdg_check_hip(e, "image_export n_contrib");
+    }
+    return 0;
+}
+
 __global__ void rdg_copy_u64_kernel(const uint64_t* __restrict__ a, uint64_t* __restrict__ b, long long cap,
                                     const int32_t* __restrict__ n_dev) {
     long long n = *n_dev; if (n > cap) return;

@@ -56,6 +56,18 @@ __device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const flo
            ((uint32_t)(x1 && y1) << 3);
 }
 
+// Staged form of a splat's conic: (A2, B, C2) = -log2(e) * (a, b, c), so that
+//   log2(G) = 0.5 (A2 dx^2 + C2 dy^2) + B dx dy      and      G = v_exp_f32(log2 G)  with no extra multiply,
+// and the products t = A2 dx, v = C2 dy are reused by the backward (dG/ddx ~ t + B dy, dG/ddy ~ v + B dx).  Forward
+// and backward evaluate exactly this expression, so they take identical blend / skip decisions.
+#define RDG_NEG_LOG2E (-1.4426950408889634f)
+__device__ __forceinline__ float rdg_log2_gauss(float A2, float B, float C2, float dx, float dy, float& t, float& v) {
+    t = A2 * dx;
+    v = C2 * dy;
+    const float u = fmaf(v, dy, t * dx);
+    return fmaf(0.5f, u, (B * dx) * dy);
+}
+
 __device__ __forceinline__ unsigned long long rdg_uniform_u64(unsigned long long v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -97,7 +109,9 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
             const uint32_t id = point_list[range.x + k];
             const RdgRec* p = rec + id;
             const float4 q0 = p->q0, q1 = p->q1;
-            sQ0[tid] = q0; sQ1[tid] = q1; sQ2[tid] = p->q2;
+            sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
+            sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
+            sQ2[tid] = p->q2;
             if (render_normal) sQ3[tid] = p->q3;
             qbits = rdg_quadrant_bits(q0, q1, X0, Y0);
         }
@@ -118,8 +132,9 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                 const float4 q0 = sQ0[j];
                 const float4 q1 = sQ1[j];
                 const float dx = q0.x - pixx, dy = q0.y - pixy;
-                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-                const float alpha = fminf(RDG_ALPHA_CAP, q1.y * __expf(power));
+                float t_, v_;
+                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
+                const float alpha = fminf(RDG_ALPHA_CAP, q1.y * __builtin_amdgcn_exp2f(power));
                 bool hit = !done && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
                 if (!__any(hit)) continue;
                 const float test_T = T * (1.0f - alpha);
@@ -172,19 +187,25 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
 #define RDG_RING 16
 // Flush a wave's ring: 16 consecutive lanes = the 64-B accumulator row of one Gaussian, 4 entries per instruction,
 // which is the access shape the global float-atomic unit runs at full rate for.
-__device__ __forceinline__ void rdg_ring_flush(float (*ring)[4][12], const uint32_t* ids, int n, int lane,
+// `scale` = this lane's constant factor for component (lane & 15), see the derivative block of the kernel.
+__device__ __forceinline__ void rdg_ring_flush(float (*ring)[4][12], const uint32_t* ids, int n, int lane, float scale,
                                                float* __restrict__ grow) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // LDS operations of one wave execute in program order; the fences only pin the compiler's ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int c = lane & 15;
     for (int e0 = 0; e0 < n; e0 += 4) {
         const int e = e0 + (lane >> 4);
         if (e < n && c < 10) {
-            const volatile float* r = &ring[e][0][c];
-            const float v = (r[0] + r[12]) + (r[24] + r[36]);
+            const float* r = &ring[e][0][c];
+            const float v = ((r[0] + r[12]) + (r[24] + r[36])) * scale;
             if (v != 0.0f) atomicAdd(grow + (size_t)ids[e] * RDG_GROW + c, v);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -241,7 +262,10 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
 
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
     int ring_n = 0;   // wave-uniform fill level of this wave's ring
-    const float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
+    const int fc = lane & 15;
+    const float flush_scale = fc == 0 ? (-0.5f / RDG_NEG_LOG2E) * (float)W
+                            : fc == 1 ? (-0.5f / RDG_NEG_LOG2E) * (float)H
+                            : (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : 1.0f;
 
     for (int r = 0; r < rounds; ++r) {
         const int kbase = kmax - 1 - r * RDG_BATCH;  // list position of slot 0 of this batch
@@ -253,7 +277,9 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const RdgRec* p = rec + id;
                 const float4 q0 = p->q0, q1 = p->q1;
                 sId[tid] = id;
-                sQ0[tid] = q0; sQ1[tid] = q1; sQ2[tid] = p->q2;
+                sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
+                sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
+                sQ2[tid] = p->q2;
                 qbits = rdg_quadrant_bits(q0, q1, X0, Y0);
                 // a quadrant whose pixels all stopped before this list position never needs the splat
                 qbits &= (uint32_t)(k < m0) | ((uint32_t)(k < m1) << 1) | ((uint32_t)(k < m2) << 2) |
@@ -276,8 +302,9 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const float4 q0 = sQ0[j];
                 const float4 q1 = sQ1[j];
                 const float dx = q0.x - pixx, dy = q0.y - pixy;
-                const float power = -0.5f * (q0.z * dx * dx + q1.x * dy * dy) - q0.w * dx * dy;
-                const float G = __expf(power);
+                float t_, v_;
+                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(RDG_ALPHA_CAP, q1.y * G);
                 const bool hit = (k < last_contributor) && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
                 if (!__any(hit)) continue;
@@ -296,51 +323,76 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 acc0 += aeff * e0; acc1 += aeff * e1; acc2 += aeff * e2; accd += aeff * ed;
                 dL_dalpha = dL_dalpha * T + (T_final * inv1ma) * tail;
                 dL_dalpha = hit ? dL_dalpha : 0.0f;
-                const float dL_dG = q1.y * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * q0.z - gdy * q0.w;
-                const float dG_ddely = -gdy * q1.x - gdx * q0.w;
-                const float g0 = dL_dG * dG_ddelx * half_w;
-                const float g1 = dL_dG * dG_ddely * half_h;
-                const float g2 = -0.5f * gdx * dx * dL_dG;
-                const float g3 = -gdx * dy * dL_dG;
-                const float g4 = -0.5f * gdy * dy * dL_dG;
+                // The constant factors of the five geometric derivatives (0.5 W / log2 e, 0.5 H / log2 e, -0.5, -1, -0.5)
+                // are applied once per flushed row total (rdg_ring_flush), not per pixel-splat pair.
                 const float g5 = G * dL_dalpha;
+                const float Gw = g5 * q1.y;                         // G * dL/dG
+                const float g0 = Gw * fmaf(q0.w, dy, t_);           // ~ dL/d(mean2D.x)
+                const float g1 = Gw * fmaf(q0.w, dx, v_);           // ~ dL/d(mean2D.y)
+                const float gX = Gw * dx, gY = Gw * dy;
+                const float g2 = gX * dx;                           // ~ dL/d(conic a)
+                const float g3 = gX * dy;                           // ~ dL/d(conic b)
+                const float g4 = gY * dy;                           // ~ dL/d(conic c)
                 const float g6 = dch * dLp0, g7 = dch * dLp1, g8 = dch * dLp2, g9 = dch * dLd;
-                // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds, everything ending in
-                // lane 63), fold the VALUE index into the lane index while reducing: xor-1 and xor-2 exchanges halve
-                // the number of live values each (lane&3 then selects the component), two row rotations finish the
-                // 16-lane rows, and the 4 row totals are summed when the ring is flushed.
+                // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds), fold the VALUE index into
+                // the lane index while reducing.  DPP write masks work on quads (bank_mask: 4 lanes) and rows, so the
+                // folding steps come FIRST and act across quads: a rotate-by-8 exchange turns two values into one (the
+                // low half-row keeps the pair sum of the first value, the high half-row of the second), a half-row
+                // mirror does it again between neighbouring quads, and two plain quad butterflies finish.  Each
+                // "two values -> one" step is TWO instructions (one DPP add per bank_mask into the same register),
+                // which the compiler cannot express (it needs two selects + one DPP add), hence the hand-scheduled
+                // block: 21 VALU for the whole 10-value reduction.  DPP needs two wait states after the VALU write of
+                // the register it reads: the order below keeps at least two instructions between every producer and
+                // its DPP consumer; s_nop 1 covers the inputs.
+                // Result: every lane of quad q (h = q >> 1, p = q & 1) holds the 16-lane row total of component
+                // 2p + h (y0), 4 + 2p + h (y1), 8 + h (y2).
+                float x0, x1, x2, x3, x4, y0, y1, y2;
+                asm volatile(
+                    "s_nop 1\n\t"
+                    "v_add_f32_dpp %[x4], %[g8], %[g8] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                    "v_add_f32_dpp %[x4], %[g9], %[g9] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                    "v_add_f32_dpp %[x0], %[g0], %[g0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                    "v_add_f32_dpp %[x0], %[g1], %[g1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                    "v_add_f32_dpp %[x1], %[g2], %[g2] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                    "v_add_f32_dpp %[x1], %[g3], %[g3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                    "v_add_f32_dpp %[x2], %[g4], %[g4] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                    "v_add_f32_dpp %[x2], %[g5], %[g5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                    "v_add_f32_dpp %[x3], %[g6], %[g6] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                    "v_add_f32_dpp %[x3], %[g7], %[g7] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                    "v_add_f32_dpp %[y0], %[x0], %[x0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                    "v_add_f32_dpp %[y0], %[x1], %[x1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                    "v_add_f32_dpp %[y1], %[x2], %[x2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                    "v_add_f32_dpp %[y1], %[x3], %[x3] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                    "v_add_f32_dpp %[y2], %[x4], %[x4] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[y0], %[y0], %[y0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[y1], %[y1], %[y1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[y2], %[y2], %[y2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[y0], %[y0], %[y0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[y1], %[y1], %[y1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_add_f32_dpp %[y2], %[y2], %[y2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                    : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4),
+                      [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2)
+                    : [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [g5] "v"(g5),
+                      [g6] "v"(g6), [g7] "v"(g7), [g8] "v"(g8), [g9] "v"(g9));
                 {
-                    const bool b0 = lane & 1, b1 = lane & 2;
-                    const float a0 = (b0 ? g1 : g0) + rdg_dpp<0xB1>(b0 ? g0 : g1);   // comp 0 + b0
-                    const float a1 = (b0 ? g3 : g2) + rdg_dpp<0xB1>(b0 ? g2 : g3);   // comp 2 + b0
-                    const float a2 = (b0 ? g5 : g4) + rdg_dpp<0xB1>(b0 ? g4 : g5);   // comp 4 + b0
-                    const float a3 = (b0 ? g7 : g6) + rdg_dpp<0xB1>(b0 ? g6 : g7);   // comp 6 + b0
-                    const float a4 = (b0 ? g9 : g8) + rdg_dpp<0xB1>(b0 ? g8 : g9);   // comp 8 + b0
-                    float s0 = (b1 ? a1 : a0) + rdg_dpp<0x4E>(b1 ? a0 : a1);         // comp (lane & 3)
-                    float s1 = (b1 ? a3 : a2) + rdg_dpp<0x4E>(b1 ? a2 : a3);         // comp 4 + (lane & 3)
-                    float s2 = a4 + rdg_dpp<0x4E>(a4);                               // comp 8 + b0
-                    s0 += rdg_dpp<0x124>(s0); s1 += rdg_dpp<0x124>(s1); s2 += rdg_dpp<0x124>(s2);   // row_ror:4
-                    s0 += rdg_dpp<0x128>(s0); s1 += rdg_dpp<0x128>(s1); s2 += rdg_dpp<0x128>(s2);   // row_ror:8
-                    // every lane of a 16-lane row now holds that row's total of component (lane & 3) [+4, +8].
-                    // Lanes 0-3 of each row park them in this wave's private ring with PLAIN LDS stores (LDS float
-                    // atomics into a table shared by the 4 waves cost 0.45 ms of 1.38 ms); the 4 row partials are
-                    // added when the ring is flushed.
-                    if ((lane & 12) == 0) {
-                        float* gr = &sRing[wv][ring_n][lane >> 4][lane & 3];
-                        gr[0] = s0;
-                        gr[4] = s1;
-                        if (!b1) gr[8] = s2;
+                    // One lane per quad parks the row totals in this wave's private ring with PLAIN LDS stores (LDS
+                    // float atomics into a table shared by the 4 waves cost a third of the kernel); the 4 row partials
+                    // are added when the ring is flushed.
+                    if ((lane & 3) == 0) {
+                        const int par = (lane >> 2) & 1, hh = (lane >> 3) & 1;
+                        float* gr = &sRing[wv][ring_n][lane >> 4][2 * par + hh];
+                        gr[0] = y0;
+                        gr[4] = y1;
+                        if (!par) gr[8] = y2;
                         if (lane == 0) sRingId[wv][ring_n] = sId[j];
                     }
-                    if (++ring_n == RDG_RING) { rdg_ring_flush(sRing[wv], sRingId[wv], ring_n, lane, grow); ring_n = 0; }
+                    if (++ring_n == RDG_RING) { rdg_ring_flush(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, grow); ring_n = 0; }
                 }
             }
         }
         __syncthreads();   // every wave is done with this round's staged records
     }
-    rdg_ring_flush(sRing[wv], sRingId[wv], ring_n, lane, grow);
+    rdg_ring_flush(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, grow);
 }
 
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,

@@ -193,6 +193,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if n <= cap:
                     break
                 cap = int(n * 1.25) + 4096
+        _LAST_IMAGE_WS[0] = (image, H, W)
         ctx.raster_settings = raster_settings
         ctx.empty_cloud = (P == 0)
         ctx.cs = cs
@@ -247,6 +248,23 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sink_sh is not None:
             d_sh = None
         return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_ro, d_cov, d_vm, None, None
+
+
+_LAST_IMAGE_WS = [None]
+
+
+def last_compositing_state():
+    """(final_T[H,W] float32, n_contrib[H,W] int32) of the most recent forward -- the per-pixel state the backward
+    replays from (``rdg_image_export``).  sum(n_contrib) is S, the pixel-splat pairs the forward walked."""
+    if _LAST_IMAGE_WS[0] is None:
+        raise RuntimeError("no rasterizer forward has run yet")
+    image, H, W = _LAST_IMAGE_WS[0]
+    with torch.cuda.device(image.device):
+        final_T = torch.empty(H, W, dtype=torch.float32, device=image.device)
+        n_contrib = torch.empty(H, W, dtype=torch.int32, device=image.device)
+        _lib.check(_lib.lib().rdg_image_export(H, W, _lib.ptr(image), _lib.ptr(final_T), _lib.ptr(n_contrib),
+                                               _lib.stream_ptr()), "rdg_image_export")
+    return final_T, n_contrib
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,

@@ -77,6 +77,8 @@ def run_pair(sc, deg, bg, cov_grad=True, sh_grad=True, use_colors=False, use_cov
     kw.update(dict(cov3Ds_precomp=hi["cov3Ds_precomp"]) if use_cov3d else dict(scales=hi["scales"],
                                                                                rotations=hi["rotations"]))
     hout = GaussianRasterizer(rs)(**kw)
+    from rodygs_amd.rasterizer import last_compositing_state
+    hout = tuple(hout) + (last_compositing_state(),)
     (hout[0] * wc.to(DEV)).sum().add((hout[1] * wd.to(DEV)).sum() * 0.1).add((hout[3] * wa.to(DEV)).sum()).backward()
     torch.cuda.synchronize()
 
@@ -107,6 +109,12 @@ def check_pair(res, grads):
         rel_ok(hi[k].grad, oi[k].grad, outliers=OUTLIER_FRAC, what="d_" + k)
     rel_ok(hm2.grad, om2.grad, outliers=OUTLIER_FRAC, what="d_means2D")
     assert float(hm2.grad[:, 2].abs().max()) == 0.0
+    # the per-pixel state the backward replays from: n_contrib is an index -> exact, except on
+    # the pixels that sit on an alpha = 1/255 or T = 1e-4 discontinuity
+    fT, nc = hout[6]
+    rel_ok(fT, oout[5]["final_T"], outliers=OUTLIER_FRAC, what="final_T")
+    mism = (nc.cpu() != oout[5]["n_contrib"]).double().mean().item()
+    assert mism <= OUTLIER_FRAC, f"n_contrib differs on {mism:.2e} of the pixels"
 
 
 # ---- stage-level bit-exactness -------------------------------------------------------------------------------
