@@ -68,6 +68,10 @@ __device__ __forceinline__ float rdg_log2_gauss(float A2, float B, float C2, flo
     return fmaf(0.5f, u, (B * dx) * dy);
 }
 
+// wave votes straight from the ballot (hip's __any/__all go through an int compare per lane)
+__device__ __forceinline__ bool rdg_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool rdg_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 __device__ __forceinline__ unsigned long long rdg_uniform_u64(unsigned long long v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -97,12 +101,14 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
     const int todo_total = (int)(range.y - range.x);
     const int rounds = (todo_total + RDG_BATCH - 1) / RDG_BATCH;
 
-    bool done = !inside;
+    // "this pixel has stopped" is folded into its alpha threshold (+inf once stopped / outside the image): the hot
+    // test is two compares, and no loop-carried lane mask has to be re-canonicalised every iteration
+    float amin = inside ? RDG_ALPHA_MIN : __builtin_inff();
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     uint32_t last_contributor = 0;
     for (int r = 0; r < rounds; ++r) {
-        if (__syncthreads_count(done) == 256) break;
+        if (__syncthreads_count(amin > 1.0f) == 256) break;
         const int k = r * RDG_BATCH + tid;
         uint32_t qbits = 0;
         if (k < todo_total) {
@@ -124,9 +130,9 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
         const uint32_t base_idx = (uint32_t)(r * RDG_BATCH);
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
+            if (rdg_all(amin > 1.0f)) break;   // once per 64 staged splats; inside the walk only after a pixel stops
             unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
             while (mask) {
-                if (__all(done)) { s = 4; break; }
                 const int j = s * 64 + __builtin_ctzll(mask);
                 mask &= mask - 1;
                 const float4 q0 = sQ0[j];
@@ -135,10 +141,11 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                 float t_, v_;
                 const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
                 const float alpha = fminf(RDG_ALPHA_CAP, q1.y * __builtin_amdgcn_exp2f(power));
-                bool hit = !done && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
-                if (!__any(hit)) continue;
+                const bool cand = power <= 0.0f && alpha >= amin;
+                if (!rdg_any(cand)) continue;
                 const float test_T = T * (1.0f - alpha);
-                if (hit && test_T < RDG_T_STOP) { done = true; hit = false; }
+                const bool stop = cand && test_T < RDG_T_STOP;
+                const bool hit = cand && !stop;
                 const float wgt = hit ? alpha * T : 0.0f;
                 const float4 q2 = sQ2[j];
                 C0 += wgt * q2.x; C1 += wgt * q2.y; C2 += wgt * q2.z;
@@ -148,6 +155,10 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                     N0 += wgt * q3.x; N1 += wgt * q3.y; N2 += wgt * q3.z;
                 }
                 if (hit) { T = test_T; last_contributor = base_idx + (uint32_t)j + 1u; }
+                if (rdg_any(stop)) {
+                    amin = stop ? __builtin_inff() : amin;
+                    if (rdg_all(amin > 1.0f)) { s = 4; break; }
+                }
             }
         }
     }
@@ -307,7 +318,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(RDG_ALPHA_CAP, q1.y * G);
                 const bool hit = (k < last_contributor) && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
-                if (!__any(hit)) continue;
+                if (!rdg_any(hit)) continue;
                 const float4 q2 = sQ2[j];
                 // Branch-free per-pixel derivatives.  A lane that does not blend this splat runs the same instructions
                 // with alpha_eff = 0, which leaves every piece of its state unchanged (T/(1-0) = T, B += 0*(c - B)) and
