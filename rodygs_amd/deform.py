@@ -82,8 +82,9 @@ class _FusedMLP(torch.autograd.Function):
     """timenet + 16 heads on v_mfma_f32_16x16x4_f32: rdg_mlp_forward / rdg_mlp_backward."""
 
     @staticmethod
-    def forward(ctx, x, W0, b0, W1, b1, W2, b2, hw1, hb1, hw2, hb2):
+    def forward(ctx, x, W0, b0, W1, b1, W2, b2, hw1, hb1, hw2, hb2, grad_sinks=None):
         L = _lib.lib()
+        ctx.grad_sinks = grad_sinks
         ps = [t.detach().to(torch.float32).contiguous() for t in (x, W0, b0, W1, b1, W2, b2, hw1, hb1, hw2, hb2)]
         x_, W0_, _, W1_, _, W2_, _, hw1_, _, hw2_, _ = ps
         NR, D0 = x_.shape
@@ -108,12 +109,24 @@ class _FusedMLP(torch.autograd.Function):
         x_, W1_, W2_, hw1_, hw2_, ws = ctx.saved_tensors
         NR, D0, H, NB, OUT = ctx.dims
         g = g_out.to(torch.float32).contiguous()
-        grads = [torch.empty(s, dtype=torch.float32, device=x_.device) for s in ctx.shapes]
+        sinks = ctx.grad_sinks
+        if sinks is not None:
+            # the kernels overwrite every element of the ten parameter gradients: write them straight into the
+            # caller's buffers (a flat gradient bucket) and hand nothing to AccumulateGrad
+            if len(sinks) != len(ctx.shapes) or any(tuple(t.shape) != tuple(sh) or not t.is_contiguous() or
+                                                     t.dtype != torch.float32 for t, sh in zip(sinks, ctx.shapes)):
+                raise RuntimeError("MLPBasisNetwork.grad_sinks must be 10 contiguous float32 tensors shaped like "
+                                   "(W0, b0, W1, b1, W2, b2, head_w1, head_b1, head_w2, head_b2)")
+            grads = list(sinks)
+        else:
+            grads = [torch.empty(s, dtype=torch.float32, device=x_.device) for s in ctx.shapes]
         with torch.cuda.device(x_.device):
             _lib.check(L.rdg_mlp_backward(NR, D0, H, NB, OUT, _lib.ptr(x_), _lib.ptr(W1_), _lib.ptr(W2_), _lib.ptr(hw1_),
                                           _lib.ptr(hw2_), _lib.ptr(ws), _lib.ptr(g), *[_lib.ptr(t) for t in grads],
                                           _lib.stream_ptr()), "rdg_mlp_backward")
-        return (None, *grads)
+        if sinks is not None:
+            return (None,) * 12
+        return (None, *grads, None)
 
 
 _HEAD_KEY = re.compile(r"^(.*)basis_xyz\.(\d+)\.basis\.(0|2)\.(weight|bias)$")
@@ -147,6 +160,7 @@ class MLPBasisNetwork(nn.Module):
         self.head_b1 = nn.Parameter(torch.zeros(num_basis, hmid))
         self.head_w2 = nn.Parameter(torch.randn(num_basis, hout, hmid) * 1e-2)
         self.head_b2 = nn.Parameter(torch.zeros(num_basis, hout))
+        self.grad_sinks = None   # optional: 10 tensors the fused backward overwrites (see _FusedMLP.backward)
         self._register_state_dict_hook(MLPBasisNetwork._to_reference_keys)
         self._register_load_state_dict_pre_hook(self._from_reference_keys)
 
@@ -191,7 +205,7 @@ class MLPBasisNetwork(nn.Module):
         if x.is_cuda and FUSED_MLP and isinstance(self.activation, nn.GELU):
             tn = self.timenet
             out = _FusedMLP.apply(x, tn[0].weight, tn[0].bias, tn[2].weight, tn[2].bias, tn[4].weight, tn[4].bias,
-                                  self.head_w1, self.head_b1, self.head_w2, self.head_b2)
+                                  self.head_w1, self.head_b1, self.head_w2, self.head_b2, self.grad_sinks)
             return out.reshape(*lead, self.num_basis, self.trans_dim + self.rot_dim)
         h = self.timenet(x)
         return self._heads(h).reshape(*lead, self.num_basis, self.trans_dim + self.rot_dim)
@@ -240,12 +254,18 @@ def _identity_order(P: int, dev) -> torch.Tensor:
 
 class _DeformFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, coeff, time_ind, basis_t, table, scale):
+    def forward(ctx, coeff, time_ind, basis_t, table, scale, grad_sinks=None, packed=None):
         L = _lib.lib()
         if not coeff.is_cuda:
             raise RuntimeError("rodygs_amd.gaussian_deformation: tensors must be on the GPU (no CPU fallback exists)")
         c = coeff.detach().to(torch.float32).contiguous()
         P, B = c.shape
+        ctx.grad_sinks = grad_sinks
+        ctx.packed = packed is not None
+        if packed is not None:
+            # bases [Tu+1,B,7]: rows 0..Tu-1 = the birth-time table, row Tu = B(t); ONE gradient tensor comes back
+            pk = packed.detach().to(torch.float32).contiguous()
+            basis_t, table = pk[-1], pk[:-1]
         bt = basis_t.detach().to(torch.float32).contiguous()
         tb = None if table is None else table.detach().to(torch.float32).contiguous()
         ti = time_ind.detach().to(torch.int64).contiguous()
@@ -269,9 +289,20 @@ class _DeformFn(torch.autograd.Function):
         dev = c.device
         g_xyz = (torch.zeros(P, 3, device=dev) if g_xyz is None else g_xyz).to(torch.float32).contiguous()
         g_rot = (torch.zeros(P, 4, device=dev) if g_rot is None else g_rot).to(torch.float32).contiguous()
-        d_c = torch.empty_like(c)
-        d_bt = torch.empty_like(bt)
-        d_tb = None if tb is None else torch.empty_like(tb)
+        sink_c = None if ctx.grad_sinks is None else ctx.grad_sinks.get("coeff")
+        if sink_c is not None:
+            if sink_c.numel() != c.numel() or not sink_c.is_contiguous() or sink_c.dtype != torch.float32:
+                raise RuntimeError("grad_sinks['coeff'] must be a contiguous float32 tensor with coeff's element count")
+            d_c = sink_c.view(P, B)
+        else:
+            d_c = torch.empty_like(c)
+        if ctx.packed:
+            d_pk = torch.empty(Tu + 1, B, bt.shape[-1], dtype=torch.float32, device=dev)
+            d_bt, d_tb = d_pk[-1], d_pk[:-1]
+        else:
+            d_pk = None
+            d_bt = torch.empty_like(bt)
+            d_tb = None if tb is None else torch.empty_like(tb)
         with torch.cuda.device(dev):
             _lib.check(L.rdg_deform_backward(P, B, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bt), _lib.ptr(tb),
                                              ctx.scale, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(d_c),
@@ -279,17 +310,31 @@ class _DeformFn(torch.autograd.Function):
                                                                                       else _identity_order(P, dev)),
                                              _lib.stream_ptr()),
                        "rdg_deform_backward")
-        return d_c, None, d_bt, d_tb, None
+        if sink_c is not None:
+            d_c = None
+        if ctx.packed:
+            return d_c, None, None, None, None, None, d_pk
+        return d_c, None, d_bt, d_tb, None, None, None
 
 
 def gaussian_deformation(coeff: torch.Tensor, time_ind: torch.Tensor, basis_t: torch.Tensor,
-                         table: Optional[torch.Tensor], spatial_lr_scale: float):
+                         table: Optional[torch.Tensor], spatial_lr_scale: float, grad_sinks=None):
     """(scaled_translation [P,3], rotation_delta [P,4]) = coeff . (B(t) - B_table[time_ind]).
 
     coeff [P,B] (or the reference's [P,1,B]); basis_t [B,7]; table [Tu,B,7] or None (inverse_motion=False);
-    translation is multiplied by ``spatial_lr_scale`` exactly as rodygs_dynamic.py:136."""
+    translation is multiplied by ``spatial_lr_scale`` exactly as rodygs_dynamic.py:136.
+    ``grad_sinks={"coeff": t}``: the backward overwrites ``t`` with dL/dcoeff instead of returning it."""
     c = coeff.reshape(coeff.shape[0], -1)
-    return _DeformFn.apply(c, time_ind, basis_t, table, spatial_lr_scale)
+    return _DeformFn.apply(c, time_ind, basis_t, table, spatial_lr_scale, grad_sinks, None)
+
+
+def gaussian_deformation_packed(coeff: torch.Tensor, time_ind: torch.Tensor, bases: torch.Tensor,
+                                spatial_lr_scale: float, grad_sinks=None):
+    """Same op with the MLP output used as it comes: ``bases`` [Tu+1,B,7] = the birth-time table followed by B(t)
+    (one MLP pass over the Tu+1 embedding rows).  Its gradient comes back as ONE tensor, so autograd has no
+    slice-backward (zeros + copy + add) to run."""
+    c = coeff.reshape(coeff.shape[0], -1)
+    return _DeformFn.apply(c, time_ind, None, None, spatial_lr_scale, grad_sinks, bases)
 
 
 class DeformationField(nn.Module):

@@ -91,8 +91,9 @@ def activate_gaussians(xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest
 
 class _PoseView(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cam_q, cam_t, frame):
+    def forward(ctx, cam_q, cam_t, frame, grad_sinks=None):
         L = _lib.lib()
+        ctx.grad_sinks = grad_sinks
         if not cam_q.is_cuda:
             raise RuntimeError("rodygs_amd.pose_view_matrix: tensors must be on the GPU (no CPU fallback exists)")
         q = cam_q.detach().to(torch.float32).contiguous()
@@ -112,15 +113,25 @@ class _PoseView(torch.autograd.Function):
         q, t = ctx.saved_tensors
         T = q.shape[0]
         g = g_view.to(torch.float32).contiguous()
-        d_q = torch.empty_like(q)
-        d_t = torch.empty_like(t)
+        sinks = ctx.grad_sinks
+        if sinks is not None:
+            d_q, d_t = sinks["q"], sinks["t"]
+            for d, ref in ((d_q, q), (d_t, t)):
+                if d.shape != ref.shape or not d.is_contiguous() or d.dtype != torch.float32:
+                    raise RuntimeError("pose_view_matrix grad_sinks must be contiguous float32 tensors shaped like "
+                                       "cam_q / cam_t")
+        else:
+            d_q = torch.empty_like(q)
+            d_t = torch.empty_like(t)
         with torch.cuda.device(q.device):
             _lib.check(L.rdg_pose_view_backward(T, ctx.frame, _lib.ptr(q), _lib.ptr(t), _lib.ptr(g), _lib.ptr(d_q),
                                                 _lib.ptr(d_t), _lib.stream_ptr()), "rdg_pose_view_backward")
-        return d_q, d_t, None
+        if sinks is not None:
+            return None, None, None, None
+        return d_q, d_t, None, None
 
 
-def pose_view_matrix(cam_q: torch.Tensor, cam_t: torch.Tensor, frame: int) -> torch.Tensor:
+def pose_view_matrix(cam_q: torch.Tensor, cam_t: torch.Tensor, frame: int, grad_sinks=None) -> torch.Tensor:
     """W2C^T (glm storage, what the rasterizer takes as ``viewmatrix``) of frame ``frame`` from the learnable
     camera-to-world quaternions cam_q[T,4] (r,i,j,k) and translations cam_t[T,3]."""
-    return _PoseView.apply(cam_q, cam_t, frame)
+    return _PoseView.apply(cam_q, cam_t, frame, grad_sinks)

@@ -161,7 +161,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             normal = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
-            nren = torch.zeros(1, dtype=torch.int32, device=dev)
+            # written by the per-Gaussian stage's scan whenever there is at least one Gaussian
+            nren = (torch.zeros if P == 0 else torch.empty)(1, dtype=torch.int32, device=dev)
             key = (P, H, W)
             cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
             stream = _lib.stream_ptr()
@@ -194,6 +195,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                     break
                 cap = int(n * 1.25) + 4096
         _LAST_IMAGE_WS[0] = (image, H, W)
+        # outputs the loss never touched (normal, alpha, usually depth) arrive as None in backward instead of as
+        # zero-filled images the kernel would then read
+        ctx.set_materialize_grads(False)
         ctx.raster_settings = raster_settings
         ctx.empty_cloud = (P == 0)
         ctx.cs = cs
@@ -207,7 +211,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_normal, g_alpha, g_radii, g_extra):
-        if ctx.empty_cloud:
+        if ctx.empty_cloud or (g_color is None and g_depth is None and g_alpha is None):
             return (None,) * 11
         L = _lib.lib()
         m3, shs, col, op, sc, ro, cov, vm, pm, bg, radii, geom, binning, image = ctx.saved_tensors

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .deform import MLPBasisNetwork, gaussian_deformation
+from .deform import MLPBasisNetwork, gaussian_deformation, gaussian_deformation_packed
 from .dp import FlatParams, allreduce_sum_, frame_for
 from .losses import fused_photometric_loss
 from .model_ops import activate_gaussians, pose_view_matrix
@@ -43,27 +43,59 @@ def world_view_transform(q_c2w: torch.Tensor, t_c2w: torch.Tensor) -> torch.Tens
     return torch.cat([top, bottom], dim=0)
 
 
-def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None) -> None:
+def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None, extra=()) -> None:
     """ONE fused HIP launch for all parameter groups of the flat buffers (rdg_adam_step_multi).
-    row_lr: {name: (row_len, head_len, lr_tail)} for segments whose rows mix two learning rates."""
+    row_lr: {name: (row_len, head_len, lr_tail)} for segments whose rows mix two learning rates.
+    extra: further FlatParams stepped by the same launch (e.g. the MLP + camera-pose bucket); neighbouring
+    segments of one buffer with the same learning rate are merged (their alignment padding has zero gradients)."""
     L = _lib.lib()
     fp.step_count += 1
-    segs = (_lib.RdgAdamSeg * len(fp.names))()
-    for i, k in enumerate(fp.names):
-        o, n = fp.offsets[k]
+    entries = []   # (flat-params, first offset, element count, lr, row_len, head_len, lr_tail)
+    for f in (fp, *extra):
+        f.step_count = fp.step_count
+        for k in f.names:
+            o, n = f.offsets[k]
+            row_len, head_len, lr_tail = ((row_lr or {}).get(k, (1, 1, f.lr[k])) if f is fp else (1, 1, f.lr[k]))
+            last = entries[-1] if entries else None
+            if last is not None and last[0] is f and last[4] == 1 and row_len == 1 and last[3] == f.lr[k]:
+                entries[-1] = (f, last[1], o + n - last[1], last[3], 1, 1, last[6])
+            else:
+                entries.append((f, o, n, f.lr[k], row_len, head_len, lr_tail))
+    segs = (_lib.RdgAdamSeg * len(entries))()
+    for i, (f, o, n, lr, row_len, head_len, lr_tail) in enumerate(entries):
         b = o * 4
-        row_len, head_len, lr_tail = (row_lr or {}).get(k, (1, 1, fp.lr[k]))
         segs[i].n = n
-        segs[i].param = fp.flat.data_ptr() + b
-        segs[i].grad = fp.flat_grad.data_ptr() + b
-        segs[i].exp_avg = fp.exp_avg.data_ptr() + b
-        segs[i].exp_avg_sq = fp.exp_avg_sq.data_ptr() + b
-        segs[i].lr_head = fp.lr[k] * lr_scale
+        segs[i].param = f.flat.data_ptr() + b
+        segs[i].grad = f.flat_grad.data_ptr() + b
+        segs[i].exp_avg = f.exp_avg.data_ptr() + b
+        segs[i].exp_avg_sq = f.exp_avg_sq.data_ptr() + b
+        segs[i].lr_head = lr * lr_scale
         segs[i].lr_tail = lr_tail * lr_scale
         segs[i].row_len = row_len
         segs[i].head_len = head_len
-    _lib.check(L.rdg_adam_step_multi(len(fp.names), segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
+    _lib.check(L.rdg_adam_step_multi(len(entries), segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
                "rdg_adam_step_multi")
+
+
+_MLP_SINK_ORDER = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias", "timenet.4.weight",
+                   "timenet.4.bias", "head_w1", "head_b1", "head_w2", "head_b2")
+
+
+def bind_module_to_flat(net: torch.nn.Module, lr: float, device, extra_spec=None) -> FlatParams:
+    """Move every parameter of ``net`` into one FlatParams bucket (values kept): the module's Parameters become
+    views of the flat buffer, so ONE all-reduce covers their gradients and ONE Adam segment steps them."""
+    spec = {name: (tuple(p.shape), lr) for name, p in net.named_parameters()}
+    spec.update(extra_spec or {})
+    sp = FlatParams(spec, device)
+    with torch.no_grad():
+        for name, p in list(net.named_parameters()):
+            sp[name].copy_(p)
+            mod_name, _, leaf = name.rpartition(".")
+            mod = net.get_submodule(mod_name) if mod_name else net
+            newp = torch.nn.Parameter(sp[name].detach())      # shares the flat storage
+            newp.grad = sp[name].grad                         # ... and the flat gradient bucket
+            mod._parameters[leaf] = newp
+    return sp
 
 
 class DynamicScene:
@@ -119,14 +151,25 @@ class DynamicScene:
             c = torch.tensor([-cz * math.sin(a), 0.0, cz - cz * math.cos(a)])
             qs.append(q)
             ts.append(c)
-        self.cam_q = torch.stack(qs).to(dev).requires_grad_(True)
-        self.cam_t = torch.stack(ts).to(dev).requires_grad_(True)
+        # the MLP and the camera poses live in a second, small flat bucket: their gradients are written by the HIP
+        # backward kernels (no AccumulateGrad), summed by one small all-reduce, and stepped by the SAME Adam launch
+        # as the Gaussians (reference groups: deform network 0.0016, pose rotation 1e-5, pose translation 1e-6)
+        sp = bind_module_to_flat(self.net, 0.0016, dev, {"cam_q": ((num_frames, 4), 1e-5),
+                                                          "cam_t": ((num_frames, 3), 1e-6)})
+        with torch.no_grad():
+            sp["cam_q"].copy_(torch.stack(qs))
+            sp["cam_t"].copy_(torch.stack(ts))
+        self.sp = sp
+        self.cam_q, self.cam_t = sp["cam_q"], sp["cam_t"]
+        self.net.grad_sinks = [sp[k].grad for k in _MLP_SINK_ORDER]
+        self.pose_sinks = {"q": sp["cam_q"].grad, "t": sp["cam_t"].grad}
         self.proj_t = scene["projmatrix"].to(dev).contiguous()   # already P^T (glm storage)
         self.bg = torch.zeros(3, device=dev)
-        self.small_opt = torch.optim.Adam([
-            {"params": list(self.net.parameters()), "lr": 0.0016},
-            {"params": [self.cam_q], "lr": 1e-5},
-            {"params": [self.cam_t], "lr": 1e-6}], eps=1e-15, fused=True)
+        # frame f: the T birth-time embedding rows followed by the frame's own row -> one MLP pass, no cat per step
+        emb = self.time_batch_embeddings
+        self.emb_rows = torch.cat([emb.unsqueeze(0).expand(num_frames, -1, -1), self.frame_embeddings.unsqueeze(1)],
+                                  dim=1).contiguous()                       # [T, T+1, 53]
+        self.m2 = torch.zeros(P, 3, device=dev, requires_grad=True)        # means2D: values unused, gradient sink
         self.gt = {}
 
     # ---- pieces of the step ------------------------------------------------------------------------------------
@@ -138,9 +181,9 @@ class DynamicScene:
         """DynRoDyGS.get_gaussian_deformation + activations for the frame's time."""
         fp, net = self.fp, self.net
         # ONE pass of the MLP over the T birth-time rows + the frame's own time (row T)
-        allb = net.motion_basis(torch.cat([self.time_batch_embeddings, self.frame_embeddings[frame:frame + 1]], dim=0))
-        table, basis_t = allb[:-1], allb[-1]
-        dxyz, drot = gaussian_deformation(fp["motion_coeff"], self.time_ind, basis_t, table, self.spatial_lr_scale)
+        allb = net.motion_basis(self.emb_rows[frame])                     # [T+1,16,7]: table rows, then B(t)
+        dxyz, drot = gaussian_deformation_packed(fp["motion_coeff"], self.time_ind, allb, self.spatial_lr_scale,
+                                                 grad_sinks={"coeff": fp["motion_coeff"].grad})
         # activations + deformation add + feature concat: 2 HIP launches; the parameter gradients are written by
         # the backward kernel straight into the flat gradient bucket (no AccumulateGrad copies)
         sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
@@ -150,8 +193,9 @@ class DynamicScene:
 
     def render(self, frame: int):
         xyz, opacity, scaling, rot, feats = self.gaussians_at(frame)
-        vm = pose_view_matrix(self.cam_q, self.cam_t, frame)
-        m2 = torch.zeros_like(xyz, requires_grad=True)
+        vm = pose_view_matrix(self.cam_q, self.cam_t, frame, grad_sinks=self.pose_sinks)
+        m2 = self.m2
+        m2.grad = None
         out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
                                                   rotations=rot, viewmatrix=vm,
                                                   grad_sinks={"shs": self.fp["features"].grad})
@@ -173,19 +217,11 @@ class DynamicScene:
     def train_step(self, step: int, rank: int = 0, world: int = 1, perm=None) -> torch.Tensor:
         perm = perm if perm is not None else list(self.gt.keys())
         frame = frame_for(step, rank, world, perm)
-        # only the motion coefficients still arrive through autograd accumulation; every other segment of the
-        # flat bucket is overwritten by the activation backward kernel
-        self.fp.segment(self.fp.flat_grad, "motion_coeff").zero_()
-        self.small_opt.zero_grad(set_to_none=True)
+        # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
         out, _ = self.render(frame)
         loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
         if world > 1:
-            small = [p.grad for p in self.net.parameters() if p.grad is not None]
-            for t in (self.cam_q, self.cam_t):
-                if t.grad is not None:
-                    small.append(t.grad)
-            allreduce_sum_(self.fp.flat_grad, small)
-        fused_adam_(self.fp, row_lr=self.row_lr)
-        self.small_opt.step()
+            allreduce_sum_(self.fp.flat_grad, [self.sp.flat_grad])
+        fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,))
         return loss.detach()

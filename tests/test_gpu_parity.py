@@ -359,6 +359,102 @@ def test_deformation_forward_backward(P, Tu, inverse):
         rel_ok(tb2.grad, tb.grad, tol=2e-5, what="d_table")
 
 
+def test_deformation_packed_bases_and_coeff_sink():
+    """gaussian_deformation_packed(bases[Tu+1]) + grad sink == gaussian_deformation(basis_t, table) through autograd."""
+    from rodygs_amd import gaussian_deformation
+    from rodygs_amd.deform import gaussian_deformation_packed
+    g = torch.Generator().manual_seed(9)
+    P, Tu, B = 3001, 23, 16
+    coeff = (0.1 * torch.randn(P, 1, B, generator=g)).to(DEV)
+    ind = torch.randint(0, Tu, (P,), generator=g).to(DEV)
+    bases = torch.randn(Tu + 1, B, 7, generator=g).to(DEV)
+    wx, wr = torch.randn(P, 3, generator=g).to(DEV), torch.randn(P, 4, generator=g).to(DEV)
+    c1 = coeff.clone().requires_grad_(True)
+    b1 = bases.clone().requires_grad_(True)
+    x1, r1 = gaussian_deformation(c1, ind, b1[-1], b1[:-1], 2.5)
+    ((x1 * wx).sum() + (r1 * wr).sum()).backward()
+    c2 = coeff.clone().requires_grad_(True)
+    b2 = bases.clone().requires_grad_(True)
+    sink = torch.full((P, 1, B), float("nan"), device=DEV)
+    x2, r2 = gaussian_deformation_packed(c2, ind, b2, 2.5, grad_sinks={"coeff": sink})
+    ((x2 * wx).sum() + (r2 * wr).sum()).backward()
+    assert torch.equal(x1, x2) and torch.equal(r1, r2)
+    assert c2.grad is None
+    rel_ok(sink, c1.grad, tol=1e-6, what="coeff sink")
+    rel_ok(b2.grad, b1.grad, tol=1e-5, what="packed bases grad")
+
+
+def test_mlp_and_pose_grad_sinks_match_autograd():
+    from rodygs_amd.deform import MLPBasisNetwork
+    from rodygs_amd.model_ops import pose_view_matrix
+    torch.manual_seed(3)
+    net = MLPBasisNetwork(128, 16, 26, False).to(DEV)
+    x = torch.randn(37, 53, device=DEV)
+    w = torch.randn(37, 16, 7, device=DEV)
+    (net.motion_basis(x) * w).sum().backward()
+    tn = net.timenet
+    params = [tn[0].weight, tn[0].bias, tn[2].weight, tn[2].bias, tn[4].weight, tn[4].bias, net.head_w1, net.head_b1,
+              net.head_w2, net.head_b2]
+    want = [p.grad.clone() for p in params]
+    for p_ in params:
+        p_.grad = None
+    net.grad_sinks = [torch.full_like(p_, float("nan")) for p_ in params]
+    (net.motion_basis(x) * w).sum().backward()
+    assert all(p_.grad is None for p_ in params)
+    for a, b in zip(net.grad_sinks, want):
+        assert torch.equal(a, b)
+    q = torch.randn(5, 4, device=DEV, requires_grad=True)
+    t = torch.randn(5, 3, device=DEV, requires_grad=True)
+    wv = torch.randn(4, 4, device=DEV)
+    (pose_view_matrix(q, t, 3) * wv).sum().backward()
+    sq, st = torch.full_like(q, float("nan")), torch.full_like(t, float("nan"))
+    q2, t2 = q.detach().clone().requires_grad_(True), t.detach().clone().requires_grad_(True)
+    (pose_view_matrix(q2, t2, 3, grad_sinks={"q": sq, "t": st}) * wv).sum().backward()
+    assert q2.grad is None and torch.equal(sq, q.grad) and torch.equal(st, t.grad)
+
+
+def test_fused_adam_over_two_flat_buckets_matches_torch_groups():
+    """One rdg_adam_step_multi launch over the Gaussian bucket + the small (MLP, pose) bucket, equal-lr neighbours
+    merged, against torch.optim.Adam with one group per tensor."""
+    from rodygs_amd.dp import FlatParams
+    from rodygs_amd.trainstep import fused_adam_
+    g = torch.Generator().manual_seed(21)
+    spec_a = {"xyz": ((1001, 3), 1e-3), "features": ((1001, 4, 3), 2e-3), "scaling": ((1001, 3), 5e-3),
+              "rotation": ((1001, 4), 5e-3)}
+    spec_b = {"w0": ((33, 7), 1e-2), "b0": ((33,), 1e-2), "cam_q": ((9, 4), 1e-4), "cam_t": ((9, 3), 1e-5)}
+    fa, fb = FlatParams(spec_a, DEV), FlatParams(spec_b, DEV)
+    ref, groups = {}, []
+    for f in (fa, fb):
+        for k in f.names:
+            v = torch.randn(f.shapes[k], generator=g)
+            with torch.no_grad():
+                f[k].copy_(v)
+            ref[k] = v.clone().requires_grad_(True)
+            if k == "features":
+                continue
+            groups.append({"params": [ref[k]], "lr": f.lr[k]})
+    # features: DC row (first 3 floats of every 12) at lr 2e-3, the rest at 1e-4 -> two torch tensors
+    fdc = ref["features"].detach()[:, :1].clone().requires_grad_(True)
+    frest = ref["features"].detach()[:, 1:].clone().requires_grad_(True)
+    groups += [{"params": [fdc], "lr": 2e-3}, {"params": [frest], "lr": 1e-4}]
+    opt = torch.optim.Adam(groups, eps=1e-15)
+    for step in range(3):
+        for f in (fa, fb):
+            for k in f.names:
+                gk = torch.randn(f.shapes[k], generator=g) * (step + 1)
+                f[k].grad.copy_(gk)
+                if k == "features":
+                    fdc.grad, frest.grad = gk[:, :1].clone(), gk[:, 1:].clone()
+                else:
+                    ref[k].grad = gk
+        opt.step()
+        fused_adam_(fa, row_lr={"features": (12, 3, 1e-4)}, extra=(fb,))
+    for f in (fa, fb):
+        for k in f.names:
+            want = torch.cat([fdc, frest], dim=1) if k == "features" else ref[k]
+            rel_ok(f[k], want.detach(), tol=2e-6, what="adam " + k)
+
+
 def test_deformation_field_matches_reference_golden_on_gpu():
     """End to end against the imported-reference golden (MLP in torch on the GPU + HIP per-Gaussian op)."""
     from rodygs_amd.deform import MLPBasisNetwork, gaussian_deformation
