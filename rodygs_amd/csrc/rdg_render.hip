@@ -222,6 +222,9 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[4][12], const uint3
 // ---------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------
+// HAS_DEPTH = false: no upstream gradient for the depth image (photometric-only losses) -- the depth channel drops out
+// of the per-pair arithmetic and of the reduction.
+template <bool HAS_DEPTH>
 __global__ void __launch_bounds__(256)
 rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
                       const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -255,7 +258,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
     if (inside) {
         if (g_color) { dLp0 = g_color[pid]; dLp1 = g_color[hw + pid]; dLp2 = g_color[2 * hw + pid]; }
-        if (g_depth) dLd = g_depth[pid];
+        if (HAS_DEPTH) dLd = g_depth[pid];
         if (g_alpha) dLa = g_alpha[pid];
     }
     const float bgdot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
@@ -276,7 +279,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     const int fc = lane & 15;
     const float flush_scale = fc == 0 ? (-0.5f / RDG_NEG_LOG2E) * (float)W
                             : fc == 1 ? (-0.5f / RDG_NEG_LOG2E) * (float)H
-                            : (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : 1.0f;
+                            : (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : (fc == 9 && !HAS_DEPTH) ? 0.0f : 1.0f;
 
     for (int r = 0; r < rounds; ++r) {
         const int kbase = kmax - 1 - r * RDG_BATCH;  // list position of slot 0 of this batch
@@ -329,9 +332,14 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const float inv1ma = __builtin_amdgcn_rcpf(1.0f - aeff);
                 T = T * inv1ma;
                 const float dch = aeff * T;
-                const float e0 = q2.x - acc0, e1 = q2.y - acc1, e2 = q2.z - acc2, ed = q1.z - accd;
-                float dL_dalpha = e0 * dLp0 + e1 * dLp1 + e2 * dLp2 + ed * dLd;
-                acc0 += aeff * e0; acc1 += aeff * e1; acc2 += aeff * e2; accd += aeff * ed;
+                const float e0 = q2.x - acc0, e1 = q2.y - acc1, e2 = q2.z - acc2;
+                float dL_dalpha = e0 * dLp0 + e1 * dLp1 + e2 * dLp2;
+                acc0 += aeff * e0; acc1 += aeff * e1; acc2 += aeff * e2;
+                if (HAS_DEPTH) {
+                    const float ed = q1.z - accd;
+                    dL_dalpha += ed * dLd;
+                    accd += aeff * ed;
+                }
                 dL_dalpha = dL_dalpha * T + (T_final * inv1ma) * tail;
                 dL_dalpha = hit ? dL_dalpha : 0.0f;
                 // The constant factors of the five geometric derivatives (0.5 W / log2 e, 0.5 H / log2 e, -0.5, -1, -0.5)
@@ -344,7 +352,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const float g2 = gX * dx;                           // ~ dL/d(conic a)
                 const float g3 = gX * dy;                           // ~ dL/d(conic b)
                 const float g4 = gY * dy;                           // ~ dL/d(conic c)
-                const float g6 = dch * dLp0, g7 = dch * dLp1, g8 = dch * dLp2, g9 = dch * dLd;
+                const float g6 = dch * dLp0, g7 = dch * dLp1, g8 = dch * dLp2, g9 = HAS_DEPTH ? dch * dLd : 0.0f;
                 // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds), fold the VALUE index into
                 // the lane index while reducing.  DPP write masks work on quads (bank_mask: 4 lanes) and rows, so the
                 // folding steps come FIRST and act across quads: a rotate-by-8 exchange turns two values into one (the
@@ -358,10 +366,21 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 // Result: every lane of quad q (h = q >> 1, p = q & 1) holds the 16-lane row total of component
                 // 2p + h (y0), 4 + 2p + h (y1), 8 + h (y2).
                 float x0, x1, x2, x3, x4, y0, y1, y2;
+                if (HAS_DEPTH) {
+                    asm volatile(
+                        "s_nop 1\n\t"
+                        "v_add_f32_dpp %[x4], %[g8], %[g8] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                        "v_add_f32_dpp %[x4], %[g9], %[g9] row_ror:8 row_mask:0xf bank_mask:0xc"
+                        : [x4] "=&v"(x4) : [g8] "v"(g8), [g9] "v"(g9));
+                } else {
+                    // both half-rows carry component 8 (the flush multiplies component 9 by zero)
+                    asm volatile(
+                        "s_nop 1\n\t"
+                        "v_add_f32_dpp %[x4], %[g8], %[g8] row_ror:8 row_mask:0xf bank_mask:0xf"
+                        : [x4] "=&v"(x4) : [g8] "v"(g8));
+                }
                 asm volatile(
                     "s_nop 1\n\t"
-                    "v_add_f32_dpp %[x4], %[g8], %[g8] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                    "v_add_f32_dpp %[x4], %[g9], %[g9] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                     "v_add_f32_dpp %[x0], %[g0], %[g0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
                     "v_add_f32_dpp %[x0], %[g1], %[g1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
                     "v_add_f32_dpp %[x1], %[g2], %[g2] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
@@ -381,10 +400,10 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     "v_add_f32_dpp %[y0], %[y0], %[y0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                     "v_add_f32_dpp %[y1], %[y1], %[y1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                     "v_add_f32_dpp %[y2], %[y2], %[y2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                    : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4),
+                    : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),
                       [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2)
                     : [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [g5] "v"(g5),
-                      [g6] "v"(g6), [g7] "v"(g7), [g8] "v"(g8), [g9] "v"(g9));
+                      [g6] "v"(g6), [g7] "v"(g7), [x4] "v"(x4));
                 {
                     // One lane per quad parks the row totals in this wave's private ring with PLAIN LDS stores (LDS
                     // float atomics into a table shared by the 4 waves cost a third of the kernel); the 4 row partials
@@ -418,9 +437,12 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const uint32_t* plist = (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a));
     const char* im = (const char*)image_ws;
     const int nblk = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(rdg_render_bwd_kernel, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,
-                       (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),
-                       (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,
-                       g_alpha, grow);
+#define RDG_BWD_LAUNCH(DEPTH)                                                                                      \
+    hipLaunchKernelGGL(rdg_render_bwd_kernel<DEPTH>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,    \
+                       (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),        \
+                       (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
+                       g_alpha, grow)
+    if (g_depth) RDG_BWD_LAUNCH(true); else RDG_BWD_LAUNCH(false);
+#undef RDG_BWD_LAUNCH
     return rdg_check_hip(hipGetLastError(), "render_bwd launch");
 }
