@@ -192,6 +192,65 @@ __device__ __forceinline__ float rdg_wave_sum_all(float x) {
     x = rdg_wave_sum_to63(x);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
+// LDS traffic of ONE wave is executed in program order; this only pins the compiler's ordering around a hand-off
+// between lanes of the same wave through LDS (no workgroup barrier involved).
+__device__ __forceinline__ void rdg_wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Wave-cooperative transposing copies between 64 consecutive rows of a row-major global array g[n_rows][row] and
+// an LDS tile S[64][stride] (stride odd -> a lane walking its own row is bank-conflict free).  One lane per
+// Gaussian reading its own 48-float SH row straight from global memory touches 64 cache lines per load
+// instruction and uses 4-16 bytes of each; through here every global instruction moves 1 KB (or 256 B) contiguous.
+__device__ __forceinline__ void rdg_rows_to_lds(const float* __restrict__ g, long long first_row, long long n_rows,
+                                                int row, int stride, float* S, int lane) {
+    const long long base = first_row * row, total = n_rows * row;
+    const float inv_row = 1.0f / (float)row;
+    if ((row & 3) == 0 && (((uintptr_t)g) & 15) == 0) {
+        for (int v = lane; v < 16 * row; v += 64) {
+            const long long e = base + 4ll * v;
+            if (e < total) {
+                const float4 val = *reinterpret_cast<const float4*>(g + e);
+                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                float* dst = S + gi * stride + (4 * v - gi * row);
+                dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * row; idx += 64) {
+            const long long e = base + idx;
+            if (e < total) {
+                const int gi = (int)(((float)idx + 0.5f) * inv_row);
+                S[gi * stride + (idx - gi * row)] = g[e];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void rdg_lds_to_rows(float* __restrict__ g, long long first_row, long long n_rows, int row,
+                                                int stride, const float* S, int lane) {
+    const long long base = first_row * row, total = n_rows * row;
+    const float inv_row = 1.0f / (float)row;
+    if ((row & 3) == 0 && (((uintptr_t)g) & 15) == 0) {
+        for (int v = lane; v < 16 * row; v += 64) {
+            const long long e = base + 4ll * v;
+            if (e < total) {
+                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                const float* src = S + gi * stride + (4 * v - gi * row);
+                *reinterpret_cast<float4*>(g + e) = make_float4(src[0], src[1], src[2], src[3]);
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * row; idx += 64) {
+            const long long e = base + idx;
+            if (e < total) {
+                const int gi = (int)(((float)idx + 0.5f) * inv_row);
+                g[e] = S[gi * stride + (idx - gi * row)];
+            }
+        }
+    }
+}
 __device__ __forceinline__ uint32_t rdg_lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

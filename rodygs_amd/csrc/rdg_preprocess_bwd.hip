@@ -30,6 +30,16 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                           float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac,
                           float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // SH coefficients in, SH gradients out: staged per wave through LDS (rdg_rows_to_lds); each lane then works on
+    // its own row IN PLACE -- every coefficient is read before its slot is overwritten with the gradient.
+    __shared__ float sSH[4][64 * 49];
+    const int sh_row = d.M * 3, sh_stride = sh_row | 1;
+    float* const mySH = sSH[threadIdx.x >> 6] + (threadIdx.x & 63) * sh_stride;
+    const long long wave_first = (long long)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
+    if (shs && wave_first < d.P) {
+        rdg_rows_to_lds(shs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
+        rdg_wave_lds_sync();
+    }
     float V[16], Pm[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = view[k]; Pm[k] = proj[k]; }
@@ -171,8 +181,8 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                 const float ln = sqrtf(ox * ox + oy * oy + oz * oz);
                 const float il = 1.0f / ln;
                 const float ux = ox * il, uy = oy * il, uz = oz * il;
-                const float* sh = shs + (size_t)i * d.M * 3;
-                float* dsh = dshs + (size_t)i * d.M * 3;
+                const float* sh = mySH;
+                float* dsh = mySH;
                 float dRx = 0.f, dRy = 0.f, dRz = 0.f;  // dL/d(unit dir)
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) dsh[ch] = SH_C0 * gcol[ch];
@@ -181,10 +191,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const float g = gcol[ch];
+                        const float h1 = sh[3 + ch], h2 = sh[6 + ch], h3 = sh[9 + ch];
                         dsh[3 + ch] = b1 * g; dsh[6 + ch] = b2 * g; dsh[9 + ch] = b3 * g;
-                        dRx += -SH_C1 * sh[9 + ch] * g;
-                        dRy += -SH_C1 * sh[3 + ch] * g;
-                        dRz += SH_C1 * sh[6 + ch] * g;
+                        dRx += -SH_C1 * h3 * g;
+                        dRy += -SH_C1 * h1 * g;
+                        dRz += SH_C1 * h2 * g;
                     }
                     if (d.deg > 1) {
                         const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, yz = uy * uz, xz = ux * uz;
@@ -193,10 +204,10 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
                             const float g = gcol[ch];
-                            dsh[12 + ch] = b4 * g; dsh[15 + ch] = b5 * g; dsh[18 + ch] = b6 * g;
-                            dsh[21 + ch] = b7 * g; dsh[24 + ch] = b8 * g;
                             const float h4 = sh[12 + ch], h5 = sh[15 + ch], h6 = sh[18 + ch], h7 = sh[21 + ch],
                                         h8 = sh[24 + ch];
+                            dsh[12 + ch] = b4 * g; dsh[15 + ch] = b5 * g; dsh[18 + ch] = b6 * g;
+                            dsh[21 + ch] = b7 * g; dsh[24 + ch] = b8 * g;
                             dRx += (BSH_C2[0] * uy * h4 + BSH_C2[2] * -2.0f * ux * h6 + BSH_C2[3] * uz * h7 +
                                     BSH_C2[4] * 2.0f * ux * h8) * g;
                             dRy += (BSH_C2[0] * ux * h4 + BSH_C2[1] * uz * h5 + BSH_C2[2] * -2.0f * uy * h6 +
@@ -212,11 +223,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
 #pragma unroll
                             for (int ch = 0; ch < 3; ++ch) {
                                 const float g = gcol[ch];
+                                const float h9 = sh[27 + ch], h10 = sh[30 + ch], h11 = sh[33 + ch], h12 = sh[36 + ch],
+                                            h13 = sh[39 + ch], h14 = sh[42 + ch], h15 = sh[45 + ch];
                                 dsh[27 + ch] = b9 * g; dsh[30 + ch] = b10 * g; dsh[33 + ch] = b11 * g;
                                 dsh[36 + ch] = b12 * g; dsh[39 + ch] = b13 * g; dsh[42 + ch] = b14 * g;
                                 dsh[45 + ch] = b15 * g;
-                                const float h9 = sh[27 + ch], h10 = sh[30 + ch], h11 = sh[33 + ch], h12 = sh[36 + ch],
-                                            h13 = sh[39 + ch], h14 = sh[42 + ch], h15 = sh[45 + ch];
                                 dRx += (BSH_C3[0] * h9 * 3.0f * 2.0f * xy + BSH_C3[1] * h10 * yz +
                                         BSH_C3[2] * h11 * -2.0f * xy + BSH_C3[3] * h12 * -3.0f * 2.0f * xz +
                                         BSH_C3[4] * h13 * (-3.0f * xx + 4.0f * zz - yy) +
@@ -282,8 +293,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                               qx * dR20 + qy * dR21);
             }
         } else if (shs) {
-            float* dsh = dshs + (size_t)i * d.M * 3;
-            for (int k = 0; k < d.M * 3; ++k) dsh[k] = 0.f;
+            for (int k = 0; k < sh_row; ++k) mySH[k] = 0.f;
         }
         dmeans3D[3 * i + 0] = dmx; dmeans3D[3 * i + 1] = dmy; dmeans3D[3 * i + 2] = dmz;
         dmeans2D[3 * i + 0] = gnx; dmeans2D[3 * i + 1] = gny; dmeans2D[3 * i + 2] = 0.f;
@@ -298,6 +308,10 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
             dscales[3 * i + 0] = dsc0; dscales[3 * i + 1] = dsc1; dscales[3 * i + 2] = dsc2;
             reinterpret_cast<float4*>(drots)[i] = make_float4(dq0, dq1, dq2, dq3);
         }
+    }
+    if (shs && wave_first < d.P) {
+        rdg_wave_lds_sync();
+        rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
     }
     // pose-gradient reduction: DPP wave sums -> LDS -> ONE partial row per workgroup (no atomics: 16 k waves
     // hammering the same 19 addresses ran 20x slower than the rest of the kernel, and this form is deterministic)

@@ -35,6 +35,14 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                           uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clampedm,
                           uint32_t* __restrict__ block_sums, int32_t* __restrict__ radii) {
     const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    // SH rows of the wave's 64 Gaussians: staged through LDS with wave-contiguous loads (rdg_rows_to_lds)
+    __shared__ float sSH[RDG_PRE_BLOCK / 64][64 * 49];
+    const int sh_row = d.M * 3, sh_stride = sh_row | 1;
+    const long long wave_first = (long long)blockIdx.x * RDG_PRE_BLOCK + (threadIdx.x >> 6) * 64;
+    if (shs && wave_first < d.P) {
+        rdg_rows_to_lds(shs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
+        rdg_wave_lds_sync();
+    }
     // camera: uniform addresses -> scalar loads into SGPRs (the matrices live on the device because the
     // viewmatrix is the output of autograd-tracked pose math; no host round trip)
     float V[16], Pm[16];
@@ -145,7 +153,7 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                         float dx = x - camx, dy = y - camy, dz = z - camz;
                         const float ln = sqrtf((dx * dx + dy * dy) + dz * dz);
                         dx = dx / ln; dy = dy / ln; dz = dz / ln;
-                        const float* sh = shs + (size_t)i * d.M * 3;
+                        const float* sh = sSH[threadIdx.x >> 6] + (threadIdx.x & 63) * sh_stride;
                         float res[3];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) res[c] = SH_C0 * sh[c];
