@@ -302,10 +302,11 @@ __global__ void rdg_copy_pairs_kernel(const uint64_t* __restrict__ k, const uint
 // ---------------------------------------------------------------------------------------------------------
 // Bucket binning (default): the 45-47-bit LSD radix sort moves every (key, value) pair 6 times through HBM with
 // a random scatter each time.  The key is (tile | depth), so the same order is reached with far less traffic:
-//   1. count   : per-tile instance counts (load-balanced expansion + integer atomics)
+//   1. count   : per-tile instance counts (load-balanced expansion + integer atomics); the value each atomic
+//                returns is the instance's rank inside its tile and is kept
 //   2. scan    : exclusive scan over tiles  ->  the tile ranges themselves (no identifyTileRanges pass)
-//   3. scatter : every instance goes to a slot of its tile (atomic cursor) as the 64-bit composite
-//                (depth_bits << 32 | gaussian_id); arrival order inside a tile is arbitrary ...
+//   3. scatter : every instance goes to slot (tile start + rank) as the 64-bit composite
+//                (depth_bits << 32 | gaussian_id), no atomics; the order inside a tile is arbitrary ...
 //   4. sort    : ... and is fixed by a per-tile bitonic sort of the composites in LDS.  Composites are unique,
 //                so the result is deterministic and identical to the stable sort on (tile | depth): equal depths
 //                come out in increasing Gaussian index = emission order.  Bit-exact against the oracle.
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(RDG_PRE_BLOCK)
 rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
                        const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
                        const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_cnt,
-                       const uint2* __restrict__ ranges, uint32_t* __restrict__ tile_fill,
+                       const uint2* __restrict__ ranges, uint32_t* __restrict__ rank_buf,
                        uint64_t* __restrict__ comp, long long capacity, const int32_t* __restrict__ num_rendered) {
     if ((long long)(*num_rendered) > capacity) return;
     __shared__ uint32_t sOff[RDG_PRE_BLOCK];
@@ -348,7 +349,8 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
     for (uint32_t k = 0; k < w; ++k) woff += wsum[k];
     sOff[tid] = woff + inc - t;
     __syncthreads();
-    const uint32_t total = block_sums[blockIdx.x + 1] - block_sums[blockIdx.x];
+    const uint32_t first = block_sums[blockIdx.x];
+    const uint32_t total = block_sums[blockIdx.x + 1] - first;
     for (uint32_t k = tid; k < total; k += RDG_PRE_BLOCK) {
         int lo = 0, hi = RDG_PRE_BLOCK - 1;
         while (lo < hi) {
@@ -360,9 +362,11 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
         const uint32_t ry = j / wd, rx = j - ry * wd;
         const uint32_t tile = (uint32_t)(sY0[lo] + ry) * (uint32_t)gx + (uint32_t)(sX0[lo] + rx);
         if (MODE == 0) {
-            atomicAdd(&tile_cnt[tile], 1u);
+            // the counting atomic already hands every instance a unique rank inside its tile: keep it (coalesced
+            // 4-B store in emission order), and the scatter pass needs no second round of atomics
+            rank_buf[first + k] = atomicAdd(&tile_cnt[tile], 1u);
         } else {
-            const uint32_t pos = ranges[tile].x + atomicAdd(&tile_fill[tile], 1u);
+            const uint32_t pos = ranges[tile].x + rank_buf[first + k];
             comp[pos] = ((uint64_t)sDepth[lo] << 32) | (uint64_t)(blockIdx.x * RDG_PRE_BLOCK + lo);
         }
     }
@@ -490,6 +494,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         uint64_t* comp = (npass & 1) ? keys_a : keys_b;          // composites live in the other key buffer
         uint32_t* tile_cnt = (uint32_t*)((char*)image_ws + I.tile_cnt);
         uint32_t* tile_fill = (uint32_t*)((char*)image_ws + I.tile_fill);
+        uint32_t* rank_buf = (npass & 1) ? vals_a : vals_b;      // the vals buffer nobody reads afterwards
         const bool want_keys = keys_unsorted_copy != nullptr || vals_unsorted_copy != nullptr || radix_export_keys;
         const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
         if (want_keys && d.P > 0 && (keys_unsorted_copy || vals_unsorted_copy)) {
@@ -507,14 +512,14 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
-                               (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, tile_fill, comp,
+                               (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
-                               (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, tile_fill, comp,
+                               (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered);
         rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
         rdg_stage_begin(RDG_STAGE_SORT, s);
