@@ -123,6 +123,48 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
     }
 }
 
+// dL/dcoeff for B = 16: d_coeff[p][b] = sum_k g_p[k] * (B(t) - table[birth(p)])[b][k].  Natural (coalesced) order;
+// the difference table lives in LDS with a row stride of 116 floats (16-B aligned rows, 116 = 20 mod 32: the
+// b128 reads of lanes holding different birth indices spread over all banks), read as 28 float4 per Gaussian
+// instead of 112 dwords, and the 64-B result row leaves as 4 float4 stores.
+#define RDG_DC_STRIDE 116
+__global__ void __launch_bounds__(1024)
+rdg_deform_dcoeff16_kernel(int P, int Tu, const long long* __restrict__ time_ind, const float* __restrict__ basis_t,
+                           const float* __restrict__ table, float scale, const float* __restrict__ g_xyz,
+                           const float* __restrict__ g_rot, float* __restrict__ d_coeff) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dc[];
+    const int Tu_eff = table ? Tu : 1;
+    for (int k = threadIdx.x; k < Tu_eff * 112; k += blockDim.x) {
+        const int u = k / 112, c = k - u * 112;
+        smem_dc[u * RDG_DC_STRIDE + c] = basis_t[c] - (table ? table[(size_t)u * 112 + c] : 0.0f);
+    }
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int u = table ? (int)time_ind[p] : 0;
+        float g[RDG_DEF_K];
+        g[0] = g_xyz[3 * p + 0] * scale; g[1] = g_xyz[3 * p + 1] * scale; g[2] = g_xyz[3 * p + 2] * scale;
+        const float4 gr = reinterpret_cast<const float4*>(g_rot)[p];
+        g[3] = gr.x; g[4] = gr.y; g[5] = gr.z; g[6] = gr.w;
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dc + u * RDG_DC_STRIDE);
+        float sacc[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) sacc[b] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float4 v = r4[j];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * j + c;          // compile-time after unrolling: e = b * 7 + k
+                sacc[e / 7] += g[e % 7] * vv[c];
+            }
+        }
+        float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dc[q] = make_float4(sacc[4 * q], sacc[4 * q + 1], sacc[4 * q + 2], sacc[4 * q + 3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // dB accumulation on the matrix cores (the one GEMM-shaped piece of this path: K = number of Gaussians).
 // acc[u] = sum_{birth(p)=u} c_p^T g_p  is a [16 x n_u] x [n_u x 7] product per birth index u.  Gaussians are
@@ -335,7 +377,14 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
         hipLaunchKernelGGL((rdg_deform_bwd_kernel<USE, ACC>), dim3(blocks), dim3(threads), LDSB, st, P, B, Tu, coeff, \
                            (const long long*)time_ind, basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff,      \
                            d_basis_t, d_table)
-        if (lds <= 128 * 1024) {
+        const size_t lds16 = (size_t)Tu_eff * RDG_DC_STRIDE * sizeof(float);
+        const bool dc16 = mfma && lds16 <= 64 * 1024 && (((uintptr_t)g_rot | (uintptr_t)d_coeff) & 15) == 0;
+        if (dc16) {
+            int nb = (P + 1023) / 1024;
+            if (nb > 256) nb = 256;
+            hipLaunchKernelGGL(rdg_deform_dcoeff16_kernel, dim3(nb), dim3(1024), lds16, st, P, Tu, (const long long*)time_ind,
+                               basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff);
+        } else if (lds <= 128 * 1024) {
             if (lds > 64 * 1024) {
                 hipError_t ea = mfma ? hipFuncSetAttribute((const void*)rdg_deform_bwd_kernel<true, false>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
