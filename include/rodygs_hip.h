@@ -179,6 +179,22 @@ size_t rdg_knn_tmp_bytes(int32_t P);
 /* out[p] = mean squared distance from points[p] to its 3 nearest other points.                              */
 int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream);
 
+/* ---- pytorch3d.ops.knn_points / knn_gather (RigidityLoss, /root/reference/src/trainer/losses.py:235-331) ---- */
+/* K nearest targets of every query: dists[Pq,K] squared Euclidean, ascending; idx[Pq,K] int64 target indices.
+ * tmp_ws: rdg_knn_tmp_bytes(Pt).  queries == targets (same pointer, Pq == Pt) is the self query the reference
+ * uses: every point is its own first neighbour (distance 0), as in pytorch3d.  1 <= K <= 32, K <= Pt.          */
+int rdg_knn_points_forward(int32_t Pq, int32_t Pt, int32_t K, const float* queries, const float* targets, float* dists,
+                           int64_t* idx, void* tmp_ws, void* stream);
+/* Gradient of dists w.r.t. the points: d_queries[Pq,3] and d_targets[Pt,3] are overwritten (either may be NULL;
+ * pass the same pointer for both when queries and targets are one tensor: the two contributions are summed).    */
+int rdg_knn_points_backward(int32_t Pq, int32_t Pt, int32_t K, const float* queries, const float* targets,
+                            const int64_t* idx, const float* g_dists, float* d_queries, float* d_targets, void* stream);
+/* out[r,:] = x[idx[r],:] for n_rows = Pq*K flattened index rows of U floats; backward scatter-adds g into d_x
+ * [n_src_rows,U], which it overwrites.                                                                          */
+int rdg_knn_gather_forward(int64_t n_rows, int32_t U, const float* x, const int64_t* idx, float* out, void* stream);
+int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const float* g, const int64_t* idx, float* d_x,
+                            void* stream);
+
 /* ---- fused Adam over a flat f32 parameter (used by bench.py's train step) ---------- */
 int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, int32_t step, void* stream);

@@ -31,3 +31,26 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, K: int):
     d = torch.cdist(p1.double(), p2.double()) ** 2
     dist, idx = torch.topk(d, K, dim=1, largest=False, sorted=True)
     return dist.float(), idx
+
+
+# ---- pytorch3d.ops.knn_points / knn_gather restated (batched, differentiable; brute force) ---------------------
+# PARITY UNPINNED: pytorch3d is an un-vendored dependency (reference .gitmodules:11-13).  Published behaviour:
+# knn_points(p1 [N,P1,D], p2 [N,P2,D], K) -> dists [N,P1,K] SQUARED Euclidean, ascending, idx [N,P1,K] int64;
+# knn_gather(x [N,M,U], idx [N,L,K]) -> [N,L,K,U].  Call sites: /root/reference/src/trainer/losses.py:235-331.
+from collections import namedtuple
+
+_KNN = namedtuple("KNN", "dists idx knn")
+
+
+def knn_points_batched(p1: torch.Tensor, p2: torch.Tensor, K: int = 1, **_unused):
+    diff = p1[:, :, None, :] - p2[:, None, :, :]
+    d2 = (diff * diff).sum(-1)
+    dists, idx = torch.topk(d2, K, dim=2, largest=False, sorted=True)
+    return _KNN(dists, idx, None)
+
+
+def knn_gather(x: torch.Tensor, idx: torch.Tensor, lengths=None) -> torch.Tensor:
+    N, L, K = idx.shape
+    U = x.shape[2]
+    flat = idx.reshape(N, L * K, 1).expand(N, L * K, U)
+    return torch.gather(x, 1, flat).reshape(N, L, K, U)

@@ -57,6 +57,10 @@ _SIGS = {
     "rdg_deform_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 7),
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
+    "rdg_knn_points_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_vp] * 6),
+    "rdg_knn_points_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_vp] * 7),
+    "rdg_knn_gather_forward": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),
+    "rdg_knn_gather_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64] + [_vp] * 4),
     "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int32, _vp]),
     "rdg_adam_step_rows": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.c_float,

@@ -13,6 +13,9 @@ What is pinned: the pieces of the hot path that exist as import
                    src/utils/general_utils.py:77-127; its hard-coded device="cuda" is neutralised by a
                    torch.zeros wrapper for the duration of the call)
   G6 losses      : l1_loss, ssim (src/utils/loss_utils.py) used by the bench train step
+  G7 rigidity    : RigidityLoss (src/trainer/losses.py:185-360), all three modes, value and gradients, with
+                   pytorch3d's knn_points / knn_gather supplied by oracle/knn_oracle.py
+                   (``python -B tests/golden/make_golden.py rigidity`` regenerates only this file)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -39,8 +42,12 @@ def _stub_modules():
     mod("diff_gauss_pose", GaussianRasterizationSettings=None, GaussianRasterizer=None)
     mod("omegaconf", DictConfig=dict, OmegaConf=None)
     mod("plyfile", PlyData=None, PlyElement=None)
+    # pytorch3d (un-vendored) is replaced by the repository's brute-force CPU restatement of its two ops, so that
+    # the reference's own RigidityLoss code can run here and pin the loss arithmetic built on top of them
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import knn_oracle as KO
     mod("pytorch3d")
-    mod("pytorch3d.ops", knn_points=None, knn_gather=None)
+    mod("pytorch3d.ops", knn_points=KO.knn_points_batched, knn_gather=KO.knn_gather)
 
 
 def main():
@@ -138,8 +145,55 @@ def main():
     b = (a + 0.1 * torch.randn(3, 48, 64)).clamp(0, 1)
     np.savez_compressed(os.path.join(OUT, "loss_golden.npz"), a=a.numpy(), b=b.numpy(),
                         l1=l1_loss(a, b).numpy(), ssim=ssim(a, b).numpy())
+    rigidity_golden()
     print("golden vectors written to", OUT)
 
 
+class _FakeDynModel:
+    """The attributes RigidityLoss reads from DynRoDyGS (rodygs_dynamic.py:47,140-161)."""
+
+    def __init__(self, xyz, coeff, fdc, table):
+        self._xyz, self._motion_coeff, self._features_dc = xyz, coeff, fdc
+        self.temporal_motion_table = table
+        self.unique_times = list(range(table.shape[0]))
+
+    def get_motion_for_times(self, timesteps, time_indices=None):
+        return self.temporal_motion_table[time_indices]
+
+
+def rigidity_golden():
+    import random
+    from src.trainer.losses import RigidityLoss
+    g = torch.Generator().manual_seed(4242)
+    P, Tu, B = 600, 12, 16
+    xyz = (torch.rand(P, 3, generator=g) * 4 - 2).requires_grad_(True)
+    transl = (0.05 * torch.randn(P, 3, generator=g)).requires_grad_(True)
+    coeff = (0.3 * torch.randn(P, 1, B, generator=g)).requires_grad_(True)
+    fdc = torch.rand(P, 1, 3, generator=g).requires_grad_(True)
+    table = (0.2 * torch.randn(Tu, B, 7, generator=g)).requires_grad_(True)
+    out = dict(xyz=xyz.detach().numpy(), transl=transl.detach().numpy(), coeff=coeff.detach().numpy(),
+               fdc=fdc.detach().numpy(), table=table.detach().numpy())
+    cases = {"coeff": dict(mode=["coeff"]),
+             "coeff_l1_nocolor": dict(mode=["coeff"], sim_metric="l1", color_sim=False),
+             "all": dict(mode=["coeff", "surface", "distance_preserving"], K=8, scale=2)}
+    for name, kw in cases.items():
+        random.seed(99)
+        torch.manual_seed(7)
+        model = _FakeDynModel(xyz, coeff, fdc, table)
+        loss = RigidityLoss(**kw)(model, transl)
+        grads = torch.autograd.grad(loss, [xyz, transl, coeff, fdc, table], allow_unused=True)
+        out[name + ".loss"] = loss.detach().numpy()
+        for k, gr in zip(("xyz", "transl", "coeff", "fdc", "table"), grads):
+            out[f"{name}.d_{k}"] = (torch.zeros(1) if gr is None else gr).numpy()
+    np.savez_compressed(os.path.join(OUT, "rigidity_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rigidity":
+        sys.dont_write_bytecode = True
+        _stub_modules()
+        sys.path.insert(0, REF)
+        rigidity_golden()
+        print("rigidity golden written to", OUT)
+    else:
+        main()

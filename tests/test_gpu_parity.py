@@ -496,6 +496,89 @@ def test_dist_cuda2(P):
     rel_ok(out, KO.dist2_knn3(pts), tol=1e-5, what="dist2")
 
 
+@pytest.mark.parametrize("Pq,Pt,K,same", [(5000, 5000, 8, True), (777, 777, 3, True), (300, 300, 16, True),
+                                          (1000, 4000, 8, False), (2500, 257, 5, False), (9, 9, 9, True),
+                                          (40000, 40000, 8, True)])
+def test_knn_points_matches_brute_force(Pq, Pt, K, same):
+    """pytorch3d.ops.knn_points replacement vs the brute-force restatement: indices exact, squared distances and
+    the gradient of the distances w.r.t. both point sets."""
+    from rodygs_amd.knn import knn_points
+    g = torch.Generator().manual_seed(Pq + K)
+    p2 = torch.randn(Pt, 3, generator=g) * torch.tensor([3.0, 1.0, 0.3])
+    p1 = p2 if same else torch.randn(Pq, 3, generator=g) * 2.0
+    w = torch.rand(Pq, K, generator=g)
+    o1 = p1.clone().double().requires_grad_(True)
+    o2 = o1 if same else p2.clone().double().requires_grad_(True)
+    d2 = ((o1[:, None, :] - o2[None, :, :]) ** 2).sum(-1) if Pq * Pt <= 25_000_000 else None
+    if d2 is not None:
+        od, oi = torch.topk(d2, K, dim=1, largest=False, sorted=True)
+    else:                       # large case: k-d tree for the indices, distances recomputed differentiably
+        from scipy.spatial import cKDTree
+        _, oi_np = cKDTree(p2.double().numpy()).query(p1.double().numpy(), k=K)
+        oi = torch.from_numpy(oi_np.reshape(Pq, K))
+        od = ((o1[:, None, :] - o2[oi]) ** 2).sum(-1)
+    (od * w.double()).sum().backward()
+    h1 = p1.clone().to(DEV).requires_grad_(True)
+    h2 = h1 if same else p2.clone().to(DEV).requires_grad_(True)
+    res = knn_points(h1[None], h2[None], K=K)
+    assert res.dists.shape == (1, Pq, K) and res.idx.shape == (1, Pq, K) and res.idx.dtype == torch.int64
+    (res.dists[0] * w.to(DEV)).sum().backward()
+    assert torch.equal(res.idx[0].cpu(), oi), "neighbour indices"
+    rel_ok(res.dists[0], od.float(), tol=1e-5, what="dists")
+    rel_ok(h1.grad, o1.grad.float(), tol=1e-5, what="d_p1")
+    if not same:
+        rel_ok(h2.grad, o2.grad.float(), tol=1e-5, what="d_p2")
+
+
+def test_knn_gather_forward_backward():
+    from rodygs_amd.knn import knn_gather
+    g = torch.Generator().manual_seed(5)
+    M, L, K, U = 1234, 777, 8, 19
+    x = torch.randn(1, M, U, generator=g)
+    idx = torch.randint(0, M, (1, L, K), generator=g)
+    w = torch.randn(1, L, K, U, generator=g)
+    xo = x.clone().requires_grad_(True)
+    oo = KO.knn_gather(xo, idx)
+    (oo * w).sum().backward()
+    xh = x.clone().to(DEV).requires_grad_(True)
+    oh = knn_gather(xh, idx.to(DEV))
+    (oh * w.to(DEV)).sum().backward()
+    assert torch.equal(oh.cpu(), oo.detach())
+    rel_ok(xh.grad, xo.grad, tol=1e-6, what="d_x")
+
+
+@pytest.mark.parametrize("name", ["coeff", "coeff_l1_nocolor", "all"])
+def test_rigidity_loss_on_hip_knn_matches_reference_golden(name):
+    """RigidityLoss on the GPU through the HIP knn_points / knn_gather against (a) what the imported reference
+    returned on the CPU (tests/golden/rigidity_golden.npz; same seeds, same random subsets) and (b) the same module
+    on the same device with the brute-force restatement of the two ops.
+
+    (b) isolates the ops: <= 1e-5.  (a) also contains torch-CPU vs torch-GPU arithmetic of the loss itself; its
+    distance_preserving term is Charbonnier with eps = 1e-6 evaluated at the self neighbour, where the two compared
+    quantities are equal up to rounding -- d/dx = (x-y)/sqrt((x-y)^2 + 1e-12) turns a 1e-7 rounding difference into
+    an O(0.1) slope, so gradients of mode "all" agree with the CPU golden to 5e-3 only (measured 2e-3, identical for
+    the HIP ops and for torch's own ops on the GPU); value and the "coeff" modes hold the 1e-4 bar."""
+    from test_oracle_golden import run_rigidity_case
+    loss, grads, gold = run_rigidity_case(name, DEV)
+    loss_o, grads_o, _ = run_rigidity_case(name, DEV, KO.knn_points_batched, KO.knn_gather)
+    want = float(gold[name + ".loss"])
+    assert abs(float(loss) - want) <= 2e-5 * abs(want)
+    assert abs(float(loss) - float(loss_o)) <= 2e-6 * abs(want)
+    for k, gr in grads.items():
+        w_ = torch.from_numpy(gold[f"{name}.d_{k}"])
+        if gr is None:
+            assert float(w_.abs().sum()) == 0.0
+            continue
+        rel_ok(gr, grads_o[k], tol=1e-5, what=f"rigidity {name} d_{k} vs same-device brute force")
+        rel_ok(gr, w_, tol=5e-3 if name == "all" else 1e-4, what=f"rigidity {name} d_{k} vs reference golden")
+
+
+def test_pytorch3d_shim_resolves_to_hip_ops():
+    import pytorch3d.ops as torch3d
+    from rodygs_amd import knn
+    assert torch3d.knn_points is knn.knn_points and torch3d.knn_gather is knn.knn_gather
+
+
 def test_fused_adam_matches_torch():
     from rodygs_amd import _lib
     L = _lib.lib()
