@@ -1,14 +1,17 @@
 // rdg_knn.hip -- simple_knn.distCUDA2 replacement: mean squared distance to the 3
 // nearest other points.  Call site: /root/reference/src/model/rodygs_static.py:130-133 (init only).
 //
-// Exact 3-NN: points are ordered along a 30-bit Morton curve with the library's own radix sort, cut into boxes
-// of 256 consecutive points with their AABBs; a thread (one point, in Morton order, so a wave's 64 points are
-// spatial neighbours and take the same branches) seeds its best-3 from its curve neighbours and then visits
-// only the boxes whose AABB is closer than its current 3rd-best distance.  Box AABBs are streamed through LDS.
+// Exact 3-NN: points are ordered along a 30-bit Morton curve with the library's own radix sort and cut into leaf
+// boxes of 32 consecutive points with their AABBs, grouped 16 by 16 into two coarser levels (512 and 8192 points).
+// A thread (one point, in Morton order, so a wave's 64 points are spatial neighbours and take the same branches)
+// seeds its best-3 from its curve neighbours and then descends only into the boxes whose AABB is closer than its
+// current 3rd-best distance.  The top level is streamed through LDS; lower levels are uniform (broadcast) loads.
 #include "rdg_common.h"
 #include <float.h>
 
-#define RDG_KNN_BOX 256
+#define RDG_KNN_BOX 32    // points per leaf box (consecutive along the Morton curve)
+#define RDG_KNN_SUP 16    // children per box of the two upper pruning levels (512 and 8192 points)
+#define RDG_KNN_MMB 256   // workgroups of the bounding-box reduction
 
 struct RdgKnnLayout {
     size_t minmax;      // float[8]
@@ -16,6 +19,9 @@ struct RdgKnnLayout {
     size_t keys_a, keys_b, vals_a, vals_b, sort_tmp;
     size_t sorted;      // float4[P]
     size_t boxes;       // float4[2*nbox]
+    size_t sboxes;      // float4[2*nsb]   AABBs of RDG_KNN_SUP consecutive boxes
+    size_t tboxes;      // float4[2*ntb]   AABBs of RDG_KNN_SUP consecutive super-boxes
+    size_t mm_part;     // float[RDG_KNN_MMB][8]
     size_t total;
 };
 static RdgKnnLayout rdg_knn_layout(int32_t P) {
@@ -32,15 +38,20 @@ static RdgKnnLayout rdg_knn_layout(int32_t P) {
     L.sort_tmp = o; o = rdg_align_up(o + rdg_sort_layout((int64_t)Pp).total, 256);
     L.sorted = o;   o = rdg_align_up(o + Pp * 16, 256);
     L.boxes = o;    o = rdg_align_up(o + nbox * 32, 256);
+    const size_t nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
+    L.sboxes = o;   o = rdg_align_up(o + nsb * 32, 256);
+    L.tboxes = o;   o = rdg_align_up(o + ((nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP) * 32, 256);
+    L.mm_part = o;  o = rdg_align_up(o + (size_t)RDG_KNN_MMB * 32, 256);
     L.total = o;
     return L;
 }
 
-__global__ void __launch_bounds__(1024) rdg_knn_minmax_kernel(int P, const float* __restrict__ pts,
-                                                              float* __restrict__ minmax, int32_t* n_dev) {
-    __shared__ float s[6][16];
+// bounding box of the cloud: RDG_KNN_MMB workgroups write partial boxes, one small workgroup finishes
+__global__ void __launch_bounds__(256) rdg_knn_minmax_partial_kernel(int P, const float* __restrict__ pts,
+                                                                     float* __restrict__ part) {
+    __shared__ float s[6][4];
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = threadIdx.x; i < P; i += 1024) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = pts[3 * i + c];
@@ -60,12 +71,30 @@ __global__ void __launch_bounds__(1024) rdg_knn_minmax_kernel(int P, const float
         for (int c = 0; c < 3; ++c) { s[c][w] = mn[c]; s[3 + c][w] = mx[c]; }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int c = 0; c < 3; ++c) {
-            float a = s[c][0], b = s[3 + c][0];
-            for (int k = 1; k < 16; ++k) { a = fminf(a, s[c][k]); b = fmaxf(b, s[3 + c][k]); }
-            minmax[c] = a; minmax[4 + c] = b;
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        part[blockIdx.x * 8 + c] = fminf(fminf(s[c][0], s[c][1]), fminf(s[c][2], s[c][3]));
+        part[blockIdx.x * 8 + 4 + c] = fmaxf(fmaxf(s[3 + c][0], s[3 + c][1]), fmaxf(s[3 + c][2], s[3 + c][3]));
+    }
+}
+__global__ void __launch_bounds__(64) rdg_knn_minmax_final_kernel(int P, int nblk, const float* __restrict__ part,
+                                                                  float* __restrict__ minmax, int32_t* n_dev) {
+    const int lane = threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int b = lane; b < nblk; b += 64) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], part[b * 8 + c]); mx[c] = fmaxf(mx[c], part[b * 8 + 4 + c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
         }
+    }
+    if (lane == 0) {
+        for (int c = 0; c < 3; ++c) { minmax[c] = mn[c]; minmax[4 + c] = mx[c]; }
         *n_dev = P;
     }
 }
@@ -95,11 +124,11 @@ __global__ void rdg_knn_morton_kernel(int P, const float* __restrict__ pts, cons
     vals[i] = (uint32_t)i;
 }
 
-__global__ void __launch_bounds__(RDG_KNN_BOX)
+// sorted[i] = (x, y, z, original index) in curve order; one AABB per 32 consecutive points (half a wave)
+__global__ void __launch_bounds__(256)
 rdg_knn_gather_box_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
                           float4* __restrict__ sorted, float4* __restrict__ boxes) {
-    __shared__ float s[6][RDG_KNN_BOX / 64];
-    const int i = blockIdx.x * RDG_KNN_BOX + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     if (i < P) {
         const uint32_t src = order[i];
@@ -110,23 +139,36 @@ rdg_knn_gather_box_kernel(int P, const float* __restrict__ pts, const uint32_t* 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = RDG_KNN_BOX / 2; o > 0; o >>= 1) {
             mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
             mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
         }
     }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { for (int c = 0; c < 3; ++c) { s[c][w] = mn[c]; s[3 + c][w] = mx[c]; } }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a[3], b[3];
-        for (int c = 0; c < 3; ++c) {
-            a[c] = s[c][0]; b[c] = s[3 + c][0];
-            for (int k = 1; k < RDG_KNN_BOX / 64; ++k) { a[c] = fminf(a[c], s[c][k]); b[c] = fmaxf(b[c], s[3 + c][k]); }
-        }
-        boxes[2 * blockIdx.x] = make_float4(a[0], a[1], a[2], 0.f);
-        boxes[2 * blockIdx.x + 1] = make_float4(b[0], b[1], b[2], 0.f);
+    if ((threadIdx.x & (RDG_KNN_BOX - 1)) == 0 && i < P) {
+        const int b = i / RDG_KNN_BOX;
+        boxes[2 * b] = make_float4(mn[0], mn[1], mn[2], 0.f);
+        boxes[2 * b + 1] = make_float4(mx[0], mx[1], mx[2], 0.f);
     }
+}
+
+__global__ void rdg_knn_superbox_kernel(int nbox, const float4* __restrict__ boxes, float4* __restrict__ sboxes) {
+    const int sb = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b0 = sb * RDG_KNN_SUP;
+    if (b0 >= nbox) return;
+    float4 lo = boxes[2 * b0], hi = boxes[2 * b0 + 1];
+    for (int b = b0 + 1; b < min(nbox, b0 + RDG_KNN_SUP); ++b) {
+        const float4 l = boxes[2 * b], h = boxes[2 * b + 1];
+        lo.x = fminf(lo.x, l.x); lo.y = fminf(lo.y, l.y); lo.z = fminf(lo.z, l.z);
+        hi.x = fmaxf(hi.x, h.x); hi.y = fmaxf(hi.y, h.y); hi.z = fmaxf(hi.z, h.z);
+    }
+    sboxes[2 * sb] = lo; sboxes[2 * sb + 1] = hi;
+}
+
+__device__ __forceinline__ float rdg_knn_box_d2(const float4 lo, const float4 hi, float x, float y, float z) {
+    const float ex = fmaxf(fmaxf(lo.x - x, x - hi.x), 0.f);
+    const float ey = fmaxf(fmaxf(lo.y - y, y - hi.y), 0.f);
+    const float ez = fmaxf(fmaxf(lo.z - z, z - hi.z), 0.f);
+    return ex * ex + ey * ey + ez * ez;
 }
 
 __device__ __forceinline__ void rdg_knn_insert(float d, float& b0, float& b1, float& b2) {
@@ -142,7 +184,7 @@ __device__ __forceinline__ void rdg_knn_insert(float d, float& b0, float& b1, fl
 
 __global__ void __launch_bounds__(256)
 rdg_knn_search_kernel(int P, int nbox, const float4* __restrict__ sorted, const float4* __restrict__ boxes,
-                      float* __restrict__ out) {
+                      const float4* __restrict__ sboxes, const float4* __restrict__ tboxes, float* __restrict__ out) {
     __shared__ float4 sBox[2 * 256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < P;
@@ -157,29 +199,35 @@ rdg_knn_search_kernel(int P, int nbox, const float4* __restrict__ sorted, const 
             rdg_knn_insert(dx * dx + dy * dy + dz * dz, b0, b1, b2);
         }
     }
-    for (int base = 0; base < nbox; base += 256) {
+    const int nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP, ntb = (nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
+    for (int base = 0; base < ntb; base += 256) {
         __syncthreads();
-        const int nb = min(256, nbox - base);
+        const int nb = min(256, ntb - base);
         if ((int)threadIdx.x < nb) {
-            sBox[2 * threadIdx.x] = boxes[2 * (base + threadIdx.x)];
-            sBox[2 * threadIdx.x + 1] = boxes[2 * (base + threadIdx.x) + 1];
+            sBox[2 * threadIdx.x] = tboxes[2 * (base + threadIdx.x)];
+            sBox[2 * threadIdx.x + 1] = tboxes[2 * (base + threadIdx.x) + 1];
         }
         __syncthreads();
         for (int k = 0; k < nb; ++k) {
-            const float4 lo = sBox[2 * k], hi = sBox[2 * k + 1];
-            const float ex = fmaxf(fmaxf(lo.x - me.x, me.x - hi.x), 0.f);
-            const float ey = fmaxf(fmaxf(lo.y - me.y, me.y - hi.y), 0.f);
-            const float ez = fmaxf(fmaxf(lo.z - me.z, me.z - hi.z), 0.f);
-            const float dbox = ex * ex + ey * ey + ez * ez;
-            const bool visit = act && dbox <= b2;
-            if (!__any(visit)) continue;
-            if (visit) {
-                const int s0 = (base + k) * RDG_KNN_BOX, s1 = min(P, s0 + RDG_KNN_BOX);
-                for (int j = s0; j < s1; ++j) {
-                    if (j == i || (j >= i - 3 && j <= i + 3)) continue;  // seeds already counted
-                    const float4 o = sorted[j];
-                    const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-                    rdg_knn_insert(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+            const bool near_top = act && rdg_knn_box_d2(sBox[2 * k], sBox[2 * k + 1], me.x, me.y, me.z) <= b2;
+            if (__builtin_amdgcn_ballot_w64(near_top) == 0ull) continue;
+            const int sx0 = (base + k) * RDG_KNN_SUP, sx1 = min(nsb, sx0 + RDG_KNN_SUP);
+            for (int sx = sx0; sx < sx1; ++sx) {
+                const bool near_sup = act && rdg_knn_box_d2(sboxes[2 * sx], sboxes[2 * sx + 1], me.x, me.y, me.z) <= b2;
+                if (__builtin_amdgcn_ballot_w64(near_sup) == 0ull) continue;
+                const int bx0 = sx * RDG_KNN_SUP, bx1 = min(nbox, bx0 + RDG_KNN_SUP);
+                for (int bx = bx0; bx < bx1; ++bx) {
+                    const bool visit = act && rdg_knn_box_d2(boxes[2 * bx], boxes[2 * bx + 1], me.x, me.y, me.z) <= b2;
+                    if (__builtin_amdgcn_ballot_w64(visit) == 0ull) continue;
+                    if (visit) {
+                        const int s0 = bx * RDG_KNN_BOX, s1 = min(P, s0 + RDG_KNN_BOX);
+                        for (int j = s0; j < s1; ++j) {
+                            if (j == i || (j >= i - 3 && j <= i + 3)) continue;  // seeds already counted
+                            const float4 o = sorted[j];
+                            const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+                            rdg_knn_insert(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+                        }
+                    }
                 }
             }
         }
@@ -230,7 +278,8 @@ template <int KM>
 __global__ void __launch_bounds__(256)
 rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const float* __restrict__ queries,
                       const float4* __restrict__ sorted, const uint64_t* __restrict__ tkeys,
-                      const float* __restrict__ minmax, const float4* __restrict__ boxes, float* __restrict__ dists,
+                      const float* __restrict__ minmax, const float4* __restrict__ boxes,
+                      const float4* __restrict__ sboxes, const float4* __restrict__ tboxes, float* __restrict__ dists,
                       long long* __restrict__ idx) {
     __shared__ float4 sBox[2 * 256];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -263,28 +312,35 @@ rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const floa
             rdg_knn_push<KM>(dx * dx + dy * dy + dz * dz, __float_as_uint(o.w), bd, bi);
         }
     }
-    for (int base = 0; base < nbox; base += 256) {
+    const int nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP, ntb = (nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
+    for (int base = 0; base < ntb; base += 256) {
         __syncthreads();
-        const int nb = min(256, nbox - base);
+        const int nb = min(256, ntb - base);
         if ((int)threadIdx.x < nb) {
-            sBox[2 * threadIdx.x] = boxes[2 * (base + threadIdx.x)];
-            sBox[2 * threadIdx.x + 1] = boxes[2 * (base + threadIdx.x) + 1];
+            sBox[2 * threadIdx.x] = tboxes[2 * (base + threadIdx.x)];
+            sBox[2 * threadIdx.x + 1] = tboxes[2 * (base + threadIdx.x) + 1];
         }
         __syncthreads();
         for (int k = 0; k < nb; ++k) {
-            const float4 lo = sBox[2 * k], hi = sBox[2 * k + 1];
-            const float ex = fmaxf(fmaxf(lo.x - mx, mx - hi.x), 0.f);
-            const float ey = fmaxf(fmaxf(lo.y - my, my - hi.y), 0.f);
-            const float ez = fmaxf(fmaxf(lo.z - mz, mz - hi.z), 0.f);
-            const bool visit = act && (ex * ex + ey * ey + ez * ez) <= bd[KM - 1];
-            if (__builtin_amdgcn_ballot_w64(visit) == 0ull) continue;
-            if (visit) {
-                const int b0 = (base + k) * RDG_KNN_BOX, b1 = min(Pt, b0 + RDG_KNN_BOX);
-                for (int j = b0; j < b1; ++j) {
-                    if (j >= s_lo && j <= s_hi) continue;   // seeds already taken
-                    const float4 o = sorted[j];
-                    const float dx = mx - o.x, dy = my - o.y, dz = mz - o.z;
-                    rdg_knn_push<KM>(dx * dx + dy * dy + dz * dz, __float_as_uint(o.w), bd, bi);
+            const bool near_top = act && rdg_knn_box_d2(sBox[2 * k], sBox[2 * k + 1], mx, my, mz) <= bd[KM - 1];
+            if (__builtin_amdgcn_ballot_w64(near_top) == 0ull) continue;
+            const int sx0 = (base + k) * RDG_KNN_SUP, sx1 = min(nsb, sx0 + RDG_KNN_SUP);
+            for (int sx = sx0; sx < sx1; ++sx) {
+                const bool near_sup = act && rdg_knn_box_d2(sboxes[2 * sx], sboxes[2 * sx + 1], mx, my, mz) <= bd[KM - 1];
+                if (__builtin_amdgcn_ballot_w64(near_sup) == 0ull) continue;
+                const int bx0 = sx * RDG_KNN_SUP, bx1 = min(nbox, bx0 + RDG_KNN_SUP);
+                for (int bx = bx0; bx < bx1; ++bx) {
+                    const bool visit = act && rdg_knn_box_d2(boxes[2 * bx], boxes[2 * bx + 1], mx, my, mz) <= bd[KM - 1];
+                    if (__builtin_amdgcn_ballot_w64(visit) == 0ull) continue;
+                    if (visit) {
+                        const int b0 = bx * RDG_KNN_BOX, b1 = min(Pt, b0 + RDG_KNN_BOX);
+                        for (int j = b0; j < b1; ++j) {
+                            if (j >= s_lo && j <= s_hi) continue;   // seeds already taken
+                            const float4 o = sorted[j];
+                            const float dx = mx - o.x, dy = my - o.y, dz = mz - o.z;
+                            rdg_knn_push<KM>(dx * dx + dy * dy + dz * dz, __float_as_uint(o.w), bd, bi);
+                        }
+                    }
                 }
             }
         }
@@ -335,30 +391,6 @@ extern "C" {
 
 size_t rdg_knn_tmp_bytes(int32_t P) { return rdg_knn_layout(P).total; }
 
-int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream) {
-    if (P <= 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const RdgKnnLayout L = rdg_knn_layout(P);
-    char* t = (char*)tmp_ws;
-    float* minmax = (float*)(t + L.minmax);
-    int32_t* n_dev = (int32_t*)(t + L.n_dev);
-    uint64_t* keys_a = (uint64_t*)(t + L.keys_a); uint64_t* keys_b = (uint64_t*)(t + L.keys_b);
-    uint32_t* vals_a = (uint32_t*)(t + L.vals_a); uint32_t* vals_b = (uint32_t*)(t + L.vals_b);
-    float4* sorted = (float4*)(t + L.sorted);
-    float4* boxes = (float4*)(t + L.boxes);
-    const int nbox = (P + RDG_KNN_BOX - 1) / RDG_KNN_BOX;
-    hipLaunchKernelGGL(rdg_knn_minmax_kernel, dim3(1), dim3(1024), 0, st, P, points, minmax, n_dev);
-    hipLaunchKernelGGL(rdg_knn_morton_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points, minmax, keys_a, vals_a);
-    int in_b = 0;
-    int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, (int64_t)P, n_dev, 30, t + L.sort_tmp, &in_b, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(rdg_knn_gather_box_kernel, dim3(nbox), dim3(RDG_KNN_BOX), 0, st, P, points,
-                       in_b ? vals_b : vals_a, sorted, boxes);
-    hipLaunchKernelGGL(rdg_knn_search_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, nbox, sorted, boxes, out);
-    return rdg_check_hip(hipGetLastError(), "knn launch");
-}
-
-
 /* Sorts the targets along the Morton curve and builds the box AABBs (shared by both entry points). */
 static int rdg_knn_prepare(int32_t P, const float* points, char* t, const RdgKnnLayout& L, int* in_b, hipStream_t st) {
     float* minmax = (float*)(t + L.minmax);
@@ -366,13 +398,37 @@ static int rdg_knn_prepare(int32_t P, const float* points, char* t, const RdgKnn
     uint64_t* keys_a = (uint64_t*)(t + L.keys_a); uint64_t* keys_b = (uint64_t*)(t + L.keys_b);
     uint32_t* vals_a = (uint32_t*)(t + L.vals_a); uint32_t* vals_b = (uint32_t*)(t + L.vals_b);
     const int nbox = (P + RDG_KNN_BOX - 1) / RDG_KNN_BOX;
-    hipLaunchKernelGGL(rdg_knn_minmax_kernel, dim3(1), dim3(1024), 0, st, P, points, minmax, n_dev);
+    int mmb = (P + 255) / 256;
+    if (mmb > RDG_KNN_MMB) mmb = RDG_KNN_MMB;
+    hipLaunchKernelGGL(rdg_knn_minmax_partial_kernel, dim3(mmb), dim3(256), 0, st, P, points, (float*)(t + L.mm_part));
+    hipLaunchKernelGGL(rdg_knn_minmax_final_kernel, dim3(1), dim3(64), 0, st, P, mmb, (const float*)(t + L.mm_part),
+                       minmax, n_dev);
     hipLaunchKernelGGL(rdg_knn_morton_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points, minmax, keys_a, vals_a);
     int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, (int64_t)P, n_dev, 30, t + L.sort_tmp, in_b, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(rdg_knn_gather_box_kernel, dim3(nbox), dim3(RDG_KNN_BOX), 0, st, P, points,
+    hipLaunchKernelGGL(rdg_knn_gather_box_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points,
                        *in_b ? vals_b : vals_a, (float4*)(t + L.sorted), (float4*)(t + L.boxes));
+    const int nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP, ntb = (nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
+    hipLaunchKernelGGL(rdg_knn_superbox_kernel, dim3((nsb + 63) / 64), dim3(64), 0, st, nbox,
+                       (const float4*)(t + L.boxes), (float4*)(t + L.sboxes));
+    hipLaunchKernelGGL(rdg_knn_superbox_kernel, dim3((ntb + 63) / 64), dim3(64), 0, st, nsb,
+                       (const float4*)(t + L.sboxes), (float4*)(t + L.tboxes));
     return 0;
+}
+
+int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream) {
+    if (P <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const RdgKnnLayout L = rdg_knn_layout(P);
+    char* t = (char*)tmp_ws;
+    int in_b = 0;
+    int rc = rdg_knn_prepare(P, points, t, L, &in_b, st);
+    if (rc) return rc;
+    const int nbox = (P + RDG_KNN_BOX - 1) / RDG_KNN_BOX;
+    hipLaunchKernelGGL(rdg_knn_search_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, nbox,
+                       (const float4*)(t + L.sorted), (const float4*)(t + L.boxes), (const float4*)(t + L.sboxes),
+                       (const float4*)(t + L.tboxes), out);
+    return rdg_check_hip(hipGetLastError(), "knn launch");
 }
 
 int rdg_knn_points_forward(int32_t Pq, int32_t Pt, int32_t K, const float* queries, const float* targets, float* dists,
@@ -392,7 +448,8 @@ int rdg_knn_points_forward(int32_t Pq, int32_t Pt, int32_t K, const float* queri
 #define RDG_KNN_LAUNCH(KM)                                                                                        \
     hipLaunchKernelGGL(rdg_knn_points_kernel<KM>, dim3((Pq + 255) / 256), dim3(256), 0, st, Pq, Pt, nbox, K, self_mode, \
                        queries, (const float4*)(t + L.sorted), tkeys, (const float*)(t + L.minmax),                \
-                       (const float4*)(t + L.boxes), dists, (long long*)idx)
+                       (const float4*)(t + L.boxes), (const float4*)(t + L.sboxes), (const float4*)(t + L.tboxes), dists, \
+                       (long long*)idx)
     if (K <= 4) RDG_KNN_LAUNCH(4); else if (K <= 8) RDG_KNN_LAUNCH(8); else if (K <= 16) RDG_KNN_LAUNCH(16);
     else RDG_KNN_LAUNCH(32);
 #undef RDG_KNN_LAUNCH
