@@ -179,6 +179,21 @@ size_t rdg_knn_tmp_bytes(int32_t P);
 /* out[p] = mean squared distance from points[p] to its 3 nearest other points.                              */
 int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream);
 
+/* ---- Pearson depth losses (GlobalPearsonDepthLoss / LocalPearsonDepthLoss, /root/reference/src/trainer/losses.py:108-182;
+ *      pearson_depth_loss, /root/reference/src/utils/loss_utils.py:100-117) -------------------------------------------
+ * n_boxes boxes of bh x bw pixels of the [H,W] depth images pred / gt; row0[n_boxes], col0[n_boxes] (int64, device)
+ * are the top-left corners (NULL, NULL with n_boxes = 1, bh = H, bw = W is the global loss).  mask: optional
+ * [H,W] bytes (torch.bool) multiplied into both images as the reference does; a box whose mask is empty contributes
+ * nothing.  loss_out[0] = weight * sum_boxes (1 - corr_box)   (weight = 1 / n_corr for the local loss).
+ * ws: rdg_pearson_ws_bytes(n_boxes), kept for backward.  Backward overwrites d_pred[H,W] with g_loss[0] * dL/dpred. */
+size_t rdg_pearson_ws_bytes(int32_t n_boxes);
+int rdg_pearson_depth_forward(int32_t H, int32_t W, int32_t n_boxes, int32_t bh, int32_t bw, const int64_t* row0,
+                              const int64_t* col0, const float* pred, const float* gt, const uint8_t* mask, float eps,
+                              float weight, void* ws, float* loss_out, void* stream);
+int rdg_pearson_depth_backward(int32_t H, int32_t W, int32_t n_boxes, int32_t bh, int32_t bw, const int64_t* row0,
+                               const int64_t* col0, const float* pred, const float* gt, const uint8_t* mask,
+                               const void* ws, const float* g_loss, float* d_pred, void* stream);
+
 /* ---- pytorch3d.ops.knn_points / knn_gather (RigidityLoss, /root/reference/src/trainer/losses.py:235-331) ---- */
 /* K nearest targets of every query: dists[Pq,K] squared Euclidean, ascending; idx[Pq,K] int64 target indices.
  * tmp_ws: rdg_knn_tmp_bytes(Pt).  queries == targets (same pointer, Pq == Pt) is the self query the reference

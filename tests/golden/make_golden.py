@@ -16,6 +16,10 @@ What is pinned: the pieces of the hot path that exist as import
   G7 rigidity    : RigidityLoss (src/trainer/losses.py:185-360), all three modes, value and gradients, with
                    pytorch3d's knn_points / knn_gather supplied by oracle/knn_oracle.py
                    (``python -B tests/golden/make_golden.py rigidity`` regenerates only this file)
+  G8 depth loss  : pearson_depth_loss (src/utils/loss_utils.py:100-117), GlobalPearsonDepthLoss and
+                   LocalPearsonDepthLoss (src/trainer/losses.py:108-182; its device="cuda" randint is redirected to
+                   the CPU generator for the call and the drawn corners are stored), value and d/dpred
+                   (``... make_golden.py depth``)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -146,6 +150,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "loss_golden.npz"), a=a.numpy(), b=b.numpy(),
                         l1=l1_loss(a, b).numpy(), ssim=ssim(a, b).numpy())
     rigidity_golden()
+    depth_loss_golden()
     print("golden vectors written to", OUT)
 
 
@@ -188,12 +193,51 @@ def rigidity_golden():
     np.savez_compressed(os.path.join(OUT, "rigidity_golden.npz"), **out)
 
 
+def depth_loss_golden():
+    from src.trainer.losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
+    g = torch.Generator().manual_seed(515)
+    H, W, box_p, p_corr = 150, 260, 32, 0.5
+    gt = torch.rand(1, H, W, generator=g) * 8 + 1
+    pred0 = gt * 0.7 + 0.5 + 0.6 * torch.randn(1, H, W, generator=g)
+    motion = torch.rand(1, H, W, generator=g) > 0.6
+    motion[:, :70, :90] = False          # some boxes have an empty "dynamic" mask -> the reference skips them
+    out = dict(pred=pred0.numpy(), gt=gt.numpy(), motion=motion.numpy(), box_p=np.int64(box_p), p_corr=np.float64(p_corr))
+    drawn = []
+    real_randint = torch.randint
+
+    def cpu_randint(*a, **k):
+        k.pop("device", None)
+        r = real_randint(*a, **k)
+        drawn.append(r.clone())
+        return r
+
+    for mode in (None, "static", "dynamic"):
+        tag = str(mode)
+        mm = None if mode is None else motion
+        pred = pred0.clone().requires_grad_(True)
+        lg = GlobalPearsonDepthLoss(mode)(pred, gt, mm)
+        (dg,) = torch.autograd.grad(lg, pred)
+        out[f"global.{tag}.loss"], out[f"global.{tag}.d_pred"] = lg.detach().numpy(), dg.numpy()
+        pred = pred0.clone().requires_grad_(True)
+        torch.manual_seed(31)
+        del drawn[:]
+        torch.randint = cpu_randint
+        try:
+            ll = LocalPearsonDepthLoss(box_p, p_corr, mode)(pred, gt, mm)
+        finally:
+            torch.randint = real_randint
+        (dl,) = torch.autograd.grad(ll, pred)
+        out[f"local.{tag}.loss"], out[f"local.{tag}.d_pred"] = ll.detach().numpy(), dl.numpy()
+        out[f"local.{tag}.rows"], out[f"local.{tag}.cols"] = drawn[0].numpy(), drawn[1].numpy()
+    np.savez_compressed(os.path.join(OUT, "depth_loss_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rigidity":
+    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth"):
         sys.dont_write_bytecode = True
         _stub_modules()
         sys.path.insert(0, REF)
-        rigidity_golden()
-        print("rigidity golden written to", OUT)
+        (rigidity_golden if sys.argv[1] == "rigidity" else depth_loss_golden)()
+        print(sys.argv[1], "golden written to", OUT)
     else:
         main()

@@ -175,3 +175,24 @@ def test_rigidity_mirror_matches_reference_with_oracle_knn(name):
             assert want.numel() == 1 and float(want.abs().sum()) == 0.0
             continue
         assert float((gr - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-12, k
+
+
+@pytest.mark.parametrize("mode", [None, "static", "dynamic"])
+def test_depth_loss_oracle_matches_reference(mode):
+    """oracle/depth_loss_oracle.py == the imported reference's Global/LocalPearsonDepthLoss (golden G8)."""
+    from oracle import depth_loss_oracle as DL
+    g = load("depth_loss_golden.npz")
+    tag = str(mode)
+    gt, motion = torch.from_numpy(g["gt"]), torch.from_numpy(g["motion"])
+    mask = None if mode is None else (~motion if mode == "static" else motion)
+    pred = torch.from_numpy(g["pred"]).requires_grad_(True)
+    lg = DL.pearson_depth_loss(pred, gt, 1e-6, mask)
+    (dg,) = torch.autograd.grad(lg, pred)
+    assert abs(float(lg) - float(g[f"global.{tag}.loss"])) <= 1e-6
+    assert float((dg - torch.from_numpy(g[f"global.{tag}.d_pred"])).abs().max()) <= 1e-9
+    pred = torch.from_numpy(g["pred"]).requires_grad_(True)
+    rows, cols = torch.from_numpy(g[f"local.{tag}.rows"]), torch.from_numpy(g[f"local.{tag}.cols"])
+    ll = DL.local_pearson_depth_loss(pred, gt, rows, cols, int(g["box_p"]), len(rows), mask)
+    (dl,) = torch.autograd.grad(ll, pred)
+    assert abs(float(ll) - float(g[f"local.{tag}.loss"])) <= 1e-6
+    assert float((dl - torch.from_numpy(g[f"local.{tag}.d_pred"])).abs().max()) <= 1e-8
