@@ -251,6 +251,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(rc, "rdg_rasterize_backward")
         if sink_sh is not None:
             d_sh = None
+            ready = ctx.grad_sinks.get("on_shs_ready")
+            if ready is not None:
+                ready()          # the sink now holds the final dL/dshs (stream-ordered): e.g. start its all-reduce
         return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_ro, d_cov, d_vm, None, None
 
 

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from . import _lib
 from .deform import MLPBasisNetwork, gaussian_deformation, gaussian_deformation_packed
-from .dp import FlatParams, allreduce_sum_, frame_for
+from .dp import BucketedAllReduce, FlatParams, allreduce_sum_, frame_for
 from .losses import fused_photometric_loss
 from .model_ops import activate_gaussians, pose_view_matrix
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
@@ -43,17 +43,24 @@ def world_view_transform(q_c2w: torch.Tensor, t_c2w: torch.Tensor) -> torch.Tens
     return torch.cat([top, bottom], dim=0)
 
 
-def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None, extra=()) -> None:
+def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None, extra=(),
+                names=None, advance: bool = True) -> None:
     """ONE fused HIP launch for all parameter groups of the flat buffers (rdg_adam_step_multi).
     row_lr: {name: (row_len, head_len, lr_tail)} for segments whose rows mix two learning rates.
     extra: further FlatParams stepped by the same launch (e.g. the MLP + camera-pose bucket); neighbouring
-    segments of one buffer with the same learning rate are merged (their alignment padding has zero gradients)."""
+    segments of one buffer with the same learning rate are merged (their alignment padding has zero gradients).
+    names: restrict ``fp`` to these segments (one piece of an overlapped gradient exchange); ``advance`` = this call
+    opens a new optimiser step (the step counter moves once per step, however many pieces it is applied in)."""
     L = _lib.lib()
-    fp.step_count += 1
+    if advance:
+        fp.step_count += 1
     entries = []   # (flat-params, first offset, element count, lr, row_len, head_len, lr_tail)
     for f in (fp, *extra):
         f.step_count = fp.step_count
         for k in f.names:
+            if f is fp and names is not None and k not in names:
+                entries.append(None)      # a gap: the neighbours must not be merged across it
+                continue
             o, n = f.offsets[k]
             row_len, head_len, lr_tail = ((row_lr or {}).get(k, (1, 1, f.lr[k])) if f is fp else (1, 1, f.lr[k]))
             last = entries[-1] if entries else None
@@ -61,6 +68,9 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
                 entries[-1] = (f, last[1], o + n - last[1], last[3], 1, 1, last[6])
             else:
                 entries.append((f, o, n, f.lr[k], row_len, head_len, lr_tail))
+    entries = [e for e in entries if e is not None]
+    if not entries:
+        return
     segs = (_lib.RdgAdamSeg * len(entries))()
     for i, (f, o, n, lr, row_len, head_len, lr_tail) in enumerate(entries):
         b = o * 4
@@ -170,6 +180,7 @@ class DynamicScene:
         self.emb_rows = torch.cat([emb.unsqueeze(0).expand(num_frames, -1, -1), self.frame_embeddings.unsqueeze(1)],
                                   dim=1).contiguous()                       # [T, T+1, 53]
         self.m2 = torch.zeros(P, 3, device=dev, requires_grad=True)        # means2D: values unused, gradient sink
+        self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
         self.gt = {}
 
     # ---- pieces of the step ------------------------------------------------------------------------------------
@@ -198,7 +209,10 @@ class DynamicScene:
         m2.grad = None
         out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
                                                   rotations=rot, viewmatrix=vm,
-                                                  grad_sinks={"shs": self.fp["features"].grad})
+                                                  grad_sinks={"shs": self.fp["features"].grad,
+                                                              # frame-DP: the SH gradient goes on the wire while the
+                                                              # rest of backward is still running
+                                                              "on_shs_ready": lambda: self.sync.ready("features")})
         return out, m2
 
     def make_ground_truth(self, target_scene: dict, frames):
@@ -222,6 +236,15 @@ class DynamicScene:
         loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
         if world > 1:
-            allreduce_sum_(self.fp.flat_grad, [self.sp.flat_grad])
-        fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,))
+            # overlapped exchange: pieces arrive in issue order; Adam steps each piece while the next one is in flight
+            self.sync.finish()
+            first = True
+            for names in self.sync.drain():
+                if names is None:                       # the small MLP + pose bucket
+                    fused_adam_(self.fp, names=(), extra=(self.sp,), advance=first)
+                else:
+                    fused_adam_(self.fp, row_lr=self.row_lr, names=names, advance=first)
+                first = False
+        else:
+            fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,))
         return loss.detach()

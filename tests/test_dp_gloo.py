@@ -43,8 +43,19 @@ def _worker(rank, world, port, outdir):
     for k, g in grads.items():
         fp[k].grad.copy_(g)
     small = [torch.full((5,), float(rank + 1)), torch.full((2, 3), 10.0 * (rank + 1))]
+    # the overlapped exchange on a second copy: "shs" goes out early (as from inside backward), the rest afterwards
+    from rodygs_amd.dp import BucketedAllReduce
+    fp2 = FlatParams(spec, "cpu")
+    fp2.flat_grad.copy_(fp.flat_grad)
+    side = torch.full((11,), float(rank + 1))
+    sync = BucketedAllReduce(fp2, [side])
+    sync.ready("shs")
+    sync.ready("shs")                       # idempotent
+    sync.finish()
+    pieces = list(sync.drain())
     allreduce_sum_(fp.flat_grad, small)
-    torch.save({"flat": fp.flat_grad.clone(), "small": small, "offsets": fp.offsets,
+    torch.save({"flat": fp.flat_grad.clone(), "small": small, "offsets": fp.offsets, "flat2": fp2.flat_grad.clone(),
+                "pieces": pieces, "side": side,
                 "frames": [frame_for(s, rank, world, list(range(7))) for s in range(7)]},
                os.path.join(outdir, f"r{rank}.pt"))
     dist.barrier()
@@ -64,6 +75,11 @@ def test_flat_bucket_allreduce_equals_sum_of_single_rank_grads():
         want = (g0[k] + g1[k]).reshape(-1)
         got = r0["flat"][o:o + n]
         assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), k
+    # bucketed / overlapped exchange: same sums, pieces = early segment, then the maximal contiguous remainders, then
+    # the side bucket
+    assert torch.equal(r0["flat2"], r0["flat"]) and torch.equal(r1["flat2"], r0["flat"])
+    assert r0["pieces"] == [["shs"], ["means3D"], ["opacities", "scales", "rotations"], None]
+    assert torch.equal(r0["side"], torch.full((11,), 3.0))
     assert float(g0["means3D"].sub(g1["means3D"]).abs().max()) > 0  # the two frames really differ
     assert torch.equal(r0["small"][0], torch.full((5,), 3.0)) and torch.equal(r1["small"][1], torch.full((2, 3), 30.0))
     # strided frame assignment: the two ranks never render the same frame in a step and cover the permutation

@@ -677,6 +677,60 @@ def test_train_step_runs_and_reduces_loss():
     assert float(ds.cam_q.grad.abs().sum()) > 0 and ds.net.head_w1.grad is not None
 
 
+def test_overlapped_exchange_path_equals_single_launch_path():
+    """The frame-DP branch of the train step (bucketed asynchronous all-reduce over RCCL + Adam applied piece by piece)
+    on a 1-rank process group must reproduce the single-launch optimiser step bit for bit from the same gradients:
+    the sum over one rank is the identity, so any difference would come from the bucketing / per-piece logic.
+    (Whole steps are not compared bitwise: the rasterizer backward accumulates with float atomics.)"""
+    import socket
+    import torch.distributed as dist
+    from rodygs_amd.dp import BucketedAllReduce
+    from rodygs_amd.losses import fused_photometric_loss
+    from rodygs_amd.trainstep import DynamicScene, fused_adam_
+    sc = O.synthetic_scene(6000, 160, 120, 3, seed=15)
+    tgt = O.synthetic_scene(1500, 160, 120, 3, seed=16)
+    ds = DynamicScene(sc, num_frames=4, device=DEV)
+    ds.make_ground_truth(tgt, range(4))
+    ds.train_step(0, perm=[2])                                  # non-trivial Adam moments
+    out, _ = ds.render(2)
+    fused_photometric_loss(out[0], ds.gt[2], 0.2).backward()    # fresh gradients in both flat buckets
+    bufs = [ds.fp.flat, ds.fp.exp_avg, ds.fp.exp_avg_sq, ds.sp.flat, ds.sp.exp_avg, ds.sp.exp_avg_sq]
+    grads0 = (ds.fp.flat_grad.clone(), ds.sp.flat_grad.clone())
+    snap = [b.clone() for b in bufs]
+    step0 = ds.fp.step_count
+    fused_adam_(ds.fp, row_lr=ds.row_lr, extra=(ds.sp,))
+    want = [b.clone() for b in bufs]
+    for b, s0 in zip(bufs, snap):
+        b.copy_(s0)
+    ds.fp.step_count = step0
+
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV, torch.cuda.current_device()))
+    real = BucketedAllReduce.active
+    BucketedAllReduce.active = staticmethod(lambda: True)
+    try:
+        ds.sync.ready("features")
+        ds.sync.finish()
+        pieces, first = [], True
+        for names in ds.sync.drain():
+            pieces.append(names)
+            if names is None:
+                fused_adam_(ds.fp, names=(), extra=(ds.sp,), advance=first)
+            else:
+                fused_adam_(ds.fp, row_lr=ds.row_lr, names=names, advance=first)
+            first = False
+        torch.cuda.synchronize()
+    finally:
+        BucketedAllReduce.active = real
+        dist.destroy_process_group()
+    assert pieces == [["features"], ["xyz"], ["scaling", "rotation", "opacity", "motion_coeff"], None]
+    assert torch.equal(ds.fp.flat_grad, grads0[0]) and torch.equal(ds.sp.flat_grad, grads0[1])
+    assert ds.fp.step_count == step0 + 1 and ds.sp.step_count == step0 + 1
+    for b, w in zip(bufs, want):
+        assert torch.equal(b, w)
+
+
 @pytest.mark.parametrize("use_sinks", [False, True])
 def test_fused_activations_match_reference_getters(use_sinks):
     """activate_gaussians vs the torch formulas of the reference getters (rodygs_static.py:82-105) + deformation add."""
