@@ -179,6 +179,15 @@ size_t rdg_knn_tmp_bytes(int32_t P);
 /* out[p] = mean squared distance from points[p] to its 3 nearest other points.                              */
 int rdg_dist2_knn3(int32_t P, const float* points, float* out, void* tmp_ws, void* stream);
 
+/* ---- densify / prune row surgery (/root/reference/src/trainer/rodygs_static.py:170-319, src/trainer/utils.py:15-95) ----
+ * dst[i,:] = src[idx[i],:] for i < n_new rows of row_len floats; idx[i] < 0 writes zeros (Adam moments of new rows). */
+int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const float* src, float* dst, void* stream);
+/* Split children (densify_and_split_update_attributes, rodygs_static.py:182-216): for child i of parent p = parent[i],
+ * xyz_out[i] = xyz[p] + R(rotation[p] / |rotation[p]|) (exp(scaling[p]) * z[i]),
+ * scaling_out[i] = log(exp(scaling[p]) / (0.8 N)); z[n,3] are standard-normal draws supplied by the caller.        */
+int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float* xyz, const float* scaling,
+                       const float* rotation, const float* z, float* xyz_out, float* scaling_out, void* stream);
+
 /* ---- Pearson depth losses (GlobalPearsonDepthLoss / LocalPearsonDepthLoss, /root/reference/src/trainer/losses.py:108-182;
  *      pearson_depth_loss, /root/reference/src/utils/loss_utils.py:100-117) -------------------------------------------
  * n_boxes boxes of bh x bw pixels of the [H,W] depth images pred / gt; row0[n_boxes], col0[n_boxes] (int64, device)

@@ -1,0 +1,65 @@
+// rdg_densify.hip -- row compaction / extension of the Gaussian tensors for densify-and-prune.
+//
+// Reference: ThreeDGSTrainer.densify_and_clone / densify_and_split / prune_points
+// (/root/reference/src/trainer/rodygs_static.py:170-319) with the optimizer surgery of
+// /root/reference/src/trainer/utils.py:15-95.  There every parameter and both Adam moments are rebuilt tensor by
+// tensor with boolean indexing and torch.cat, three times per densification (clone, split, prune).  Here the three
+// steps are composed into ONE source-row list on the host side (rodygs_amd/densify.py) and every buffer is rebuilt
+// by one gather:  dst[i,:] = src[idx[i],:]  (idx < 0 -> zeros: the Adam moments of new Gaussians), plus one small
+// kernel that places the split children: xyz = parent + R(q/|q|) (exp(s) * z), scaling = log(exp(s) / (0.8 N)).
+#include "rdg_common.h"
+
+__global__ void rdg_gather_rows_kernel(long long n_new, int row_len, const long long* __restrict__ idx,
+                                       const float* __restrict__ src, float* __restrict__ dst) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_new * row_len) return;
+    const long long r = e / row_len;
+    const int c = (int)(e - r * row_len);
+    const long long s = idx[r];
+    dst[e] = s < 0 ? 0.0f : src[s * row_len + c];
+}
+
+__global__ void rdg_split_children_kernel(long long n, const long long* __restrict__ parent, float inv_shrink,
+                                          const float* __restrict__ xyz, const float* __restrict__ scaling,
+                                          const float* __restrict__ rotation, const float* __restrict__ z,
+                                          float* __restrict__ xyz_out, float* __restrict__ scaling_out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long p = parent[i];
+    const float s0 = expf(scaling[3 * p]), s1 = expf(scaling[3 * p + 1]), s2 = expf(scaling[3 * p + 2]);
+    const float qr0 = rotation[4 * p], qx0 = rotation[4 * p + 1], qy0 = rotation[4 * p + 2], qz0 = rotation[4 * p + 3];
+    const float nrm = sqrtf(qr0 * qr0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
+    const float r = qr0 / nrm, x = qx0 / nrm, y = qy0 / nrm, w = qz0 / nrm;
+    const float v0 = s0 * z[3 * i], v1 = s1 * z[3 * i + 1], v2 = s2 * z[3 * i + 2];   // sample ~ N(0, diag(s)^2)
+    const float R00 = 1.f - 2.f * (y * y + w * w), R01 = 2.f * (x * y - r * w), R02 = 2.f * (x * w + r * y);
+    const float R10 = 2.f * (x * y + r * w), R11 = 1.f - 2.f * (x * x + w * w), R12 = 2.f * (y * w - r * x);
+    const float R20 = 2.f * (x * w - r * y), R21 = 2.f * (y * w + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+    xyz_out[3 * i] = (R00 * v0 + R01 * v1 + R02 * v2) + xyz[3 * p];
+    xyz_out[3 * i + 1] = (R10 * v0 + R11 * v1 + R12 * v2) + xyz[3 * p + 1];
+    xyz_out[3 * i + 2] = (R20 * v0 + R21 * v1 + R22 * v2) + xyz[3 * p + 2];
+    scaling_out[3 * i] = logf(s0 * inv_shrink);
+    scaling_out[3 * i + 1] = logf(s1 * inv_shrink);
+    scaling_out[3 * i + 2] = logf(s2 * inv_shrink);
+}
+
+extern "C" {
+
+int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const float* src, float* dst, void* stream) {
+    if (n_new <= 0 || row_len <= 0) return 0;
+    const long long n = n_new * row_len;
+    hipLaunchKernelGGL(rdg_gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long long)n_new, row_len, (const long long*)idx, src, dst);
+    return rdg_check_hip(hipGetLastError(), "gather_rows launch");
+}
+
+int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float* xyz, const float* scaling,
+                       const float* rotation, const float* z, float* xyz_out, float* scaling_out, void* stream) {
+    if (n <= 0) return 0;
+    if (N < 1) return rdg_set_error("split_children: N must be >= 1");
+    hipLaunchKernelGGL(rdg_split_children_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long long)n, (const long long*)parent, 1.0f / (0.8f * (float)N), xyz, scaling, rotation, z,
+                       xyz_out, scaling_out);
+    return rdg_check_hip(hipGetLastError(), "split_children launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+"""Densify-and-prune over the flat parameter buckets.
+
+Reference: ``ThreeDGSTrainer.densify_and_prune`` and helpers (/root/reference/src/trainer/rodygs_static.py:170-319,
+dynamic overrides /root/reference/src/trainer/rodygs_dynamic.py:150-197) + the optimizer surgery of
+/root/reference/src/trainer/utils.py:15-95.  The reference rebuilds every parameter tensor and both Adam moments
+three times per call (clone -> cat, split -> cat + mask, prune -> mask).  Here the three steps are composed into one
+list of source rows, and each buffer of the flat buckets (parameters, exp_avg, exp_avg_sq) is rebuilt by ONE HIP
+gather (csrc/rdg_densify.hip); the split children are placed by one more small kernel.  Result rows are in the
+reference's order: surviving originals, clones, split children (N copies, ``repeat`` order), then the final prune.
+
+Reference quirks kept on purpose:
+* ``densification_postfix`` zeroes ``max_radii2D`` before the final prune, so the screen-size criterion never fires
+  there; only the world-size criterion (``> 0.1 * extent``) does when ``max_screen_size`` is truthy.
+* Clones are appended before the split selection runs; their padded gradient is 0, so they are never split.
+* New Gaussians start with zero Adam moments; survivors keep theirs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .dp import FlatParams
+
+
+@dataclass
+class DensifyStats:
+    xyz_gradient_accum: torch.Tensor   # [P,1]
+    denom: torch.Tensor                # [P,1]
+    max_radii2D: torch.Tensor          # [P]
+
+    @staticmethod
+    def zeros(P: int, device) -> "DensifyStats":
+        return DensifyStats(torch.zeros(P, 1, device=device), torch.zeros(P, 1, device=device),
+                            torch.zeros(P, device=device))
+
+    def add(self, viewspace_grad: torch.Tensor, update_filter: torch.Tensor, radii: Optional[torch.Tensor] = None):
+        """add_densification_stats (rodygs_static.py:317-319) with the gradient norm of rodygs.py:319-341, and the
+        running max of the screen radii (rodygs.py:334-337)."""
+        g = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum[update_filter] += g[update_filter]
+        self.denom[update_filter] += 1
+        if radii is not None:
+            self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter],
+                                                        radii[update_filter].to(self.max_radii2D.dtype))
+
+
+@dataclass
+class DensifyResult:
+    fp: FlatParams
+    stats: DensifyStats
+    per_point: Dict[str, torch.Tensor]
+    n_clone: int
+    n_split: int
+    n_pruned: int
+
+
+def _gather_rows(src_flat: torch.Tensor, row_len: int, idx: torch.Tensor, dst_flat: torch.Tensor) -> None:
+    _lib.check(_lib.lib().rdg_gather_rows(idx.numel(), row_len, _lib.ptr(idx), _lib.ptr(src_flat), _lib.ptr(dst_flat),
+                                          _lib.stream_ptr()), "rdg_gather_rows")
+
+
+def rebuild_flat_params(fp: FlatParams, src: torch.Tensor, keep_moments: torch.Tensor) -> FlatParams:
+    """New FlatParams whose row i of every segment is row src[i] of ``fp``; Adam moments are carried over where
+    ``keep_moments[i]`` and start at zero elsewhere.  Every segment's first dimension is the Gaussian count."""
+    dev = fp.flat.device
+    n_new = int(src.numel())
+    spec = {k: ((n_new, *fp.shapes[k][1:]), fp.lr[k]) for k in fp.names}
+    out = FlatParams(spec, dev)
+    out.step_count = fp.step_count
+    src = src.to(torch.int64).contiguous()
+    src_m = torch.where(keep_moments, src, torch.full_like(src, -1)).contiguous()
+    with torch.cuda.device(dev):
+        for k in fp.names:
+            row_len = 1
+            for s_ in fp.shapes[k][1:]:
+                row_len *= int(s_)
+            so, sn = fp.offsets[k]
+            do, dn = out.offsets[k]
+            for a, b, idx in ((fp.flat, out.flat, src), (fp.exp_avg, out.exp_avg, src_m),
+                              (fp.exp_avg_sq, out.exp_avg_sq, src_m)):
+                _gather_rows(a[so:so + sn], row_len, idx, b[do:do + dn])
+    return out
+
+
+def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad: float,
+                      min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01, N: int = 2,
+                      z: Optional[torch.Tensor] = None) -> DensifyResult:
+    """``fp`` holds at least xyz [P,3], scaling [P,3] (log), rotation [P,4] (raw), opacity [P,1] (logit); every other
+    segment (SH features, motion coefficients, ...) is carried along row-wise.  ``per_point``: further [P,...]
+    tensors that follow the Gaussians (gaussian_to_time, gaussian_to_time_ind).  ``z``: optional standard-normal
+    draws [N * n_split, 3] for the split children (default: torch.randn on the device)."""
+    if not fp.flat.is_cuda:
+        raise RuntimeError("rodygs_amd.densify_and_prune: buffers must be on the GPU (no CPU fallback exists)")
+    if fp.shapes["scaling"][1:] != (3,):
+        raise NotImplementedError("isotropic scaling ([P,1]) is not supported")
+    dev = fp.flat.device
+    P = fp.shapes["xyz"][0]
+    with torch.no_grad():
+        grads = stats.xyz_gradient_accum / stats.denom
+        grads[grads.isnan()] = 0.0
+        max_s = torch.exp(fp["scaling"].detach()).max(dim=1).values
+        small = max_s <= percent_dense * extent
+        clone_mask = (torch.norm(grads, dim=-1) >= max_grad) & small                    # rodygs_static.py:244-251
+        split_mask = (grads.squeeze(-1) >= max_grad) & ~small                            # :185-193 (clones: grad 0)
+        idx_all = torch.arange(P, device=dev)
+        idx_clone = idx_all[clone_mask]
+        idx_split = idx_all[split_mask]
+        n_clone, n_sel = int(idx_clone.numel()), int(idx_split.numel())
+        idx_child = idx_split.repeat(N)                                                  # repeat(N, 1) order
+        n_child = n_sel * N
+        src = torch.cat([idx_all[~split_mask], idx_clone, idx_child])
+        kind = torch.cat([torch.zeros(P - n_sel, dtype=torch.int64, device=dev),
+                          torch.ones(n_clone, dtype=torch.int64, device=dev),
+                          torch.full((n_child,), 2, dtype=torch.int64, device=dev)])
+        child_no = torch.cat([torch.full((P - n_sel + n_clone,), -1, dtype=torch.int64, device=dev),
+                              torch.arange(n_child, device=dev)])
+        # final prune on the rows as they stand after clone + split (rodygs_static.py:286-298)
+        opac = torch.sigmoid(fp["opacity"].detach().reshape(-1))[src]
+        scale_now = torch.where(kind == 2, max_s[src] / (0.8 * N), max_s[src])
+        prune = opac < min_opacity
+        if max_screen_size:
+            prune = prune | (scale_now > 0.1 * extent)                                   # max_radii2D was just zeroed
+        keep = ~prune
+        src, kind, child_no = src[keep], kind[keep], child_no[keep]
+        out = rebuild_flat_params(fp, src, kind == 0)
+        # split children: contiguous tail of the new buffers
+        n_child_kept = int((kind == 2).sum())
+        if n_child_kept:
+            if z is None:
+                z = torch.randn(n_child, 3, device=dev)
+            zz = z.to(device=dev, dtype=torch.float32)[child_no[kind == 2]].contiguous()
+            parents = src[kind == 2].contiguous()
+            n_new = int(src.numel())
+            first = n_new - n_child_kept
+            xo, so_ = out["xyz"].detach()[first:], out["scaling"].detach()[first:]
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().rdg_split_children(n_child_kept, N, _lib.ptr(parents), _lib.ptr(fp["xyz"].detach()),
+                                                         _lib.ptr(fp["scaling"].detach()),
+                                                         _lib.ptr(fp["rotation"].detach()), _lib.ptr(zz), _lib.ptr(xo),
+                                                         _lib.ptr(so_), _lib.stream_ptr()), "rdg_split_children")
+        new_pp = {k: v[src] for k, v in per_point.items()}
+        n_new = int(src.numel())
+        return DensifyResult(out, DensifyStats.zeros(n_new, dev), new_pp, n_clone, n_sel,
+                             int(prune.sum()) + n_sel)

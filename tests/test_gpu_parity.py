@@ -624,6 +624,65 @@ def test_pearson_depth_loss_full_hd_against_oracle():
     rel_ok(pred.grad, po.grad, tol=1e-4, what="d_pred 1080p")
 
 
+@pytest.mark.parametrize("max_screen_size", [None, 20])
+def test_densify_and_prune_matches_oracle(max_screen_size):
+    """One-gather-per-buffer densify/prune over the flat buckets vs the tensor-by-tensor restatement of the reference
+    trainer: same rows in the same order, Adam moments carried / zeroed alike, split children placed alike."""
+    from oracle import densify_oracle as DZ
+    from rodygs_amd.densify import DensifyStats, densify_and_prune
+    from rodygs_amd.dp import FlatParams
+    g = torch.Generator().manual_seed(77)
+    P, K, B, N = 5000, 16, 16, 2
+    extent, percent_dense, max_grad, min_opacity = 5.0, 0.01, 0.0002, 0.05
+    spec = {"xyz": ((P, 3), 1e-3), "features": ((P, K, 3), 1e-3), "scaling": ((P, 3), 1e-3), "rotation": ((P, 4), 1e-3),
+            "opacity": ((P, 1), 1e-3), "motion_coeff": ((P, 1, B), 1e-3)}
+    vals = {"xyz": torch.randn(P, 3, generator=g), "features": torch.randn(P, K, 3, generator=g),
+            # half of the Gaussians below the percent_dense * extent = 0.05 size threshold, a few huge ones
+            "scaling": torch.log(torch.rand(P, 3, generator=g) * 0.08 + 0.005 + (torch.rand(P, 1, generator=g) > 0.97) * 1.0),
+            "rotation": torch.randn(P, 4, generator=g), "opacity": torch.randn(P, 1, generator=g) * 2.5,
+            "motion_coeff": torch.randn(P, 1, B, generator=g)}
+    fp = FlatParams(spec, DEV)
+    m1 = {k: torch.randn(v.shape, generator=g) for k, v in vals.items()}
+    m2 = {k: torch.rand(v.shape, generator=g) for k, v in vals.items()}
+    with torch.no_grad():
+        for k in fp.names:
+            o, n = fp.offsets[k]
+            fp[k].copy_(vals[k])
+            fp.exp_avg[o:o + n].copy_(m1[k].reshape(-1))
+            fp.exp_avg_sq[o:o + n].copy_(m2[k].reshape(-1))
+    fp.step_count = 41
+    denom = torch.randint(0, 4, (P, 1), generator=g).float()                       # zeros -> NaN average -> 0
+    accum = torch.rand(P, 1, generator=g) * 0.0006 * denom
+    radii = torch.rand(P, generator=g) * 40
+    t_ind = torch.randint(0, 30, (P,), generator=g)
+    t_val = t_ind.float() / 30
+    z = torch.randn(2 * P, 3, generator=g)
+    stats = DensifyStats(accum.clone().to(DEV), denom.clone().to(DEV), radii.clone().to(DEV))
+    res = densify_and_prune(fp, stats, {"gaussian_to_time": t_val.to(DEV), "gaussian_to_time_ind": t_ind.to(DEV)},
+                            max_grad, min_opacity, extent, max_screen_size, percent_dense, N, z=z.to(DEV))
+    st = DZ.State({k: v.clone() for k, v in vals.items()}, {k: v.clone() for k, v in m1.items()},
+                  {k: v.clone() for k, v in m2.items()}, accum.clone(), denom.clone(), radii.clone(),
+                  {"gaussian_to_time": t_val.clone(), "gaussian_to_time_ind": t_ind.clone()})
+    n_clone, n_sel = DZ.densify_and_prune(st, max_grad, min_opacity, extent, max_screen_size, percent_dense, N, z)
+    assert n_clone > 100 and n_sel > 100 and (res.n_clone, res.n_split) == (n_clone, n_sel)
+    Pn = st.P
+    assert Pn != P and res.fp.shapes["xyz"][0] == Pn and res.fp.step_count == 41
+    for k in fp.names:
+        o, n = res.fp.offsets[k]
+        got = res.fp[k].detach().cpu()
+        if k in ("xyz", "scaling"):
+            rel_ok(got, st.params[k], tol=2e-6, what="densify " + k)
+        else:
+            assert torch.equal(got, st.params[k]), k
+        assert torch.equal(res.fp.exp_avg[o:o + n].cpu().view_as(st.exp_avg[k]), st.exp_avg[k]), k
+        assert torch.equal(res.fp.exp_avg_sq[o:o + n].cpu().view_as(st.exp_avg_sq[k]), st.exp_avg_sq[k]), k
+    assert float(res.fp.flat_grad.abs().sum()) == 0.0
+    for k, v in st.per_point.items():
+        assert torch.equal(res.per_point[k].cpu(), v), k
+    assert torch.equal(res.stats.xyz_gradient_accum.cpu(), st.accum) and torch.equal(res.stats.max_radii2D.cpu(), st.max_radii)
+    assert res.n_pruned == P + n_clone + N * n_sel - Pn
+
+
 def test_fused_adam_matches_torch():
     from rodygs_amd import _lib
     L = _lib.lib()
