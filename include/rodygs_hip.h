@@ -152,11 +152,15 @@ int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, con
 /* d_coeff [P,B]; d_basis_t [B,7] and d_table [Tu,B,7] are zeroed then accumulated by the library.
  * order: optional int32 [P] permutation that sorts the Gaussians by time_ind (it changes only when time_ind
  * does, so the caller caches it).  With it (and B == 16) the two dB reductions run on the matrix cores
- * (v_mfma_f32_16x16x4_f32, one per 4 Gaussians); NULL selects the order-free LDS-atomic form.              */
+ * (v_mfma_f32_16x16x4_f32, one per 4 Gaussians); NULL selects the order-free LDS-atomic form.
+ * inv_order (int32 [P], inv_order[order[i]] = i) + sorted_ws (rdg_deform_sorted_ws_bytes(P), 16-B aligned):
+ * optional; with them the gradient rows are re-laid once in birth-sorted order so that the dB reduction
+ * streams them instead of gathering 12/16/8-byte pieces (either may be NULL).                              */
+size_t rdg_deform_sorted_ws_bytes(int32_t P);
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
                         const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table,
-                        const int32_t* order, void* stream);
+                        const int32_t* order, const int32_t* inv_order, void* sorted_ws, void* stream);
 
 /* ---- time-deformation MLP on the matrix cores (csrc/rdg_mlp.hip) --------------------------------------------
  * MLPBasisNetwork.batch_inference / the basis part of forward (/root/reference/src/model/rodygs_dynamic.py:296-327):

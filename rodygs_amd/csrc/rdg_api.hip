@@ -101,7 +101,8 @@ size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles) { (void)n_tiles; ret
 size_t rdg_image_bytes(int32_t H, int32_t W) { return rdg_image_layout(H, W).total; }
 size_t rdg_grad_bytes(int32_t P) {
     const size_t Pp = (size_t)(P > 0 ? P : 1);
-    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 255) / 256) * 19 * 4, 256);
+    // gradient rows + one pose partial row per per-Gaussian workgroup + 32 second-level pose partial rows
+    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 255) / 256) * 19 * 4, 256) + 4096;
 }
 size_t rdg_sort_tmp_bytes(int64_t capacity) {
     // alternate key/value buffers + tables

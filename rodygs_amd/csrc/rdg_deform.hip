@@ -131,7 +131,8 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
 __global__ void __launch_bounds__(1024)
 rdg_deform_dcoeff16_kernel(int P, int Tu, const long long* __restrict__ time_ind, const float* __restrict__ basis_t,
                            const float* __restrict__ table, float scale, const float* __restrict__ g_xyz,
-                           const float* __restrict__ g_rot, float* __restrict__ d_coeff) {
+                           const float* __restrict__ g_rot, float* __restrict__ d_coeff,
+                           const int* __restrict__ inv_order, float4* __restrict__ gs) {
     extern __shared__ __attribute__((aligned(16))) float smem_dc[];
     const int Tu_eff = table ? Tu : 1;
     for (int k = threadIdx.x; k < Tu_eff * 112; k += blockDim.x) {
@@ -145,6 +146,14 @@ rdg_deform_dcoeff16_kernel(int P, int Tu, const long long* __restrict__ time_ind
         g[0] = g_xyz[3 * p + 0] * scale; g[1] = g_xyz[3 * p + 1] * scale; g[2] = g_xyz[3 * p + 2] * scale;
         const float4 gr = reinterpret_cast<const float4*>(g_rot)[p];
         g[3] = gr.x; g[4] = gr.y; g[5] = gr.z; g[6] = gr.w;
+        if (gs) {
+            // compact copy of (scaled gradient, birth index) at the Gaussian's position in birth-sorted order: the
+            // dB accumulation then streams 32 contiguous bytes per Gaussian instead of gathering 12 + 16 + 8 bytes
+            // out of three 64-B sectors (PMC: that kernel fetched 4.8x its algorithmic bytes)
+            const size_t sidx = (size_t)inv_order[p];
+            gs[2 * sidx] = make_float4(g[0], g[1], g[2], g[3]);
+            gs[2 * sidx + 1] = make_float4(g[4], g[5], g[6], __int_as_float(u));
+        }
         const float4* r4 = reinterpret_cast<const float4*>(smem_dc + u * RDG_DC_STRIDE);
         float sacc[16];
 #pragma unroll
@@ -198,7 +207,8 @@ __global__ void __launch_bounds__(256)
 rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const long long* __restrict__ time_ind,
                                const int* __restrict__ order, const float* __restrict__ g_xyz,
                                const float* __restrict__ g_rot, float scale, int has_table,
-                               float* __restrict__ d_basis_t, float* __restrict__ d_table) {
+                               float* __restrict__ d_basis_t, float* __restrict__ d_table,
+                               const float* __restrict__ gs) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
@@ -220,15 +230,30 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
             v4[q] = idx < end;
             p4[q] = order[min(idx, end - 1)];
         }
+        if (gs) {
+            // sorted compact copy available: (g[0..6], birth index) are 8 contiguous floats at the sorted position
 #pragma unroll
-        for (int q = 0; q < RDG_DEF_G; ++q) {
-            const size_t p = (size_t)p4[q];
-            const long long tu = time_ind[p];
-            const float av = coeff[p * 16 + j];
-            const float gx = g_xyz[p * 3 + jx], gr = g_rot[p * 4 + jr];
-            u4[q] = v4[q] ? (has_table ? (int)tu : 0) : -1;
-            a4[q] = v4[q] ? av : 0.0f;
-            g4[q] = v4[q] ? (gx * wx + gr * wr) : 0.0f;   // arithmetic blend: keeps both loads unconditional
+            for (int q = 0; q < RDG_DEF_G; ++q) {
+                const size_t p = (size_t)p4[q];
+                const size_t sidx = (size_t)min(base + 4 * q + slot, end - 1);
+                const float av = coeff[p * 16 + j];
+                const float gv = gs[sidx * 8 + min(j, 6)];
+                const int tu = __float_as_int(gs[sidx * 8 + 7]);
+                u4[q] = v4[q] ? (has_table ? tu : 0) : -1;
+                a4[q] = v4[q] ? av : 0.0f;
+                g4[q] = (v4[q] && j < RDG_DEF_K) ? gv : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RDG_DEF_G; ++q) {
+                const size_t p = (size_t)p4[q];
+                const long long tu = time_ind[p];
+                const float av = coeff[p * 16 + j];
+                const float gx = g_xyz[p * 3 + jx], gr = g_rot[p * 4 + jr];
+                u4[q] = v4[q] ? (has_table ? (int)tu : 0) : -1;
+                a4[q] = v4[q] ? av : 0.0f;
+                g4[q] = v4[q] ? (gx * wx + gr * wr) : 0.0f;   // arithmetic blend: keeps both loads unconditional
+            }
         }
 #pragma unroll
         for (int q = 0; q < RDG_DEF_G; ++q) {
@@ -355,10 +380,12 @@ int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, con
     return rdg_check_hip(hipGetLastError(), "deform_fwd launch");
 }
 
+size_t rdg_deform_sorted_ws_bytes(int32_t P) { return (size_t)(P > 0 ? P : 1) * 32 + 256; }
+
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
                         const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table, const int32_t* order,
-                        void* stream) {
+                        const int32_t* inv_order, void* sorted_ws, void* stream) {
     if (B <= 0 || B > RDG_DEF_MAXB * 4) return rdg_set_error("deform: bad basis count %d", B);
     hipStream_t st = (hipStream_t)stream;
     const int row = B * RDG_DEF_K;
@@ -378,12 +405,15 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
                            (const long long*)time_ind, basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff,      \
                            d_basis_t, d_table)
         const size_t lds16 = (size_t)Tu_eff * RDG_DC_STRIDE * sizeof(float);
+        bool use_gs = false;
         const bool dc16 = mfma && lds16 <= 64 * 1024 && (((uintptr_t)g_rot | (uintptr_t)d_coeff) & 15) == 0;
         if (dc16) {
             int nb = (P + 1023) / 1024;
             if (nb > 256) nb = 256;
+            use_gs = inv_order != nullptr && sorted_ws != nullptr && (((uintptr_t)sorted_ws) & 15) == 0;
             hipLaunchKernelGGL(rdg_deform_dcoeff16_kernel, dim3(nb), dim3(1024), lds16, st, P, Tu, (const long long*)time_ind,
-                               basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff);
+                               basis_t, table, spatial_scale, g_xyz, g_rot, d_coeff, (const int*)inv_order,
+                               use_gs ? (float4*)sorted_ws : (float4*)nullptr);
         } else if (lds <= 128 * 1024) {
             if (lds > 64 * 1024) {
                 hipError_t ea = mfma ? hipFuncSetAttribute((const void*)rdg_deform_bwd_kernel<true, false>,
@@ -400,7 +430,7 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
             // without a table every wave flushes into the same 112 floats: keep the wave count low there
             hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? 2048 : 64), dim3(256), 0, st, P, coeff,
                                (const long long*)time_ind, (const int*)order, g_xyz, g_rot, spatial_scale,
-                               table ? 1 : 0, d_basis_t, d_table);
+                               table ? 1 : 0, d_basis_t, d_table, use_gs ? (const float*)sorted_ws : (const float*)nullptr);
             if (table)
                 hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3((row + 127) / 128), dim3(128), 0, st, Tu, row, d_table,
                                    d_basis_t);

@@ -328,32 +328,44 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
             (sPose[0][threadIdx.x] + sPose[1][threadIdx.x]) + (sPose[2][threadIdx.x] + sPose[3][threadIdx.x]);
 }
 
-// Fixed-order reduction of the per-workgroup partial rows, then the campos = -R^T t chain, written into
-// dL/dviewmatrix (glm flat).  One 1024-thread block: 32 row-groups x 32 components.
-__global__ void __launch_bounds__(1024)
-rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict__ posebuf, int nblk,
-                         float* __restrict__ dview) {
-    __shared__ float sred[32][33];
-    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;
+// Fixed-order reduction of the per-workgroup partial rows in two small launches (a single workgroup walking all
+// ~4 k rows was a 19 us dependent-load chain): RDG_POSE_L2 workgroups fold every RDG_POSE_L2-th row into one
+// second-level row each, then one wave adds those and applies the campos = -R^T t chain, writing dL/dviewmatrix
+// (glm flat).  Deterministic: the summation order is fixed by the row indices alone.
+#define RDG_POSE_L2 32
+__global__ void __launch_bounds__(256)
+rdg_pose_partial_kernel(const float* __restrict__ posebuf, int nblk, float* __restrict__ part) {
+    __shared__ float sred[8][32];
+    const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 8 row groups x 32 component slots
     float acc = 0.0f;
     if (k < RDG_POSE_N) {
-        // 8 independent loads in flight per thread (a single dependent chain of 122 L2 reads took 40 us)
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int r = grp;
-        for (; r + 7 * 32 < nblk; r += 8 * 32) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const int step = RDG_POSE_L2 * 8;
+        int r = blockIdx.x * 8 + grp;
+        for (; r + 3 * step < nblk; r += 4 * step) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += posebuf[(size_t)(r + 32 * u) * RDG_POSE_N + k];
+            for (int u = 0; u < 4; ++u) a[u] += posebuf[(size_t)(r + step * u) * RDG_POSE_N + k];
         }
-        for (; r < nblk; r += 32) a[0] += posebuf[(size_t)r * RDG_POSE_N + k];
-        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        for (; r < nblk; r += step) a[0] += posebuf[(size_t)r * RDG_POSE_N + k];
+        acc = (a[0] + a[1]) + (a[2] + a[3]);
     }
     sred[grp][k] = acc;
     __syncthreads();
-    // second level: 19 threads each fold their 32 partials (fixed order), thread 0 finishes
+    if (threadIdx.x < RDG_POSE_N) {
+        float t = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sred[g][threadIdx.x];
+        part[blockIdx.x * RDG_POSE_N + threadIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict__ part, int nrows,
+                         float* __restrict__ dview) {
     __shared__ float stot[32];
     if (threadIdx.x < RDG_POSE_N) {
         float t = 0.0f;
-        for (int r = 0; r < 32; ++r) t += sred[r][threadIdx.x];
+        for (int r = 0; r < nrows; ++r) t += part[r * RDG_POSE_N + threadIdx.x];
         stot[threadIdx.x] = t;
     }
     __syncthreads();
@@ -386,6 +398,10 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                            opac, scales, rots, cov3D, radii, (const uint8_t*)((const char*)geom_ws + G.clamped),
                            grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D);
     }
-    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(1024), 0, s, view, posebuf, d.P > 0 ? nblk : 0, dview);
+    // second-level rows live behind the per-workgroup rows (rdg_grad_bytes reserves them)
+    float* part = (float*)((char*)posebuf + rdg_align_up((size_t)(nblk > 0 ? nblk : 1) * RDG_POSE_N * 4, 256));
+    const int rows = d.P > 0 ? nblk : 0;
+    hipLaunchKernelGGL(rdg_pose_partial_kernel, dim3(RDG_POSE_L2), dim3(256), 0, s, posebuf, rows, part);
+    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(64), 0, s, view, part, RDG_POSE_L2, dview);
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd launch");
 }

@@ -230,15 +230,18 @@ class MLPBasisNetwork(nn.Module):
 _ORDER_CACHE = {}
 
 
-def _birth_order(time_ind: torch.Tensor) -> torch.Tensor:
-    """int32 permutation sorting the Gaussians by birth index; cached until time_ind changes (it only does at
-    densification), so the sort is not part of the step."""
+def _birth_order(time_ind: torch.Tensor):
+    """(order, inverse): int32 permutation sorting the Gaussians by birth index and its inverse; cached until
+    time_ind changes (it only does at densification), so the sort is not part of the step."""
     key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device))
     o = _ORDER_CACHE.get(key)
     if o is None:
         if len(_ORDER_CACHE) > 8:
             _ORDER_CACHE.clear()
-        o = torch.argsort(time_ind, stable=True).to(torch.int32).contiguous()
+        order = torch.argsort(time_ind, stable=True)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous())
         _ORDER_CACHE[key] = o
     return o
 
@@ -304,11 +307,15 @@ class _DeformFn(torch.autograd.Function):
             d_bt = torch.empty_like(bt)
             d_tb = None if tb is None else torch.empty_like(tb)
         with torch.cuda.device(dev):
+            if tb is not None:
+                order, inv = _birth_order(ti)
+                sws = torch.empty(L.rdg_deform_sorted_ws_bytes(P), dtype=torch.uint8, device=dev)
+            else:
+                order, inv, sws = _identity_order(P, dev), None, None
             _lib.check(L.rdg_deform_backward(P, B, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bt), _lib.ptr(tb),
                                              ctx.scale, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(d_c),
-                                             _lib.ptr(d_bt), _lib.ptr(d_tb), _lib.ptr(_birth_order(ti) if tb is not None
-                                                                                      else _identity_order(P, dev)),
-                                             _lib.stream_ptr()),
+                                             _lib.ptr(d_bt), _lib.ptr(d_tb), _lib.ptr(order), _lib.ptr(inv),
+                                             _lib.ptr(sws), _lib.stream_ptr()),
                        "rdg_deform_backward")
         if sink_c is not None:
             d_c = None
