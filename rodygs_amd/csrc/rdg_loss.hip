@@ -5,8 +5,9 @@
 //
 // The reference runs five 121-tap depth-wise convolutions forward and their transposes backward through the
 // framework's conv library (3.6 ms per step at 1080p on MI355X, more than the whole rasterizer).  Here:
-//   forward : one pass per 16x16 tile -- the 26x26 halo tile of x and y goes to LDS once, the five windowed
-//             moments are produced separably (11 + 11 taps) from LDS, and the kernel stores, per pixel, the three
+//   forward : one pass per 32x32 tile -- the 42x42 halo tile of x and y goes to LDS once, the five windowed
+//             moments are produced separably (11 + 11 taps, register-blocked 4 outputs per work item so that an
+//             output costs ~27 LDS reads instead of ~90) from LDS, and the kernel stores, per pixel, the three
 //             partial derivatives dm/dmu1, dm/dE[x^2], dm/dE[xy] of the SSIM map; |x-y| and the map are block-
 //             reduced into two floats.
 //   backward: dL/dx(p) = g * (conv(dm/dmu1) + 2 x(p) conv(dm/dE11) + y(p) conv(dm/dE12))(p) + L1 term, i.e. the
@@ -15,9 +16,11 @@
 #include "rdg_common.h"
 #include <math.h>
 
-#define LT 16
+#define LTX 32                 // output tile: 32 x 32 pixels per 256-thread workgroup
+#define LTY 32
 #define LH 5
-#define LW (LT + 2 * LH)  // 26
+#define LWX (LTX + 2 * LH)    // 42: tile + halo
+#define LWY (LTY + 2 * LH)
 
 struct RdgWin { float w[11]; };
 
@@ -30,7 +33,7 @@ __device__ __forceinline__ bool rdg_loss_tile(int gx, int gy, int C, int& ox, in
     if ((int)(blockIdx.x >> 3) >= per || t >= n) return false;
     c = t / (gx * gy);
     const int r = t - c * gx * gy;
-    oy = (r / gx) * LT; ox = (r - (r / gx) * gx) * LT;
+    oy = (r / gx) * LTY; ox = (r - (r / gx) * gx) * LTX;
     bid = (size_t)t;
     return true;
 }
@@ -46,65 +49,92 @@ static RdgWin rdg_make_window() {
     return W;
 }
 
+// Register blocking: a work item of the horizontal pass produces RB adjacent outputs of a row from RB + 10 LDS
+// reads per input (instead of 11 each), a thread of the vertical pass RB vertically adjacent pixels from RB + 10 rows.
+#define RB 4
+
 __global__ void __launch_bounds__(256)
 rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
                     float* __restrict__ maps, float* __restrict__ sums) {
-    __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
-    __shared__ float sh[5][LW][LT];
+    __shared__ float sx[LWY][LWX + 1], sy[LWY][LWX + 1];
+    __shared__ float sh[5][LWY][LTX];
     __shared__ float sred[2][4];
     const int tid = threadIdx.x;
     int ox, oy, c; size_t bid;
-    if (!rdg_loss_tile((Wd + LT - 1) / LT, (H + LT - 1) / LT, C, ox, oy, c, bid)) return;
+    if (!rdg_loss_tile((Wd + LTX - 1) / LTX, (H + LTY - 1) / LTY, C, ox, oy, c, bid)) return;
     const size_t hw = (size_t)H * Wd;
     const float* X = img + c * hw;
     const float* Y = gt + c * hw;
-    for (int idx = tid; idx < LW * LW; idx += 256) {
-        const int r = idx / LW, cc = idx - r * LW;
+    for (int idx = tid; idx < LWY * LWX; idx += 256) {
+        const int r = idx / LWX, cc = idx - r * LWX;
         const int gy = oy + r - LH, gx = ox + cc - LH;
         float xv = 0.f, yv = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < Wd) { xv = X[(size_t)gy * Wd + gx]; yv = Y[(size_t)gy * Wd + gx]; }
         sx[r][cc] = xv; sy[r][cc] = yv;
     }
     __syncthreads();
-    for (int idx = tid; idx < LW * LT; idx += 256) {
-        const int r = idx / LT, cc = idx - r * LT;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+    // horizontal pass: LWY rows x (LTX / RB) groups of RB outputs
+    for (int item = tid; item < LWY * (LTX / RB); item += 256) {
+        const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+        float xs[RB + 10], ys[RB + 10];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k], xv = sx[r][cc + k], yv = sy[r][cc + k];
-            const float wx = w * xv, wy = w * yv;
-            h0 += wx; h1 += wy; h2 += wx * xv; h3 += wy * yv; h4 += wx * yv;
+        for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float w = win.w[k], xv = xs[o + k], yv = ys[o + k];
+                const float wx = w * xv, wy = w * yv;
+                h0 += wx; h1 += wy; h2 += wx * xv; h3 += wy * yv; h4 += wx * yv;
+            }
+            sh[0][r][c0 + o] = h0; sh[1][r][c0 + o] = h1; sh[2][r][c0 + o] = h2; sh[3][r][c0 + o] = h3;
+            sh[4][r][c0 + o] = h4;
         }
-        sh[0][r][cc] = h0; sh[1][r][cc] = h1; sh[2][r][cc] = h2; sh[3][r][cc] = h3; sh[4][r][cc] = h4;
     }
     __syncthreads();
-    const int ty = tid / LT, tx = tid - ty * LT;
-    const int py = oy + ty, px = ox + tx;
+    // vertical pass: thread = column tx, RB rows starting at ty0
+    const int tx = tid % LTX, ty0 = (tid / LTX) * RB;
+    const int px = ox + tx;
     float l1 = 0.f, ms = 0.f;
-    if (py < H && px < Wd) {
-        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    float mu1[RB], mu2[RB], e11[RB], e22[RB], e12[RB];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            mu1 += w * sh[0][ty + k][tx]; mu2 += w * sh[1][ty + k][tx]; e11 += w * sh[2][ty + k][tx];
-            e22 += w * sh[3][ty + k][tx]; e12 += w * sh[4][ty + k][tx];
+    for (int o = 0; o < RB; ++o) { mu1[o] = 0.f; mu2[o] = 0.f; e11[o] = 0.f; e22[o] = 0.f; e12[o] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < RB + 10; ++rr) {
+        const float a0 = sh[0][ty0 + rr][tx], a1 = sh[1][ty0 + rr][tx], a2 = sh[2][ty0 + rr][tx],
+                    a3 = sh[3][ty0 + rr][tx], a4 = sh[4][ty0 + rr][tx];
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            const int k = rr - o;
+            if (k >= 0 && k < 11) {
+                const float w = win.w[k];
+                mu1[o] += w * a0; mu2[o] += w * a1; e11[o] += w * a2; e22[o] += w * a3; e12[o] += w * a4;
+            }
         }
-        const float C1 = 0.0001f, C2 = 0.0009f;
-        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
-        const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
-        const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
-        const float m = A1 * A2 * iB1 * iB2;
-        const float dmu1 = 2.f * mu2 * (A2 - A1) * iB1 * iB2 - 2.f * mu1 * m * (iB1 - iB2);
-        const float de11 = -m * iB2;
-        const float de12 = 2.f * A1 * iB1 * iB2;
-        const size_t p = (size_t)py * Wd + px;
-        const size_t stride = (size_t)C * hw;  // maps layout: [3 maps][C][H][W]
-        maps[c * hw + p] = dmu1;
-        maps[stride + c * hw + p] = de11;
-        maps[2 * stride + c * hw + p] = de12;
-        ms = m;
-        l1 = fabsf(sx[ty + LH][tx + LH] - sy[ty + LH][tx + LH]);
+    }
+    const size_t stride = (size_t)C * hw;  // maps layout: [3 maps][C][H][W]
+#pragma unroll
+    for (int o = 0; o < RB; ++o) {
+        const int py = oy + ty0 + o;
+        if (py < H && px < Wd) {
+            const float C1 = 0.0001f, C2 = 0.0009f;
+            const float m1 = mu1[o], m2 = mu2[o];
+            const float mu1s = m1 * m1, mu2s = m2 * m2, mu12 = m1 * m2;
+            const float s1 = e11[o] - mu1s, s2 = e22[o] - mu2s, s12 = e12[o] - mu12;
+            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
+            const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
+            const float m = A1 * A2 * iB1 * iB2;
+            const float dmu1 = 2.f * m2 * (A2 - A1) * iB1 * iB2 - 2.f * m1 * m * (iB1 - iB2);
+            const float de11 = -m * iB2;
+            const float de12 = 2.f * A1 * iB1 * iB2;
+            const size_t p = (size_t)py * Wd + px;
+            maps[c * hw + p] = dmu1;
+            maps[stride + c * hw + p] = de11;
+            maps[2 * stride + c * hw + p] = de12;
+            ms += m;
+            l1 += fabsf(sx[ty0 + o + LH][tx + LH] - sy[ty0 + o + LH][tx + LH]);
+        }
     }
     l1 = rdg_wave_sum_to63(l1);
     ms = rdg_wave_sum_to63(ms);
@@ -140,15 +170,15 @@ __global__ void __launch_bounds__(256)
 rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
                     const float* __restrict__ maps, const float* __restrict__ grad_loss, float inv_n, float lambda,
                     float* __restrict__ d_img) {
-    __shared__ float sa[3][LW][LW + 1];
-    __shared__ float sh[3][LW][LT];
+    __shared__ float sa[3][LWY][LWX + 1];
+    __shared__ float sh[3][LWY][LTX];
     const int tid = threadIdx.x;
     int ox, oy, c; size_t bid;
-    if (!rdg_loss_tile((Wd + LT - 1) / LT, (H + LT - 1) / LT, C, ox, oy, c, bid)) return;
+    if (!rdg_loss_tile((Wd + LTX - 1) / LTX, (H + LTY - 1) / LTY, C, ox, oy, c, bid)) return;
     const size_t hw = (size_t)H * Wd;
     const size_t stride = (size_t)C * hw;
-    for (int idx = tid; idx < LW * LW; idx += 256) {
-        const int r = idx / LW, cc = idx - r * LW;
+    for (int idx = tid; idx < LWY * LWX; idx += 256) {
+        const int r = idx / LWX, cc = idx - r * LWX;
         const int gy = oy + r - LH, gx = ox + cc - LH;
         float a = 0.f, b = 0.f, d = 0.f;
         if (gy >= 0 && gy < H && gx >= 0 && gx < Wd) {
@@ -158,41 +188,57 @@ rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
         sa[0][r][cc] = a; sa[1][r][cc] = b; sa[2][r][cc] = d;
     }
     __syncthreads();
-    for (int idx = tid; idx < LW * LT; idx += 256) {
-        const int r = idx / LT, cc = idx - r * LT;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+    for (int item = tid; item < LWY * (LTX / RB); item += 256) {
+        const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+        float v0[RB + 10], v1[RB + 10], v2[RB + 10];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            h0 += w * sa[0][r][cc + k]; h1 += w * sa[1][r][cc + k]; h2 += w * sa[2][r][cc + k];
+        for (int k = 0; k < RB + 10; ++k) { v0[k] = sa[0][r][c0 + k]; v1[k] = sa[1][r][c0 + k]; v2[k] = sa[2][r][c0 + k]; }
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float w = win.w[k];
+                h0 += w * v0[o + k]; h1 += w * v1[o + k]; h2 += w * v2[o + k];
+            }
+            sh[0][r][c0 + o] = h0; sh[1][r][c0 + o] = h1; sh[2][r][c0 + o] = h2;
         }
-        sh[0][r][cc] = h0; sh[1][r][cc] = h1; sh[2][r][cc] = h2;
     }
     __syncthreads();
-    const int ty = tid / LT, tx = tid - ty * LT;
-    const int py = oy + ty, px = ox + tx;
-    if (py < H && px < Wd) {
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    const int tx = tid % LTX, ty0 = (tid / LTX) * RB;
+    const int px = ox + tx;
+    float u0[RB], u1[RB], u2[RB];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float w = win.w[k];
-            v0 += w * sh[0][ty + k][tx]; v1 += w * sh[1][ty + k][tx]; v2 += w * sh[2][ty + k][tx];
+    for (int o = 0; o < RB; ++o) { u0[o] = 0.f; u1[o] = 0.f; u2[o] = 0.f; }
+#pragma unroll
+    for (int rr = 0; rr < RB + 10; ++rr) {
+        const float a0 = sh[0][ty0 + rr][tx], a1 = sh[1][ty0 + rr][tx], a2 = sh[2][ty0 + rr][tx];
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            const int k = rr - o;
+            if (k >= 0 && k < 11) { const float w = win.w[k]; u0[o] += w * a0; u1[o] += w * a1; u2[o] += w * a2; }
         }
-        const size_t p = c * hw + (size_t)py * Wd + px;
-        const float x = img[p], y = gt[p];
-        const float go = grad_loss ? grad_loss[0] : 1.0f;
-        const float gs = -lambda * inv_n * go;           // d loss / d ssim_map(q)
-        const float gl = (1.0f - lambda) * inv_n * go;   // d loss / d |x - y|
-        const float d = x - y;
-        const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
-        d_img[p] = gs * (v0 + 2.0f * x * v1 + y * v2) + gl * sgn;
+    }
+    const float go = grad_loss ? grad_loss[0] : 1.0f;
+    const float gs = -lambda * inv_n * go;           // d loss / d ssim_map(q)
+    const float gl = (1.0f - lambda) * inv_n * go;   // d loss / d |x - y|
+#pragma unroll
+    for (int o = 0; o < RB; ++o) {
+        const int py = oy + ty0 + o;
+        if (py < H && px < Wd) {
+            const size_t p = c * hw + (size_t)py * Wd + px;
+            const float x = img[p], y = gt[p];
+            const float d = x - y;
+            const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
+            d_img[p] = gs * (u0[o] + 2.0f * x * u1[o] + y * u2[o]) + gl * sgn;
+        }
     }
 }
 
 extern "C" {
 
 size_t rdg_loss_ws_bytes(int32_t C, int32_t H, int32_t W) {
-    const size_t nblk = (size_t)((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C;
+    const size_t nblk = (size_t)((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * C;
     return (size_t)3 * C * H * W * 4 + nblk * 8 + 256;
 }
 
@@ -204,7 +250,7 @@ int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* i
     float* sums = (float*)((char*)ws + (size_t)3 * C * H * W * 4);
     rdg_stage_begin(RDG_STAGE_LOSS_FWD, st);
     const RdgWin win = rdg_make_window();
-    const int n_tiles = ((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C;
+    const int n_tiles = ((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * C;
     hipLaunchKernelGGL(rdg_loss_fwd_kernel, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, st, H, W, C, win, img, gt, maps,
                        sums);
     hipLaunchKernelGGL(rdg_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, n_tiles,
@@ -218,7 +264,7 @@ int rdg_photometric_loss_backward(int32_t C, int32_t H, int32_t W, const float* 
     if (C <= 0 || H <= 0 || W <= 0) return rdg_set_error("loss: bad image size");
     hipStream_t st = (hipStream_t)stream;
     const RdgWin win = rdg_make_window();
-    const int n_tiles = ((W + LT - 1) / LT) * ((H + LT - 1) / LT) * C;
+    const int n_tiles = ((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * C;
     rdg_stage_begin(RDG_STAGE_LOSS_BWD, st);
     hipLaunchKernelGGL(rdg_loss_bwd_kernel, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, st, H, W, C, win, img, gt,
                        (const float*)ws, grad_loss,
