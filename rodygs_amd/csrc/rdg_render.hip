@@ -33,27 +33,42 @@ __device__ __forceinline__ int rdg_tile_of_block(int bid, int n_tiles) {
 }
 
 // 4-bit mask: bit q set = the splat may reach quadrant q (q = qy*2+qx) of the tile whose top-left pixel is
-// (X0, Y0).  Region where alpha >= 1/255 and power <= 0 is { d : 0.5 d^T M d <= tau }, tau = ln(255 o);
-// its axis-aligned half extents are sqrt(2 tau c/det), sqrt(2 tau a/det).  Anything unusual (indefinite conic,
-// NaN) keeps the splat for every quadrant.
+// (X0, Y0).  A pixel blends the splat only where alpha >= 1/255 and power <= 0, i.e. where the quadratic form
+// Q(d) = a dx^2 + 2 b dx dy + c dy^2 <= r2 = 2 ln(255 o).  The test is EXACT for the quadrant's rectangle of pixel
+// centres (not the axis-aligned box of the ellipse, which lets diagonal splats through): the minimum of the convex Q
+// over a box is 0 if the centre is inside, otherwise it sits on one of the four edges, where it is a clamped 1-D
+// parabola.  r2 carries a margin (0.02 in the log + 1e-3 relative) that dwarfs the rounding of this evaluation, so no
+// blending pixel is ever skipped; the result is identical to visiting every splat.  Anything unusual (indefinite
+// conic, NaN) keeps the splat for every quadrant.
+__device__ __forceinline__ float rdg_edge_min(float a, float b2, float c, float inv_c, float ue, float v0, float v1) {
+    // min over v in [v0, v1] of a ue^2 + 2 b ue v + c v^2   (b2 = 2 b)
+    const float t = b2 * ue;
+    const float vs = __builtin_amdgcn_fmed3f(-0.5f * t * inv_c, v0, v1);
+    return fmaf(fmaf(c, vs, t), vs, a * ue * ue);
+}
 __device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const float4 q1, float X0, float Y0) {
     const float a = q0.z, b = q0.w, c = q1.x, o = q1.y;
     const float t255 = 255.0f * o;
     if (t255 < 0.99f) return 0u;  // alpha can never reach 1/255 (margin below)
     const float det = a * c - b * b;
     if (!(det > 0.0f) || !(a > 0.0f) || !(c > 0.0f)) return 0xFu;
-    const float r2 = 2.0f * (__logf(t255) + 0.02f);
-    const float idet = 1.0f / det;
-    const float ex = sqrtf(r2 * c * idet) * 1.001f + 0.05f;
-    const float ey = sqrtf(r2 * a * idet) * 1.001f + 0.05f;
-    const float xl = q0.x - ex, xh = q0.x + ex, yl = q0.y - ey, yh = q0.y + ey;
-    // pixel-centre ranges of the quadrants: [X0, X0+7], [X0+8, X0+15]
-    const bool x0 = !(xh < X0) && !(xl > X0 + 7.0f);
-    const bool x1 = !(xh < X0 + 8.0f) && !(xl > X0 + 15.0f);
-    const bool y0 = !(yh < Y0) && !(yl > Y0 + 7.0f);
-    const bool y1 = !(yh < Y0 + 8.0f) && !(yl > Y0 + 15.0f);
-    return (uint32_t)(x0 && y0) | ((uint32_t)(x1 && y0) << 1) | ((uint32_t)(x0 && y1) << 2) |
-           ((uint32_t)(x1 && y1) << 3);
+    const float r2 = 2.0f * (__logf(t255) + 0.02f) * 1.001f;
+    const float inv_a = 1.0f / a, inv_c = 1.0f / c, b2 = 2.0f * b;
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy) {
+        const float v1 = q0.y - (Y0 + 8.0f * qy), v0 = v1 - 7.0f;       // v = py - y over the quadrant's pixel rows
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx) {
+            const float u1 = q0.x - (X0 + 8.0f * qx), u0 = u1 - 7.0f;
+            const bool inside = u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f;
+            const float m = fminf(fminf(rdg_edge_min(a, b2, c, inv_c, u0, v0, v1), rdg_edge_min(a, b2, c, inv_c, u1, v0, v1)),
+                                  fminf(rdg_edge_min(c, b2, a, inv_a, v0, u0, u1), rdg_edge_min(c, b2, a, inv_a, v1, u0, u1)));
+            // written so that a NaN keeps the quadrant
+            bits |= (uint32_t)(inside || !(m > r2)) << (qy * 2 + qx);
+        }
+    }
+    return bits;
 }
 
 // Staged form of a splat's conic: (A2, B, C2) = -log2(e) * (a, b, c), so that
