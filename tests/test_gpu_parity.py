@@ -189,6 +189,16 @@ def test_sh3_nonidentity_pose_background_ragged_image():
     check_pair(run_pair(sc, 3, (0.1, 0.2, 0.3)), NAMES)
 
 
+@pytest.mark.parametrize("deg_max,deg,P", [(0, 0, 700), (1, 1, 2111), (2, 2, 3000), (2, 1, 513), (3, 3, 64)])
+def test_sh_storage_widths(deg_max, deg, P):
+    """shs stored as [P,1,3] / [P,4,3] / [P,9,3] (the wave-level LDS staging of the SH rows takes its scalar path for
+    rows of 3 and 27 floats, its float4 path for 12 and 48), active degree <= stored degree, P not a multiple of 64."""
+    sc = O.synthetic_scene(P, 200, 136, deg_max, seed=40 + deg_max)
+    assert sc["shs"].shape[1] == (deg_max + 1) ** 2
+    sc["viewmatrix"] = orbit_view(5.0, 3.0, (0.2, 0.1, 0.4))
+    check_pair(run_pair(sc, deg, (0.05, 0.0, 0.1)), NAMES)
+
+
 @pytest.mark.parametrize("cov_grad,sh_grad", [(False, False), (True, False), (False, True)])
 def test_pose_gradient_gates(cov_grad, sh_grad):
     sc = O.synthetic_scene(3000, 200, 152, 3, seed=6)
