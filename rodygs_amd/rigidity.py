@@ -36,7 +36,7 @@ def charbonnier_bc(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-6) -> torch
 class RigidityLoss(nn.Module):
     def __init__(self, scale: float = 2, K: int = 8, sim_metric: str = "l2", dist_weight_lambda: float = 0.1,
                  color_sim: bool = True, dist_preserving_ratio=4, mode: Sequence[str] = ("coeff",),
-                 knn_points=None, knn_gather=None):
+                 knn_points=None, knn_gather=None, device_sampling: bool = False):
         super().__init__()
         for m in mode:
             if m not in _MODES:
@@ -50,6 +50,10 @@ class RigidityLoss(nn.Module):
         # the two native ops; replaceable so the CPU suite can run this module against the brute-force oracle
         self._knn_points = knn_points or _knn.knn_points
         self._knn_gather = knn_gather or _knn.knn_gather
+        # False (default): the reference's own draw, random.sample on the host -- seed-for-seed reproducible against
+        # it, but 0.3 s of Python per call at 1 M Gaussians.  True: the same uniform draw without replacement from
+        # torch.randperm on the device.
+        self.device_sampling = device_sampling
 
     def _neighbours(self, rows: torch.Tensor, nn_idx: torch.Tensor) -> torch.Tensor:
         """rows [n, ...] -> [n, K, ...]: the rows of every query's K neighbours."""
@@ -62,7 +66,10 @@ class RigidityLoss(nn.Module):
         moved = canon + pred_translation
         frac = 1 / self.scale if self.scale > 1 else self.scale
         n_all = len(moved)
-        pick = torch.tensor(random.sample(range(n_all), int(n_all * frac)))          # losses.py:225-229
+        if self.device_sampling:
+            pick = torch.randperm(n_all, device=moved.device)[:int(n_all * frac)]
+        else:
+            pick = torch.tensor(random.sample(range(n_all), int(n_all * frac)))      # losses.py:225-229
         pts, coeffs, colors = moved[pick], coeff_all[pick], model._features_dc[pick]
         n = pts.shape[0]
         res = self._knn_points(pts[None], pts[None], K=self.K)                        # losses.py:235
@@ -93,7 +100,11 @@ class RigidityLoss(nn.Module):
             t_idx = torch.randint(0, len(times) - 1, (len(times) // self.dist_preserving_ratio,))
             nt = len(t_idx)
             basis_xyz = model.get_motion_for_times(timesteps=None, time_indices=t_idx)[..., :3]   # [t,B,3]
-            own = (coeffs[:, None] @ basis_xyz).squeeze()                             # [n,t,3] translation at each t
+            # translation of every sampled Gaussian at each drawn time, [n,t,3].  The reference writes this as a
+            # broadcast matmul ([n,1,1,B] @ [t,B,3], losses.py:305-306), which the BLAS sees as n*t batched 1xB
+            # products (50 M batches at config-5 size: it faulted there); one [n,B] x [B,3t] product is the same sum
+            bmat = basis_xyz.permute(1, 0, 2).reshape(basis_xyz.shape[1], nt * 3)
+            own = (coeffs.reshape(n, -1) @ bmat).reshape(n, nt, 3)
             nb = self._knn_gather(own[None].reshape(1, n, -1), nn_idx).reshape(1, n, self.K, own.shape[1], 3)
             nb = nb.squeeze().permute(2, 0, 1, 3)                                     # [t,n,K,3]
             canon_s = canon[pick]

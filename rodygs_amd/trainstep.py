@@ -113,7 +113,7 @@ class DynamicScene:
     SURVEY.md §8d (seeded), replicated on every rank."""
 
     def __init__(self, scene: dict, num_frames: int = 100, sh_degree: int = 3, device="cuda", seed: int = 777,
-                 spatial_lr_scale: float = 5.0, orbit_deg: float = 15.0):
+                 spatial_lr_scale: float = 5.0, orbit_deg: float = 15.0, full_losses: bool = False):
         g = torch.Generator().manual_seed(seed + 1)
         dev = torch.device(device)
         self.device = dev
@@ -182,6 +182,21 @@ class DynamicScene:
         self.m2 = torch.zeros(P, 3, device=dev, requires_grad=True)        # means2D: values unused, gradient sink
         self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
         self.gt = {}
+        self.gt_depth = {}
+        # full_losses: the whole loss set of the reference's dynamic sub-step (config 5,
+        # configs/train/train_kubric_mrig.yaml:186-232): photometric + motion L1 / sparsity / basis regularisers +
+        # global and local Pearson depth + rigidity every 5th step.  Several losses then feed the same parameters, so
+        # only the SH features keep an overwriting gradient sink; the other segments are zeroed and accumulated.
+        self.full_losses = full_losses
+        if full_losses:
+            from .depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
+            from .motion_losses import MotionBasisRegularizaiton, MotionL1Loss, MotionSparsityLoss
+            from .rigidity import RigidityLoss
+            self.loss_terms = {"motion_l1": (0.01, MotionL1Loss()), "motion_sparsity": (0.002, MotionSparsityLoss()),
+                               "motion_basis_reg": (0.1, MotionBasisRegularizaiton(transl_degree=0))}
+            self.depth_terms = [(0.05, GlobalPearsonDepthLoss("all")), (0.15, LocalPearsonDepthLoss(128, 0.5, "all"))]
+            self.rigidity = (0.5, 5, RigidityLoss(mode=["distance_preserving", "surface"], K=8,
+                                                  device_sampling=True))
 
     # ---- pieces of the step ------------------------------------------------------------------------------------
     def settings(self) -> GaussianRasterizationSettings:
@@ -193,13 +208,15 @@ class DynamicScene:
         fp, net = self.fp, self.net
         # ONE pass of the MLP over the T birth-time rows + the frame's own time (row T)
         allb = net.motion_basis(self.emb_rows[frame])                     # [T+1,16,7]: table rows, then B(t)
+        coeff_sink = None if self.full_losses else {"coeff": fp["motion_coeff"].grad}
         dxyz, drot = gaussian_deformation_packed(fp["motion_coeff"], self.time_ind, allb, self.spatial_lr_scale,
-                                                 grad_sinks={"coeff": fp["motion_coeff"].grad})
+                                                 grad_sinks=coeff_sink)
         # activations + deformation add + feature concat: 2 HIP launches; the parameter gradients are written by
         # the backward kernel straight into the flat gradient bucket (no AccumulateGrad copies)
-        sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
+        sinks = None if self.full_losses else {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
         xyz, scaling, rot, opacity, _ = activate_gaussians(fp["xyz"], dxyz, fp["scaling"], fp["rotation"], drot,
                                                            fp["opacity"], None, None, grad_sinks=sinks)
+        self._last = (dxyz, allb)
         return xyz, opacity, scaling, rot, fp["features"]
 
     def render(self, frame: int):
@@ -227,13 +244,50 @@ class DynamicScene:
                     opacities=target_scene["opacities"].to(dev), scales=target_scene["scales"].to(dev),
                     rotations=target_scene["rotations"].to(dev), viewmatrix=vm)
                 self.gt[int(f)] = out[0].clamp(0, 1).clone()
+                self.gt_depth[int(f)] = out[1].clone()
+
+    def _full_loss(self, step: int, frame: int) -> torch.Tensor:
+        fp = self.fp
+        o0 = fp.offsets["features"][0]
+        o1, n1 = fp.offsets["features"]
+        fp.flat_grad[:o0].zero_()                                   # accumulated segments (features keep their sink)
+        fp.flat_grad[o1 + n1:].zero_()
+        out, _ = self.render(frame)
+        dxyz, allb = self._last
+        scene = self
+
+        class _Model:                                               # what the reference's loss modules read
+            _xyz, _motion_coeff = fp["xyz"], fp["motion_coeff"]
+            _features_dc = fp["features"].detach()[:, :1]
+            unique_times = list(range(scene.T))
+
+            @staticmethod
+            def get_total_motion_table():
+                return allb[:-1]
+
+            @staticmethod
+            def get_motion_for_times(timesteps, time_indices=None):
+                return allb[:-1][time_indices.to(allb.device)]
+
+        loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
+        for w, mod in self.loss_terms.values():
+            loss = loss + w * mod(_Model)
+        for w, mod in self.depth_terms:
+            loss = loss + w * mod(out[1], self.gt_depth[frame])
+        w, freq, mod = self.rigidity
+        if step % freq == 0:
+            loss = loss + w * mod(_Model, dxyz)
+        return loss
 
     def train_step(self, step: int, rank: int = 0, world: int = 1, perm=None) -> torch.Tensor:
         perm = perm if perm is not None else list(self.gt.keys())
         frame = frame_for(step, rank, world, perm)
-        # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
-        out, _ = self.render(frame)
-        loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
+        if self.full_losses:
+            loss = self._full_loss(step, frame)
+        else:
+            # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
+            out, _ = self.render(frame)
+            loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
         if world > 1:
             # overlapped exchange: pieces arrive in issue order; Adam steps each piece while the next one is in flight

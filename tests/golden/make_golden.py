@@ -20,6 +20,8 @@ What is pinned: the pieces of the hot path that exist as import
                    LocalPearsonDepthLoss (src/trainer/losses.py:108-182; its device="cuda" randint is redirected to
                    the CPU generator for the call and the drawn corners are stored), value and d/dpred
                    (``... make_golden.py depth``)
+  G9 motion reg  : MotionL1Loss, MotionSparsityLoss, MotionBasisRegularizaiton (src/trainer/losses.py:363-525; the
+                   constructor's ``.cuda()`` is neutralised for the call), value and gradients (``... motion``)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -151,6 +153,7 @@ def main():
                         l1=l1_loss(a, b).numpy(), ssim=ssim(a, b).numpy())
     rigidity_golden()
     depth_loss_golden()
+    motion_reg_golden()
     print("golden vectors written to", OUT)
 
 
@@ -232,12 +235,44 @@ def depth_loss_golden():
     np.savez_compressed(os.path.join(OUT, "depth_loss_golden.npz"), **out)
 
 
+def motion_reg_golden():
+    from src.trainer import losses as RL
+    g = torch.Generator().manual_seed(909)
+    P, Tu, B = 257, 9, 16
+    coeff = (0.3 * torch.randn(P, 1, B, generator=g)).requires_grad_(True)
+    table = (0.4 * torch.randn(Tu, B, 7, generator=g)).requires_grad_(True)
+
+    class M:
+        _motion_coeff = coeff
+
+        @staticmethod
+        def get_total_motion_table():
+            return table
+
+    out = dict(coeff=coeff.detach().numpy(), table=table.detach().numpy())
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        cases = {"l1": RL.MotionL1Loss(), "sparsity": RL.MotionSparsityLoss(),
+                 "basis_d0": RL.MotionBasisRegularizaiton(transl_degree=0),
+                 "basis_d1_gauss": RL.MotionBasisRegularizaiton(transl_degree=1, rot_degree=1, freq_div_mode="gaussian")}
+        for name, mod in cases.items():
+            v = mod(M)
+            gc, gt = torch.autograd.grad(v, [coeff, table], allow_unused=True)
+            out[name + ".loss"] = v.detach().numpy()
+            out[name + ".d_coeff"] = (torch.zeros(1) if gc is None else gc).numpy()
+            out[name + ".d_table"] = (torch.zeros(1) if gt is None else gt).numpy()
+    finally:
+        torch.Tensor.cuda = real_cuda
+    np.savez_compressed(os.path.join(OUT, "motion_reg_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion"):
         sys.dont_write_bytecode = True
         _stub_modules()
         sys.path.insert(0, REF)
-        (rigidity_golden if sys.argv[1] == "rigidity" else depth_loss_golden)()
+        {"rigidity": rigidity_golden, "depth": depth_loss_golden, "motion": motion_reg_golden}[sys.argv[1]]()
         print(sys.argv[1], "golden written to", OUT)
     else:
         main()

@@ -746,6 +746,22 @@ def test_train_step_runs_and_reduces_loss():
     assert float(ds.cam_q.grad.abs().sum()) > 0 and ds.net.head_w1.grad is not None
 
 
+def test_full_loss_train_step_runs_and_reduces_loss():
+    """Config-5 loss set in the loop: photometric + Pearson depth (global + local) + motion regularisers + rigidity on
+    the HIP K-NN every 5th step; gradients of several losses accumulate into the same flat segments."""
+    from rodygs_amd.trainstep import DynamicScene
+    sc = O.synthetic_scene(20000, 320, 256, 3, seed=5)
+    tgt = O.synthetic_scene(5000, 320, 256, 3, seed=6)
+    ds = DynamicScene(sc, num_frames=8, device=DEV, full_losses=True)
+    ds.make_ground_truth(tgt, range(8))
+    losses = [float(ds.train_step(s_, perm=list(range(8)))) for s_ in range(30)]
+    assert all(np.isfinite(losses))
+    rig = [l for i, l in enumerate(losses) if i % 5 == 0]
+    plain = [l for i, l in enumerate(losses) if i % 5 != 0]
+    assert np.mean(plain[-8:]) < np.mean(plain[:8]) and rig[-1] < rig[0]
+    assert float(ds.fp["motion_coeff"].grad.abs().sum()) > 0 and float(ds.sp["cam_t"].grad.abs().sum()) > 0
+
+
 def test_overlapped_exchange_path_equals_single_launch_path():
     """The frame-DP branch of the train step (bucketed asynchronous all-reduce over RCCL + Adam applied piece by piece)
     on a 1-rank process group must reproduce the single-launch optimiser step bit for bit from the same gradients:

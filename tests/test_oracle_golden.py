@@ -196,3 +196,33 @@ def test_depth_loss_oracle_matches_reference(mode):
     (dl,) = torch.autograd.grad(ll, pred)
     assert abs(float(ll) - float(g[f"local.{tag}.loss"])) <= 1e-6
     assert float((dl - torch.from_numpy(g[f"local.{tag}.d_pred"])).abs().max()) <= 1e-8
+
+
+@pytest.mark.parametrize("name,build", [
+    ("l1", lambda ML: ML.MotionL1Loss()), ("sparsity", lambda ML: ML.MotionSparsityLoss()),
+    ("basis_d0", lambda ML: ML.MotionBasisRegularizaiton(transl_degree=0)),
+    ("basis_d1_gauss", lambda ML: ML.MotionBasisRegularizaiton(transl_degree=1, rot_degree=1, freq_div_mode="gaussian"))])
+def test_motion_regularisers_match_reference(name, build):
+    """rodygs_amd.motion_losses == the imported reference's MotionL1Loss / MotionSparsityLoss /
+    MotionBasisRegularizaiton (golden G9): value and gradients w.r.t. coefficients and motion table."""
+    from rodygs_amd import motion_losses as ML
+    g = load("motion_reg_golden.npz")
+    coeff = torch.from_numpy(g["coeff"]).requires_grad_(True)
+    table = torch.from_numpy(g["table"]).requires_grad_(True)
+
+    class M:
+        _motion_coeff = coeff
+
+        @staticmethod
+        def get_total_motion_table():
+            return table
+
+    v = build(ML)(M)
+    gc, gt = torch.autograd.grad(v, [coeff, table], allow_unused=True)
+    assert abs(float(v) - float(g[name + ".loss"])) <= 1e-6 * max(1.0, abs(float(g[name + ".loss"])))
+    for got, key in ((gc, ".d_coeff"), (gt, ".d_table")):
+        want = torch.from_numpy(g[name + key])
+        if got is None:
+            assert float(want.abs().sum()) == 0.0
+        else:
+            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max()) + 1e-12
