@@ -297,16 +297,36 @@ __global__ void rdg_deform_dbt_kernel(int Tu, int row, const float* __restrict__
 // Fused Adam over a flat f32 segment.  row_len > 1 gives the segment a row structure whose first head_len floats
 // take step_head and the rest step_tail: the SH features [P,16,3] are ONE tensor whose DC coefficient trains 20x
 // faster than the rest (feature_lr vs feature_lr/20), so no cat/split of f_dc/f_rest is ever needed.
+typedef float rdg_f4 __attribute__((ext_vector_type(4)));
+template <int VAR>
+__device__ __forceinline__ float4 rdg_ld4(const float* base, long long i) {
+    if (VAR & 1) {
+        const rdg_f4 t = __builtin_nontemporal_load(reinterpret_cast<const rdg_f4*>(base) + i);
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+    return reinterpret_cast<const float4*>(base)[i];
+}
+template <int VAR>
+__device__ __forceinline__ void rdg_st4(float* base, long long i, float4 v) {
+    if (VAR & 1) {
+        rdg_f4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<rdg_f4*>(base) + i);
+    } else {
+        reinterpret_cast<float4*>(base)[i] = v;
+    }
+}
+
+template <int VAR>
 __device__ __forceinline__ void
 rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                  float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
                  float eps, float bc2_sqrt) {
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        const float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float4 pp = rdg_ld4<VAR>(p, i);
+        const float4 gg = rdg_ld4<VAR>(g, i);
+        float4 mm = rdg_ld4<VAR>(m, i);
+        float4 vv = rdg_ld4<VAR>(v, i);
         float s0 = step_tail, s1 = step_tail, s2 = step_tail, s3 = step_tail;
         if (row_len > 1) {
             const unsigned r = (unsigned)((i * 4) % row_len);   // row_len is a multiple of 4 or handled per lane below
@@ -322,9 +342,9 @@ rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g
         vv.c = b2 * vv.c + (1.0f - b2) * gg.c * gg.c;                  \
         pp.c -= st * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
         RDG_ADAM1(x, s0) RDG_ADAM1(y, s1) RDG_ADAM1(z, s2) RDG_ADAM1(w, s3)
-        reinterpret_cast<float4*>(p)[i] = pp;
-        reinterpret_cast<float4*>(m)[i] = mm;
-        reinterpret_cast<float4*>(v)[i] = vv;
+        rdg_st4<VAR>(p, i, pp);
+        rdg_st4<VAR>(m, i, mm);
+        rdg_st4<VAR>(v, i, vv);
     }
     // tail
     const long long t0 = n4 << 2;
@@ -343,15 +363,16 @@ __global__ void __launch_bounds__(256)
 rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                 float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
                 float eps, float bc2_sqrt) {
-    rdg_adam_segment(n, p, g, m, v, step_head, step_tail, row_len, head_len, b1, b2, eps, bc2_sqrt);
+    rdg_adam_segment<0>(n, p, g, m, v, step_head, step_tail, row_len, head_len, b1, b2, eps, bc2_sqrt);
 }
 
 // all parameter groups of a model in ONE launch: blockIdx.y selects the segment
 struct RdgAdamSegs { RdgAdamSeg s[RDG_ADAM_MAX_SEGS]; };
+template <int VAR>
 __global__ void __launch_bounds__(256)
 rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float eps, float bc2_sqrt) {
     const RdgAdamSeg sg = segs.s[blockIdx.y];
-    rdg_adam_segment(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, sg.lr_head * inv_bc1, sg.lr_tail * inv_bc1,
+    rdg_adam_segment<VAR>(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, sg.lr_head * inv_bc1, sg.lr_tail * inv_bc1,
                      sg.row_len, sg.head_len, b1, b2, eps, bc2_sqrt);
 }
 
@@ -479,12 +500,23 @@ int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, 
     }
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    // measured at 75 M parameters (scripts/adam_probe.py): streaming (nontemporal) loads/stores + 16 k workgroups per
+    // segment 367 us = 5.7 TB/s; cached accesses + 2 k workgroups 416 us.  RDG_ADAM_VAR=0 / RDG_ADAM_BLOCKS override.
+    static int var = -1, cap = 16384;
+    if (var < 0) {
+        const char* ev = getenv("RDG_ADAM_VAR"); var = ev ? atoi(ev) : 1;
+        const char* ec = getenv("RDG_ADAM_BLOCKS"); if (ec) cap = atoi(ec);
+    }
     long long blocks = ((nmax >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > cap) blocks = cap;
     rdg_stage_begin(RDG_STAGE_ADAM, st);
-    hipLaunchKernelGGL(rdg_adam_multi_kernel, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs, (float)(1.0 / bc1),
-                       beta1, beta2, eps, (float)sqrt(bc2));
+    if (var & 1)
+        hipLaunchKernelGGL(rdg_adam_multi_kernel<1>, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs,
+                           (float)(1.0 / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+    else
+        hipLaunchKernelGGL(rdg_adam_multi_kernel<0>, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs,
+                           (float)(1.0 / bc1), beta1, beta2, eps, (float)sqrt(bc2));
     rdg_stage_end(RDG_STAGE_ADAM, st);
     return rdg_check_hip(hipGetLastError(), "adam multi launch");
 }
