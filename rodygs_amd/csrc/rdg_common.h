@@ -212,7 +212,8 @@ __device__ __forceinline__ void rdg_rows_to_lds(const float* __restrict__ g, lon
         for (int v = lane; v < 16 * row; v += 64) {
             const long long e = base + 4ll * v;
             if (e < total) {
-                const float4 val = *reinterpret_cast<const float4*>(g + e);
+                typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
+                const rdg_nt4 val = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(g + e));
                 const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
                 float* dst = S + gi * stride + (4 * v - gi * row);
                 dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
@@ -238,7 +239,9 @@ __device__ __forceinline__ void rdg_lds_to_rows(float* __restrict__ g, long long
             if (e < total) {
                 const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
                 const float* src = S + gi * stride + (4 * v - gi * row);
-                *reinterpret_cast<float4*>(g + e) = make_float4(src[0], src[1], src[2], src[3]);
+                typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
+                const rdg_nt4 val = {src[0], src[1], src[2], src[3]};
+                __builtin_nontemporal_store(val, reinterpret_cast<rdg_nt4*>(g + e));
             }
         }
     } else {
