@@ -192,6 +192,16 @@ int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const fl
 int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float* xyz, const float* scaling,
                        const float* rotation, const float* z, float* xyz_out, float* scaling_out, void* stream);
 
+/* Distance-preserving term of RigidityLoss (/root/reference/src/trainer/losses.py:293-358) without the [t,n,K,3]
+ * intermediates: pos_t4 [nt,n,4] = position (canonical + translation, w unused) of every sampled Gaussian at the
+ * drawn times, nn_idx [n,K] (indices into the sample), d2 [n,K] squared neighbour distances, and the reverse
+ * adjacency of nn_idx (rev_off [n+1], rev_edge [n*K] = edge ids i*K+k sorted by destination) so that every gradient
+ * row is written once instead of through scattered atomics.  Writes loss_sum[0] (f64) = sum over (tau, i, k) of
+ * sqrt((gap - d2_flat[f / nt])^2 + eps^2), its unscaled gradient G_t4 [nt,n,4] w.r.t. pos_t4 and d_d2 [n,K].       */
+int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const float* pos_t4, const int64_t* nn_idx,
+                            const float* d2, const int64_t* rev_off, const int64_t* rev_edge, float eps,
+                            double* loss_sum, float* G_t4, float* d_d2, void* stream);
+
 /* ---- Pearson depth losses (GlobalPearsonDepthLoss / LocalPearsonDepthLoss, /root/reference/src/trainer/losses.py:108-182;
  *      pearson_depth_loss, /root/reference/src/utils/loss_utils.py:100-117) -------------------------------------------
  * n_boxes boxes of bh x bw pixels of the [H,W] depth images pred / gt; row0[n_boxes], col0[n_boxes] (int64, device)

@@ -33,6 +33,42 @@ def charbonnier_bc(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-6) -> torch
     return torch.sqrt((x - y).pow(2) + eps ** 2).sum() / (x.shape[0] * x.shape[1])
 
 
+class _FusedDistancePreserving(torch.autograd.Function):
+    """sum over (tau, i, k) of Charbonnier(gap, d2_flat[f // nt]) and its gradients in one HIP kernel
+    (rdg_rigidity_dp_forward): no [t,n,K,3] intermediates.  pos_t [nt,n,3] = canonical position + translation."""
+
+    @staticmethod
+    def forward(ctx, pos_t, nn_idx, d2, eps):
+        from . import _lib
+        L = _lib.lib()
+        nt, n = pos_t.shape[0], pos_t.shape[1]
+        dev = pos_t.device
+        ii = nn_idx.detach().to(torch.int64).contiguous()
+        dd = d2.detach().to(torch.float32).contiguous()
+        K = ii.shape[-1]
+        with torch.cuda.device(dev):
+            p4 = torch.zeros(nt, n, 4, dtype=torch.float32, device=dev)
+            p4[..., :3] = pos_t.detach()
+            # reverse adjacency of the K-NN graph: edge ids (i*K + k) grouped by their destination
+            flat = ii.reshape(-1)
+            rev_edge = torch.argsort(flat, stable=True).contiguous()
+            rev_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            rev_off[1:] = torch.cumsum(torch.bincount(flat, minlength=n), dim=0)
+            loss = torch.empty(1, dtype=torch.float64, device=dev)
+            G4 = torch.empty_like(p4)
+            d_d2 = torch.empty_like(dd)
+            _lib.check(L.rdg_rigidity_dp_forward(n, K, nt, _lib.ptr(p4), _lib.ptr(ii), _lib.ptr(dd), _lib.ptr(rev_off),
+                                                 _lib.ptr(rev_edge), float(eps), _lib.ptr(loss), _lib.ptr(G4),
+                                                 _lib.ptr(d_d2), _lib.stream_ptr()), "rdg_rigidity_dp_forward")
+        ctx.save_for_backward(G4, d_d2)
+        return loss[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        G4, d_d2 = ctx.saved_tensors
+        return G4[..., :3] * g, None, d_d2 * g, None
+
+
 class RigidityLoss(nn.Module):
     def __init__(self, scale: float = 2, K: int = 8, sim_metric: str = "l2", dist_weight_lambda: float = 0.1,
                  color_sim: bool = True, dist_preserving_ratio=4, mode: Sequence[str] = ("coeff",),
@@ -54,6 +90,8 @@ class RigidityLoss(nn.Module):
         # it, but 0.3 s of Python per call at 1 M Gaussians.  True: the same uniform draw without replacement from
         # torch.randperm on the device.
         self.device_sampling = device_sampling
+        # distance_preserving through the fused HIP kernel whenever the native ops are in use (GPU tensors)
+        self.fused_dp = knn_points is None and knn_gather is None
 
     def _neighbours(self, rows: torch.Tensor, nn_idx: torch.Tensor) -> torch.Tensor:
         """rows [n, ...] -> [n, K, ...]: the rows of every query's K neighbours."""
@@ -105,6 +143,10 @@ class RigidityLoss(nn.Module):
             # products (50 M batches at config-5 size: it faulted there); one [n,B] x [B,3t] product is the same sum
             bmat = basis_xyz.permute(1, 0, 2).reshape(basis_xyz.shape[1], nt * 3)
             own = (coeffs.reshape(n, -1) @ bmat).reshape(n, nt, 3)
+            if self.fused_dp and own.is_cuda:
+                pos_t = own.permute(1, 0, 2) + canon[pick][None]                       # [t,n,3]: one slab per time
+                dp_sum = _FusedDistancePreserving.apply(pos_t, nn_idx[0], d2[0], 1e-6)
+                return total + dp_sum / (n * self.K * nt)
             nb = self._knn_gather(own[None].reshape(1, n, -1), nn_idx).reshape(1, n, self.K, own.shape[1], 3)
             nb = nb.squeeze().permute(2, 0, 1, 3)                                     # [t,n,K,3]
             canon_s = canon[pick]

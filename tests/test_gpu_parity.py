@@ -583,6 +583,33 @@ def test_rigidity_loss_on_hip_knn_matches_reference_golden(name):
         rel_ok(gr, w_, tol=5e-3 if name == "all" else 1e-4, what=f"rigidity {name} d_{k} vs reference golden")
 
 
+def test_fused_distance_preserving_equals_unfused_on_the_same_device():
+    """The fused HIP kernel for the distance-preserving term vs the module's own tensor-by-tensor expression (the
+    reference's formulation) on the same device and the same random draws: value and all gradients."""
+    import random
+    from rodygs_amd.rigidity import RigidityLoss
+    from test_oracle_golden import _FakeDynModel
+    g = torch.Generator().manual_seed(12)
+    P, Tu, B = 3000, 16, 16
+    base = dict(xyz=torch.rand(P, 3, generator=g) * 4 - 2, transl=0.05 * torch.randn(P, 3, generator=g),
+                coeff=0.3 * torch.randn(P, 1, B, generator=g), fdc=torch.rand(P, 1, 3, generator=g),
+                table=0.2 * torch.randn(Tu, B, 7, generator=g))
+    outs = []
+    for fused in (True, False):
+        t = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+        random.seed(5)
+        torch.manual_seed(6)
+        mod = RigidityLoss(mode=["distance_preserving"], K=8)
+        mod.fused_dp = fused
+        loss = mod(_FakeDynModel(t["xyz"], t["coeff"], t["fdc"], t["table"]), t["transl"])
+        grads = torch.autograd.grad(loss, [t["xyz"], t["transl"], t["coeff"], t["table"]])
+        outs.append((loss, grads))
+    (lf, gf), (lu, gu) = outs
+    assert abs(float(lf) - float(lu)) <= 2e-6 * abs(float(lu))
+    for a, b, nm in zip(gf, gu, ("xyz", "transl", "coeff", "table")):
+        rel_ok(a, b, tol=2e-5, what="fused dp d_" + nm)
+
+
 def test_pytorch3d_shim_resolves_to_hip_ops():
     import pytorch3d.ops as torch3d
     from rodygs_amd import knn
