@@ -97,7 +97,7 @@ int rdg_abi_version(void) { return RDG_ABI_VERSION; }
 const char* rdg_last_error(void) { return g_err; }
 
 size_t rdg_geom_bytes(int32_t P) { return rdg_geom_layout(P).total; }
-size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles) { (void)n_tiles; return rdg_bin_layout(capacity).total; }
+size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles) { return rdg_bin_layout(capacity, n_tiles).total; }
 size_t rdg_image_bytes(int32_t H, int32_t W) { return rdg_image_layout(H, W).total; }
 size_t rdg_grad_bytes(int32_t P) {
     const size_t Pp = (size_t)(P > 0 ? P : 1);

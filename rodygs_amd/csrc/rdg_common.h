@@ -86,9 +86,11 @@ struct RdgBinLayout {
     size_t keys_a, keys_b;  // uint64[cap]
     size_t vals_a, vals_b;  // uint32[cap]
     size_t sort_tmp;        // RdgSortLayout
+    size_t hit;             // uint64[cap/64 + n_tiles + 2][4]: per 64 list slots of a tile, per quadrant, "the forward
+                            // had a pixel that could blend this splat" (lets the backward skip the other visits)
     size_t total;
 };
-static inline RdgBinLayout rdg_bin_layout(int64_t capacity) {
+static inline RdgBinLayout rdg_bin_layout(int64_t capacity, int32_t n_tiles = 0) {
     RdgBinLayout L;
     size_t cap = (size_t)(capacity > 0 ? capacity : 1);
     size_t o = 0;
@@ -97,8 +99,12 @@ static inline RdgBinLayout rdg_bin_layout(int64_t capacity) {
     L.vals_a = o;  o = rdg_align_up(o + cap * 4, 256);
     L.vals_b = o;  o = rdg_align_up(o + cap * 4, 256);
     L.sort_tmp = o; o = rdg_align_up(o + rdg_sort_layout(capacity).total, 256);
+    L.hit = o;     o = rdg_align_up(o + (cap / 64 + (size_t)(n_tiles > 0 ? n_tiles : 262144) + 2) * 32, 256);
     L.total = o;
     return L;
+}
+static inline size_t rdg_hit_bytes(int64_t capacity, int32_t n_tiles) {
+    return ((size_t)(capacity > 0 ? capacity : 1) / 64 + (size_t)n_tiles + 2) * 32;
 }
 
 // ---- image workspace layout ------------------------------------------------------------------------------
@@ -154,7 +160,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                    uint32_t* vals_unsorted_copy, hipStream_t s, bool export_sorted_keys = false);
 int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
                     const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s);
-int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
+int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, void* bin_ws,
                           int64_t capacity, void* image_ws, const int32_t* num_rendered, float* out_color,
                           float* out_depth, float* out_normal, float* out_alpha, hipStream_t s);
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,

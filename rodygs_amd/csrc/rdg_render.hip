@@ -98,7 +98,8 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                       const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RdgRec* __restrict__ rec, long long capacity, const int32_t* __restrict__ num_rendered,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                      float* __restrict__ out_depth, float* __restrict__ out_normal, float* __restrict__ out_alpha) {
+                      float* __restrict__ out_depth, float* __restrict__ out_normal, float* __restrict__ out_alpha,
+                      unsigned long long* __restrict__ hitbits) {
     // on capacity overflow the binning stage has emptied every tile range: this kernel then renders the background
     const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
@@ -115,6 +116,9 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
     const uint2 range = ranges[tile];
     const int todo_total = (int)(range.y - range.x);
     const int rounds = (todo_total + RDG_BATCH - 1) / RDG_BATCH;
+    // visit record for the backward: word w of this tile covers list slots [64 w, 64 w + 63]; the words of a tile
+    // start at (range.x / 64 + tile), which cannot overlap the next tile's; zeroed by the launcher
+    unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
 
     // "this pixel has stopped" is folded into its alpha threshold (+inf once stopped / outside the image): the hot
     // test is two compares, and no loop-carried lane mask has to be re-canonicalised every iteration
@@ -147,8 +151,10 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
         for (int s = 0; s < 4; ++s) {
             if (rdg_all(amin > 1.0f)) break;   // once per 64 staged splats; inside the walk only after a pixel stops
             unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
+            unsigned long long seen = 0ull;    // splats of this 64-slot word that some pixel of the quadrant may blend
             while (mask) {
-                const int j = s * 64 + __builtin_ctzll(mask);
+                const int jb = __builtin_ctzll(mask);
+                const int j = s * 64 + jb;
                 mask &= mask - 1;
                 const float4 q0 = sQ0[j];
                 const float4 q1 = sQ1[j];
@@ -158,6 +164,7 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                 const float alpha = fminf(RDG_ALPHA_CAP, q1.y * __builtin_amdgcn_exp2f(power));
                 const bool cand = power <= 0.0f && alpha >= amin;
                 if (!rdg_any(cand)) continue;
+                seen |= 1ull << jb;
                 const float test_T = T * (1.0f - alpha);
                 const bool stop = cand && test_T < RDG_T_STOP;
                 const bool hit = cand && !stop;
@@ -172,9 +179,10 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                 if (hit) { T = test_T; last_contributor = base_idx + (uint32_t)j + 1u; }
                 if (rdg_any(stop)) {
                     amin = stop ? __builtin_inff() : amin;
-                    if (rdg_all(amin > 1.0f)) { s = 4; break; }
+                    if (rdg_all(amin > 1.0f)) { mask = 0ull; }
                 }
             }
+            if (lane == 0 && seen) hit[(size_t)(r * 4 + s) * 4 + wv] = seen;
         }
     }
     if (inside) {
@@ -191,7 +199,7 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
     }
 }
 
-int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
+int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, void* bin_ws,
                           int64_t capacity, void* image_ws, const int32_t* num_rendered, float* out_color,
                           float* out_depth, float* out_normal, float* out_alpha, hipStream_t s) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
@@ -203,10 +211,13 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const uint32_t* plist = (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a));
     char* im = (char*)image_ws;
     const int nblk = ((n_tiles + 7) / 8) * 8;
+    unsigned long long* hitbits = (unsigned long long*)((char*)bin_ws + B.hit);
+    hipError_t em = hipMemsetAsync(hitbits, 0, rdg_hit_bytes(capacity, n_tiles), s);
+    if (em != hipSuccess) return rdg_check_hip(em, "hit bits memset");
     hipLaunchKernelGGL(rdg_render_fwd_kernel, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, d.render_normal,
                        bg, (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),
                        (long long)capacity, num_rendered, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),
-                       out_color, out_depth, out_normal, out_alpha);
+                       out_color, out_depth, out_normal, out_alpha, hitbits);
     return rdg_check_hip(hipGetLastError(), "render_fwd launch");
 }
 
@@ -246,7 +257,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                       const RdgRec* __restrict__ rec, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ g_color,
                       const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
-                      float* __restrict__ grow) {
+                      float* __restrict__ grow, const unsigned long long* __restrict__ hitbits) {
     const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];
@@ -262,11 +273,11 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
     const float pixx = (float)pxi, pixy = (float)pyi;
-    const float X0 = (float)(tx * RDG_TILE), Y0 = (float)(ty * RDG_TILE);
     const uint2 range = ranges[tile];
     const size_t hw = (size_t)H * W;
     const size_t pid = (size_t)pyi * W + pxi;
 
+    const unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
     const float T_final = inside ? final_T[pid] : 0.0f;
     float T = T_final;
     const int last_contributor = inside ? (int)n_contrib[pid] : 0;
@@ -309,10 +320,15 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
                 sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
                 sQ2[tid] = p->q2;
-                qbits = rdg_quadrant_bits(q0, q1, X0, Y0);
-                // a quadrant whose pixels all stopped before this list position never needs the splat
-                qbits &= (uint32_t)(k < m0) | ((uint32_t)(k < m1) << 1) | ((uint32_t)(k < m2) << 2) |
-                         ((uint32_t)(k < m3) << 3);
+                // a quadrant whose pixels all stopped before this list position never needs the splat ...
+                qbits = (uint32_t)(k < m0) | ((uint32_t)(k < m1) << 1) | ((uint32_t)(k < m2) << 2) |
+                        ((uint32_t)(k < m3) << 3);
+                // ... and neither does one in which the forward found no pixel that could blend it (same staged
+                // values, same expression: every backward hit was a forward candidate)
+                const unsigned long long* hw = hit + (size_t)(k >> 6) * 4;
+                const int hb = k & 63;
+                qbits &= (uint32_t)((hw[0] >> hb) & 1ull) | ((uint32_t)((hw[1] >> hb) & 1ull) << 1) |
+                         ((uint32_t)((hw[2] >> hb) & 1ull) << 2) | ((uint32_t)((hw[3] >> hb) & 1ull) << 3);
             }
         }
 #pragma unroll
@@ -456,7 +472,7 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
     hipLaunchKernelGGL(rdg_render_bwd_kernel<DEPTH>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,    \
                        (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),        \
                        (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
-                       g_alpha, grow)
+                       g_alpha, grow, (const unsigned long long*)(b + B.hit))
     if (g_depth) RDG_BWD_LAUNCH(true); else RDG_BWD_LAUNCH(false);
 #undef RDG_BWD_LAUNCH
     return rdg_check_hip(hipGetLastError(), "render_bwd launch");
