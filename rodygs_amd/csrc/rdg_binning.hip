@@ -1,4 +1,5 @@
-// rdg_binning.hip -- tile binning: duplicateWithKeys, stable LSD radix sort, tile ranges.
+// rdg_binning.hip -- tile binning: bucket binning (default, second half of the file) and the
+// duplicateWithKeys + stable LSD radix sort + tile ranges path it replaced (kept: rdg_sort_pairs, K-NN, A/B switch).
 //
 // Integer/byte work, HBM-bound.  Nothing here needs the host to know D (= num_rendered): every kernel is
 // launched with a D-independent grid and reads D from device memory, so the forward pass has no D2H stall.

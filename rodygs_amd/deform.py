@@ -197,7 +197,7 @@ class MLPBasisNetwork(nn.Module):
     def motion_basis(self, t_emb: torch.Tensor) -> torch.Tensor:
         """t_emb [..., 53] -> motion basis [..., num_basis, 7].
 
-        GPU tensors with the default GELU run the whole network as 5 MFMA launches forward / 16 backward
+        GPU tensors with the default GELU run the whole network as 5 MFMA launches forward / 5 backward
         (csrc/rdg_mlp.hip); the torch expression below is the same arithmetic and serves CPU tensors (checkpoint
         tooling, golden tests) and the ReLU variant."""
         lead = t_emb.shape[:-1]
