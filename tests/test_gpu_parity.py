@@ -338,6 +338,47 @@ def test_full_size_properties_1m_1080p():
     rel_ok(g2, 2.5 * g1, tol=2e-5, what="backward linearity")      # float atomics: order-dependent rounding only
 
 
+def test_full_size_sampled_tiles_against_oracle_1m_1080p():
+    """BASELINE configs[2] size (1 M Gaussians, 1080p, SH-3), the frame bench.py renders: the oracle is affordable on
+    a SAMPLE of tiles (its per-Gaussian stage and binning run in full).  Image, depth and alpha of those tiles, and
+    every gradient of a loss restricted to those tiles, against the HIP path rendering the whole frame."""
+    from rodygs_amd import GaussianRasterizer
+    import hip_stages as HS
+    P, W, H = 1000000, 1920, 1080
+    sc = O.synthetic_scene(P, W, H, 3, seed=777)
+    sc["viewmatrix"] = orbit_view(4.0, -2.0, (0.3, -0.2, 0.5))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    subset = list(range(37, gx * gy, (gx * gy) // 20))[:20]
+    mask = torch.zeros(1, H, W)
+    for t in subset:
+        ty, tx = divmod(t, gx)
+        mask[:, ty * 16:min(ty * 16 + 16, H), tx * 16:min(tx * 16 + 16, W)] = 1.0
+    g = torch.Generator().manual_seed(1)
+    wc, wd = torch.rand(3, H, W, generator=g) * mask, torch.rand(1, H, W, generator=g) * mask
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    # oracle: full per-Gaussian stage + binning, compositing of the sampled tiles only
+    oi = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], bg, 1.0, sc["projmatrix"], 3)
+    om2 = torch.zeros(P, 3, requires_grad=True)
+    geom = O.preprocess(oi["means3D"], om2, oi["opacities"], oi["viewmatrix"], st, shs=oi["shs"], scales=oi["scales"],
+                        rotations=oi["rotations"])
+    img = O.render_tiles(geom, O.bin_and_sort(geom), st.bg, H, W, tile_subset=subset)
+    ((img["color"] * wc).sum() + 0.1 * (img["depth"] * wd).sum()).backward()
+    # HIP: the whole frame, loss weights zero outside the sample
+    hi = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+    hm2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(HS.make_settings(sc, 3, bg=bg))(means3D=hi["means3D"], means2D=hm2, shs=hi["shs"],
+                                                             opacities=hi["opacities"], scales=hi["scales"],
+                                                             rotations=hi["rotations"], viewmatrix=hi["viewmatrix"])
+    ((out[0] * wc.to(DEV)).sum() + 0.1 * (out[1] * wd.to(DEV)).sum()).backward()
+    m = mask.to(DEV)
+    for i_, name in ((0, "color"), (1, "depth"), (3, "alpha")):
+        rel_ok(out[i_] * m, img[name] * mask, outliers=OUTLIER_FRAC, what="sampled tiles " + name)
+    for k in NAMES:
+        rel_ok(hi[k].grad, oi[k].grad, outliers=OUTLIER_FRAC, what="sampled tiles d_" + k)
+    rel_ok(hm2.grad, om2.grad, outliers=OUTLIER_FRAC, what="sampled tiles d_means2D")
+
+
 # ---- deformation, knn, adam ------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("P,Tu,inverse", [(5000, 37, True), (1, 1, True), (4097, 100, True), (3000, 0, False),
