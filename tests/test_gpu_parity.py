@@ -338,17 +338,18 @@ def test_full_size_properties_1m_1080p():
     rel_ok(g2, 2.5 * g1, tol=2e-5, what="backward linearity")      # float atomics: order-dependent rounding only
 
 
-def test_full_size_sampled_tiles_against_oracle_1m_1080p():
-    """BASELINE configs[2] size (1 M Gaussians, 1080p, SH-3), the frame bench.py renders: the oracle is affordable on
-    a SAMPLE of tiles (its per-Gaussian stage and binning run in full).  Image, depth and alpha of those tiles, and
-    every gradient of a loss restricted to those tiles, against the HIP path rendering the whole frame."""
+@pytest.mark.parametrize("P,W,H,n_sample", [(1000000, 1920, 1080, 20),      # BASELINE configs[2..3]
+                                            (4000000, 3840, 2160, 10)])     # configs[4]: the largest size
+def test_full_size_sampled_tiles_against_oracle(P, W, H, n_sample):
+    """BASELINE's full sizes (the frames bench.py renders): the oracle is affordable on a SAMPLE of tiles (its
+    per-Gaussian stage and binning run in full).  Image, depth and alpha of those tiles, and every gradient of a loss
+    restricted to those tiles, against the HIP path rendering the whole frame."""
     from rodygs_amd import GaussianRasterizer
     import hip_stages as HS
-    P, W, H = 1000000, 1920, 1080
     sc = O.synthetic_scene(P, W, H, 3, seed=777)
     sc["viewmatrix"] = orbit_view(4.0, -2.0, (0.3, -0.2, 0.5))
     gx, gy = (W + 15) // 16, (H + 15) // 16
-    subset = list(range(37, gx * gy, (gx * gy) // 20))[:20]
+    subset = list(range(37, gx * gy, (gx * gy) // n_sample))[:n_sample]
     mask = torch.zeros(1, H, W)
     for t in subset:
         ty, tx = divmod(t, gx)
