@@ -178,6 +178,26 @@ int rdg_mlp_backward(int32_t NR, int32_t D0, int32_t H, int32_t NB, int32_t OUT,
                      float* db0, float* dW1, float* db1, float* dW2, float* db2, float* dhw1, float* dhb1, float* dhw2,
                      float* dhb2, void* stream);
 
+/* ---- fused dynamic getter: deformation + activations in one pass each way ---------------------------------------
+ * What get_GS_properties (/root/reference/src/trainer/rodygs.py:68-113) assembles from get_gaussian_deformation
+ * (rodygs_dynamic.py:122-138) and the model getters (rodygs_static.py:82-105), for B = 16 motion bases:
+ *   means3D = xyz + spatial_scale * (coeff . dB)[0:3],  scales = exp(scaling),
+ *   rots = normalize(rotation) + (coeff . dB)[3:7],     opac = sigmoid(opacity),   dB = bases[Tu] - bases[birth]
+ * bases [Tu+1,16,7]: the Tu birth-time rows of the motion table followed by B(t).  rdg_dyn_getter_supported(B, Tu)
+ * tells whether the table fits the kernel (else use rdg_deform_* + rdg_activate_*).  Backward overwrites the five
+ * parameter gradients and d_bases [Tu+1,16,7]; g_* may be NULL (no upstream gradient); order / inv_order /
+ * sorted_ws as for rdg_deform_backward (all required here).                                                      */
+int rdg_dyn_getter_supported(int32_t B, int32_t Tu);
+int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
+                           float spatial_scale, const float* xyz, const float* scaling, const float* rotation,
+                           const float* opacity, float* means3D, float* scales, float* rots, float* opac, void* stream);
+int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
+                            float spatial_scale, const float* scaling, const float* rotation, const float* opacity,
+                            const float* g_means3D, const float* g_scales, const float* g_rots, const float* g_opac,
+                            float* d_xyz, float* d_scaling, float* d_rotation, float* d_opacity, float* d_coeff,
+                            float* d_bases, const int32_t* order, const int32_t* inv_order, void* sorted_ws,
+                            void* stream);
+
 /* ---- simple_knn ------------------------------------------------------------------------------------------ */
 size_t rdg_knn_tmp_bytes(int32_t P);
 /* out[p] = mean squared distance from points[p] to its 3 nearest other points.                              */

@@ -56,6 +56,9 @@ _SIGS = {
     "rdg_sort_pairs": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int32, _vp, _vp]),
     "rdg_deform_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 9),
+    "rdg_dyn_getter_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "rdg_dyn_getter_forward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 9),
+    "rdg_dyn_getter_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 17),
     "rdg_deform_sorted_ws_bytes": (C.c_size_t, [C.c_int32]),
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_gather_rows": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),

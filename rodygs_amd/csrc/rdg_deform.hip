@@ -14,6 +14,7 @@
 
 #define RDG_DEF_K 7
 #define RDG_DEF_MAXB 16
+#define RDG_DC_STRIDE 116   // LDS row stride of the [Tu][112] difference table (16-B aligned rows, 116 = 20 mod 32)
 
 template <bool USE_LDS>
 __global__ void __launch_bounds__(1024)
@@ -127,7 +128,6 @@ rdg_deform_bwd_kernel(int P, int B, int Tu, const float* __restrict__ coeff, con
 // the difference table lives in LDS with a row stride of 116 floats (16-B aligned rows, 116 = 20 mod 32: the
 // b128 reads of lanes holding different birth indices spread over all banks), read as 28 float4 per Gaussian
 // instead of 112 dwords, and the 64-B result row leaves as 4 float4 stores.
-#define RDG_DC_STRIDE 116
 __global__ void __launch_bounds__(1024)
 rdg_deform_dcoeff16_kernel(int P, int Tu, const long long* __restrict__ time_ind, const float* __restrict__ basis_t,
                            const float* __restrict__ table, float scale, const float* __restrict__ g_xyz,
@@ -166,6 +166,133 @@ rdg_deform_dcoeff16_kernel(int P, int Tu, const long long* __restrict__ time_ind
             for (int c = 0; c < 4; ++c) {
                 const int e = 4 * j + c;          // compile-time after unrolling: e = b * 7 + k
                 sacc[e / 7] += g[e % 7] * vv[c];
+            }
+        }
+        float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dc[q] = make_float4(sacc[4 * q], sacc[4 * q + 1], sacc[4 * q + 2], sacc[4 * q + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused "dynamic getter": deformation + activations of the dynamic Gaussians in one pass each way, i.e. what
+// /root/reference/src/trainer/rodygs.py:68-113 (get_GS_properties) assembles from get_gaussian_deformation
+// (rodygs_dynamic.py:122-138) and the model getters (rodygs_static.py:82-105):
+//   means3D = xyz + scale * (c . dB)[0:3]        scales = exp(scaling)
+//   rots    = normalize(rotation) + (c . dB)[3:7]   opac = sigmoid(opacity)         dB = B(t) - table[birth]
+// Separate kernels write the 28-B deformation per Gaussian only for the next kernel to read it back (and the same
+// for its gradient on the way back); fused, a Gaussian's parameters are read once and its activated values written
+// once.  B = 16; the difference table sits in LDS exactly as in rdg_deform_dcoeff16_kernel.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rdg_diff16_to_lds(float* sm, int Tu, const float* __restrict__ bases) {
+    const float* bt = bases + (size_t)Tu * 112;          // packed bases: Tu table rows, then B(t)
+    for (int k = threadIdx.x; k < Tu * 112; k += blockDim.x) {
+        const int u = k / 112, c = k - u * 112;
+        sm[u * RDG_DC_STRIDE + c] = bt[c] - bases[(size_t)u * 112 + c];
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+rdg_dyn_getter_fwd_kernel(int P, int Tu, const float* __restrict__ coeff, const long long* __restrict__ time_ind,
+                          const float* __restrict__ bases, float scale, const float* __restrict__ xyz,
+                          const float* __restrict__ scaling, const float* __restrict__ rotation,
+                          const float* __restrict__ opacity, float* __restrict__ means3D, float* __restrict__ scales,
+                          float* __restrict__ rots, float* __restrict__ opac) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dg[];
+    rdg_diff16_to_lds(smem_dg, Tu, bases);
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int u = (int)time_ind[p];
+        const float4* c4 = reinterpret_cast<const float4*>(coeff + (size_t)p * 16);
+        float c[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t = c4[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
+        float acc[RDG_DEF_K];
+#pragma unroll
+        for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float4 v = r4[j];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * j + e4;          // compile-time: e = b * 7 + k
+                acc[e % 7] += c[e / 7] * vv[e4];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            means3D[3 * p + k] = xyz[3 * p + k] + acc[k] * scale;
+            scales[3 * p + k] = __expf(scaling[3 * p + k]);
+        }
+        const float4 q = reinterpret_cast<const float4*>(rotation)[p];
+        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+        reinterpret_cast<float4*>(rots)[p] = make_float4(q.x * inv + acc[3], q.y * inv + acc[4], q.z * inv + acc[5],
+                                                         q.w * inv + acc[6]);
+        opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind, const float* __restrict__ bases,
+                          float scale, const float* __restrict__ scaling, const float* __restrict__ rotation,
+                          const float* __restrict__ opacity, const float* __restrict__ g_means3D,
+                          const float* __restrict__ g_scales, const float* __restrict__ g_rots,
+                          const float* __restrict__ g_opac, float* __restrict__ d_xyz, float* __restrict__ d_scaling,
+                          float* __restrict__ d_rotation, float* __restrict__ d_opacity, float* __restrict__ d_coeff,
+                          const int* __restrict__ inv_order, float4* __restrict__ gs) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dg[];
+    rdg_diff16_to_lds(smem_dg, Tu, bases);
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int u = (int)time_ind[p];
+        float g[RDG_DEF_K] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // ---- activations backward (as rdg_activate_bwd_kernel) ----
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gm = g_means3D ? g_means3D[3 * p + k] : 0.0f;
+            d_xyz[3 * p + k] = gm;
+            g[k] = gm * scale;
+            d_scaling[3 * p + k] = g_scales ? g_scales[3 * p + k] * __expf(scaling[3 * p + k]) : 0.0f;
+        }
+        float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_rots) {
+            const float4 q = reinterpret_cast<const float4*>(rotation)[p];
+            const float4 gr = reinterpret_cast<const float4*>(g_rots)[p];
+            g[3] = gr.x; g[4] = gr.y; g[5] = gr.z; g[6] = gr.w;
+            const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+            if (nn > 1e-12f) {
+                const float inv = 1.0f / nn;
+                const float yx = q.x * inv, yy = q.y * inv, yz = q.z * inv, yw = q.w * inv;
+                const float dot = yx * gr.x + yy * gr.y + yz * gr.z + yw * gr.w;
+                dq = make_float4((gr.x - yx * dot) * inv, (gr.y - yy * dot) * inv, (gr.z - yz * dot) * inv,
+                                 (gr.w - yw * dot) * inv);
+            } else {
+                dq = make_float4(gr.x * 1e12f, gr.y * 1e12f, gr.z * 1e12f, gr.w * 1e12f);
+            }
+        }
+        reinterpret_cast<float4*>(d_rotation)[p] = dq;
+        const float sg = 1.0f / (1.0f + __expf(-opacity[p]));
+        d_opacity[p] = g_opac ? g_opac[p] * sg * (1.0f - sg) : 0.0f;
+        // ---- deformation backward: sorted compact copy for the dB reduction + dL/dcoeff ----
+        if (gs) {
+            const size_t sidx = (size_t)inv_order[p];
+            gs[2 * sidx] = make_float4(g[0], g[1], g[2], g[3]);
+            gs[2 * sidx + 1] = make_float4(g[4], g[5], g[6], __int_as_float(u));
+        }
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
+        float sacc[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) sacc[b] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float4 v = r4[j];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * j + e4;
+                sacc[e / 7] += g[e % 7] * vv[e4];
             }
         }
         float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
@@ -459,6 +586,60 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
     }
     rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);
     return rdg_check_hip(hipGetLastError(), "deform_bwd launch");
+}
+
+
+int rdg_dyn_getter_supported(int32_t B, int32_t Tu) { return B == 16 && Tu >= 1 && (size_t)Tu * RDG_DC_STRIDE * 4 <= 64 * 1024; }
+
+int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
+                           float spatial_scale, const float* xyz, const float* scaling, const float* rotation,
+                           const float* opacity, float* means3D, float* scales, float* rots, float* opac, void* stream) {
+    if (!rdg_dyn_getter_supported(16, Tu)) return rdg_set_error("dyn_getter: unsupported table size Tu = %d", Tu);
+    if ((((uintptr_t)coeff | (uintptr_t)rotation | (uintptr_t)rots)) & 15) return rdg_set_error("dyn_getter: 16-B alignment");
+    if (P <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (P + 1023) / 1024;
+    if (nb > 256) nb = 256;
+    rdg_stage_begin(RDG_STAGE_DEFORM_FWD, st);
+    hipLaunchKernelGGL(rdg_dyn_getter_fwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu, coeff,
+                       (const long long*)time_ind, bases, spatial_scale, xyz, scaling, rotation, opacity, means3D, scales,
+                       rots, opac);
+    rdg_stage_end(RDG_STAGE_DEFORM_FWD, st);
+    return rdg_check_hip(hipGetLastError(), "dyn_getter_fwd launch");
+}
+
+int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
+                            float spatial_scale, const float* scaling, const float* rotation, const float* opacity,
+                            const float* g_means3D, const float* g_scales, const float* g_rots, const float* g_opac,
+                            float* d_xyz, float* d_scaling, float* d_rotation, float* d_opacity, float* d_coeff,
+                            float* d_bases, const int32_t* order, const int32_t* inv_order, void* sorted_ws,
+                            void* stream) {
+    if (!rdg_dyn_getter_supported(16, Tu)) return rdg_set_error("dyn_getter: unsupported table size Tu = %d", Tu);
+    if (!order || !inv_order || !sorted_ws || (((uintptr_t)sorted_ws) & 15))
+        return rdg_set_error("dyn_getter_backward needs order, inv_order and a 16-B aligned sorted workspace");
+    if ((((uintptr_t)coeff | (uintptr_t)rotation | (uintptr_t)d_rotation | (uintptr_t)d_coeff |
+          (uintptr_t)(g_rots ? g_rots : coeff))) & 15)
+        return rdg_set_error("dyn_getter: 16-B alignment");
+    hipStream_t st = (hipStream_t)stream;
+    float* d_table = d_bases;
+    float* d_basis_t = d_bases + (size_t)Tu * 112;
+    rdg_stage_begin(RDG_STAGE_DEFORM_BWD, st);
+    hipError_t e = hipMemsetAsync(d_bases, 0, (size_t)(Tu + 1) * 112 * 4, st);
+    if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_bwd memset");
+    if (P > 0) {
+        int nb = (P + 1023) / 1024;
+        if (nb > 256) nb = 256;
+        hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu,
+                           (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
+                           g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
+                           (const int*)inv_order, (float4*)sorted_ws);
+        hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(2048), dim3(256), 0, st, P, coeff,
+                           (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,
+                           spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws);
+        hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3(1), dim3(128), 0, st, Tu, 112, d_table, d_basis_t);
+    }
+    rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);
+    return rdg_check_hip(hipGetLastError(), "dyn_getter_bwd launch");
 }
 
 static int rdg_adam_launch(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int row_len,

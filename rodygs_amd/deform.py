@@ -344,6 +344,79 @@ def gaussian_deformation_packed(coeff: torch.Tensor, time_ind: torch.Tensor, bas
     return _DeformFn.apply(c, time_ind, None, None, spatial_lr_scale, grad_sinks, bases)
 
 
+class _DynamicGetter(torch.autograd.Function):
+    """rdg_dyn_getter_forward / backward: deformation + activations fused (see ``dynamic_gaussians``)."""
+
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, opacity, coeff, time_ind, bases, scale, grad_sinks):
+        L = _lib.lib()
+        if not xyz.is_cuda:
+            raise RuntimeError("rodygs_amd.dynamic_gaussians: tensors must be on the GPU (no CPU fallback exists)")
+        f = lambda t: t.detach().to(torch.float32).contiguous()   # noqa: E731
+        x, sc, ro, op, c, bs = f(xyz), f(scaling), f(rotation), f(opacity), f(coeff), f(bases)
+        ti = time_ind.detach().to(torch.int64).contiguous()
+        P, Tu, dev = x.shape[0], bs.shape[0] - 1, x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        means3D, scales = torch.empty(P, 3, **f32), torch.empty(P, 3, **f32)
+        rots, opac = torch.empty(P, 4, **f32), torch.empty(P, 1, **f32)
+        with torch.cuda.device(dev):
+            _lib.check(L.rdg_dyn_getter_forward(P, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bs), float(scale), _lib.ptr(x),
+                                                _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(op), _lib.ptr(means3D),
+                                                _lib.ptr(scales), _lib.ptr(rots), _lib.ptr(opac), _lib.stream_ptr()),
+                       "rdg_dyn_getter_forward")
+        ctx.save_for_backward(sc, ro, op, c, ti, bs)
+        ctx.scale, ctx.grad_sinks = float(scale), grad_sinks
+        ctx.set_materialize_grads(False)
+        return means3D, scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_m, g_s, g_r, g_o):
+        L = _lib.lib()
+        sc, ro, op, c, ti, bs = ctx.saved_tensors
+        P, Tu, dev = sc.shape[0], bs.shape[0] - 1, sc.device
+        g = lambda t: None if t is None else t.to(torch.float32).contiguous()   # noqa: E731
+        g_m, g_s, g_r, g_o = g(g_m), g(g_s), g(g_r), g(g_o)
+        sinks = ctx.grad_sinks or {}
+        f32 = dict(dtype=torch.float32, device=dev)
+        shapes = {"xyz": (P, 3), "scaling": (P, 3), "rotation": (P, 4), "opacity": (P, 1), "coeff": (P, 16)}
+        out = {}
+        for k, shp in shapes.items():
+            t = sinks.get(k)
+            if t is not None and (t.numel() != shp[0] * shp[1] or not t.is_contiguous() or t.dtype != torch.float32):
+                raise RuntimeError(f"dynamic_gaussians grad_sinks[{k!r}] must be a contiguous float32 tensor of "
+                                   f"{shp[0] * shp[1]} elements")
+            out[k] = t if t is not None else torch.empty(*shp, **f32)
+        d_bases = torch.empty_like(bs)
+        with torch.cuda.device(dev):
+            order, inv = _birth_order(ti)
+            sws = torch.empty(L.rdg_deform_sorted_ws_bytes(P), dtype=torch.uint8, device=dev)
+            _lib.check(L.rdg_dyn_getter_backward(P, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bs), ctx.scale, _lib.ptr(sc),
+                                                 _lib.ptr(ro), _lib.ptr(op), _lib.ptr(g_m), _lib.ptr(g_s), _lib.ptr(g_r),
+                                                 _lib.ptr(g_o), _lib.ptr(out["xyz"]), _lib.ptr(out["scaling"]),
+                                                 _lib.ptr(out["rotation"]), _lib.ptr(out["opacity"]),
+                                                 _lib.ptr(out["coeff"]), _lib.ptr(d_bases), _lib.ptr(order), _lib.ptr(inv),
+                                                 _lib.ptr(sws), _lib.stream_ptr()), "rdg_dyn_getter_backward")
+        ret = [None if k in sinks and sinks[k] is not None else out[k] for k in ("xyz", "scaling", "rotation", "opacity")]
+        d_c = None if sinks.get("coeff") is not None else out["coeff"]
+        return ret[0], ret[1], ret[2], ret[3], d_c, None, d_bases, None, None
+
+
+def dynamic_getter_supported(num_basis: int, num_birth_times: int) -> bool:
+    return bool(_lib.lib().rdg_dyn_getter_supported(int(num_basis), int(num_birth_times)))
+
+
+def dynamic_gaussians(xyz, scaling, rotation, opacity, coeff, time_ind, bases, spatial_lr_scale, grad_sinks=None):
+    """Deformed + activated dynamic Gaussians in one kernel each way:
+    ``means3D = xyz + spatial_lr_scale * (c . dB)[:, :3]``, ``scales = exp(scaling)``,
+    ``rots = normalize(rotation) + (c . dB)[:, 3:]``, ``opac = sigmoid(opacity)``, ``dB = bases[-1] - bases[birth]``
+    -- what rodygs.py:68-113 builds from get_gaussian_deformation (rodygs_dynamic.py:122-138) and the getters
+    (rodygs_static.py:82-105).  ``bases`` [Tu+1,16,7] as for ``gaussian_deformation_packed``; ``coeff`` [P,16] or
+    [P,1,16].  ``grad_sinks``: optional {"xyz","scaling","rotation","opacity","coeff"} tensors the backward
+    overwrites instead of returning the gradients."""
+    c = coeff.reshape(coeff.shape[0], -1)
+    return _DynamicGetter.apply(xyz, scaling, rotation, opacity, c, time_ind, bases, spatial_lr_scale, grad_sinks)
+
+
 class DeformationField(nn.Module):
     """The deformation bookkeeping of ``DynRoDyGS`` (rodygs_dynamic.py:56-147) around the HIP op.
 

@@ -17,7 +17,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .deform import MLPBasisNetwork, gaussian_deformation, gaussian_deformation_packed
+from .deform import (MLPBasisNetwork, dynamic_gaussians, dynamic_getter_supported, gaussian_deformation,
+                     gaussian_deformation_packed)
 from .dp import BucketedAllReduce, FlatParams, allreduce_sum_, frame_for
 from .losses import fused_photometric_loss
 from .model_ops import activate_gaussians, pose_view_matrix
@@ -208,6 +209,14 @@ class DynamicScene:
         fp, net = self.fp, self.net
         # ONE pass of the MLP over the T birth-time rows + the frame's own time (row T)
         allb = net.motion_basis(self.emb_rows[frame])                     # [T+1,16,7]: table rows, then B(t)
+        if not self.full_losses and dynamic_getter_supported(allb.shape[1], allb.shape[0] - 1):
+            # deformation + activations in ONE kernel each way; all five parameter gradients go straight to the bucket
+            sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
+            sinks["coeff"] = fp["motion_coeff"].grad
+            xyz, scaling, rot, opacity = dynamic_gaussians(fp["xyz"], fp["scaling"], fp["rotation"], fp["opacity"],
+                                                           fp["motion_coeff"], self.time_ind, allb,
+                                                           self.spatial_lr_scale, grad_sinks=sinks)
+            return xyz, opacity, scaling, rot, fp["features"]
         coeff_sink = None if self.full_losses else {"coeff": fp["motion_coeff"].grad}
         dxyz, drot = gaussian_deformation_packed(fp["motion_coeff"], self.time_ind, allb, self.spatial_lr_scale,
                                                  grad_sinks=coeff_sink)

@@ -507,6 +507,42 @@ def test_fused_adam_over_two_flat_buckets_matches_torch_groups():
             rel_ok(f[k], want.detach(), tol=2e-6, what="adam " + k)
 
 
+@pytest.mark.parametrize("use_sinks", [False, True])
+def test_fused_dynamic_getter_equals_deformation_plus_activations(use_sinks):
+    """dynamic_gaussians (one kernel each way) vs gaussian_deformation_packed + activate_gaussians (each pinned to the
+    reference / oracle by its own tests): outputs and all gradients."""
+    from rodygs_amd.deform import dynamic_gaussians, gaussian_deformation_packed
+    from rodygs_amd.model_ops import activate_gaussians
+    g = torch.Generator().manual_seed(17)
+    P, Tu, B = 4099, 31, 16
+    raw = dict(xyz=torch.randn(P, 3, generator=g), scaling=torch.randn(P, 3, generator=g) - 2,
+               rotation=torch.randn(P, 4, generator=g), opacity=torch.randn(P, 1, generator=g),
+               coeff=0.2 * torch.randn(P, 1, B, generator=g), bases=torch.randn(Tu + 1, B, 7, generator=g))
+    ind = torch.randint(0, Tu, (P,), generator=g).to(DEV)
+    ws = [torch.randn(P, 3, generator=g).to(DEV), torch.randn(P, 3, generator=g).to(DEV),
+          torch.randn(P, 4, generator=g).to(DEV), torch.randn(P, 1, generator=g).to(DEV)]
+    a = {k: v.clone().to(DEV).requires_grad_(True) for k, v in raw.items()}
+    dx, dr = gaussian_deformation_packed(a["coeff"], ind, a["bases"], 3.5)
+    m, s_, r, o, _ = activate_gaussians(a["xyz"], dx, a["scaling"], a["rotation"], dr, a["opacity"], None, None)
+    ((m * ws[0]).sum() + (s_ * ws[1]).sum() + (r * ws[2]).sum() + (o * ws[3]).sum()).backward()
+    b = {k: v.clone().to(DEV).requires_grad_(True) for k, v in raw.items()}
+    sinks = None
+    if use_sinks:
+        sinks = {k: torch.full_like(b[k], float("nan")) for k in ("xyz", "scaling", "rotation", "opacity")}
+        sinks["coeff"] = torch.full((P, 1, B), float("nan"), device=DEV)
+    m2, s2, r2, o2 = dynamic_gaussians(b["xyz"], b["scaling"], b["rotation"], b["opacity"], b["coeff"], ind, b["bases"],
+                                       3.5, grad_sinks=sinks)
+    ((m2 * ws[0]).sum() + (s2 * ws[1]).sum() + (r2 * ws[2]).sum() + (o2 * ws[3]).sum()).backward()
+    for x, y, nm in ((m2, m, "means3D"), (s2, s_, "scales"), (r2, r, "rots"), (o2, o, "opac")):
+        rel_ok(x, y, tol=2e-6, what="fused getter " + nm)
+    for k in ("xyz", "scaling", "rotation", "opacity", "coeff"):
+        got = sinks[k] if use_sinks else b[k].grad
+        if use_sinks:
+            assert b[k].grad is None
+        rel_ok(got.reshape(a[k].grad.shape), a[k].grad, tol=2e-6, what="fused getter d_" + k)
+    rel_ok(b["bases"].grad, a["bases"].grad, tol=2e-5, what="fused getter d_bases")
+
+
 def test_deformation_field_matches_reference_golden_on_gpu():
     """End to end against the imported-reference golden (MLP in torch on the GPU + HIP per-Gaussian op)."""
     from rodygs_amd.deform import MLPBasisNetwork, gaussian_deformation
