@@ -224,7 +224,7 @@ def main():
                          "note": "compositing kernels are VALU/exp/LDS-bound (SURVEY.md §8d); the HBM fraction is "
                                  "reported because north_star asks for it"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # contract: the CPU leg runs at N = 1 only
             try:
                 res["cpu_baseline"] = cpu_baseline(scene, 3)
             except Exception as e:  # the baseline must never take the GPU number down with it
