@@ -3,6 +3,8 @@
 * ``activate_gaussians`` = the reference's model getters + the deformation add + the feature concat
   (/root/reference/src/model/rodygs_static.py:82-105, /root/reference/src/trainer/rodygs.py:68-113) in two HIP
   launches forward and two backward, instead of ~25 elementwise framework kernels and a cat.
+* ``gs_properties`` = ``get_GS_properties`` for a static + a dynamic cloud: both activated straight into the two row
+  segments of one set of rasterizer inputs (no ``torch.cat``).
 * ``pose_view_matrix`` = ``FixedCameraTorch.world_view_transform(...).transpose(0, 1)``
   (/root/reference/src/data/utils.py:161-170; the transpose is the "glm storage" of renderer.py:97-99) for one
   frame of the learnable pose tables, one launch each way instead of ~130 scalar-tensor kernels.
@@ -87,6 +89,81 @@ def activate_gaussians(xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest
     OVERWRITES those tensors with the parameter gradients instead of returning them through autograd -- used to
     write straight into the flat gradient bucket of ``rodygs_amd.dp.FlatParams`` (no AccumulateGrad copies)."""
     return _Activate.apply(xyz, dxyz, scaling, rotation, drot, opacity, f_dc, f_rest, grad_sinks)
+
+
+class _GSProperties(torch.autograd.Function):
+    """Static and dynamic clouds activated straight into the two segments of ONE set of rasterizer inputs."""
+
+    @staticmethod
+    def forward(ctx, s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_frest,
+                d_xyz, d_scaling, d_rotation, d_opacity, d_fdc, d_frest, dxyz, drot):
+        L = _lib.lib()
+        if not s_xyz.is_cuda:
+            raise RuntimeError("rodygs_amd.gs_properties: tensors must be on the GPU (no CPU fallback exists)")
+        dev = s_xyz.device
+        c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()   # noqa: E731
+        S = list(map(c, (s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_frest)))
+        D = list(map(c, (d_xyz, d_scaling, d_rotation, d_opacity, d_fdc, d_frest)))
+        dx, dr = c(dxyz), c(drot)
+        Ps, Pd = S[0].shape[0], D[0].shape[0]
+        K = 1 + S[5].shape[1]
+        if 1 + D[5].shape[1] != K:
+            raise RuntimeError("static and dynamic Gaussians must store the same number of SH coefficients")
+        P = Ps + Pd
+        f32 = dict(dtype=torch.float32, device=dev)
+        means3D, scales = torch.empty(P, 3, **f32), torch.empty(P, 3, **f32)
+        rots, opac, shs = torch.empty(P, 4, **f32), torch.empty(P, 1, **f32), torch.empty(P, K, 3, **f32)
+        outs = (means3D, scales, rots, opac, shs)
+        with torch.cuda.device(dev):
+            for n, first, src, a, b in ((Ps, 0, S, None, None), (Pd, Ps, D, dx, dr)):
+                if n == 0:
+                    continue
+                seg = [t[first:] for t in outs]      # a row offset into the shared buffers: nothing is copied
+                _lib.check(L.rdg_activate_forward(n, K, _lib.ptr(src[0]), _lib.ptr(a), _lib.ptr(src[1]), _lib.ptr(src[2]),
+                                                  _lib.ptr(b), _lib.ptr(src[3]), _lib.ptr(src[4]), _lib.ptr(src[5]),
+                                                  *[_lib.ptr(t) for t in seg], _lib.stream_ptr()),
+                           "rdg_activate_forward")
+        ctx.save_for_backward(S[1], S[2], S[3], D[1], D[2], D[3])
+        ctx.dims = (Ps, Pd, K)
+        ctx.shapes = [t.shape for t in (s_xyz, s_scaling, s_rotation, s_opacity, s_fdc, s_frest)] + \
+                     [t.shape for t in (d_xyz, d_scaling, d_rotation, d_opacity, d_fdc, d_frest)]
+        ctx.has_d = (dxyz is not None, drot is not None)
+        ctx.set_materialize_grads(False)
+        return means3D, scales, rots, opac, shs
+
+    @staticmethod
+    def backward(ctx, g_m, g_s, g_r, g_o, g_sh):
+        L = _lib.lib()
+        s_sc, s_ro, s_op, d_sc, d_ro, d_op = ctx.saved_tensors
+        Ps, Pd, K = ctx.dims
+        dev = s_sc.device
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()   # noqa: E731
+        g_m, g_s, g_r, g_o, g_sh = map(c, (g_m, g_s, g_r, g_o, g_sh))
+        grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        with torch.cuda.device(dev):
+            for n, first, par, out in ((Ps, 0, (s_sc, s_ro, s_op), grads[0:6]), (Pd, Ps, (d_sc, d_ro, d_op), grads[6:12])):
+                if n == 0:
+                    continue
+                gs = [None if t is None else t[first:] for t in (g_m, g_s, g_r, g_o, g_sh)]
+                _lib.check(L.rdg_activate_backward(n, K, _lib.ptr(par[0]), _lib.ptr(par[1]), _lib.ptr(par[2]),
+                                                   *[_lib.ptr(t) for t in gs], *[_lib.ptr(t) for t in out],
+                                                   _lib.stream_ptr()), "rdg_activate_backward")
+        d_dxyz = g_m[Ps:] if (ctx.has_d[0] and g_m is not None) else None      # identities: views, no kernel
+        d_drot = g_r[Ps:] if (ctx.has_d[1] and g_r is not None) else None
+        return (*grads, d_dxyz, d_drot)
+
+
+def gs_properties(static: Dict[str, torch.Tensor], dynamic: Dict[str, torch.Tensor],
+                  dyn_translation: Optional[torch.Tensor] = None, dyn_rotation: Optional[torch.Tensor] = None):
+    """``RoDyGSTrainer.get_GS_properties`` (/root/reference/src/trainer/rodygs.py:68-113) without its five
+    ``torch.cat`` copies (236 B per Gaussian per call): the static cloud's getters and the
+    dynamic cloud's getters + deformation add write directly into the two row segments (static first, as the
+    reference concatenates) of one set of rasterizer inputs; the backward hands each cloud its slice of the
+    gradients by pointer offset.  ``static`` / ``dynamic``: dicts with the raw parameters ``xyz, scaling, rotation,
+    opacity, f_dc, f_rest``.  Returns ``(xyz, opacity, scaling, rotation, features)`` in the reference's order."""
+    k = ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")
+    m, s_, r, o, sh = _GSProperties.apply(*[static[n] for n in k], *[dynamic[n] for n in k], dyn_translation, dyn_rotation)
+    return m, o, s_, r, sh
 
 
 class _PoseView(torch.autograd.Function):

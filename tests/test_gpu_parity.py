@@ -968,6 +968,46 @@ def test_fused_activations_match_reference_getters(use_sinks):
     rel_ok(dxg.grad, dxc.grad, tol=1e-6, what="d_dxyz"); rel_ok(drg.grad, drc.grad, tol=1e-6, what="d_drot")
 
 
+def test_gs_properties_static_plus_dynamic_without_cat():
+    """gs_properties (static ‖ dynamic written into one set of buffers) vs the reference's expression: getters,
+    deformation add, torch.cat (rodygs.py:68-113), values and gradients of every raw parameter and of the deltas."""
+    import torch.nn.functional as F
+    from rodygs_amd.model_ops import gs_properties
+    g = torch.Generator().manual_seed(23)
+    Ps, Pd, K = 1777, 2049, 16
+    def cloud(P):
+        return dict(xyz=torch.randn(P, 3, generator=g), scaling=torch.randn(P, 3, generator=g) - 2,
+                    rotation=torch.randn(P, 4, generator=g), opacity=torch.randn(P, 1, generator=g),
+                    f_dc=torch.randn(P, 1, 3, generator=g), f_rest=torch.randn(P, K - 1, 3, generator=g))
+    st, dy = cloud(Ps), cloud(Pd)
+    dxyz, drot = 0.1 * torch.randn(Pd, 3, generator=g), 0.1 * torch.randn(Pd, 4, generator=g)
+    P = Ps + Pd
+    ws = [torch.randn(P, 3, generator=g), torch.randn(P, 1, generator=g), torch.randn(P, 3, generator=g),
+          torch.randn(P, 4, generator=g), torch.randn(P, K, 3, generator=g)]
+
+    def leaves(dev):
+        return ({k: v.clone().to(dev).requires_grad_(True) for k, v in st.items()},
+                {k: v.clone().to(dev).requires_grad_(True) for k, v in dy.items()},
+                dxyz.clone().to(dev).requires_grad_(True), drot.clone().to(dev).requires_grad_(True))
+
+    s0, d0, x0, r0 = leaves("cpu")
+    ref = (torch.cat([s0["xyz"], d0["xyz"] + x0]), torch.cat([torch.sigmoid(s0["opacity"]), torch.sigmoid(d0["opacity"])]),
+           torch.cat([torch.exp(s0["scaling"]), torch.exp(d0["scaling"])]),
+           torch.cat([F.normalize(s0["rotation"]), F.normalize(d0["rotation"]) + r0]),
+           torch.cat([torch.cat([s0["f_dc"], s0["f_rest"]], 1), torch.cat([d0["f_dc"], d0["f_rest"]], 1)]))
+    sum((a * w).sum() for a, w in zip(ref, ws)).backward()
+    s1, d1, x1, r1 = leaves(DEV)
+    out = gs_properties(s1, d1, x1, r1)
+    sum((a * w.to(DEV)).sum() for a, w in zip(out, ws)).backward()
+    for a, b, nm in zip(out, ref, ("xyz", "opacity", "scaling", "rotation", "features")):
+        rel_ok(a, b, tol=2e-6, what="gs_properties " + nm)
+    for k in st:
+        rel_ok(s1[k].grad, s0[k].grad, tol=2e-6, what="static d_" + k)
+        rel_ok(d1[k].grad, d0[k].grad, tol=2e-6, what="dynamic d_" + k)
+    rel_ok(x1.grad, x0.grad, tol=1e-6, what="d_translation")
+    rel_ok(r1.grad, r0.grad, tol=1e-6, what="d_rotation_delta")
+
+
 def test_pose_view_matrix_matches_reference_camera():
     """pose_view_matrix vs the torch restatement of FixedCameraTorch.world_view_transform (pinned to the reference by
     tests/golden/camera_golden.npz), forward and gradients, including non-unit quaternions."""
