@@ -47,6 +47,18 @@ class DensifyStats:
                                                         radii[update_filter].to(self.max_radii2D.dtype))
 
 
+def allreduce_stats_(stats: "DensifyStats") -> None:
+    """Frame-DP: every rank saw a different camera, so before densifying the statistics are combined
+    -- gradient accumulators and visit counts summed, screen radii maxed -- and every rank then takes the same
+    clone / split / prune decisions from identical data."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    dist.all_reduce(stats.xyz_gradient_accum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(stats.denom, op=dist.ReduceOp.SUM)
+    dist.all_reduce(stats.max_radii2D, op=dist.ReduceOp.MAX)
+
+
 @dataclass
 class DensifyResult:
     fp: FlatParams

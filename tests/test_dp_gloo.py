@@ -53,8 +53,11 @@ def _worker(rank, world, port, outdir):
     sync.ready("shs")                       # idempotent
     sync.finish()
     pieces = list(sync.drain())
+    from rodygs_amd.densify import DensifyStats, allreduce_stats_
+    stats = DensifyStats(torch.full((4, 1), float(rank + 1)), torch.full((4, 1), 1.0), torch.tensor([1.0, 5.0, 2.0, 0.0]) * (rank + 1))
+    allreduce_stats_(stats)
     allreduce_sum_(fp.flat_grad, small)
-    torch.save({"flat": fp.flat_grad.clone(), "small": small, "offsets": fp.offsets, "flat2": fp2.flat_grad.clone(),
+    torch.save({"stats": (stats.xyz_gradient_accum, stats.denom, stats.max_radii2D), "flat": fp.flat_grad.clone(), "small": small, "offsets": fp.offsets, "flat2": fp2.flat_grad.clone(),
                 "pieces": pieces, "side": side,
                 "frames": [frame_for(s, rank, world, list(range(7))) for s in range(7)]},
                os.path.join(outdir, f"r{rank}.pt"))
@@ -80,6 +83,9 @@ def test_flat_bucket_allreduce_equals_sum_of_single_rank_grads():
     assert torch.equal(r0["flat2"], r0["flat"]) and torch.equal(r1["flat2"], r0["flat"])
     assert r0["pieces"] == [["shs"], ["means3D"], ["opacities", "scales", "rotations"], None]
     assert torch.equal(r0["side"], torch.full((11,), 3.0))
+    acc, den, rad = r0["stats"]
+    assert torch.equal(acc, torch.full((4, 1), 3.0)) and torch.equal(den, torch.full((4, 1), 2.0))
+    assert torch.equal(rad, torch.tensor([2.0, 10.0, 4.0, 0.0]))
     assert float(g0["means3D"].sub(g1["means3D"]).abs().max()) > 0  # the two frames really differ
     assert torch.equal(r0["small"][0], torch.full((5,), 3.0)) and torch.equal(r1["small"][1], torch.full((2, 3), 30.0))
     # strided frame assignment: the two ranks never render the same frame in a step and cover the permutation
