@@ -184,6 +184,7 @@ class DynamicScene:
         self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
         self.gt = {}
         self.gt_depth = {}
+        self.stats = None        # DensifyStats once track_densification() is called
         # full_losses: the whole loss set of the reference's dynamic sub-step (config 5,
         # configs/train/train_kubric_mrig.yaml:186-232): photometric + motion L1 / sparsity / basis regularisers +
         # global and local Pearson depth + rigidity every 5th step.  Several losses then feed the same parameters, so
@@ -239,7 +240,29 @@ class DynamicScene:
                                                               # frame-DP: the SH gradient goes on the wire while the
                                                               # rest of backward is still running
                                                               "on_shs_ready": lambda: self.sync.ready("features")})
+        self._last_radii = out[4]
         return out, m2
+
+    # ---- densification in the loop (rodygs.py:319-362) ----------------------------------------------------------
+    def track_densification(self) -> None:
+        from .densify import DensifyStats
+        self.stats = DensifyStats.zeros(self.P, self.device)
+
+    def densify(self, max_grad: float = 0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
+                max_screen_size=None, percent_dense: float = 0.01) -> dict:
+        """densify_and_prune over the flat bucket, then re-point everything that referred to the old buffers
+        (gradient sinks live in the new bucket, birth indices follow the Gaussians, exchange object rebuilt)."""
+        from .densify import allreduce_stats_, densify_and_prune
+        if self.stats is None:
+            raise RuntimeError("call track_densification() first")
+        allreduce_stats_(self.stats)
+        res = densify_and_prune(self.fp, self.stats, {"time_ind": self.time_ind}, max_grad, min_opacity,
+                                extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense)
+        self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
+        self.P = self.fp.shapes["xyz"][0]
+        self.m2 = torch.zeros(self.P, 3, device=self.device, requires_grad=True)
+        self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
+        return {"P": self.P, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned}
 
     def make_ground_truth(self, target_scene: dict, frames):
         """GT images = HIP render of a different-seed static cloud from each frame's camera."""
@@ -298,6 +321,9 @@ class DynamicScene:
             out, _ = self.render(frame)
             loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
+        if self.stats is not None:
+            # add_densification_stats: screen-space gradient norm of the Gaussians visible in this frame
+            self.stats.add(self.m2.grad, self._last_radii > 0, self._last_radii)
         if world > 1:
             # overlapped exchange: pieces arrive in issue order; Adam steps each piece while the next one is in flight
             self.sync.finish()

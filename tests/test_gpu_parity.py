@@ -851,6 +851,28 @@ def test_train_step_runs_and_reduces_loss():
     assert float(ds.cam_q.grad.abs().sum()) > 0 and ds.net.head_w1.grad is not None
 
 
+def test_train_loop_with_densification():
+    """Build-plan item 8: the train step with densify-and-prune in the loop -- statistics gathered from the
+    rasterizer's means2D gradient and radii, the flat bucket rebuilt (Adam moments carried for survivors), sinks and
+    birth indices re-pointed, and the optimisation carries on."""
+    from rodygs_amd.trainstep import DynamicScene
+    sc = O.synthetic_scene(20000, 320, 240, 3, seed=5)
+    tgt = O.synthetic_scene(5000, 320, 240, 3, seed=6)
+    ds = DynamicScene(sc, num_frames=8, device=DEV)
+    ds.make_ground_truth(tgt, range(8))
+    ds.track_densification()
+    losses = [float(ds.train_step(s_, perm=list(range(8)))) for s_ in range(24)]
+    assert float(ds.stats.denom.sum()) > 0 and float(ds.stats.max_radii2D.max()) > 0
+    m_before = ds.fp.exp_avg_sq.abs().sum().item()
+    info = ds.densify(max_grad=2e-5, min_opacity=0.05, percent_dense=0.002)
+    assert info["cloned"] > 0 and info["split"] > 0 and info["pruned"] > 0 and info["P"] == ds.fp.shapes["xyz"][0] != 20000
+    assert ds.time_ind.shape[0] == info["P"] and 0 < ds.fp.exp_avg_sq.abs().sum().item() <= m_before
+    assert float(ds.stats.denom.sum()) == 0.0
+    losses += [float(ds.train_step(s_, perm=list(range(8)))) for s_ in range(24, 48)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-8:]) < np.mean(losses[:8])
+    assert float(ds.fp["xyz"].grad.abs().sum()) > 0 and ds.m2.grad.shape[0] == info["P"]
+
+
 def test_full_loss_train_step_runs_and_reduces_loss():
     """Config-5 loss set in the loop: photometric + Pearson depth (global + local) + motion regularisers + rigidity on
     the HIP K-NN every 5th step; gradients of several losses accumulate into the same flat segments."""
