@@ -507,14 +507,17 @@ int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const
 __global__ void __launch_bounds__(256)
 rdg_rigidity_dp_kernel(long long n, int K, int nt, const float4* __restrict__ pos_t, const long long* __restrict__ nn_idx,
                        const float* __restrict__ d2, const long long* __restrict__ rev_off,
-                       const long long* __restrict__ rev_edge, float eps2, double* __restrict__ loss_sum,
-                       float4* __restrict__ G_t, float* __restrict__ d_d2) {
+                       const long long* __restrict__ rev_edge, const long long* __restrict__ orig, float eps2,
+                       double* __restrict__ loss_sum, float4* __restrict__ G_t, float* __restrict__ d_d2) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
     double local = 0.0;
     if (tid < n * nt) {
         const long long tau = tid / n, i = tid - tau * n;
         const float4* slab = pos_t + tau * n;          // positions of all sampled Gaussians at this time, 16 B each
         const float4 p = slab[i];
+        // `orig` (optional): the sample is stored in a cache-friendly order (neighbours close in memory); the
+        // reference's pairing of gaps with d2 entries is defined on the ORIGINAL sample order, so rows use orig[]
+        const long long i_row = orig ? orig[i] : i;
         float gx = 0.f, gy = 0.f, gz = 0.f;            // d/d(pos_i(tau))
         // (1) edges leaving i: the loss terms themselves, -u on this end, the d2 gradient
         long long row_prev = -1;
@@ -523,7 +526,7 @@ rdg_rigidity_dp_kernel(long long n, int K, int nt, const float4* __restrict__ po
             const float4 q = slab[nn_idx[i * K + k]];
             const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
             const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-            const long long row = ((tau * n + i) * K + k) / nt;
+            const long long row = ((tau * n + i_row) * K + k) / nt;
             const float diff = gap - d2[row];
             const float term = sqrtf(diff * diff + eps2);
             local += (double)term;
@@ -546,7 +549,7 @@ rdg_rigidity_dp_kernel(long long n, int K, int nt, const float4* __restrict__ po
             const float4 q = slab[src];
             const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
             const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-            const long long row = ((tau * n + src) * K + k) / nt;
+            const long long row = ((tau * n + (orig ? orig[src] : src)) * K + k) / nt;
             const float diff = gap - d2[row];
             const float s = diff / sqrtf(diff * diff + eps2);
             const float ig = gap > 0.f ? s / gap : 0.f;
@@ -564,8 +567,9 @@ rdg_rigidity_dp_kernel(long long n, int K, int nt, const float4* __restrict__ po
 }
 
 extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const float* pos_t4, const int64_t* nn_idx,
-                                       const float* d2, const int64_t* rev_off, const int64_t* rev_edge, float eps,
-                                       double* loss_sum, float* G_t4, float* d_d2, void* stream) {
+                                       const float* d2, const int64_t* rev_off, const int64_t* rev_edge,
+                                       const int64_t* orig, float eps, double* loss_sum, float* G_t4, float* d_d2,
+                                       void* stream) {
     if (n <= 0 || K <= 0 || nt <= 0) return rdg_set_error("rigidity_dp: bad sizes");
     if ((((uintptr_t)pos_t4) | ((uintptr_t)G_t4)) & 15) return rdg_set_error("rigidity_dp: buffers must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -575,6 +579,6 @@ extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const f
     const long long total = n * nt;
     hipLaunchKernelGGL(rdg_rigidity_dp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K, nt,
                        (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
-                       (const long long*)rev_edge, eps * eps, loss_sum, (float4*)G_t4, d_d2);
+                       (const long long*)rev_edge, (const long long*)orig, eps * eps, loss_sum, (float4*)G_t4, d_d2);
     return rdg_check_hip(hipGetLastError(), "rigidity_dp launch");
 }

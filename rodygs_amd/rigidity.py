@@ -33,6 +33,20 @@ def charbonnier_bc(x: torch.Tensor, y: torch.Tensor, eps: float = 1e-6) -> torch
     return torch.sqrt((x - y).pow(2) + eps ** 2).sum() / (x.shape[0] * x.shape[1])
 
 
+def _curve_order(p: torch.Tensor) -> torch.Tensor:
+    """Permutation that sorts points [n,3] along a 30-bit Morton curve (a handful of elementwise ops + one sort)."""
+    lo, hi = p.min(dim=0).values, p.max(dim=0).values
+    q = ((p - lo) / (hi - lo).clamp_min(1e-12) * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    return torch.argsort((spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2]))
+
+
 class _FusedDistancePreserving(torch.autograd.Function):
     """sum over (tau, i, k) of Charbonnier(gap, d2_flat[f // nt]) and its gradients in one HIP kernel
     (rdg_rigidity_dp_forward): no [t,n,K,3] intermediates.  pos_t [nt,n,3] = canonical position + translation."""
@@ -47,8 +61,14 @@ class _FusedDistancePreserving(torch.autograd.Function):
         dd = d2.detach().to(torch.float32).contiguous()
         K = ii.shape[-1]
         with torch.cuda.device(dev):
+            # the sample is a random subset: store it along a space-filling curve so that a Gaussian's neighbours
+            # (and the threads next to it) gather from nearby addresses (4.6 -> ~1.5 ms at n = 500 k, t = 25)
+            order = _curve_order(pos_t[0].detach())
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(n, device=dev)
+            ii = rank[ii[order]].contiguous()                       # neighbour lists in stored order
             p4 = torch.zeros(nt, n, 4, dtype=torch.float32, device=dev)
-            p4[..., :3] = pos_t.detach()
+            p4[..., :3] = pos_t.detach()[:, order]
             # reverse adjacency of the K-NN graph: edge ids (i*K + k) grouped by their destination
             flat = ii.reshape(-1)
             rev_edge = torch.argsort(flat, stable=True).contiguous()
@@ -58,15 +78,16 @@ class _FusedDistancePreserving(torch.autograd.Function):
             G4 = torch.empty_like(p4)
             d_d2 = torch.empty_like(dd)
             _lib.check(L.rdg_rigidity_dp_forward(n, K, nt, _lib.ptr(p4), _lib.ptr(ii), _lib.ptr(dd), _lib.ptr(rev_off),
-                                                 _lib.ptr(rev_edge), float(eps), _lib.ptr(loss), _lib.ptr(G4),
-                                                 _lib.ptr(d_d2), _lib.stream_ptr()), "rdg_rigidity_dp_forward")
-        ctx.save_for_backward(G4, d_d2)
+                                                 _lib.ptr(rev_edge), _lib.ptr(order), float(eps), _lib.ptr(loss),
+                                                 _lib.ptr(G4), _lib.ptr(d_d2), _lib.stream_ptr()),
+                       "rdg_rigidity_dp_forward")
+        ctx.save_for_backward(G4, d_d2, rank)
         return loss[0].to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        G4, d_d2 = ctx.saved_tensors
-        return G4[..., :3] * g, None, d_d2 * g, None
+        G4, d_d2, rank = ctx.saved_tensors
+        return G4[:, rank, :3] * g, None, d_d2 * g, None
 
 
 class RigidityLoss(nn.Module):
