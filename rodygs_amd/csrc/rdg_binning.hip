@@ -383,28 +383,24 @@ rdg_tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_cnt, uint2* 
         for (int i = threadIdx.x; i < n_tiles; i += 1024) { ranges[i] = make_uint2(0u, 0u); tile_fill[i] = 0u; }
         return;
     }
+    // every thread owns a run of consecutive tiles (local sums), ONE block-level scan of the 1024 run totals, then the
+    // runs are written out: two barriers in all instead of two per 1024 tiles
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < n_tiles ? tile_cnt[i] : 0u;
-        const uint32_t inc = rdg_wave_scan_incl(v);
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
-        const uint32_t carry = carry_s;
-        if (i < n_tiles) {
-            const uint32_t st = carry + woff + inc - v;
-            ranges[i] = v ? make_uint2(st, st + v) : make_uint2(0u, 0u);
-            tile_fill[i] = 0u;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
+    const int per = (n_tiles + 1023) / 1024;
+    const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
+    uint32_t mine = 0;
+    for (int i = t0; i < t1; ++i) mine += tile_cnt[i];
+    const uint32_t inc = rdg_wave_scan_incl(mine);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (uint32_t k = 0; k < w; ++k) run += wtot[k];
+    for (int i = t0; i < t1; ++i) {
+        const uint32_t v = tile_cnt[i];
+        ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
+        tile_fill[i] = 0u;
+        run += v;
     }
 }
 
