@@ -313,13 +313,6 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         {
             const int k = kbase - tid;
             if (k >= 0) {
-                const uint32_t id = point_list[range.x + k];
-                const RdgRec* p = rec + id;
-                const float4 q0 = p->q0, q1 = p->q1;
-                sId[tid] = id;
-                sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
-                sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
-                sQ2[tid] = p->q2;
                 // a quadrant whose pixels all stopped before this list position never needs the splat ...
                 qbits = (uint32_t)(k < m0) | ((uint32_t)(k < m1) << 1) | ((uint32_t)(k < m2) << 2) |
                         ((uint32_t)(k < m3) << 3);
@@ -329,6 +322,15 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const int hb = k & 63;
                 qbits &= (uint32_t)((hw[0] >> hb) & 1ull) | ((uint32_t)((hw[1] >> hb) & 1ull) << 1) |
                          ((uint32_t)((hw[2] >> hb) & 1ull) << 2) | ((uint32_t)((hw[3] >> hb) & 1ull) << 3);
+                if (qbits) {   // nobody will look at the other slots: skip their record gathers
+                    const uint32_t id = point_list[range.x + k];
+                    const RdgRec* p = rec + id;
+                    const float4 q0 = p->q0, q1 = p->q1;
+                    sId[tid] = id;
+                    sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
+                    sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
+                    sQ2[tid] = p->q2;
+                }
             }
         }
 #pragma unroll
