@@ -316,6 +316,15 @@ __global__ void rdg_copy_pairs_kernel(const uint64_t* __restrict__ k, const uint
 #define RDG_TSORT_SMALL 1024
 #define RDG_TSORT_LDS 8192
 
+// position of tile (x, y) on the Z curve of the counter array (rdg_cnt_entries)
+__device__ __forceinline__ uint32_t rdg_zidx(uint32_t x, uint32_t y) {
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    y = (y | (y << 8)) & 0x00FF00FFu; y = (y | (y << 4)) & 0x0F0F0F0Fu; y = (y | (y << 2)) & 0x33333333u;
+    y = (y | (y << 1)) & 0x55555555u;
+    return x | (y << 1);
+}
+
 template <int MODE>  // 0 = count, 1 = scatter
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
 rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
@@ -365,7 +374,7 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
         if (MODE == 0) {
             // the counting atomic already hands every instance a unique rank inside its tile: keep it (coalesced
             // 4-B store in emission order), and the scatter pass needs no second round of atomics
-            rank_buf[first + k] = atomicAdd(&tile_cnt[tile], 1u);
+            rank_buf[first + k] = atomicAdd(&tile_cnt[rdg_zidx((uint32_t)(sX0[lo] + rx), (uint32_t)(sY0[lo] + ry))], 1u);
         } else {
             const uint32_t pos = ranges[tile].x + rank_buf[first + k];
             comp[pos] = ((uint64_t)sDepth[lo] << 32) | (uint64_t)(blockIdx.x * RDG_PRE_BLOCK + lo);
@@ -375,7 +384,7 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
 
 // exclusive scan of tile_cnt -> ranges (untouched tiles stay (0,0), as identifyTileRanges leaves them); clears cursors
 __global__ void __launch_bounds__(1024)
-rdg_tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
+rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
                      uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered) {
     if ((long long)(*num_rendered) > capacity) {
         // capacity overflow: leave EVERY tile empty, so the compositing kernels (forward and backward) see a valid,
@@ -390,14 +399,14 @@ rdg_tile_scan_kernel(int n_tiles, const uint32_t* __restrict__ tile_cnt, uint2* 
     const int per = (n_tiles + 1023) / 1024;
     const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
     uint32_t mine = 0;
-    for (int i = t0; i < t1; ++i) mine += tile_cnt[i];
+    for (int i = t0; i < t1; ++i) mine += tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))];
     const uint32_t inc = rdg_wave_scan_incl(mine);
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
     uint32_t run = inc - mine;
     for (uint32_t k = 0; k < w; ++k) run += wtot[k];
     for (int i = t0; i < t1; ++i) {
-        const uint32_t v = tile_cnt[i];
+        const uint32_t v = tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))];
         ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
         tile_fill[i] = 0u;
         run += v;
@@ -504,14 +513,14 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                                vals_unsorted_copy, (long long)capacity, num_rendered);
         }
         rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
-        hipError_t em = hipMemsetAsync(tile_cnt, 0, (size_t)n_tiles * 4, s);
+        hipError_t em = hipMemsetAsync(tile_cnt, 0, rdg_cnt_entries(d.gx, d.gy) * 4, s);
         if (em != hipSuccess) return rdg_check_hip(em, "tile_cnt memset");
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered);
-        hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_cnt, ranges, tile_fill,
+        hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,

@@ -116,15 +116,24 @@ struct RdgImageLayout {
     size_t tile_fill;  // uint32[n_tiles]  scatter cursors
     size_t total;
 };
+// The per-tile instance counters are indexed along a Z curve over the tile grid: the 2x2 .. 3x3 tiles one Gaussian
+// touches then share one or two 64-B lines, and the counting atomics of a wave merge better than with row-major rows
+// 480 B apart.  The curve covers the power-of-two square around the grid.
+static inline size_t rdg_cnt_entries(int32_t gx, int32_t gy) {
+    size_t side = 1;
+    while ((int64_t)side < gx || (int64_t)side < gy) side <<= 1;
+    return side * side;
+}
 static inline RdgImageLayout rdg_image_layout(int32_t H, int32_t W) {
     RdgImageLayout L;
     size_t hw = (size_t)H * W;
     size_t nt = (size_t)((W + RDG_TILE - 1) / RDG_TILE) * ((H + RDG_TILE - 1) / RDG_TILE);
+    const size_t nz = rdg_cnt_entries((W + RDG_TILE - 1) / RDG_TILE, (H + RDG_TILE - 1) / RDG_TILE);
     size_t o = 0;
     L.final_T = o;    o = rdg_align_up(o + hw * 4, 256);
     L.n_contrib = o;  o = rdg_align_up(o + hw * 4, 256);
     L.ranges = o;     o = rdg_align_up(o + nt * 8, 256);
-    L.tile_cnt = o;   o = rdg_align_up(o + nt * 4, 256);
+    L.tile_cnt = o;   o = rdg_align_up(o + nz * 4, 256);
     L.tile_fill = o;  o = rdg_align_up(o + nt * 4, 256);
     L.total = o;
     return L;
