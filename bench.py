@@ -7,9 +7,11 @@
 Workload (BASELINE.json configs[2], the one the metric is quoted on): 1 M dynamic Gaussians + time-deformation
 MLP, 1920x1080, SH degree 3, 100-frame synthetic video (SURVEY.md §8d generator, seed 777).  A "step" is one
 full train step on one camera per GPU: deformation -> rasterize forward -> 0.8 L1 + 0.2 D-SSIM -> backward ->
-(N > 1: one RCCL all-reduce of the flat gradient bucket) -> fused Adam over every parameter.  Inputs are resident
-in HBM before the timed region.  Weak scaling: every GPU renders its own frame of the replicated cloud, value =
-frames (train steps x GPUs) per second.
+fused Adam over every parameter.  Inputs are resident in HBM before the timed region.  Weak scaling: every GPU
+renders its own frame, value = frames (train steps x GPUs) per second.  N > 1 (--dp-mode): "shard" (default) keeps
+the Gaussians sharded over the ranks and exchanges 64-byte splat records / gradient rows with two all-to-alls per
+step (rodygs_amd/sharded.py); "allreduce" replicates the cloud and all-reduces the flat gradient bucket (RCCL,
+overlapped with backward and Adam).
 
 The JSON line also carries
   roofline     : the dominant kernel (render backward) -- ALGORITHMIC bytes per launch / its average duration,
@@ -80,6 +82,10 @@ def main():
     ap.add_argument("--full-losses", action="store_true",
                     help="config-5 loss set (depth, motion regularisers, rigidity every 5th step) instead of the "
                          "photometric-only step the headline metric is quoted on")
+    ap.add_argument("--dp-mode", choices=["shard", "allreduce"], default=os.environ.get("RDG_DP_MODE", "shard"),
+                    help="N > 1: 'shard' = Gaussians sharded over the ranks, splat records / gradient rows exchanged "
+                         "with two all-to-alls (rodygs_amd/sharded.py); 'allreduce' = replicated cloud, overlapped "
+                         "bucketed all-reduce of the 75-float-per-Gaussian gradient")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,8 +95,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the rodygs_amd hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RDG_FORCE_SHARD=1: run the sharded step on a 1-rank group too (single-GPU check of the collective path)
+    force_shard = bool(os.environ.get("RDG_FORCE_SHARD")) and world == 1
+    if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from oracle import rasterizer_oracle as O          # synthetic-scene generator + cpu_baseline only
@@ -107,6 +116,15 @@ def main():
     gt_frames = sorted(set(gt_frames))
     ds.make_ground_truth(target, gt_frames)
     perm = gt_frames
+    sharded = (world > 1 or force_shard) and args.dp_mode == "shard" and not args.full_losses
+    if sharded:
+        from rodygs_amd.sharded import ShardedDynamicScene
+        ss = ShardedDynamicScene.from_replica(ds, rank, world)
+        ds.fp = ds.sync = ds.m2 = None           # the replica's full-size buffers are not needed any more
+        torch.cuda.empty_cache()
+        train_step = lambda st_: ss.train_step(st_, perm)                       # noqa: E731
+    else:
+        train_step = lambda st_: ds.train_step(st_, rank, world, perm)          # noqa: E731
 
     def sync():
         if world > 1:
@@ -115,7 +133,7 @@ def main():
 
     step = 0
     for _ in range(args.warmup):
-        ds.train_step(step, rank, world, perm)
+        train_step(step)
         step += 1
     from rodygs_amd import rasterizer
     # After the warm-up the instance count D of every frame is known to within a few percent: stop reading it back
@@ -129,7 +147,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = ds.train_step(step, rank, world, perm)
+        loss = train_step(step)
         step += 1
     sync()
     dt = time.perf_counter() - t0
@@ -138,7 +156,7 @@ def main():
     _lib.timing_enable(True)
     _lib.timing_reset()
     for _ in range(min(5, args.steps)):
-        ds.train_step(step, rank, world, perm)
+        train_step(step)
         step += 1
     sync()
     rasterizer.poll_overflow(block=True)
@@ -152,10 +170,14 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        D = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
-        with torch.no_grad():
-            out, _ = ds.render(perm[0])
-            V = int((out[4] > 0).sum().item())
+        if sharded:
+            D = int(rasterizer._CAPACITY_HINT.get(ss.key, 0))
+            V = ss.visible_count()
+        else:
+            D = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
+            with torch.no_grad():
+                out, _ = ds.render(perm[0])
+                V = int((out[4] > 0).sum().item())
         fps = args.steps * world / dt
         per_stage = {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}
         # dominant kernel: render backward.  Algorithmic bytes per launch (DESIGN.md §5 / SURVEY.md §8d):
@@ -207,7 +229,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{P} dynamic Gaussians + deformation MLP, {W}x{H}, SH3, {args.frames}-frame "
                                    f"synthetic video (BASELINE configs[2])", "points": P, "width": W, "height": H,
-                       "frames": args.frames, "parallelism": f"frame-dp{world}", "num_rendered_D": D, "visible_V": V,
+                       "frames": args.frames,
+                       "parallelism": (f"frame-dp{world}, Gaussian-sharded (records/gradient rows all-to-all)" if sharded
+                                       else f"frame-dp{world}" + (", replicated + bucketed all-reduce" if world > 1 else "")), "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric"},
             "gaussians_per_s": fps * P,
             "loss": float(loss.item()),
@@ -231,7 +255,7 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

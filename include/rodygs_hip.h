@@ -41,6 +41,7 @@ extern "C" {
 #endif
 
 #define RDG_ABI_VERSION 1
+#define RDG_MAX_VIEWS 16   /* cameras per step in the *_views entry points */
 
 /* Mirror of GaussianRasterizationSettings (renderer.py:50-63) + sizes. Host struct, passed by pointer. */
 typedef struct RdgRasterSettings {
@@ -114,6 +115,54 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
                            const float* grad_out_alpha, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dshs, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3D, float* dL_dviewmatrix, void* stream);
+
+/* ---- the rasterizer in two halves (Gaussian-sharded frame-DP, rodygs_amd/sharded.py) ----------------------------
+ * rdg_rasterize_forward == rdg_preprocess_forward + rdg_composite_forward, rdg_rasterize_backward ==
+ * rdg_composite_backward + rdg_preprocess_backward.  The halves meet in two row formats that can cross the wire:
+ *   - splat records: the first P*64 bytes of geom_ws, one 64-B row per Gaussian
+ *       (px, py, conic_a, conic_b | conic_c, opacity, depth, radius as int bits | r, g, b, - | nx, ny, nz, -);
+ *   - gradient rows: the first P*64 bytes of grad_ws, one 16-float row per Gaussian
+ *       (dL/dndc_x, dL/dndc_y, dL/dconic a b c, dL/dopacity, dL/drgb, dL/ddepth, pad).
+ * A rank that owns a slice of the Gaussians runs the per-Gaussian halves for every camera of the step; the rank that
+ * owns a camera gathers that camera's records into one geom_ws, calls rdg_geom_from_records (tile counts, radii and
+ * the instance count D rebuilt from the records alone) and runs the compositing halves over all P records.        */
+int rdg_geom_from_records(const RdgRasterSettings* s_host, void* geom_ws, int32_t* radii, int32_t* num_rendered_dev,
+                          void* stream);
+int rdg_composite_forward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws, const int32_t* radii,
+                          void* binning_ws, int64_t capacity, void* image_ws, const int32_t* num_rendered_dev,
+                          float* out_color, float* out_depth, float* out_normal, float* out_alpha, void* stream);
+/* zeroes the gradient rows of grad_ws, then accumulates the compositing backward into them                         */
+int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
+                           const void* binning_ws, int64_t capacity, const void* image_ws,
+                           const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
+                           void* grad_ws, void* stream);
+/* gradient rows (grad_ws) -> input gradients; geom_ws / radii are those of THIS rank's rdg_preprocess_forward      */
+int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const int32_t* radii, const void* geom_ws, void* grad_ws,
+                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                            float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                            float* dL_dviewmatrix, void* stream);
+
+/* The per-Gaussian halves for the nviews (<= RDG_MAX_VIEWS) cameras of one step over the SAME P Gaussians (s_host->P),
+ * whose time-dependent inputs are stacked with a row stride of stride_rows (multiple of 256, >= P): means3D
+ * [nviews,stride,3], rotations [nviews,stride,4]; shs [P,M,3], scales [P,3] and opacities [P] are shared;
+ * viewmatrices [nviews,16].  geom_ws = rdg_geom_bytes(nviews*stride), radii [nviews*stride], grad_ws = rdg_grad_bytes(nviews*stride):
+ * camera v owns rows [v*stride, v*stride + P) of each, so the records / gradient rows of all cameras are one
+ * contiguous buffer that an equal-split all-to-all can send / fill.  Rows [P, stride) of a camera are never written:
+ * zero the records once and they stay invisible.  Backward outputs are all stacked per camera (dL_dshs
+ * [nviews,stride,M,3], dL_dscales [nviews,stride,3], dL_dopacities [nviews,stride]) and are overwritten on rows [0, P) of each camera; dL_dviewmatrices [nviews,16].           */
+int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                 const float* means3D, const float* shs, const float* opacities, const float* scales,
+                                 const float* rotations, const float* viewmatrices, const float* projmatrix,
+                                 void* geom_ws, int32_t* radii, void* stream);
+int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                  const float* means3D, const float* shs, const float* opacities, const float* scales,
+                                  const float* rotations, const float* viewmatrices, const float* projmatrix,
+                                  const int32_t* radii, const void* geom_ws, void* grad_ws, float* dL_dmeans3D,
+                                  float* dL_dmeans2D, float* dL_dshs, float* dL_dopacities, float* dL_dscales,
+                                  float* dL_drotations, float* dL_dviewmatrices, void* stream);
 
 /* ---- stage entry points (bit-exact parity tests) -------------------------------------------------------- */
 /* Runs only the per-Gaussian stage; fills geom_ws, radii, and *num_rendered_dev.                            */
@@ -197,6 +246,25 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
                             float* d_xyz, float* d_scaling, float* d_rotation, float* d_opacity, float* d_coeff,
                             float* d_bases, const int32_t* order, const int32_t* inv_order, void* sorted_ws,
                             void* stream);
+
+/* The fused getter for the nviews (<= RDG_MAX_VIEWS) camera times of one step over the same P Gaussians (sharded
+ * frame-DP): bases_all [nviews,Tu+1,16,7] (table rows identical in every view); means3D / rots are stacked per view
+ * with a row stride of stride_rows (>= P), scales [P,3] / opac [P] do not depend on the time and are written once.
+ * Backward: g_* stacked per view [nviews,stride,*]; the five parameter gradients [P,*] are OVERWRITTEN with the sum
+ * over the views; d_bases_all [nviews,Tu+1,16,7] per view; sorted_ws = rdg_deform_sorted_views_ws_bytes(P, nviews). */
+int rdg_dyn_getter_views_supported(int32_t B, int32_t Tu, int32_t nviews);
+size_t rdg_deform_sorted_views_ws_bytes(int32_t P, int32_t nviews);
+int rdg_dyn_getter_views_forward(int32_t P, int32_t Tu, int32_t nviews, int32_t stride_rows, const float* coeff,
+                                 const int64_t* time_ind, const float* bases_all, float spatial_scale, const float* xyz,
+                                 const float* scaling, const float* rotation, const float* opacity, float* means3D,
+                                 float* scales, float* rots, float* opac, void* stream);
+int rdg_dyn_getter_views_backward(int32_t P, int32_t Tu, int32_t nviews, int32_t stride_rows, const float* coeff,
+                                  const int64_t* time_ind, const float* bases_all, float spatial_scale,
+                                  const float* scaling, const float* rotation, const float* opacity,
+                                  const float* g_means3D, const float* g_scales, const float* g_rots,
+                                  const float* g_opac, float* d_xyz, float* d_scaling, float* d_rotation,
+                                  float* d_opacity, float* d_coeff, float* d_bases_all, const int32_t* order,
+                                  const int32_t* inv_order, void* sorted_ws, void* stream);
 
 /* ---- simple_knn ------------------------------------------------------------------------------------------ */
 size_t rdg_knn_tmp_bytes(int32_t P);
@@ -315,6 +383,12 @@ int rdg_pose_view_forward(int32_t T, int32_t frame, const float* cam_q, const fl
                           void* stream);
 int rdg_pose_view_backward(int32_t T, int32_t frame, const float* cam_q, const float* cam_t, const float* g_view16,
                            float* d_q, float* d_t, void* stream);
+/* The same for the nviews (<= RDG_MAX_VIEWS) frames of one step: out_views [nviews,16]; backward zeroes d_q / d_t and
+ * adds the rows of the frames in order (a frame may appear twice).  frames_host is a HOST array.                  */
+int rdg_pose_views_forward(int32_t T, int32_t nviews, const int32_t* frames_host, const float* cam_q,
+                           const float* cam_t, float* out_views, void* stream);
+int rdg_pose_views_backward(int32_t T, int32_t nviews, const int32_t* frames_host, const float* cam_q,
+                            const float* cam_t, const float* g_views, float* d_q, float* d_t, void* stream);
 
 /* ---- measurement hooks -----------------------------------------------------------------------------------
  * When enabled, every stage is bracketed by hipEvents recorded on the launch stream.  rdg_stage_time_ms()

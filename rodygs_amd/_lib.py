@@ -50,6 +50,12 @@ _SIGS = {
     "rdg_rasterize_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 12 + [C.c_int64] + [_vp] * 8),
     "rdg_rasterize_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13 + [C.c_int64] + [_vp] * 15),
     "rdg_preprocess_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13),
+    "rdg_geom_from_records": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 4),
+    "rdg_composite_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, _vp, C.c_int64] + [_vp] * 7),
+    "rdg_composite_backward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6),
+    "rdg_preprocess_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 22),
+    "rdg_preprocess_forward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 10),
+    "rdg_preprocess_backward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 18),
     "rdg_geom_export": (C.c_int, [C.c_int32] + [_vp] * 8),
     "rdg_image_export": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 4),
     "rdg_bin_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 8),
@@ -59,6 +65,10 @@ _SIGS = {
     "rdg_dyn_getter_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "rdg_dyn_getter_forward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 9),
     "rdg_dyn_getter_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 17),
+    "rdg_dyn_getter_views_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "rdg_deform_sorted_views_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "rdg_dyn_getter_views_forward": (C.c_int, [C.c_int32] * 4 + [_vp, _vp, _vp, C.c_float] + [_vp] * 9),
+    "rdg_dyn_getter_views_backward": (C.c_int, [C.c_int32] * 4 + [_vp, _vp, _vp, C.c_float] + [_vp] * 17),
     "rdg_deform_sorted_ws_bytes": (C.c_size_t, [C.c_int32]),
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_gather_rows": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),
@@ -85,6 +95,8 @@ _SIGS = {
     "rdg_activate_backward": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 15),
     "rdg_pose_view_forward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_pose_view_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdg_pose_views_forward": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
+    "rdg_pose_views_backward": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdg_mlp_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rdg_mlp_forward": (C.c_int, [C.c_int32] * 5 + [_vp] * 14),
     "rdg_mlp_backward": (C.c_int, [C.c_int32] * 5 + [_vp] * 18),

@@ -102,7 +102,9 @@ size_t rdg_image_bytes(int32_t H, int32_t W) { return rdg_image_layout(H, W).tot
 size_t rdg_grad_bytes(int32_t P) {
     const size_t Pp = (size_t)(P > 0 ? P : 1);
     // gradient rows + one pose partial row per per-Gaussian workgroup + 32 second-level pose partial rows
-    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 255) / 256) * 19 * 4, 256) + 4096;
+    // (one set of second-level rows per camera for the *_views entry points)
+    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 255) / 256) * 19 * 4, 256) + 4096 +
+           (size_t)RDG_MAX_VIEWS * 32 * 19 * 4;
 }
 size_t rdg_sort_tmp_bytes(int64_t capacity) {
     // alternate key/value buffers + tables
@@ -126,24 +128,79 @@ int rdg_preprocess_forward(const RdgRasterSettings* s_host, const float* means3D
     return rc;
 }
 
+int rdg_geom_from_records(const RdgRasterSettings* s_host, void* geom_ws, int32_t* radii, int32_t* num_rendered_dev,
+                          void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (!geom_ws || !radii || !num_rendered_dev) return rdg_set_error("rdg_geom_from_records: NULL argument");
+    return rdg_launch_geom_from_records(d, geom_ws, radii, num_rendered_dev, (hipStream_t)stream);
+}
+
+int rdg_composite_forward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws, const int32_t* radii,
+                          void* binning_ws, int64_t capacity, void* image_ws, const int32_t* num_rendered_dev,
+                          float* out_color, float* out_depth, float* out_normal, float* out_alpha, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = rdg_launch_bin(d, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev, nullptr, nullptr, st);
+    if (rc) return rc;
+    rdg_stage_begin(RDG_STAGE_RENDER_FWD, st);
+    rc = rdg_launch_render_fwd(d, bg, geom_ws, binning_ws, capacity, image_ws, num_rendered_dev, out_color, out_depth,
+                               out_normal, out_alpha, st);
+    rdg_stage_end(RDG_STAGE_RENDER_FWD, st);
+    return rc;
+}
+
 int rdg_rasterize_forward(const RdgRasterSettings* s_host, const float* bg, const float* means3D, const float* shs,
                           const float* colors_precomp, const float* opacities, const float* scales,
                           const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                           const float* projmatrix, void* geom_ws, void* binning_ws, int64_t capacity, void* image_ws,
                           float* out_color, float* out_depth, float* out_normal, float* out_alpha, int32_t* radii,
                           int32_t* num_rendered_dev, void* stream) {
-    RdgDev d;
-    if (rdg_make_dev(s_host, &d)) return -1;
-    hipStream_t st = (hipStream_t)stream;
     int rc = rdg_preprocess_forward(s_host, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                     viewmatrix, projmatrix, geom_ws, radii, num_rendered_dev, stream);
     if (rc) return rc;
-    rc = rdg_launch_bin(d, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev, nullptr, nullptr, st);
-    if (rc) return rc;
-    rdg_stage_begin(RDG_STAGE_RENDER_FWD, st);
-    rc = rdg_launch_render_fwd(d, bg, geom_ws, binning_ws, capacity, image_ws, num_rendered_dev, out_color, out_depth,
-                               out_normal, out_alpha, st);
-    rdg_stage_end(RDG_STAGE_RENDER_FWD, st);
+    return rdg_composite_forward(s_host, bg, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev,
+                                 out_color, out_depth, out_normal, out_alpha, stream);
+}
+
+int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
+                           const void* binning_ws, int64_t capacity, const void* image_ws,
+                           const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
+                           void* grad_ws, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    float* grow = (float*)grad_ws;
+    const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
+    rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
+    hipError_t e = hipMemsetAsync(grow, 0, grow_bytes, st);
+    if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
+    int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
+                                   grad_out_alpha, grow, st);
+    rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
+    return rc;
+}
+
+int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const int32_t* radii, const void* geom_ws, void* grad_ws,
+                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                            float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
+                            float* dL_dviewmatrix, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
+    float* posebuf = (float*)((char*)grad_ws + grow_bytes);
+    rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
+    int rc = rdg_launch_preprocess_bwd(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                       viewmatrix, projmatrix, radii, geom_ws, (const float*)grad_ws, posebuf,
+                                       dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
+                                       dL_drotations, dL_dcov3D, dL_dviewmatrix, st);
+    rdg_stage_end(RDG_STAGE_PREPROCESS_BWD, st);
     return rc;
 }
 
@@ -156,27 +213,78 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                            float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                            float* dL_dviewmatrix, void* stream) {
+    if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    int rc = rdg_composite_backward(s_host, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color,
+                                    grad_out_depth, grad_out_alpha, grad_ws, stream);
+    if (rc) return rc;
+    return rdg_preprocess_backward(s_host, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   viewmatrix, projmatrix, radii, geom_ws, grad_ws, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                                   dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D, dL_dviewmatrix,
+                                   stream);
+}
+
+static int rdg_views_args(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows, const float* shs,
+                          const float* scales, const float* rotations) {
+    if (nviews < 1 || nviews > RDG_MAX_VIEWS) return rdg_set_error("views: nviews must be 1..%d", RDG_MAX_VIEWS);
+    if (stride_rows % RDG_PRE_BLOCK || stride_rows < s_host->P)
+        return rdg_set_error("views: stride_rows must be a multiple of %d and >= P", RDG_PRE_BLOCK);
+    if (!shs || !scales || !rotations) return rdg_set_error("views: shs, scales and rotations are required");
+    if (s_host->M < (s_host->sh_degree + 1) * (s_host->sh_degree + 1)) return rdg_set_error("views: too few SH rows");
+    return 0;
+}
+
+int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                 const float* means3D, const float* shs, const float* opacities, const float* scales,
+                                 const float* rotations, const float* viewmatrices, const float* projmatrix,
+                                 void* geom_ws, int32_t* radii, void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
-    if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    if (rdg_views_args(s_host, nviews, stride_rows, shs, scales, rotations)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    float* grow = (float*)grad_ws;
-    const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
+    const int32_t total = nviews * stride_rows;
+    rdg_stage_begin(RDG_STAGE_PREPROCESS, st);
+    for (int v = 0; v < nviews; ++v) {
+        const size_t o = (size_t)v * stride_rows;
+        int rc = rdg_launch_preprocess_fwd_slice(d, total, (int32_t)o, means3D + o * 3, shs, opacities, scales,
+                                                 rotations + o * 4, viewmatrices + 16 * v, projmatrix, geom_ws, radii, st);
+        if (rc) return rc;
+    }
+    rdg_stage_end(RDG_STAGE_PREPROCESS, st);
+    return 0;
+}
+
+int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                  const float* means3D, const float* shs, const float* opacities, const float* scales,
+                                  const float* rotations, const float* viewmatrices, const float* projmatrix,
+                                  const int32_t* radii, const void* geom_ws, void* grad_ws, float* dL_dmeans3D,
+                                  float* dL_dmeans2D, float* dL_dshs, float* dL_dopacities, float* dL_dscales,
+                                  float* dL_drotations, float* dL_dviewmatrices, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (rdg_views_args(s_host, nviews, stride_rows, shs, scales, rotations)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const int32_t total = nviews * stride_rows;
+    const size_t grow_bytes = rdg_align_up((size_t)total * RDG_GROW * 4, 256);
     float* posebuf = (float*)((char*)grad_ws + grow_bytes);
-    rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
-    hipError_t e = hipMemsetAsync(grow, 0, grow_bytes, st);
-    if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
-    int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
-                                   grad_out_alpha, grow, st);
-    rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
-    if (rc) return rc;
     rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
-    rc = rdg_launch_preprocess_bwd(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   viewmatrix, projmatrix, radii, geom_ws, grow, posebuf, dL_dmeans3D, dL_dmeans2D,
-                                   dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3D,
-                                   dL_dviewmatrix, st);
+    for (int v = 0; v < nviews; ++v) {
+        const size_t o = (size_t)v * stride_rows;
+        int rc = rdg_launch_preprocess_bwd_slice(d, total, (int32_t)o, means3D + o * 3, shs, opacities, scales,
+                                                 rotations + o * 4, viewmatrices + 16 * v, projmatrix, radii, geom_ws,
+                                                 (const float*)grad_ws, posebuf, dL_dmeans3D + o * 3, dL_dmeans2D + o * 3,
+                                                 dL_dshs + o * (size_t)d.M * 3, dL_dopacities + o, dL_dscales + o * 3,
+                                                 dL_drotations + o * 4, st);
+        if (rc) return rc;
+    }
+    {
+        const int view_rows = stride_rows / 256, nblk = (d.P + 255) / 256;
+        float* part = (float*)((char*)posebuf + rdg_align_up(((size_t)total / 256 + 1) * 19 * 4, 256));
+        int rc = rdg_launch_pose_reduce_views(nviews, view_rows, d.P > 0 ? nblk : 0, viewmatrices, posebuf, part,
+                                              dL_dviewmatrices, st);
+        if (rc) return rc;
+    }
     rdg_stage_end(RDG_STAGE_PREPROCESS_BWD, st);
-    return rc;
+    return 0;
 }
 
 // ---- geom export ---------------------------------------------------------------------------------------------

@@ -164,6 +164,8 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, void* geom_ws, int32_t* radii,
                               int32_t* num_rendered, hipStream_t s);
+int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii, int32_t* num_rendered,
+                                 hipStream_t s);
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
                    void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
                    uint32_t* vals_unsorted_copy, hipStream_t s, bool export_sorted_keys = false);
@@ -181,6 +183,17 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                               const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
                               float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
                               float* dview, hipStream_t s);
+
+int rdg_launch_preprocess_fwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+                                    const float* shs, const float* opac, const float* scales, const float* rots,
+                                    const float* view, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s);
+int rdg_launch_preprocess_bwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+                                    const float* shs, const float* opac, const float* scales, const float* rots,
+                                    const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
+                                    const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
+                                    float* dopac, float* dscales, float* drots, hipStream_t s);
+int rdg_launch_pose_reduce_views(int nviews, int view_rows, int nblk, const float* views, float* posebuf, float* part,
+                                 float* dviews, hipStream_t s);
 
 // ---- small device helpers --------------------------------------------------------------------------------
 #ifdef __HIPCC__

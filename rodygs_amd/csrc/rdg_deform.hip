@@ -193,48 +193,6 @@ __device__ __forceinline__ void rdg_diff16_to_lds(float* sm, int Tu, const float
 }
 
 __global__ void __launch_bounds__(1024)
-rdg_dyn_getter_fwd_kernel(int P, int Tu, const float* __restrict__ coeff, const long long* __restrict__ time_ind,
-                          const float* __restrict__ bases, float scale, const float* __restrict__ xyz,
-                          const float* __restrict__ scaling, const float* __restrict__ rotation,
-                          const float* __restrict__ opacity, float* __restrict__ means3D, float* __restrict__ scales,
-                          float* __restrict__ rots, float* __restrict__ opac) {
-    extern __shared__ __attribute__((aligned(16))) float smem_dg[];
-    rdg_diff16_to_lds(smem_dg, Tu, bases);
-    __syncthreads();
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const int u = (int)time_ind[p];
-        const float4* c4 = reinterpret_cast<const float4*>(coeff + (size_t)p * 16);
-        float c[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const float4 t = c4[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
-        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
-        float acc[RDG_DEF_K];
-#pragma unroll
-        for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 28; ++j) {
-            const float4 v = r4[j];
-            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const int e = 4 * j + e4;          // compile-time: e = b * 7 + k
-                acc[e % 7] += c[e / 7] * vv[e4];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            means3D[3 * p + k] = xyz[3 * p + k] + acc[k] * scale;
-            scales[3 * p + k] = __expf(scaling[3 * p + k]);
-        }
-        const float4 q = reinterpret_cast<const float4*>(rotation)[p];
-        const float inv = 1.0f / fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
-        reinterpret_cast<float4*>(rots)[p] = make_float4(q.x * inv + acc[3], q.y * inv + acc[4], q.z * inv + acc[5],
-                                                         q.w * inv + acc[6]);
-        opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
-    }
-}
-
-__global__ void __launch_bounds__(1024)
 rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind, const float* __restrict__ bases,
                           float scale, const float* __restrict__ scaling, const float* __restrict__ rotation,
                           const float* __restrict__ opacity, const float* __restrict__ g_means3D,
@@ -407,6 +365,282 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
     rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Multi-view dynamic getter (Gaussian-sharded frame-DP, rodygs_amd/sharded.py): the same Gaussians deformed to the
+// times of the NV cameras of one step.  A Gaussian's parameters and coefficients are read once; scales / opacities
+// do not depend on the time and are written once; backward sums the gradients over the views in registers, so the
+// five parameter gradients leave the kernel final (no per-view copies, no reduction pass).
+// bases_all [NV][Tu+1][112]: every view's packed bases (table rows, then B(t_v)); the table rows are identical in
+// all views and are taken from view 0.  LDS: raw table [Tu][RDG_DC_STRIDE] + B(t_v) [NV][112].
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void rdg_views_to_lds(float* sm, int Tu, int NV, const float* __restrict__ bases_all) {
+    for (int k = threadIdx.x; k < Tu * 112; k += blockDim.x) {
+        const int u = k / 112, c = k - u * 112;
+        sm[u * RDG_DC_STRIDE + c] = bases_all[(size_t)u * 112 + c];
+    }
+    float* bt = sm + Tu * RDG_DC_STRIDE;
+    for (int k = threadIdx.x; k < NV * 112; k += blockDim.x) {
+        const int v = k / 112, c = k - v * 112;
+        bt[k] = bases_all[((size_t)v * (Tu + 1) + Tu) * 112 + c];
+    }
+}
+
+// Forward: c . (B(t_v) - table[birth]) is evaluated as c . B(t_v) - c . table[birth]: the table row of a lane (the
+// expensive LDS operand, 64 different rows per instruction) is then read once for all views instead of once per view
+// (that form was LDS-bound: 137 us for 125 k Gaussians x 8 views).  The single-view getter runs this same kernel with
+// NV = 1, so both frame-DP modes produce the same bits.
+__global__ void __launch_bounds__(512)
+rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* __restrict__ coeff,
+                                const long long* __restrict__ time_ind, const float* __restrict__ bases_all,
+                                float scale, const float* __restrict__ xyz, const float* __restrict__ scaling,
+                                const float* __restrict__ rotation, const float* __restrict__ opacity,
+                                float* __restrict__ means3D, float* __restrict__ scales, float* __restrict__ rots,
+                                float* __restrict__ opac) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dg[];
+    rdg_views_to_lds(smem_dg, Tu, NV, bases_all);
+    __syncthreads();
+    const float* sbt = smem_dg + Tu * RDG_DC_STRIDE;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int u = (int)time_ind[p];
+        const float4* c4 = reinterpret_cast<const float4*>(coeff + (size_t)p * 16);
+        float c[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t = c4[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
+        const float x0 = xyz[3 * p], x1 = xyz[3 * p + 1], x2 = xyz[3 * p + 2];
+        const float4 q = reinterpret_cast<const float4*>(rotation)[p];
+        const float inv = 1.0f / fmaxf(sqrtf(__fmaf_rn(q.w, q.w, __fmaf_rn(q.z, q.z, __fmaf_rn(q.y, q.y, q.x * q.x)))), 1e-12f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) scales[3 * p + k] = __expf(scaling[3 * p + k]);
+        opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
+        // c . table[birth]: the expensive LDS operand (64 different rows per instruction), once for all views
+        float tdot[RDG_DEF_K];
+#pragma unroll
+        for (int k = 0; k < RDG_DEF_K; ++k) tdot[k] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float4 t = r4[j];
+            const float vv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * j + e4;
+                tdot[e % 7] = __fmaf_rn(c[e / 7], vv[e4], tdot[e % 7]);
+            }
+        }
+        for (int v = 0; v < NV; ++v) {
+            // c . B(t_v): broadcast reads (one address for the whole wave)
+            const float4* b4 = reinterpret_cast<const float4*>(sbt + v * 112);
+            float acc[RDG_DEF_K];
+#pragma unroll
+            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 28; ++j) {
+                const float4 bb = b4[j];
+                const float vv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = 4 * j + e4;
+                    acc[e % 7] = __fmaf_rn(c[e / 7], vv[e4], acc[e % 7]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] -= tdot[k];
+            const size_t row = (size_t)v * stride + p;
+            means3D[3 * row] = __fmaf_rn(acc[0], scale, x0);
+            means3D[3 * row + 1] = __fmaf_rn(acc[1], scale, x1);
+            means3D[3 * row + 2] = __fmaf_rn(acc[2], scale, x2);
+            reinterpret_cast<float4*>(rots)[row] = make_float4(__fmaf_rn(q.x, inv, acc[3]), __fmaf_rn(q.y, inv, acc[4]),
+                                                               __fmaf_rn(q.z, inv, acc[5]), __fmaf_rn(q.w, inv, acc[6]));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512)
+rdg_dyn_getter_views_bwd_kernel(int P, int Tu, int NV, int stride, const long long* __restrict__ time_ind,
+                                const float* __restrict__ bases_all, float scale, const float* __restrict__ scaling,
+                                const float* __restrict__ rotation, const float* __restrict__ opacity,
+                                const float* __restrict__ g_means3D, const float* __restrict__ g_scales,
+                                const float* __restrict__ g_rots, const float* __restrict__ g_opac,
+                                float* __restrict__ d_xyz, float* __restrict__ d_scaling,
+                                float* __restrict__ d_rotation, float* __restrict__ d_opacity,
+                                float* __restrict__ d_coeff, const int* __restrict__ inv_order,
+                                float4* __restrict__ gs) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dg[];
+    rdg_views_to_lds(smem_dg, Tu, NV, bases_all);
+    __syncthreads();
+    const float* sbt = smem_dg + Tu * RDG_DC_STRIDE;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int u = (int)time_ind[p];
+        const size_t sidx = (size_t)inv_order[p];
+        float gsum[RDG_DEF_K] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float sm3[3] = {0.f, 0.f, 0.f}, ssc[3] = {0.f, 0.f, 0.f}, sop = 0.f;
+        float sacc[16];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) sacc[b] = 0.0f;
+        for (int v = 0; v < NV; ++v) {
+            const size_t row = (size_t)v * stride + p;
+            const float m0 = g_means3D[3 * row], m1 = g_means3D[3 * row + 1], m2 = g_means3D[3 * row + 2];
+            const float4 gr = reinterpret_cast<const float4*>(g_rots)[row];
+            sm3[0] += m0; sm3[1] += m1; sm3[2] += m2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ssc[k] += g_scales[3 * row + k];
+            sop += g_opac[row];
+            const float g[RDG_DEF_K] = {m0 * scale, m1 * scale, m2 * scale, gr.x, gr.y, gr.z, gr.w};
+#pragma unroll
+            for (int k = 0; k < RDG_DEF_K; ++k) gsum[k] += g[k];
+            // compact copy at the birth-sorted position, views interleaved: [sorted Gaussian][view][g0..g6, birth]
+            gs[(sidx * NV + v) * 2] = make_float4(g[0], g[1], g[2], g[3]);
+            gs[(sidx * NV + v) * 2 + 1] = make_float4(g[4], g[5], g[6], __int_as_float(u));
+            const float4* b4 = reinterpret_cast<const float4*>(sbt + v * 112);
+#pragma unroll
+            for (int j = 0; j < 28; ++j) {
+                const float4 b = b4[j];
+                const float vv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int e = 4 * j + e4;
+                    sacc[e / 7] += g[e % 7] * vv[e4];
+                }
+            }
+        }
+        // dL/dcoeff = sum_v g_v . B(t_v)  -  (sum_v g_v) . table[birth]
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float4 t = r4[j];
+            const float vv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * j + e4;
+                sacc[e / 7] -= gsum[e % 7] * vv[e4];
+            }
+        }
+        float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dc[q] = make_float4(sacc[4 * q], sacc[4 * q + 1], sacc[4 * q + 2], sacc[4 * q + 3]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d_xyz[3 * p + k] = sm3[k];
+            d_scaling[3 * p + k] = ssc[k] * __expf(scaling[3 * p + k]);
+        }
+        const float4 q = reinterpret_cast<const float4*>(rotation)[p];
+        const float4 gr = make_float4(gsum[3], gsum[4], gsum[5], gsum[6]);
+        const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        float4 dq;
+        if (nn > 1e-12f) {
+            const float inv = 1.0f / nn;
+            const float yx = q.x * inv, yy = q.y * inv, yz = q.z * inv, yw = q.w * inv;
+            const float dot = yx * gr.x + yy * gr.y + yz * gr.z + yw * gr.w;
+            dq = make_float4((gr.x - yx * dot) * inv, (gr.y - yy * dot) * inv, (gr.z - yz * dot) * inv,
+                             (gr.w - yw * dot) * inv);
+        } else {
+            dq = make_float4(gr.x * 1e12f, gr.y * 1e12f, gr.z * 1e12f, gr.w * 1e12f);
+        }
+        reinterpret_cast<float4*>(d_rotation)[p] = dq;
+        const float sg = 1.0f / (1.0f + __expf(-opacity[p]));
+        d_opacity[p] = sop * sg * (1.0f - sg);
+    }
+}
+
+// dB accumulation for all views in one pass over the birth-sorted Gaussians: the coefficient fragment of a group of 4
+// Gaussians is gathered once and multiplied with the gradient rows of two views per MFMA (columns 0-6 and 8-14 of the
+// 16-column B operand), NPAIR accumulators per wave; flushed per birth index into that view's d_table (negated, as in
+// the single-view kernel), from which rdg_deform_dbt_views_kernel forms dB(t_v).
+#define RDG_DEFV_G 4
+template <int NPAIR>
+__global__ void __launch_bounds__(256)
+rdg_deform_bwd_acc_views_kernel(int P, int NV, int Tu, const float* __restrict__ coeff, const int* __restrict__ order,
+                                float* __restrict__ d_bases_all, const float* __restrict__ gs) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    int per = (P + nwaves - 1) / nwaves;
+    per = (per + 4 * RDG_DEFV_G - 1) / (4 * RDG_DEFV_G) * (4 * RDG_DEFV_G);
+    const int beg = min(P, wave * per), end = min(P, beg + per);
+    const int slot = lane >> 4, j = lane & 15;
+    const int jh = j >> 3, jk = j & 7;                  // which view of the pair, which gradient component
+    rdg_f32x4 acc[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) acc[q] = rdg_f32x4{0.f, 0.f, 0.f, 0.f};
+    int cur_u = -1;
+    const size_t vrow = (size_t)(Tu + 1) * 112;
+
+    auto flush = [&](int u) {
+        if (u < 0 || jk >= RDG_DEF_K) return;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int v = 2 * q + jh;
+            if (v >= NV) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = (lane >> 4) * 4 + r;
+                const float val = acc[q][r];
+                if (val != 0.0f) atomicAdd(&d_bases_all[v * vrow + (size_t)u * 112 + b * RDG_DEF_K + jk], -val);
+            }
+        }
+    };
+
+    for (int base = beg; base < end; base += 4 * RDG_DEFV_G) {
+        int u4[RDG_DEFV_G]; float a4[RDG_DEFV_G]; float g4[RDG_DEFV_G][NPAIR]; bool v4[RDG_DEFV_G];
+#pragma unroll
+        for (int q = 0; q < RDG_DEFV_G; ++q) {
+            const int idx = base + 4 * q + slot;
+            v4[q] = idx < end;
+            const size_t sidx = (size_t)min(idx, end - 1);
+            const size_t p = (size_t)order[sidx];
+            a4[q] = v4[q] ? coeff[p * 16 + j] : 0.0f;
+            const float* row = gs + sidx * NV * 8;
+            u4[q] = v4[q] ? __float_as_int(row[7]) : -1;
+#pragma unroll
+            for (int w = 0; w < NPAIR; ++w) {
+                const int v = 2 * w + jh;
+                const float gv = row[min(v, NV - 1) * 8 + jk];
+                g4[q][w] = (v4[q] && v < NV && jk < RDG_DEF_K) ? gv : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RDG_DEFV_G; ++q) {
+            const int u = u4[q];
+            if (__ballot(v4[q] && u != cur_u) == 0ull) {
+#pragma unroll
+                for (int w = 0; w < NPAIR; ++w) acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q], g4[q][w], acc[w], 0, 0, 0);
+            } else {
+#pragma unroll 1
+                for (int sl = 0; sl < 4; ++sl) {
+                    const int us = __builtin_amdgcn_readlane(u, sl * 16);
+                    if (us < 0) continue;
+                    if (us != cur_u) {
+                        flush(cur_u);
+#pragma unroll
+                        for (int w = 0; w < NPAIR; ++w) acc[w] = rdg_f32x4{0.f, 0.f, 0.f, 0.f};
+                        cur_u = us;
+                    }
+#pragma unroll
+                    for (int w = 0; w < NPAIR; ++w)
+                        acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q], slot == sl ? g4[q][w] : 0.0f, acc[w], 0, 0, 0);
+                }
+            }
+        }
+    }
+    flush(cur_u);
+}
+
+// dB(t_v)[c] = -sum_u d_table_v[u][c] for every view (blockIdx.y = view)
+__global__ void rdg_deform_dbt_views_kernel(int Tu, float* __restrict__ d_bases_all) {
+    const int c = threadIdx.x;
+    if (c >= 112) return;
+    float* dv = d_bases_all + (size_t)blockIdx.y * (Tu + 1) * 112;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int u = 0;
+    for (; u + 3 < Tu; u += 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] += dv[(size_t)(u + q) * 112 + c];
+    }
+    for (; u < Tu; ++u) a[0] += dv[(size_t)u * 112 + c];
+    dv[(size_t)Tu * 112 + c] = -((a[0] + a[1]) + (a[2] + a[3]));
+}
+
 // dB(t)[c] = -sum_u dB_table[u][c]   (fixed order: deterministic given dB_table)
 __global__ void rdg_deform_dbt_kernel(int Tu, int row, const float* __restrict__ d_table, float* __restrict__ d_basis_t) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -529,6 +763,9 @@ int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, con
 }
 
 size_t rdg_deform_sorted_ws_bytes(int32_t P) { return (size_t)(P > 0 ? P : 1) * 32 + 256; }
+size_t rdg_deform_sorted_views_ws_bytes(int32_t P, int32_t nviews) {
+    return (size_t)(P > 0 ? P : 1) * 32 * (size_t)(nviews > 0 ? nviews : 1) + 256;
+}
 
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
@@ -589,7 +826,7 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
 }
 
 
-int rdg_dyn_getter_supported(int32_t B, int32_t Tu) { return B == 16 && Tu >= 1 && (size_t)Tu * RDG_DC_STRIDE * 4 <= 64 * 1024; }
+int rdg_dyn_getter_supported(int32_t B, int32_t Tu) { return B == 16 && Tu >= 1 && ((size_t)Tu * RDG_DC_STRIDE + 112) * 4 <= 64 * 1024; }
 
 int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
                            float spatial_scale, const float* xyz, const float* scaling, const float* rotation,
@@ -598,12 +835,12 @@ int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int6
     if ((((uintptr_t)coeff | (uintptr_t)rotation | (uintptr_t)rots)) & 15) return rdg_set_error("dyn_getter: 16-B alignment");
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    int nb = (P + 1023) / 1024;
-    if (nb > 256) nb = 256;
+    int nb = (P + 511) / 512;
+    if (nb > 768) nb = 768;
     rdg_stage_begin(RDG_STAGE_DEFORM_FWD, st);
-    hipLaunchKernelGGL(rdg_dyn_getter_fwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu, coeff,
-                       (const long long*)time_ind, bases, spatial_scale, xyz, scaling, rotation, opacity, means3D, scales,
-                       rots, opac);
+    hipLaunchKernelGGL(rdg_dyn_getter_views_fwd_kernel, dim3(nb), dim3(512), ((size_t)Tu * RDG_DC_STRIDE + 112) * 4, st, P,
+                       Tu, 1, P, coeff, (const long long*)time_ind, bases, spatial_scale, xyz, scaling, rotation, opacity,
+                       means3D, scales, rots, opac);
     rdg_stage_end(RDG_STAGE_DEFORM_FWD, st);
     return rdg_check_hip(hipGetLastError(), "dyn_getter_fwd launch");
 }
@@ -640,6 +877,78 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
     }
     rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);
     return rdg_check_hip(hipGetLastError(), "dyn_getter_bwd launch");
+}
+
+int rdg_dyn_getter_views_supported(int32_t B, int32_t Tu, int32_t nviews) {
+    return B == 16 && Tu >= 1 && nviews >= 1 && nviews <= RDG_MAX_VIEWS &&
+           ((size_t)Tu * RDG_DC_STRIDE + (size_t)nviews * 112) * 4 <= 64 * 1024;
+}
+
+int rdg_dyn_getter_views_forward(int32_t P, int32_t Tu, int32_t nviews, int32_t stride_rows, const float* coeff,
+                                 const int64_t* time_ind, const float* bases_all, float spatial_scale, const float* xyz,
+                                 const float* scaling, const float* rotation, const float* opacity, float* means3D,
+                                 float* scales, float* rots, float* opac, void* stream) {
+    if (!rdg_dyn_getter_views_supported(16, Tu, nviews))
+        return rdg_set_error("dyn_getter_views: unsupported sizes Tu = %d, nviews = %d", Tu, nviews);
+    if (stride_rows < P) return rdg_set_error("dyn_getter_views: stride_rows < P");
+    if ((((uintptr_t)coeff | (uintptr_t)rotation | (uintptr_t)rots)) & 15) return rdg_set_error("dyn_getter_views: 16-B alignment");
+    if (P <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (P + 511) / 512;
+    if (nb > 768) nb = 768;
+    const size_t lds = ((size_t)Tu * RDG_DC_STRIDE + (size_t)nviews * 112) * 4;
+    rdg_stage_begin(RDG_STAGE_DEFORM_FWD, st);
+    hipLaunchKernelGGL(rdg_dyn_getter_views_fwd_kernel, dim3(nb), dim3(512), lds, st, P, Tu, nviews, stride_rows, coeff,
+                       (const long long*)time_ind, bases_all, spatial_scale, xyz, scaling, rotation, opacity, means3D,
+                       scales, rots, opac);
+    rdg_stage_end(RDG_STAGE_DEFORM_FWD, st);
+    return rdg_check_hip(hipGetLastError(), "dyn_getter_views_fwd launch");
+}
+
+int rdg_dyn_getter_views_backward(int32_t P, int32_t Tu, int32_t nviews, int32_t stride_rows, const float* coeff,
+                                  const int64_t* time_ind, const float* bases_all, float spatial_scale,
+                                  const float* scaling, const float* rotation, const float* opacity,
+                                  const float* g_means3D, const float* g_scales, const float* g_rots,
+                                  const float* g_opac, float* d_xyz, float* d_scaling, float* d_rotation,
+                                  float* d_opacity, float* d_coeff, float* d_bases_all, const int32_t* order,
+                                  const int32_t* inv_order, void* sorted_ws, void* stream) {
+    if (!rdg_dyn_getter_views_supported(16, Tu, nviews))
+        return rdg_set_error("dyn_getter_views: unsupported sizes Tu = %d, nviews = %d", Tu, nviews);
+    if (!order || !inv_order || !sorted_ws || (((uintptr_t)sorted_ws) & 15))
+        return rdg_set_error("dyn_getter_views_backward needs order, inv_order and a 16-B aligned sorted workspace");
+    if (!g_means3D || !g_scales || !g_rots || !g_opac) return rdg_set_error("dyn_getter_views_backward: NULL gradient");
+    if ((((uintptr_t)coeff | (uintptr_t)rotation | (uintptr_t)d_rotation | (uintptr_t)d_coeff | (uintptr_t)g_rots)) & 15)
+        return rdg_set_error("dyn_getter_views: 16-B alignment");
+    hipStream_t st = (hipStream_t)stream;
+    rdg_stage_begin(RDG_STAGE_DEFORM_BWD, st);
+    hipError_t e = hipMemsetAsync(d_bases_all, 0, (size_t)nviews * (Tu + 1) * 112 * 4, st);
+    if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_views_bwd memset");
+    if (P > 0) {
+        int nb = (P + 511) / 512;
+        if (nb > 768) nb = 768;
+        const size_t lds = ((size_t)Tu * RDG_DC_STRIDE + (size_t)nviews * 112) * 4;
+        hipLaunchKernelGGL(rdg_dyn_getter_views_bwd_kernel, dim3(nb), dim3(512), lds, st, P, Tu, nviews, stride_rows,
+                           (const long long*)time_ind, bases_all, spatial_scale, scaling, rotation, opacity, g_means3D,
+                           g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
+                           (const int*)inv_order, (float4*)sorted_ws);
+        const int npair = (nviews + 1) / 2;
+        const dim3 grid(256), block(256);
+        if (npair <= 1)
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_views_kernel<1>, grid, block, 0, st, P, nviews, Tu, coeff,
+                               (const int*)order, d_bases_all, (const float*)sorted_ws);
+        else if (npair <= 2)
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_views_kernel<2>, grid, block, 0, st, P, nviews, Tu, coeff,
+                               (const int*)order, d_bases_all, (const float*)sorted_ws);
+        else if (npair <= 4)
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_views_kernel<4>, grid, block, 0, st, P, nviews, Tu, coeff,
+                               (const int*)order, d_bases_all, (const float*)sorted_ws);
+        else
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_views_kernel<8>, grid, block, 0, st, P, nviews, Tu, coeff,
+                               (const int*)order, d_bases_all, (const float*)sorted_ws);
+        hipLaunchKernelGGL(rdg_deform_dbt_views_kernel, dim3(1, nviews), dim3(128), 0, st, Tu, d_bases_all);
+    }
+    rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);
+    return rdg_check_hip(hipGetLastError(), "dyn_getter_views_bwd launch");
 }
 
 static int rdg_adam_launch(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int row_len,

@@ -97,9 +97,8 @@ __device__ __forceinline__ void rdg_quat_to_R(const float q[4], float R[9], floa
     R[6] = two_s * (i * k - j * r); R[7] = two_s * (j * k + i * r); R[8] = 1.f - two_s * (i * i + j * j);
 }
 
-__global__ void rdg_pose_view_fwd_kernel(int frame, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
-                                         float* __restrict__ view) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void rdg_pose_view_row(int frame, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+                                  float* __restrict__ view) {
     float q[4], t[3], R[9], s;
     for (int c = 0; c < 4; ++c) q[c] = cam_q[4 * frame + c];
     for (int c = 0; c < 3; ++c) t[c] = cam_t[3 * frame + c];
@@ -114,13 +113,23 @@ __global__ void rdg_pose_view_fwd_kernel(int frame, const float* __restrict__ ca
     view[15] = 1.0f;
 }
 
-__global__ void rdg_pose_view_bwd_kernel(int T, int frame, const float* __restrict__ cam_q,
-                                         const float* __restrict__ cam_t, const float* __restrict__ g_view,
-                                         float* __restrict__ d_q, float* __restrict__ d_t) {
-    // zero the other frames' rows, then thread 0 writes the rendered frame's row
-    for (int k = threadIdx.x; k < T * 4; k += blockDim.x) if (k / 4 != frame) d_q[k] = 0.0f;
-    for (int k = threadIdx.x; k < T * 3; k += blockDim.x) if (k / 3 != frame) d_t[k] = 0.0f;
-    if (threadIdx.x != 0) return;
+__global__ void rdg_pose_view_fwd_kernel(int frame, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+                                         float* __restrict__ view) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    rdg_pose_view_row(frame, cam_q, cam_t, view);
+}
+
+// several frames of one step (Gaussian-sharded frame-DP: every rank needs the cameras of all ranks)
+struct RdgFrames { int32_t f[RDG_MAX_VIEWS]; };
+__global__ void rdg_pose_views_fwd_kernel(int nviews, RdgFrames fr, const float* __restrict__ cam_q,
+                                          const float* __restrict__ cam_t, float* __restrict__ views) {
+    if (threadIdx.x < nviews) rdg_pose_view_row(fr.f[threadIdx.x], cam_q, cam_t, views + 16 * threadIdx.x);
+}
+
+template <bool ADD>
+__device__ void rdg_pose_view_bwd_row(int frame, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+                                      const float* __restrict__ g_view, float* __restrict__ d_q,
+                                      float* __restrict__ d_t) {
     float q[4], t[3], R[9], s;
     for (int c = 0; c < 4; ++c) q[c] = cam_q[4 * frame + c];
     for (int c = 0; c < 3; ++c) t[c] = cam_t[3 * frame + c];
@@ -133,7 +142,7 @@ __global__ void rdg_pose_view_bwd_kernel(int T, int frame, const float* __restri
             dR[c * 3 + r] = g_view[c * 4 + r] - g_view[12 + r] * t[c];
             dt += R[c * 3 + r] * g_view[12 + r];
         }
-        d_t[3 * frame + c] = -dt;
+        d_t[3 * frame + c] = (ADD ? d_t[3 * frame + c] : 0.0f) - dt;
     }
     // R = I + two_s * M(q):  dL/dq_m = two_s * sum dR_ab dM_ab/dq_m + (sum dR_ab M_ab) * d(two_s)/dq_m
     const float r = q[0], i = q[1], j = q[2], k = q[3];
@@ -147,10 +156,33 @@ __global__ void rdg_pose_view_bwd_kernel(int T, int frame, const float* __restri
     const float gi = j * dR[1] + k * dR[2] + j * dR[3] - 2.f * i * dR[4] - r * dR[5] + k * dR[6] + r * dR[7] - 2.f * i * dR[8];
     const float gj = -2.f * j * dR[0] + i * dR[1] + r * dR[2] + i * dR[3] + k * dR[5] - r * dR[6] + k * dR[7] - 2.f * j * dR[8];
     const float gk = -2.f * k * dR[0] - r * dR[1] + i * dR[2] + r * dR[3] - 2.f * k * dR[4] + j * dR[5] + i * dR[6] + j * dR[7];
-    d_q[4 * frame + 0] = s * gr + dotM * ds_scale * r;
-    d_q[4 * frame + 1] = s * gi + dotM * ds_scale * i;
-    d_q[4 * frame + 2] = s * gj + dotM * ds_scale * j;
-    d_q[4 * frame + 3] = s * gk + dotM * ds_scale * k;
+    const float o0 = ADD ? d_q[4 * frame + 0] : 0.0f, o1 = ADD ? d_q[4 * frame + 1] : 0.0f;
+    const float o2 = ADD ? d_q[4 * frame + 2] : 0.0f, o3 = ADD ? d_q[4 * frame + 3] : 0.0f;
+    d_q[4 * frame + 0] = o0 + (s * gr + dotM * ds_scale * r);
+    d_q[4 * frame + 1] = o1 + (s * gi + dotM * ds_scale * i);
+    d_q[4 * frame + 2] = o2 + (s * gj + dotM * ds_scale * j);
+    d_q[4 * frame + 3] = o3 + (s * gk + dotM * ds_scale * k);
+}
+
+__global__ void rdg_pose_view_bwd_kernel(int T, int frame, const float* __restrict__ cam_q,
+                                         const float* __restrict__ cam_t, const float* __restrict__ g_view,
+                                         float* __restrict__ d_q, float* __restrict__ d_t) {
+    // zero the other frames' rows, then thread 0 writes the rendered frame's row
+    for (int k = threadIdx.x; k < T * 4; k += blockDim.x) if (k / 4 != frame) d_q[k] = 0.0f;
+    for (int k = threadIdx.x; k < T * 3; k += blockDim.x) if (k / 3 != frame) d_t[k] = 0.0f;
+    if (threadIdx.x != 0) return;
+    rdg_pose_view_bwd_row<false>(frame, cam_q, cam_t, g_view, d_q, d_t);
+}
+
+// zero both tables, then one thread adds the rows of the step's frames in order (a frame may repeat)
+__global__ void rdg_pose_views_bwd_kernel(int T, int nviews, RdgFrames fr, const float* __restrict__ cam_q,
+                                          const float* __restrict__ cam_t, const float* __restrict__ g_views,
+                                          float* __restrict__ d_q, float* __restrict__ d_t) {
+    for (int k = threadIdx.x; k < T * 4; k += blockDim.x) d_q[k] = 0.0f;
+    for (int k = threadIdx.x; k < T * 3; k += blockDim.x) d_t[k] = 0.0f;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int v = 0; v < nviews; ++v) rdg_pose_view_bwd_row<true>(fr.f[v], cam_q, cam_t, g_views + 16 * v, d_q, d_t);
 }
 
 extern "C" {
@@ -203,6 +235,34 @@ int rdg_pose_view_backward(int32_t T, int32_t frame, const float* cam_q, const f
     hipLaunchKernelGGL(rdg_pose_view_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, frame, cam_q, cam_t,
                        g_view16, d_q, d_t);
     return rdg_check_hip(hipGetLastError(), "pose_view_bwd launch");
+}
+
+static int rdg_frames_arg(int32_t T, int32_t nviews, const int32_t* frames_host, RdgFrames* fr) {
+    if (nviews < 1 || nviews > RDG_MAX_VIEWS) return rdg_set_error("pose: nviews must be 1..%d", RDG_MAX_VIEWS);
+    for (int v = 0; v < nviews; ++v) {
+        if (frames_host[v] < 0 || frames_host[v] >= T)
+            return rdg_set_error("pose: frame %d out of range [0,%d)", frames_host[v], T);
+        fr->f[v] = frames_host[v];
+    }
+    return 0;
+}
+
+int rdg_pose_views_forward(int32_t T, int32_t nviews, const int32_t* frames_host, const float* cam_q,
+                           const float* cam_t, float* out_views, void* stream) {
+    RdgFrames fr;
+    if (rdg_frames_arg(T, nviews, frames_host, &fr)) return -1;
+    hipLaunchKernelGGL(rdg_pose_views_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nviews, fr, cam_q, cam_t,
+                       out_views);
+    return rdg_check_hip(hipGetLastError(), "pose_views_fwd launch");
+}
+
+int rdg_pose_views_backward(int32_t T, int32_t nviews, const int32_t* frames_host, const float* cam_q,
+                            const float* cam_t, const float* g_views, float* d_q, float* d_t, void* stream) {
+    RdgFrames fr;
+    if (rdg_frames_arg(T, nviews, frames_host, &fr)) return -1;
+    hipLaunchKernelGGL(rdg_pose_views_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, nviews, fr, cam_q,
+                       cam_t, g_views, d_q, d_t);
+    return rdg_check_hip(hipGetLastError(), "pose_views_bwd launch");
 }
 
 }  // extern "C"

@@ -334,7 +334,10 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
 // (glm flat).  Deterministic: the summation order is fixed by the row indices alone.
 #define RDG_POSE_L2 32
 __global__ void __launch_bounds__(256)
-rdg_pose_partial_kernel(const float* __restrict__ posebuf, int nblk, float* __restrict__ part) {
+rdg_pose_partial_kernel(const float* __restrict__ posebuf, int nblk, float* __restrict__ part, int view_rows = 0) {
+    // blockIdx.y = camera (multi-view launches): its partial rows start view_rows rows further on
+    posebuf += (size_t)blockIdx.y * view_rows * RDG_POSE_N;
+    part += (size_t)blockIdx.y * RDG_POSE_L2 * RDG_POSE_N;
     __shared__ float sred[8][32];
     const int k = threadIdx.x & 31, grp = threadIdx.x >> 5;   // 8 row groups x 32 component slots
     float acc = 0.0f;
@@ -362,6 +365,8 @@ rdg_pose_partial_kernel(const float* __restrict__ posebuf, int nblk, float* __re
 __global__ void __launch_bounds__(64)
 rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict__ part, int nrows,
                          float* __restrict__ dview) {
+    view += 16 * blockIdx.x; dview += 16 * blockIdx.x;        // blockIdx.x = camera
+    part += (size_t)blockIdx.x * nrows * RDG_POSE_N;
     __shared__ float stot[32];
     if (threadIdx.x < RDG_POSE_N) {
         float t = 0.0f;
@@ -404,4 +409,28 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
     hipLaunchKernelGGL(rdg_pose_partial_kernel, dim3(RDG_POSE_L2), dim3(256), 0, s, posebuf, rows, part);
     hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(64), 0, s, view, part, RDG_POSE_L2, dview);
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd launch");
+}
+
+int rdg_launch_preprocess_bwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+                                    const float* shs, const float* opac, const float* scales, const float* rots,
+                                    const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
+                                    const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
+                                    float* dopac, float* dscales, float* drots, hipStream_t s) {
+    const RdgGeomLayout G = rdg_geom_layout(total);
+    const int nblk = (d.P + 255) / 256;
+    if (d.P > 0)
+        hipLaunchKernelGGL(rdg_preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs,
+                           (const float*)nullptr, opac, scales, rots, (const float*)nullptr, radii + first,
+                           (const uint8_t*)((const char*)geom_ws + G.clamped) + first, grow + (size_t)first * RDG_GROW,
+                           posebuf + (size_t)(first / 256) * RDG_POSE_N, dmeans3D, dmeans2D, dshs, (float*)nullptr,
+                           dopac, dscales, drots, (float*)nullptr);
+    return rdg_check_hip(hipGetLastError(), "preprocess_bwd slice launch");
+}
+
+// pose-gradient reduction of all slices in two launches (camera v: partial rows [v*view_rows, v*view_rows + nblk))
+int rdg_launch_pose_reduce_views(int nviews, int view_rows, int nblk, const float* views, float* posebuf, float* part,
+                                 float* dviews, hipStream_t s) {
+    hipLaunchKernelGGL(rdg_pose_partial_kernel, dim3(RDG_POSE_L2, nviews), dim3(256), 0, s, posebuf, nblk, part, view_rows);
+    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(nviews), dim3(64), 0, s, views, part, RDG_POSE_L2, dviews);
+    return rdg_check_hip(hipGetLastError(), "pose reduce views launch");
 }

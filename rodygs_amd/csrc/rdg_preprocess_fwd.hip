@@ -190,7 +190,8 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                         cr = fmaxf(res[0], 0.f); cg = fmaxf(res[1], 0.f); cbl = fmaxf(res[2], 0.f);
                     }
                     R.q0 = make_float4(px, py, cc * det_inv, -cb * det_inv);
-                    R.q1 = make_float4(ca * det_inv, opac[i], vz, 0.f);
+                    // q1.w carries the pixel radius: a record is then self-contained (another rank can bin it, rdg_geom_from_records)
+                    R.q1 = make_float4(ca * det_inv, opac[i], vz, __int_as_float(radius));
                     R.q2 = make_float4(cr, cg, cbl, 0.f);
                     R.q3 = make_float4(nx, ny, nz, 0.f);
                 }
@@ -239,6 +240,47 @@ __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __r
     }
 }
 
+// Gaussian-sharded frame-DP: the records of this camera arrived from the ranks that own the Gaussians; rebuild what
+// the binning stage reads besides them (tile counts, radii, per-block sums) from the record itself.
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_geom_from_records_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
+                             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums,
+                             int32_t* __restrict__ radii) {
+    const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    uint32_t my_tiles = 0;
+    if (i < P) {
+        const float4 q0 = rec[i].q0;
+        const int radius = __float_as_int(rec[i].q1.w);
+        if (radius > 0) {
+            int x0, y0, x1, y1;
+            rdg_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+            my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+        }
+        tiles_touched[i] = my_tiles;
+        radii[i] = my_tiles ? radius : 0;
+    }
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    uint32_t inc = rdg_wave_scan_incl(my_tiles);
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii, int32_t* num_rendered,
+                                 hipStream_t s) {
+    const RdgGeomLayout L = rdg_geom_layout(d.P);
+    char* g = (char*)geom_ws;
+    const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    uint32_t* block_sums = (uint32_t*)(g + L.block_sums);
+    if (d.P > 0)
+        hipLaunchKernelGGL(rdg_geom_from_records_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+                           (const RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), block_sums, radii);
+    hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
+                       num_rendered);
+    return rdg_check_hip(hipGetLastError(), "geom_from_records launch");
+}
+
 int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, void* geom_ws, int32_t* radii,
@@ -255,4 +297,21 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
                        num_rendered);
     return rdg_check_hip(hipGetLastError(), "preprocess_fwd launch");
+}
+
+// One camera's slice [first, first + d.P) of a workspace laid out for `total` rows (first % 256 == 0): the sharded
+// frame-DP owner stage, whose records for all cameras of a step must sit in ONE contiguous send buffer.
+int rdg_launch_preprocess_fwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+                                    const float* shs, const float* opac, const float* scales, const float* rots,
+                                    const float* view, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s) {
+    const RdgGeomLayout L = rdg_geom_layout(total);
+    char* g = (char*)geom_ws;
+    const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    if (d.P > 0)
+        hipLaunchKernelGGL(rdg_preprocess_fwd_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
+                           shs, (const float*)nullptr, opac, scales, rots, (const float*)nullptr,
+                           (RdgRec*)(g + L.rec) + first, (uint32_t*)(g + L.tiles_touched) + first,
+                           (uint8_t*)(g + L.clamped) + first, (uint32_t*)(g + L.block_sums) + first / RDG_PRE_BLOCK,
+                           radii + first);
+    return rdg_check_hip(hipGetLastError(), "preprocess_fwd slice launch");
 }

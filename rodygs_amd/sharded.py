@@ -1,0 +1,341 @@
+"""Gaussian-sharded frame data parallelism: the 8-GPU train step without a parameter
+all-reduce.
+
+Plain frame-DP replicates the cloud, renders one camera per rank and all-reduces 75 floats per Gaussian (300 MB at
+1 M Gaussians): over point-to-point xGMI that exchange costs about as much as the whole backward pass.  Here the
+Gaussians -- parameters, Adam moments, gradients -- are SHARDED over the ranks and the cameras stay one per rank:
+
+  owner stage     every rank runs the per-Gaussian half of the rasterizer (deformation + activations, projection, SH
+                  colour) on ITS slice of the cloud for the cameras of ALL ranks: same work as one camera over the
+                  whole cloud, and it leaves one 64-byte splat record per (camera, Gaussian);
+  all-to-all #1   records go to the rank that renders the camera (56 MB in, 56 MB out per GPU at 1 M / 8 ranks; an
+                  all-to-all drives all seven xGMI links of a GPU at once);
+  camera stage    tile binning, sort, compositing, loss and compositing backward over all records of the camera --
+                  exactly the kernels of the single-GPU path -- leaving one 64-byte gradient row per Gaussian;
+  all-to-all #2   gradient rows go back to the owners;
+  owner stage     per-Gaussian backward for every camera, gradients summed over cameras locally, fused Adam on the
+                  slice.  Only the MLP + camera-pose bucket (~0.1 MB) is all-reduced.
+
+The two row formats and the *_views entry points are described in include/rodygs_hip.h.  Every collective is an
+equal-split ``all_to_all_single`` / ``all_reduce`` of ``torch.distributed`` (RCCL on the GPUs, gloo in the CPU
+tests of the exchange pattern); ``run_virtual_step`` drives several ranks inside one process for the single-GPU
+parity tests.  The reference has no distributed code: this is the build's own capability.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, rasterizer
+from .deform import MLPBasisNetwork, _birth_order
+from .dp import FlatParams, frame_for
+from .rasterizer import GaussianRasterizationSettings, _c_settings
+
+_ROW = 16          # floats per splat record / gradient row (64 bytes)
+
+
+class DistExchange:
+    """The three collectives of a sharded step over the default process group."""
+
+    def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        dist.all_to_all_single(recv, send)
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def shard_rows(P: int, world: int):
+    """(per, stride): Gaussians per rank (the last rank may hold fewer) and the 256-aligned row stride of a shard in
+    the exchanged buffers."""
+    per = (P + world - 1) // world
+    return per, (per + 255) // 256 * 256
+
+
+class ShardedDynamicScene:
+    """One rank's slice of a ``trainstep.DynamicScene`` (same parameters, same step arithmetic, gradients summed over
+    the cameras of all ranks before Adam) -- build it with ``from_replica``."""
+
+    @classmethod
+    def from_replica(cls, ds, rank: int, world: int, exchange=None) -> "ShardedDynamicScene":
+        return cls(ds, rank, world, exchange)
+
+    def __init__(self, ds, rank: int, world: int, exchange=None):
+        from .trainstep import _MLP_SINK_ORDER, bind_module_to_flat
+        if not 1 <= world <= 16:
+            raise ValueError("world must be 1..16 (RDG_MAX_VIEWS)")
+        if ds.full_losses:
+            raise NotImplementedError("the sharded step covers the photometric train step only")
+        T = ds.T
+        L = _lib.lib()
+        if not L.rdg_dyn_getter_views_supported(16, T, world):
+            raise NotImplementedError(f"motion table of {T} birth times x {world} views does not fit the fused getter")
+        dev = ds.device
+        self.device, self.rank, self.world = dev, rank, world
+        self.ex = exchange if exchange is not None else DistExchange()
+        self.H, self.W, self.T, self.sh_degree = ds.H, ds.W, T, ds.sh_degree
+        self.tanfovx, self.tanfovy = ds.tanfovx, ds.tanfovy
+        self.spatial_lr_scale = ds.spatial_lr_scale
+        self.P_total = ds.P
+        per, stride = shard_rows(ds.P, world)
+        lo, hi = min(rank * per, ds.P), min((rank + 1) * per, ds.P)
+        n = hi - lo
+        self.lo, self.n, self.per, self.stride = lo, n, per, stride
+        self.rows = world * stride
+        # ---- my slice of the parameters (+ fresh Adam moments copied from the replica's)
+        spec = {k: ((n, *ds.fp.shapes[k][1:]), ds.fp.lr[k]) for k in ds.fp.names}
+        fp = FlatParams(spec, dev)
+        with torch.no_grad():
+            for k in ds.fp.names:
+                fp[k].copy_(ds.fp[k][lo:hi])
+                o, m = fp.offsets[k]
+                so, _ = ds.fp.offsets[k]
+                row = m // max(n, 1)
+                for dst, src in ((fp.exp_avg, ds.fp.exp_avg), (fp.exp_avg_sq, ds.fp.exp_avg_sq)):
+                    dst[o:o + m].copy_(src[so + lo * row:so + hi * row])
+        fp.step_count = ds.fp.step_count
+        self.fp, self.row_lr = fp, dict(ds.row_lr)
+        self.K = ds.fp.shapes["features"][1]
+        self.time_ind = ds.time_ind[lo:hi].to(torch.int64).contiguous()
+        # ---- replicated small bucket: deformation MLP + camera poses
+        self.net = MLPBasisNetwork(128, 16, 26, False).to(dev)
+        self.sp = bind_module_to_flat(self.net, 0.0016, dev, {"cam_q": ((T, 4), 1e-5), "cam_t": ((T, 3), 1e-6)})
+        with torch.no_grad():
+            self.sp.flat.copy_(ds.sp.flat)
+            self.sp.exp_avg.copy_(ds.sp.exp_avg)
+            self.sp.exp_avg_sq.copy_(ds.sp.exp_avg_sq)
+        self.net.grad_sinks = [self.sp[k].grad for k in _MLP_SINK_ORDER]
+        self.time_batch_embeddings = ds.time_batch_embeddings
+        self.frame_embeddings = ds.frame_embeddings
+        self.proj_t, self.bg = ds.proj_t, ds.bg
+        self.gt = ds.gt
+        self._rows_cache = {}
+        # ---- persistent buffers: owner side (my Gaussians x all cameras) and camera side (all Gaussians x my camera)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        Wn, R = world, self.rows
+        with torch.cuda.device(dev):
+            self.geom_own = torch.zeros(L.rdg_geom_bytes(R), **u8)      # records of unused rows stay zero = invisible
+            self.geom_cam = torch.zeros(L.rdg_geom_bytes(R), **u8)
+            self.grad_own = torch.zeros(L.rdg_grad_bytes(R), **u8)
+            self.grad_cam = torch.zeros(L.rdg_grad_bytes(R), **u8)
+            self.radii_own = torch.zeros(R, dtype=torch.int32, device=dev)
+            self.radii_cam = torch.zeros(R, dtype=torch.int32, device=dev)
+            self.nren = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.rec_own = self.geom_own[:R * 64].view(torch.float32)
+            self.rec_cam = self.geom_cam[:R * 64].view(torch.float32)
+            self.row_own = self.grad_own[:R * 64].view(torch.float32)
+            self.row_cam = self.grad_cam[:R * 64].view(torch.float32)
+            # activated + deformed Gaussians of every camera, and the gradients coming back for them
+            self.m3, self.g_m3 = torch.zeros(Wn, stride, 3, **f32), torch.zeros(Wn, stride, 3, **f32)
+            self.ro, self.g_ro = torch.zeros(Wn, stride, 4, **f32), torch.zeros(Wn, stride, 4, **f32)
+            self.sc, self.g_sc = torch.zeros(max(n, 1), 3, **f32), torch.zeros(Wn, stride, 3, **f32)   # time-independent
+            self.op, self.g_op = torch.zeros(max(n, 1), 1, **f32), torch.zeros(Wn, stride, 1, **f32)
+            self.d_m2 = torch.zeros(Wn, stride, 3, **f32)
+            self.d_sh = torch.zeros(Wn, stride, self.K * 3, **f32)
+            self.views = torch.zeros(Wn, 16, **f32)
+            self.d_views = torch.zeros(Wn, 16, **f32)
+            self.d_bases = torch.zeros(Wn, T + 1, 16, 7, **f32)
+            self.sorted_ws = torch.empty(L.rdg_deform_sorted_views_ws_bytes(max(n, 1), Wn), **u8)
+            self.image_ws = torch.empty(L.rdg_image_bytes(self.H, self.W), **u8)
+            self.color = torch.empty(3, self.H, self.W, **f32)
+            self.depth = torch.empty(1, self.H, self.W, **f32)
+            self.normal = torch.empty(3, self.H, self.W, **f32)
+            self.alpha = torch.empty(1, self.H, self.W, **f32)
+            self.d_img = torch.empty(3, self.H, self.W, **f32)
+            self.loss_ws = torch.empty(L.rdg_loss_ws_bytes(3, self.H, self.W), **u8)
+            self.loss3 = torch.zeros(3, **f32)
+        self._binning = None
+        self._capacity = 0
+        rs = GaussianRasterizationSettings(self.H, self.W, self.tanfovx, self.tanfovy, self.bg, 1.0, self.proj_t,
+                                           self.sh_degree, False, False, True, True)
+        self.cs_own = _c_settings(rs, n, self.K)        # per-Gaussian stages: my n Gaussians (per camera)
+        self.cs_cam = _c_settings(rs, R, self.K)        # compositing stages: every row of the gathered records
+        self.key = (R, self.H, self.W)
+        self.frames: List[int] = []
+
+    # ---- the four local phases of a step; the collectives sit between them -------------------------------------------
+    def _emb_rows(self, frames: Sequence[int]) -> torch.Tensor:
+        key = tuple(frames)
+        r = self._rows_cache.get(key)
+        if r is None:
+            if len(self._rows_cache) > 512:
+                self._rows_cache.clear()
+            idx = torch.tensor(list(frames), dtype=torch.int64, device=self.device)
+            r = torch.cat([self.time_batch_embeddings, self.frame_embeddings[idx]], dim=0).contiguous()
+            self._rows_cache[key] = r
+        return r
+
+    def phase_owner_forward(self, step: int, perm: Sequence[int]) -> None:
+        """Deformation + activations + projection of MY Gaussians for the cameras of every rank -> ``rec_own``."""
+        L, Wn, T, n, dev = _lib.lib(), self.world, self.T, self.n, self.device
+        self.frames = [frame_for(step, r, Wn, perm) for r in range(Wn)]
+        self._frames_c = (C.c_int32 * Wn)(*self.frames)
+        fp = self.fp
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr()
+            # ONE pass of the MLP over the T birth-time rows + the W frame times
+            allb = self.net.motion_basis(self._emb_rows(self.frames))                   # [T+W,16,7]
+            self._bases_all = torch.cat([allb[:T].unsqueeze(0).expand(Wn, -1, -1, -1), allb[T:].unsqueeze(1)], dim=1)
+            b = self._bases_all.detach()
+            # my Gaussians at the times of all W cameras: parameters read once, one launch
+            _lib.check(L.rdg_dyn_getter_views_forward(n, T, Wn, self.stride, _lib.ptr(fp["motion_coeff"]),
+                                                      _lib.ptr(self.time_ind), _lib.ptr(b), float(self.spatial_lr_scale),
+                                                      _lib.ptr(fp["xyz"]), _lib.ptr(fp["scaling"]),
+                                                      _lib.ptr(fp["rotation"]), _lib.ptr(fp["opacity"]),
+                                                      _lib.ptr(self.m3), _lib.ptr(self.sc), _lib.ptr(self.ro),
+                                                      _lib.ptr(self.op), st), "rdg_dyn_getter_views_forward")
+            sp = self.sp
+            _lib.check(L.rdg_pose_views_forward(T, Wn, self._frames_c, _lib.ptr(sp["cam_q"]), _lib.ptr(sp["cam_t"]),
+                                                _lib.ptr(self.views), st), "rdg_pose_views_forward")
+            _lib.check(L.rdg_preprocess_forward_views(C.byref(self.cs_own), Wn, self.stride, _lib.ptr(self.m3),
+                                                      _lib.ptr(fp["features"]), _lib.ptr(self.op), _lib.ptr(self.sc),
+                                                      _lib.ptr(self.ro), _lib.ptr(self.views), _lib.ptr(self.proj_t),
+                                                      _lib.ptr(self.geom_own), _lib.ptr(self.radii_own), st),
+                       "rdg_preprocess_forward_views")
+
+    def _composite_forward(self) -> None:
+        L, dev = _lib.lib(), self.device
+        n_tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
+        hint = rasterizer._CAPACITY_HINT
+        cap = max(int(hint.get(self.key, 0) * 1.25) + 4096, 4 * self.P_total + 4096)
+        deferred = rasterizer.DEFERRED_OVERFLOW_CHECK and self.key in hint
+        if deferred:
+            rasterizer.poll_overflow(block=False)
+        st = _lib.stream_ptr()
+        while True:
+            if self._binning is None or self._capacity != cap:
+                self._binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), dtype=torch.uint8, device=dev)
+                self._capacity = cap
+            _lib.check(L.rdg_composite_forward(C.byref(self.cs_cam), _lib.ptr(self.bg), _lib.ptr(self.geom_cam),
+                                               _lib.ptr(self.radii_cam), _lib.ptr(self._binning), cap,
+                                               _lib.ptr(self.image_ws), _lib.ptr(self.nren), _lib.ptr(self.color),
+                                               _lib.ptr(self.depth), _lib.ptr(self.normal), _lib.ptr(self.alpha), st),
+                       "rdg_composite_forward")
+            if deferred:
+                host = rasterizer._pinned_slot()
+                host.copy_(self.nren, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                rasterizer._PENDING.append((ev, host, self.key, cap))
+                break
+            D = int(self.nren.item())
+            hint[self.key] = D
+            if D <= cap:
+                break
+            cap = int(D * 1.25) + 4096
+        rasterizer._LAST_IMAGE_WS[0] = (self.image_ws, self.H, self.W)
+
+    def phase_camera(self) -> torch.Tensor:
+        """Records of MY camera have arrived in ``rec_cam``: bin, composite, loss, compositing backward ->
+        ``row_cam`` (one gradient row per Gaussian of the whole cloud).  Returns the camera's loss."""
+        L, dev = _lib.lib(), self.device
+        frame = self.frames[self.rank]
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr()
+            _lib.check(L.rdg_geom_from_records(C.byref(self.cs_cam), _lib.ptr(self.geom_cam), _lib.ptr(self.radii_cam),
+                                               _lib.ptr(self.nren), st), "rdg_geom_from_records")
+            self._composite_forward()
+            gt = self.gt[frame]
+            _lib.check(L.rdg_photometric_loss_forward(3, self.H, self.W, _lib.ptr(self.color), _lib.ptr(gt), 0.2,
+                                                      _lib.ptr(self.loss_ws), _lib.ptr(self.loss3), st),
+                       "rdg_photometric_loss_forward")
+            _lib.check(L.rdg_photometric_loss_backward(3, self.H, self.W, _lib.ptr(self.color), _lib.ptr(gt), 0.2,
+                                                       _lib.ptr(self.loss_ws), None, _lib.ptr(self.d_img), st),
+                       "rdg_photometric_loss_backward")
+            _lib.check(L.rdg_composite_backward(C.byref(self.cs_cam), _lib.ptr(self.bg), _lib.ptr(self.geom_cam),
+                                                _lib.ptr(self._binning), self._capacity, _lib.ptr(self.image_ws),
+                                                _lib.ptr(self.d_img), None, None, _lib.ptr(self.grad_cam), st),
+                       "rdg_composite_backward")
+        return self.loss3[0]
+
+    def phase_owner_backward(self) -> None:
+        """Gradient rows of MY Gaussians from every camera have arrived in ``row_own``: per-Gaussian backward per
+        camera, sum over cameras into the flat gradient bucket, MLP + pose gradients into the small bucket (partial
+        sums over my slice -- the caller all-reduces ``sp.flat_grad``)."""
+        L, Wn, T, n, dev, fp = _lib.lib(), self.world, self.T, self.n, self.device, self.fp
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr()
+            _lib.check(L.rdg_preprocess_backward_views(
+                C.byref(self.cs_own), Wn, self.stride, _lib.ptr(self.m3), _lib.ptr(fp["features"]), _lib.ptr(self.op),
+                _lib.ptr(self.sc), _lib.ptr(self.ro), _lib.ptr(self.views), _lib.ptr(self.proj_t),
+                _lib.ptr(self.radii_own), _lib.ptr(self.geom_own), _lib.ptr(self.grad_own), _lib.ptr(self.g_m3),
+                _lib.ptr(self.d_m2), _lib.ptr(self.d_sh), _lib.ptr(self.g_op), _lib.ptr(self.g_sc), _lib.ptr(self.g_ro),
+                _lib.ptr(self.d_views), st), "rdg_preprocess_backward_views")
+            b = self._bases_all.detach()
+            if n:
+                order, inv = _birth_order(self.time_ind)
+                # all cameras in one pass: the five parameter gradients come out summed over the cameras, straight
+                # into the flat gradient bucket
+                _lib.check(L.rdg_dyn_getter_views_backward(
+                    n, T, Wn, self.stride, _lib.ptr(fp["motion_coeff"]), _lib.ptr(self.time_ind), _lib.ptr(b),
+                    float(self.spatial_lr_scale), _lib.ptr(fp["scaling"]), _lib.ptr(fp["rotation"]),
+                    _lib.ptr(fp["opacity"]), _lib.ptr(self.g_m3), _lib.ptr(self.g_sc), _lib.ptr(self.g_ro),
+                    _lib.ptr(self.g_op), _lib.ptr(fp["xyz"].grad), _lib.ptr(fp["scaling"].grad),
+                    _lib.ptr(fp["rotation"].grad), _lib.ptr(fp["opacity"].grad), _lib.ptr(fp["motion_coeff"].grad),
+                    _lib.ptr(self.d_bases), _lib.ptr(order), _lib.ptr(inv), _lib.ptr(self.sorted_ws), st),
+                    "rdg_dyn_getter_views_backward")
+                torch.sum(self.d_sh[:, :n], dim=0, out=fp["features"].grad.view(n, -1))
+            else:
+                self.d_bases.zero_()
+            self._bases_all.backward(self.d_bases)          # MLP backward: overwrites its ten sinks in sp.flat_grad
+            self._bases_all = None
+            sp = self.sp
+            _lib.check(L.rdg_pose_views_backward(T, Wn, self._frames_c, _lib.ptr(sp["cam_q"]), _lib.ptr(sp["cam_t"]),
+                                                 _lib.ptr(self.d_views), _lib.ptr(sp["cam_q"].grad),
+                                                 _lib.ptr(sp["cam_t"].grad), st), "rdg_pose_views_backward")
+
+    def phase_update(self) -> None:
+        from .trainstep import fused_adam_
+        fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,))
+
+    # ---- one step over the process group ---------------------------------------------------------------------------
+    def train_step(self, step: int, perm: Sequence[int]) -> torch.Tensor:
+        self.phase_owner_forward(step, perm)
+        self.ex.all_to_all(self.rec_cam, self.rec_own)
+        loss = self.phase_camera()
+        self.ex.all_to_all(self.row_own, self.row_cam)
+        self.phase_owner_backward()
+        self.ex.all_reduce(self.sp.flat_grad)
+        self.phase_update()
+        return loss.detach()
+
+    # ---- inspection ---------------------------------------------------------------------------------------------------
+    def visible_count(self) -> int:
+        return int((self.radii_cam > 0).sum().item())
+
+    def gather_params(self) -> Optional[dict]:
+        """{name: full [P,...] tensor} assembled from all ranks (checkpointing, tests); collective."""
+        out = {}
+        for k in self.fp.names:
+            mine = self.fp[k].detach()
+            pad = torch.zeros(self.per, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
+            pad[:self.n] = mine
+            parts = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(parts, pad)
+            out[k] = torch.cat(parts)[:self.P_total]
+        return out
+
+
+def run_virtual_step(scenes: Sequence[ShardedDynamicScene], step: int, perm: Sequence[int]) -> List[torch.Tensor]:
+    """All ranks of a sharded step inside ONE process (same device, same stream): the exchanges become block copies.
+    Used by the single-GPU parity tests; the arithmetic per rank is exactly that of ``train_step``."""
+    Wn = len(scenes)
+    for s in scenes:
+        s.phase_owner_forward(step, perm)
+    for c in range(Wn):
+        for s in range(Wn):
+            scenes[c].rec_cam.view(Wn, -1)[s].copy_(scenes[s].rec_own.view(Wn, -1)[c])
+    losses = [s.phase_camera() for s in scenes]
+    for s in range(Wn):
+        for c in range(Wn):
+            scenes[s].row_own.view(Wn, -1)[c].copy_(scenes[c].row_cam.view(Wn, -1)[s])
+    for s in scenes:
+        s.phase_owner_backward()
+    total = torch.stack([s.sp.flat_grad for s in scenes]).sum(0)
+    for s in scenes:
+        s.sp.flat_grad.copy_(total)
+        s.phase_update()
+    return [x.detach().clone() for x in losses]

@@ -105,3 +105,120 @@ def test_flat_params_views_and_single_process_noop():
     assert torch.equal(before, fp.flat_grad)
     fp.zero_grad()
     assert float(fp["a"].grad.abs().sum()) == 0.0
+
+
+# ---- Gaussian-sharded frame-DP (rodygs_amd/sharded.py): the exchange pattern with the oracle doing the arithmetic --------
+_SH_P, _SH_W, _SH_H = 301, 64, 48
+_FCOLS = ("px", "py", "conic", "opacity", "depth", "rgb", "normal")          # float part of a record (13 columns)
+_ICOLS = ("radii", "tiles_touched", "rminx", "rminy", "rmaxx", "rmaxy")       # integer part (exact as floats)
+
+
+def _sh_scene():
+    from oracle import rasterizer_oracle as O
+    sc = O.synthetic_scene(_SH_P, _SH_W, _SH_H, 1, seed=33)
+    st = O.OracleSettings(_SH_H, _SH_W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 1)
+    views = []
+    for c in range(2):
+        v = sc["viewmatrix"].clone()
+        v[3, 0] = 0.15 * (c + 1)
+        views.append(v)
+    return O, sc, st, views
+
+
+def _sh_records(O, sc, st, view, lo, hi, leaves=None):
+    """Oracle per-Gaussian stage on Gaussians [lo, hi) -> (record rows [n,19] attached to autograd, leaves)."""
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    leaves = leaves or {k: sc[k][lo:hi].clone().requires_grad_(True) for k in names}
+    g = O.preprocess(leaves["means3D"], torch.zeros(hi - lo, 3), leaves["opacities"], view, st, shs=leaves["shs"],
+                     scales=leaves["scales"], rotations=leaves["rotations"])
+    f = [g[k].reshape(hi - lo, -1) for k in _FCOLS]
+    rect = dict(zip(("rminx", "rminy", "rmaxx", "rmaxy"), g["rect"]))
+    i = [(g[k] if k in g else rect[k]).reshape(hi - lo, 1).to(torch.float32) for k in _ICOLS]
+    return torch.cat(f + i, dim=1), leaves, g["grid"]
+
+
+def _sh_geom(rows, grid):
+    """Camera side: the oracle's geom dict rebuilt from gathered record rows (a leaf requiring grad)."""
+    cols, o = {}, 0
+    for k, w in zip(_FCOLS, (1, 1, 3, 1, 1, 3, 3)):
+        cols[k] = rows[:, o:o + w] if w > 1 else rows[:, o]
+        o += w
+    ints = {k: rows[:, o + j].detach().to(torch.int32) for j, k in enumerate(_ICOLS)}
+    geom = dict(cols)
+    geom.update(radii=ints["radii"], tiles_touched=ints["tiles_touched"], grid=grid,
+                rect=tuple(ints[k].to(torch.int64) for k in ("rminx", "rminy", "rmaxx", "rmaxy")))
+    return geom
+
+
+def _sh_loss(O, geom, st):
+    img = O.render_tiles(geom, O.bin_and_sort(geom), st.bg, _SH_H, _SH_W)
+    return img["color"].sum() + 0.5 * img["depth"].sum()
+
+
+def _shard_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rodygs_amd.sharded import DistExchange, shard_rows
+    O, sc, st, views = _sh_scene()
+    ex = DistExchange()
+    per, stride = shard_rows(_SH_P, world)
+    lo, hi = rank * per, min((rank + 1) * per, _SH_P)
+    n, ncol = hi - lo, 13 + len(_ICOLS)
+    vleaf = [v.clone().requires_grad_(True) for v in views]
+    # owner forward: my slice for BOTH cameras -> one contiguous send buffer, camera c in rows [c*stride, c*stride+n)
+    send = torch.zeros(world, stride, ncol)
+    recs, leaves, grid = [], None, None
+    for c in range(world):
+        r, leaves, grid = _sh_records(O, sc, st, vleaf[c], lo, hi, leaves)
+        recs.append(r)
+        send[c, :n] = r.detach()
+    recv = torch.empty_like(send)
+    ex.all_to_all(recv.view(-1), send.view(-1))
+    # camera stage: every Gaussian of the cloud (shard s in rows [s*stride, ...)), my camera
+    rows = recv.view(world * stride, ncol).clone().requires_grad_(True)
+    loss = _sh_loss(O, _sh_geom(rows, grid), st)
+    loss.backward()
+    back = torch.empty_like(send)
+    ex.all_to_all(back.view(-1), rows.grad.view(-1).contiguous())
+    # owner backward: gradient rows of my slice from both cameras
+    torch.autograd.backward(recs, [back[c, :n] for c in range(world)])
+    dview = torch.stack([v.grad if v.grad is not None else torch.zeros(4, 4) for v in vleaf])
+    ex.all_reduce(dview)
+    torch.save({"loss": loss.detach(), "grads": {k: v.grad for k, v in leaves.items()}, "dview": dview, "lo": lo, "hi": hi,
+                "stride": stride}, os.path.join(outdir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_reproduces_replicated_gradients():
+    """Two gloo ranks, each owning half of the Gaussians and rendering one camera, with the oracle as the arithmetic:
+    records out (all_to_all_single), gradient rows back, per-Gaussian backward at the owner.  The parameter gradients
+    must equal the SUM over both cameras of the unsharded oracle's gradients, the pose gradients (all-reduced partial
+    sums) the unsharded ones, and each rank's loss its camera's unsharded loss."""
+    world = 2
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_shard_worker, args=(world, port, d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f"s{r}.pt"), weights_only=False) for r in range(world)]
+    O, sc, st, views = _sh_scene()
+    want, want_view, want_loss = None, [], []
+    for c in range(world):
+        v = views[c].clone().requires_grad_(True)
+        rows, leaves, grid = _sh_records(O, sc, st, v, 0, _SH_P)
+        full = rows.detach().clone().requires_grad_(True)
+        loss = _sh_loss(O, _sh_geom(full, grid), st)
+        loss.backward()
+        rows.backward(full.grad)
+        want_loss.append(loss.detach())
+        want_view.append(v.grad)
+        g = {k: t.grad for k, t in leaves.items()}
+        want = g if want is None else {k: want[k] + g[k] for k in g}
+    assert res[0]["stride"] == 256 and (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 151, 151, 301)
+    for r in range(world):
+        assert torch.allclose(res[r]["loss"], want_loss[r], rtol=1e-6, atol=0)
+        for k, gr in res[r]["grads"].items():
+            ref = want[k][res[r]["lo"]:res[r]["hi"]]
+            assert float(ref.abs().max()) > 0
+            assert torch.allclose(gr, ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max())), (r, k)
+        assert torch.allclose(res[r]["dview"], torch.stack(want_view), rtol=1e-4, atol=1e-5)
