@@ -151,8 +151,11 @@ int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3
  * viewmatrices [nviews,16].  geom_ws = rdg_geom_bytes(nviews*stride), radii [nviews*stride], grad_ws = rdg_grad_bytes(nviews*stride):
  * camera v owns rows [v*stride, v*stride + P) of each, so the records / gradient rows of all cameras are one
  * contiguous buffer that an equal-split all-to-all can send / fill.  Rows [P, stride) of a camera are never written:
- * zero the records once and they stay invisible.  Backward outputs are all stacked per camera (dL_dshs
- * [nviews,stride,M,3], dL_dscales [nviews,stride,3], dL_dopacities [nviews,stride]) and are overwritten on rows [0, P) of each camera; dL_dviewmatrices [nviews,16].           */
+ * zero the records once and they stay invisible.  Backward: dL_dshs [P,M,3] is overwritten with the SUM over the
+ * cameras; the other outputs are stacked per camera (dL_dmeans3D / dL_dmeans2D / dL_dscales [nviews,stride,3],
+ * dL_drotations [nviews,stride,4], dL_dopacities [nviews,stride]) and overwritten on rows [0, P) of each camera;
+ * dL_dviewmatrices [nviews,16].  Both run as ONE launch that loops over the cameras per Gaussian, so the SH rows are
+ * read (and their gradients written) once per step instead of once per camera.           */
 int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
                                  const float* means3D, const float* shs, const float* opacities, const float* scales,
                                  const float* rotations, const float* viewmatrices, const float* projmatrix,

@@ -103,7 +103,7 @@ size_t rdg_grad_bytes(int32_t P) {
     const size_t Pp = (size_t)(P > 0 ? P : 1);
     // gradient rows + one pose partial row per per-Gaussian workgroup + 32 second-level pose partial rows
     // (one set of second-level rows per camera for the *_views entry points)
-    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 255) / 256) * 19 * 4, 256) + 4096 +
+    return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 127) / 128) * 19 * 4, 256) + 4096 +
            (size_t)RDG_MAX_VIEWS * 32 * 19 * 4;
 }
 size_t rdg_sort_tmp_bytes(int64_t capacity) {
@@ -241,14 +241,10 @@ int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews
     if (rdg_make_dev(s_host, &d)) return -1;
     if (rdg_views_args(s_host, nviews, stride_rows, shs, scales, rotations)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    const int32_t total = nviews * stride_rows;
     rdg_stage_begin(RDG_STAGE_PREPROCESS, st);
-    for (int v = 0; v < nviews; ++v) {
-        const size_t o = (size_t)v * stride_rows;
-        int rc = rdg_launch_preprocess_fwd_slice(d, total, (int32_t)o, means3D + o * 3, shs, opacities, scales,
-                                                 rotations + o * 4, viewmatrices + 16 * v, projmatrix, geom_ws, radii, st);
-        if (rc) return rc;
-    }
+    int rc = rdg_launch_preprocess_fwd_views(d, nviews, stride_rows, means3D, shs, opacities, scales, rotations,
+                                             viewmatrices, projmatrix, geom_ws, radii, st);
+    if (rc) return rc;
     rdg_stage_end(RDG_STAGE_PREPROCESS, st);
     return 0;
 }
@@ -267,18 +263,17 @@ int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nview
     const size_t grow_bytes = rdg_align_up((size_t)total * RDG_GROW * 4, 256);
     float* posebuf = (float*)((char*)grad_ws + grow_bytes);
     rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
-    for (int v = 0; v < nviews; ++v) {
-        const size_t o = (size_t)v * stride_rows;
-        int rc = rdg_launch_preprocess_bwd_slice(d, total, (int32_t)o, means3D + o * 3, shs, opacities, scales,
-                                                 rotations + o * 4, viewmatrices + 16 * v, projmatrix, radii, geom_ws,
-                                                 (const float*)grad_ws, posebuf, dL_dmeans3D + o * 3, dL_dmeans2D + o * 3,
-                                                 dL_dshs + o * (size_t)d.M * 3, dL_dopacities + o, dL_dscales + o * 3,
-                                                 dL_drotations + o * 4, st);
+    {
+        int rc = rdg_launch_preprocess_bwd_views(d, nviews, stride_rows, means3D, shs, opacities, scales, rotations,
+                                                 viewmatrices, projmatrix, radii, geom_ws, (const float*)grad_ws, posebuf,
+                                                 dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dopacities, dL_dscales,
+                                                 dL_drotations, st);
         if (rc) return rc;
     }
     {
-        const int view_rows = stride_rows / 256, nblk = (d.P + 255) / 256;
-        float* part = (float*)((char*)posebuf + rdg_align_up(((size_t)total / 256 + 1) * 19 * 4, 256));
+        // the multi-camera kernel runs 128-thread workgroups: one partial pose row per 128 Gaussians
+        const int view_rows = stride_rows / 128, nblk = (d.P + 127) / 128;
+        float* part = (float*)((char*)posebuf + rdg_align_up(((size_t)total / 128 + 1) * 19 * 4, 256));
         int rc = rdg_launch_pose_reduce_views(nviews, view_rows, d.P > 0 ? nblk : 0, viewmatrices, posebuf, part,
                                               dL_dviewmatrices, st);
         if (rc) return rc;

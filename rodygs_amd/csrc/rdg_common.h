@@ -184,12 +184,12 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                               float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
                               float* dview, hipStream_t s);
 
-int rdg_launch_preprocess_fwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+int rdg_launch_preprocess_fwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
                                     const float* shs, const float* opac, const float* scales, const float* rots,
-                                    const float* view, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s);
-int rdg_launch_preprocess_bwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+                                    const float* views, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s);
+int rdg_launch_preprocess_bwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
                                     const float* shs, const float* opac, const float* scales, const float* rots,
-                                    const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
+                                    const float* views, const float* proj, const int32_t* radii, const void* geom_ws,
                                     const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
                                     float* dopac, float* dscales, float* drots, hipStream_t s);
 int rdg_launch_pose_reduce_views(int nviews, int view_rows, int nblk, const float* views, float* posebuf, float* part,
@@ -232,6 +232,7 @@ __device__ __forceinline__ void rdg_wave_lds_sync() {
 // an LDS tile S[64][stride] (stride odd -> a lane walking its own row is bank-conflict free).  One lane per
 // Gaussian reading its own 48-float SH row straight from global memory touches 64 cache lines per load
 // instruction and uses 4-16 bytes of each; through here every global instruction moves 1 KB (or 256 B) contiguous.
+template <bool NT = true>
 __device__ __forceinline__ void rdg_rows_to_lds(const float* __restrict__ g, long long first_row, long long n_rows,
                                                 int row, int stride, float* S, int lane) {
     const long long base = first_row * row, total = n_rows * row;
@@ -241,7 +242,9 @@ __device__ __forceinline__ void rdg_rows_to_lds(const float* __restrict__ g, lon
             const long long e = base + 4ll * v;
             if (e < total) {
                 typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
-                const rdg_nt4 val = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(g + e));
+                // NT = false: the rows will be read again soon (another camera of the same step): keep them cached
+                const rdg_nt4 val = NT ? __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(g + e))
+                                       : *reinterpret_cast<const rdg_nt4*>(g + e);
                 const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
                 float* dst = S + gi * stride + (4 * v - gi * row);
                 dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
@@ -278,6 +281,36 @@ __device__ __forceinline__ void rdg_lds_to_rows(float* __restrict__ g, long long
             if (e < total) {
                 const int gi = (int)(((float)idx + 0.5f) * inv_row);
                 g[e] = S[gi * stride + (idx - gi * row)];
+            }
+        }
+    }
+}
+// g[rows] += S (or = S when !ACC): the accumulate form of rdg_lds_to_rows with ordinary (cached) accesses, for outputs
+// that several cameras of one step add into back to back.
+template <bool ACC>
+__device__ __forceinline__ void rdg_lds_acc_rows(float* __restrict__ g, long long first_row, long long n_rows, int row,
+                                                 int stride, const float* S, int lane) {
+    const long long base = first_row * row, total = n_rows * row;
+    const float inv_row = 1.0f / (float)row;
+    if ((row & 3) == 0 && (((uintptr_t)g) & 15) == 0) {
+        for (int v = lane; v < 16 * row; v += 64) {
+            const long long e = base + 4ll * v;
+            if (e < total) {
+                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                const float* src = S + gi * stride + (4 * v - gi * row);
+                float4* dst = reinterpret_cast<float4*>(g + e);
+                float4 val = make_float4(src[0], src[1], src[2], src[3]);
+                if (ACC) { const float4 o = *dst; val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w; }
+                *dst = val;
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * row; idx += 64) {
+            const long long e = base + idx;
+            if (e < total) {
+                const int gi = (int)(((float)idx + 0.5f) * inv_row);
+                const float val = S[gi * stride + (idx - gi * row)];
+                g[e] = ACC ? g[e] + val : val;
             }
         }
     }

@@ -386,9 +386,9 @@ __device__ __forceinline__ void rdg_views_to_lds(float* sm, int Tu, int NV, cons
     }
 }
 
-// Forward: c . (B(t_v) - table[birth]) is evaluated as c . B(t_v) - c . table[birth]: the table row of a lane (the
-// expensive LDS operand, 64 different rows per instruction) is then read once for all views instead of once per view
-// (that form was LDS-bound: 137 us for 125 k Gaussians x 8 views).  The single-view getter runs this same kernel with
+// Forward: c . (B(t_v) - table[birth]) is evaluated as c . B(t_v) - c . table[birth] with f64 accumulators: the table
+// row of a lane (the expensive LDS operand, 64 different rows per instruction) is then read once for all views instead
+// of once per view (that form was LDS-bound: 137 us for 125 k Gaussians x 8 views).  The single-view getter runs this same kernel with
 // NV = 1, so both frame-DP modes produce the same bits.
 __global__ void __launch_bounds__(512)
 rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* __restrict__ coeff,
@@ -414,10 +414,15 @@ rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* 
 #pragma unroll
         for (int k = 0; k < 3; ++k) scales[3 * p + k] = __expf(scaling[3 * p + k]);
         opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
-        // c . table[birth]: the expensive LDS operand (64 different rows per instruction), once for all views
-        float tdot[RDG_DEF_K];
+        // c . table[birth]: the expensive LDS operand (64 different rows per instruction), once for all views.
+        // Both dot products accumulate in f64: B(t_v) and the birth row are close for a smooth motion basis, and the
+        // difference of two f32 dot products would lose the digits the reference keeps by subtracting first.
+        double cd[16];
 #pragma unroll
-        for (int k = 0; k < RDG_DEF_K; ++k) tdot[k] = 0.0f;
+        for (int b = 0; b < 16; ++b) cd[b] = (double)c[b];
+        double tdot[RDG_DEF_K];
+#pragma unroll
+        for (int k = 0; k < RDG_DEF_K; ++k) tdot[k] = 0.0;
 #pragma unroll
         for (int j = 0; j < 28; ++j) {
             const float4 t = r4[j];
@@ -425,15 +430,15 @@ rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* 
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const int e = 4 * j + e4;
-                tdot[e % 7] = __fmaf_rn(c[e / 7], vv[e4], tdot[e % 7]);
+                tdot[e % 7] = fma(cd[e / 7], (double)vv[e4], tdot[e % 7]);
             }
         }
         for (int v = 0; v < NV; ++v) {
             // c . B(t_v): broadcast reads (one address for the whole wave)
             const float4* b4 = reinterpret_cast<const float4*>(sbt + v * 112);
-            float acc[RDG_DEF_K];
+            double accd[RDG_DEF_K];
 #pragma unroll
-            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = 0.0f;
+            for (int k = 0; k < RDG_DEF_K; ++k) accd[k] = 0.0;
 #pragma unroll
             for (int j = 0; j < 28; ++j) {
                 const float4 bb = b4[j];
@@ -441,11 +446,12 @@ rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* 
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int e = 4 * j + e4;
-                    acc[e % 7] = __fmaf_rn(c[e / 7], vv[e4], acc[e % 7]);
+                    accd[e % 7] = fma(cd[e / 7], (double)vv[e4], accd[e % 7]);
                 }
             }
+            float acc[RDG_DEF_K];
 #pragma unroll
-            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] -= tdot[k];
+            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = (float)(accd[k] - tdot[k]);
             const size_t row = (size_t)v * stride + p;
             means3D[3 * row] = __fmaf_rn(acc[0], scale, x0);
             means3D[3 * row + 1] = __fmaf_rn(acc[1], scale, x1);
@@ -475,9 +481,9 @@ rdg_dyn_getter_views_bwd_kernel(int P, int Tu, int NV, int stride, const long lo
         const size_t sidx = (size_t)inv_order[p];
         float gsum[RDG_DEF_K] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float sm3[3] = {0.f, 0.f, 0.f}, ssc[3] = {0.f, 0.f, 0.f}, sop = 0.f;
-        float sacc[16];
+        double sacc[16];           // f64: sum_v g_v . B(t_v) and (sum_v g_v) . table[birth] nearly cancel (see forward)
 #pragma unroll
-        for (int b = 0; b < 16; ++b) sacc[b] = 0.0f;
+        for (int b = 0; b < 16; ++b) sacc[b] = 0.0;
         for (int v = 0; v < NV; ++v) {
             const size_t row = (size_t)v * stride + p;
             const float m0 = g_means3D[3 * row], m1 = g_means3D[3 * row + 1], m2 = g_means3D[3 * row + 2];
@@ -500,7 +506,7 @@ rdg_dyn_getter_views_bwd_kernel(int P, int Tu, int NV, int stride, const long lo
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int e = 4 * j + e4;
-                    sacc[e / 7] += g[e % 7] * vv[e4];
+                    sacc[e / 7] = fma((double)g[e % 7], (double)vv[e4], sacc[e / 7]);
                 }
             }
         }
@@ -513,12 +519,13 @@ rdg_dyn_getter_views_bwd_kernel(int P, int Tu, int NV, int stride, const long lo
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const int e = 4 * j + e4;
-                sacc[e / 7] -= gsum[e % 7] * vv[e4];
+                sacc[e / 7] = fma(-(double)gsum[e % 7], (double)vv[e4], sacc[e / 7]);
             }
         }
         float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dc[q] = make_float4(sacc[4 * q], sacc[4 * q + 1], sacc[4 * q + 2], sacc[4 * q + 3]);
+        for (int q = 0; q < 4; ++q)
+            dc[q] = make_float4((float)sacc[4 * q], (float)sacc[4 * q + 1], (float)sacc[4 * q + 2], (float)sacc[4 * q + 3]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             d_xyz[3 * p + k] = sm3[k];
@@ -677,6 +684,16 @@ __device__ __forceinline__ void rdg_st4(float* base, long long i, float4 v) {
     }
 }
 
+// One element of the update, with the fused multiply-adds written out: the float4 body and the scalar tail of a segment
+// must round identically, or a parameter's value would depend on where its segment happens to end (sharded vs
+// replicated layouts of the same cloud differed by one ulp on the tail elements).
+__device__ __forceinline__ void rdg_adam_elem(float& p, float g, float& m, float& v, float st, float b1, float b2,
+                                              float eps, float bc2_sqrt) {
+    m = __fmaf_rn(b1, m, (1.0f - b1) * g);
+    v = __fmaf_rn(b2, v, ((1.0f - b2) * g) * g);
+    p = __fmaf_rn(-st, m / (sqrtf(v) / bc2_sqrt + eps), p);
+}
+
 template <int VAR>
 __device__ __forceinline__ void
 rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -698,10 +715,7 @@ rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g
         } else {
             s0 = s1 = s2 = s3 = step_head;
         }
-#define RDG_ADAM1(c, st)                                               \
-        mm.c = b1 * mm.c + (1.0f - b1) * gg.c;                         \
-        vv.c = b2 * vv.c + (1.0f - b2) * gg.c * gg.c;                  \
-        pp.c -= st * (mm.c / (sqrtf(vv.c) / bc2_sqrt + eps));
+#define RDG_ADAM1(c, st) rdg_adam_elem(pp.c, gg.c, mm.c, vv.c, st, b1, b2, eps, bc2_sqrt);
         RDG_ADAM1(x, s0) RDG_ADAM1(y, s1) RDG_ADAM1(z, s2) RDG_ADAM1(w, s3)
         rdg_st4<VAR>(p, i, pp);
         rdg_st4<VAR>(m, i, mm);
@@ -712,11 +726,9 @@ rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g
     const long long i = t0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const float st = (row_len > 1) ? ((int)(i % row_len) < head_len ? step_head : step_tail) : step_head;
-        const float gi = g[i];
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= st * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        float pi = p[i], mi = m[i], vi = v[i];
+        rdg_adam_elem(pi, g[i], mi, vi, st, b1, b2, eps, bc2_sqrt);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 
@@ -932,7 +944,13 @@ int rdg_dyn_getter_views_backward(int32_t P, int32_t Tu, int32_t nviews, int32_t
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
                            (const int*)inv_order, (float4*)sorted_ws);
         const int npair = (nviews + 1) / 2;
-        const dim3 grid(256), block(256);
+        // ~256 birth-sorted Gaussians per wave: fewer leaves the gathers latency-bound, more multiplies the flush
+        // atomics (measured at 125 k Gaussians x 8 views: 128 workgroups 20 % faster than 512)
+        static int accv_grid = -1;
+        if (accv_grid < 0) { const char* ev = getenv("RDG_ACCV_GRID"); accv_grid = ev ? atoi(ev) : 0; }
+        int accv = accv_grid > 0 ? accv_grid : (P + 1023) / 1024;
+        if (accv_grid <= 0) accv = accv < 128 ? 128 : (accv > 2048 ? 2048 : accv);
+        const dim3 grid(accv), block(256);
         if (npair <= 1)
             hipLaunchKernelGGL(rdg_deform_bwd_acc_views_kernel<1>, grid, block, 0, st, P, nviews, Tu, coeff,
                                (const int*)order, d_bases_all, (const float*)sorted_ws);

@@ -19,24 +19,56 @@ __device__ static const float BSH_C3[7] = {-0.5900435899266435f, 2.8906114426405
 // posebuf layout: [0..15] dL/dV (glm flat), [16..18] dL/dcampos
 #define RDG_POSE_N 19
 
+template <bool MULTI>
 __global__ void __launch_bounds__(256)
-rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float* __restrict__ proj,
-                          const float* __restrict__ means3D, const float* __restrict__ shs,
+rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const float* __restrict__ proj,
+                          const float* __restrict__ means3D_b, const float* __restrict__ shs,
                           const float* __restrict__ colors, const float* __restrict__ opac,
-                          const float* __restrict__ scales, const float* __restrict__ rots,
-                          const float* __restrict__ cov3Dp, const int32_t* __restrict__ radii,
-                          const uint8_t* __restrict__ clampedm, const float* __restrict__ grow,
-                          float* __restrict__ posebuf, float* __restrict__ dmeans3D, float* __restrict__ dmeans2D,
-                          float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac,
-                          float* __restrict__ dscales, float* __restrict__ drots, float* __restrict__ dcov3D) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                          const float* __restrict__ scales, const float* __restrict__ rots_b,
+                          const float* __restrict__ cov3Dp, const int32_t* __restrict__ radii_b,
+                          const uint8_t* __restrict__ clampedm_b, const float* __restrict__ grow_b,
+                          float* __restrict__ posebuf_b, float* __restrict__ dmeans3D_b, float* __restrict__ dmeans2D_b,
+                          float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac_b,
+                          float* __restrict__ dscales_b, float* __restrict__ drots_b, float* __restrict__ dcov3D,
+                          int nviews_arg, int vstride_arg) {
+    const int nviews = MULTI ? nviews_arg : 1, vstride = MULTI ? vstride_arg : 0;   // MULTI = false: the single-camera kernel
+    // nviews > 1 (sharded frame-DP owner stage): the same Gaussians under the cameras of a whole step; per-camera
+    // inputs / outputs are stacked with a row stride of vstride, SH rows, scales and opacities are shared, and dL/dshs
+    // [P,M,3] is the SUM over the cameras (camera 0 stores, the others add: the rows stay cache-resident in between).
+    // MULTI runs 128-thread workgroups: besides the SH rows each wave keeps a second LDS tile that ACCUMULATES dL/dshs
+    // over the cameras (25 KB per wave; 3 workgroups = 6 waves per CU), so the rows are staged once and the gradient is
+    // written once however many cameras the step has.
+    constexpr int BT = MULTI ? 128 : 256, NW = BT / 64;
+    const int i = blockIdx.x * BT + threadIdx.x;
     // SH coefficients in, SH gradients out: staged per wave through LDS (rdg_rows_to_lds); each lane then works on
     // its own row IN PLACE -- every coefficient is read before its slot is overwritten with the gradient.
-    __shared__ float sSH[4][64 * 49];
+    __shared__ float sSH[NW][64 * 49];
+    __shared__ float sGR[MULTI ? NW : 1][MULTI ? 64 * 49 : 1];
     const int sh_row = d.M * 3, sh_stride = sh_row | 1;
     float* const mySH = sSH[threadIdx.x >> 6] + (threadIdx.x & 63) * sh_stride;
-    const long long wave_first = (long long)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;
-    if (shs && wave_first < d.P) {
+    float* const myGR = MULTI ? sGR[threadIdx.x >> 6] + (threadIdx.x & 63) * sh_stride : mySH;
+    const long long wave_first = (long long)blockIdx.x * BT + (threadIdx.x >> 6) * 64;
+    __shared__ float sPose[NW][RDG_POSE_N];
+    if (MULTI && shs && wave_first < d.P) {
+        rdg_rows_to_lds(shs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
+        for (int k = 0; k < sh_row; ++k) myGR[k] = 0.0f;
+        rdg_wave_lds_sync();
+    }
+    for (int vw = 0; vw < nviews; ++vw) {
+    const size_t vo = (size_t)vw * vstride;
+    const float* __restrict__ view = view_b + 16 * vw;
+    const float* __restrict__ means3D = means3D_b + vo * 3;
+    const float* __restrict__ rots = rots_b ? rots_b + vo * 4 : nullptr;
+    const int32_t* __restrict__ radii = radii_b + vo;
+    const uint8_t* __restrict__ clampedm = clampedm_b + vo;
+    const float* __restrict__ grow = grow_b + vo * RDG_GROW;
+    float* __restrict__ posebuf = posebuf_b + (vo / BT) * RDG_POSE_N;
+    float* __restrict__ dmeans3D = dmeans3D_b + vo * 3;
+    float* __restrict__ dmeans2D = dmeans2D_b + vo * 3;
+    float* __restrict__ dopac = dopac_b + vo;
+    float* __restrict__ dscales = dscales_b ? dscales_b + vo * 3 : nullptr;
+    float* __restrict__ drots = drots_b ? drots_b + vo * 4 : nullptr;
+    if (!MULTI && shs && wave_first < d.P) {
         rdg_rows_to_lds(shs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
         rdg_wave_lds_sync();
     }
@@ -182,17 +214,18 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                 const float il = 1.0f / ln;
                 const float ux = ox * il, uy = oy * il, uz = oz * il;
                 const float* sh = mySH;
-                float* dsh = mySH;
+                float* dsh = myGR;          // single camera: in place (every coefficient is read before it is overwritten)
+#define RDG_DSH(idx, val) do { if (MULTI) dsh[idx] += (val); else dsh[idx] = (val); } while (0)
                 float dRx = 0.f, dRy = 0.f, dRz = 0.f;  // dL/d(unit dir)
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) dsh[ch] = SH_C0 * gcol[ch];
+                for (int ch = 0; ch < 3; ++ch) RDG_DSH(ch, SH_C0 * gcol[ch]);
                 if (d.deg > 0) {
                     const float b1 = -SH_C1 * uy, b2 = SH_C1 * uz, b3 = -SH_C1 * ux;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const float g = gcol[ch];
                         const float h1 = sh[3 + ch], h2 = sh[6 + ch], h3 = sh[9 + ch];
-                        dsh[3 + ch] = b1 * g; dsh[6 + ch] = b2 * g; dsh[9 + ch] = b3 * g;
+                        RDG_DSH(3 + ch, b1 * g); RDG_DSH(6 + ch, b2 * g); RDG_DSH(9 + ch, b3 * g);
                         dRx += -SH_C1 * h3 * g;
                         dRy += -SH_C1 * h1 * g;
                         dRz += SH_C1 * h2 * g;
@@ -206,8 +239,8 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                             const float g = gcol[ch];
                             const float h4 = sh[12 + ch], h5 = sh[15 + ch], h6 = sh[18 + ch], h7 = sh[21 + ch],
                                         h8 = sh[24 + ch];
-                            dsh[12 + ch] = b4 * g; dsh[15 + ch] = b5 * g; dsh[18 + ch] = b6 * g;
-                            dsh[21 + ch] = b7 * g; dsh[24 + ch] = b8 * g;
+                            RDG_DSH(12 + ch, b4 * g); RDG_DSH(15 + ch, b5 * g); RDG_DSH(18 + ch, b6 * g);
+                            RDG_DSH(21 + ch, b7 * g); RDG_DSH(24 + ch, b8 * g);
                             dRx += (BSH_C2[0] * uy * h4 + BSH_C2[2] * -2.0f * ux * h6 + BSH_C2[3] * uz * h7 +
                                     BSH_C2[4] * 2.0f * ux * h8) * g;
                             dRy += (BSH_C2[0] * ux * h4 + BSH_C2[1] * uz * h5 + BSH_C2[2] * -2.0f * uy * h6 +
@@ -225,9 +258,9 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                                 const float g = gcol[ch];
                                 const float h9 = sh[27 + ch], h10 = sh[30 + ch], h11 = sh[33 + ch], h12 = sh[36 + ch],
                                             h13 = sh[39 + ch], h14 = sh[42 + ch], h15 = sh[45 + ch];
-                                dsh[27 + ch] = b9 * g; dsh[30 + ch] = b10 * g; dsh[33 + ch] = b11 * g;
-                                dsh[36 + ch] = b12 * g; dsh[39 + ch] = b13 * g; dsh[42 + ch] = b14 * g;
-                                dsh[45 + ch] = b15 * g;
+                                RDG_DSH(27 + ch, b9 * g); RDG_DSH(30 + ch, b10 * g); RDG_DSH(33 + ch, b11 * g);
+                                RDG_DSH(36 + ch, b12 * g); RDG_DSH(39 + ch, b13 * g); RDG_DSH(42 + ch, b14 * g);
+                                RDG_DSH(45 + ch, b15 * g);
                                 dRx += (BSH_C3[0] * h9 * 3.0f * 2.0f * xy + BSH_C3[1] * h10 * yz +
                                         BSH_C3[2] * h11 * -2.0f * xy + BSH_C3[3] * h12 * -3.0f * 2.0f * xz +
                                         BSH_C3[4] * h13 * (-3.0f * xx + 4.0f * zz - yy) +
@@ -244,9 +277,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                     }
                 }
                 // zero the inactive-degree coefficients of this Gaussian
-                for (int k = (d.deg + 1) * (d.deg + 1); k < d.M; ++k) {
-                    dsh[3 * k + 0] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f;
-                }
+                if (!MULTI)
+                    for (int k = (d.deg + 1) * (d.deg + 1); k < d.M; ++k) {
+                        dsh[3 * k + 0] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f;
+                    }
+#undef RDG_DSH
                 // unit-vector normalisation backward
                 const float dotg = ux * dRx + uy * dRy + uz * dRz;
                 ddx = (dRx - ux * dotg) * il; ddy = (dRy - uy * dotg) * il; ddz = (dRz - uz * dotg) * il;
@@ -292,7 +327,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
                 dq3 = 2.0f * (-2.0f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.0f * qz * dR11 + qy * dR12 +
                               qx * dR20 + qy * dR21);
             }
-        } else if (shs) {
+        } else if (shs && !MULTI) {
             for (int k = 0; k < sh_row; ++k) mySH[k] = 0.f;
         }
         dmeans3D[3 * i + 0] = dmx; dmeans3D[3 * i + 1] = dmy; dmeans3D[3 * i + 2] = dmz;
@@ -309,13 +344,13 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
             reinterpret_cast<float4*>(drots)[i] = make_float4(dq0, dq1, dq2, dq3);
         }
     }
-    if (shs && wave_first < d.P) {
+    if (shs && wave_first < d.P && vw == nviews - 1) {
         rdg_wave_lds_sync();
-        rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
+        rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, MULTI ? sGR[threadIdx.x >> 6] : sSH[threadIdx.x >> 6],
+                        threadIdx.x & 63);
     }
     // pose-gradient reduction: DPP wave sums -> LDS -> ONE partial row per workgroup (no atomics: 16 k waves
     // hammering the same 19 addresses ran 20x slower than the rest of the kernel, and this form is deterministic)
-    __shared__ float sPose[4][RDG_POSE_N];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < RDG_POSE_N; ++k) {
@@ -325,7 +360,10 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view, const float*
     __syncthreads();
     if (threadIdx.x < RDG_POSE_N)
         posebuf[(size_t)blockIdx.x * RDG_POSE_N + threadIdx.x] =
-            (sPose[0][threadIdx.x] + sPose[1][threadIdx.x]) + (sPose[2][threadIdx.x] + sPose[3][threadIdx.x]);
+            MULTI ? sPose[0][threadIdx.x] + sPose[NW - 1][threadIdx.x]
+                  : (sPose[0][threadIdx.x] + sPose[1][threadIdx.x]) + (sPose[2][threadIdx.x] + sPose[NW - 1][threadIdx.x]);
+    if (nviews > 1) __syncthreads();       // sPose is reused by the next camera
+    }
 }
 
 // Fixed-order reduction of the per-workgroup partial rows in two small launches (a single workgroup walking all
@@ -399,9 +437,9 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const int nblk = (d.P + 255) / 256;
     if (d.P > 0) {
-        hipLaunchKernelGGL(rdg_preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs, colors,
+        hipLaunchKernelGGL(rdg_preprocess_bwd_kernel<false>, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs, colors,
                            opac, scales, rots, cov3D, radii, (const uint8_t*)((const char*)geom_ws + G.clamped),
-                           grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D);
+                           grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D, 1, 0);
     }
     // second-level rows live behind the per-workgroup rows (rdg_grad_bytes reserves them)
     float* part = (float*)((char*)posebuf + rdg_align_up((size_t)(nblk > 0 ? nblk : 1) * RDG_POSE_N * 4, 256));
@@ -411,20 +449,19 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd launch");
 }
 
-int rdg_launch_preprocess_bwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+int rdg_launch_preprocess_bwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
                                     const float* shs, const float* opac, const float* scales, const float* rots,
-                                    const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
+                                    const float* views, const float* proj, const int32_t* radii, const void* geom_ws,
                                     const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
                                     float* dopac, float* dscales, float* drots, hipStream_t s) {
-    const RdgGeomLayout G = rdg_geom_layout(total);
-    const int nblk = (d.P + 255) / 256;
+    const RdgGeomLayout G = rdg_geom_layout(nviews * stride);
+    const int nblk = (d.P + 127) / 128;
     if (d.P > 0)
-        hipLaunchKernelGGL(rdg_preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs,
-                           (const float*)nullptr, opac, scales, rots, (const float*)nullptr, radii + first,
-                           (const uint8_t*)((const char*)geom_ws + G.clamped) + first, grow + (size_t)first * RDG_GROW,
-                           posebuf + (size_t)(first / 256) * RDG_POSE_N, dmeans3D, dmeans2D, dshs, (float*)nullptr,
-                           dopac, dscales, drots, (float*)nullptr);
-    return rdg_check_hip(hipGetLastError(), "preprocess_bwd slice launch");
+        hipLaunchKernelGGL(rdg_preprocess_bwd_kernel<true>, dim3(nblk), dim3(128), 0, s, d, views, proj, means3D, shs,
+                           (const float*)nullptr, opac, scales, rots, (const float*)nullptr, radii,
+                           (const uint8_t*)((const char*)geom_ws + G.clamped), grow, posebuf, dmeans3D, dmeans2D, dshs,
+                           (float*)nullptr, dopac, dscales, drots, (float*)nullptr, nviews, stride);
+    return rdg_check_hip(hipGetLastError(), "preprocess_bwd views launch");
 }
 
 // pose-gradient reduction of all slices in two launches (camera v: partial rows [v*view_rows, v*view_rows + nblk))

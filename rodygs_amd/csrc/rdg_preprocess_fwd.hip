@@ -26,14 +26,20 @@ __device__ __forceinline__ void rdg_rect(float px, float py, int radius, int gx,
     y1 = min(gy, max(0, (int)((((py + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
 }
 
+template <bool MULTI>
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float* __restrict__ proj,
-                          const float* __restrict__ means3D, const float* __restrict__ shs,
+rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const float* __restrict__ proj,
+                          const float* __restrict__ means3D_b, const float* __restrict__ shs,
                           const float* __restrict__ colors, const float* __restrict__ opac,
-                          const float* __restrict__ scales, const float* __restrict__ rots,
-                          const float* __restrict__ cov3Dp, RdgRec* __restrict__ rec,
-                          uint32_t* __restrict__ tiles_touched, uint8_t* __restrict__ clampedm,
-                          uint32_t* __restrict__ block_sums, int32_t* __restrict__ radii) {
+                          const float* __restrict__ scales, const float* __restrict__ rots_b,
+                          const float* __restrict__ cov3Dp, RdgRec* __restrict__ rec_b,
+                          uint32_t* __restrict__ tiles_touched_b, uint8_t* __restrict__ clampedm_b,
+                          uint32_t* __restrict__ block_sums_b, int32_t* __restrict__ radii_b, int nviews_arg,
+                          int vstride_arg) {
+    const int nviews = MULTI ? nviews_arg : 1, vstride = MULTI ? vstride_arg : 0;   // MULTI = false: the single-camera kernel
+    // nviews > 1 (sharded frame-DP owner stage): the same Gaussians under the cameras of a whole step.  Time-dependent
+    // inputs (means3D, rotations) and all outputs are stacked per camera with a row stride of vstride (multiple of
+    // 256); SH rows, scales and opacities are shared -- the SH rows are staged into LDS once for all cameras.
     const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
     // SH rows of the wave's 64 Gaussians: staged through LDS with wave-contiguous loads (rdg_rows_to_lds)
     __shared__ float sSH[RDG_PRE_BLOCK / 64][64 * 49];
@@ -45,6 +51,17 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float*
     }
     // camera: uniform addresses -> scalar loads into SGPRs (the matrices live on the device because the
     // viewmatrix is the output of autograd-tracked pose math; no host round trip)
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    for (int vw = 0; vw < nviews; ++vw) {
+    const size_t vo = (size_t)vw * vstride;
+    const float* __restrict__ view = view_b + 16 * vw;
+    const float* __restrict__ means3D = means3D_b + vo * 3;
+    const float* __restrict__ rots = rots_b ? rots_b + vo * 4 : nullptr;
+    RdgRec* __restrict__ rec = rec_b + vo;
+    uint32_t* __restrict__ tiles_touched = tiles_touched_b + vo;
+    uint8_t* __restrict__ clampedm = clampedm_b + vo;
+    int32_t* __restrict__ radii = radii_b + vo;
+    uint32_t* __restrict__ block_sums = block_sums_b + vo / RDG_PRE_BLOCK;
     float V[16], Pm[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = view[k]; Pm[k] = proj[k]; }
@@ -203,12 +220,13 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view, const float*
         radii[i] = radius_out;
     }
     // block sum of tiles_touched -> block_sums[blockIdx.x]
-    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
     uint32_t inc = rdg_wave_scan_incl(my_tiles);
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (nviews > 1) __syncthreads();       // wsum is reused by the next camera
+    }
 }
 
 // Exclusive scan of block_sums[0..nblk) in place by ONE 1024-thread block; block_sums[nblk] and *num_rendered
@@ -290,28 +308,27 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
     const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
     uint32_t* block_sums = (uint32_t*)(g + L.block_sums);
     if (d.P > 0) {
-        hipLaunchKernelGGL(rdg_preprocess_fwd_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
+        hipLaunchKernelGGL(rdg_preprocess_fwd_kernel<false>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
                            shs, colors, opac, scales, rots, cov3D, (RdgRec*)(g + L.rec),
-                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii);
+                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0);
     }
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
                        num_rendered);
     return rdg_check_hip(hipGetLastError(), "preprocess_fwd launch");
 }
 
-// One camera's slice [first, first + d.P) of a workspace laid out for `total` rows (first % 256 == 0): the sharded
-// frame-DP owner stage, whose records for all cameras of a step must sit in ONE contiguous send buffer.
-int rdg_launch_preprocess_fwd_slice(const RdgDev& d, int32_t total, int32_t first, const float* means3D,
+// All cameras of a step in one launch (sharded frame-DP owner stage): camera v owns rows [v*stride, v*stride + d.P) of
+// a workspace laid out for nviews*stride rows, so that the records of all cameras form ONE contiguous send buffer.
+int rdg_launch_preprocess_fwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
                                     const float* shs, const float* opac, const float* scales, const float* rots,
-                                    const float* view, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s) {
-    const RdgGeomLayout L = rdg_geom_layout(total);
+                                    const float* views, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s) {
+    const RdgGeomLayout L = rdg_geom_layout(nviews * stride);
     char* g = (char*)geom_ws;
     const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
     if (d.P > 0)
-        hipLaunchKernelGGL(rdg_preprocess_fwd_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
+        hipLaunchKernelGGL(rdg_preprocess_fwd_kernel<true>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, views, proj, means3D,
                            shs, (const float*)nullptr, opac, scales, rots, (const float*)nullptr,
-                           (RdgRec*)(g + L.rec) + first, (uint32_t*)(g + L.tiles_touched) + first,
-                           (uint8_t*)(g + L.clamped) + first, (uint32_t*)(g + L.block_sums) + first / RDG_PRE_BLOCK,
-                           radii + first);
-    return rdg_check_hip(hipGetLastError(), "preprocess_fwd slice launch");
+                           (RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped),
+                           (uint32_t*)(g + L.block_sums), radii, nviews, stride);
+    return rdg_check_hip(hipGetLastError(), "preprocess_fwd views launch");
 }

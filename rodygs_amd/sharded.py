@@ -134,7 +134,6 @@ class ShardedDynamicScene:
             self.sc, self.g_sc = torch.zeros(max(n, 1), 3, **f32), torch.zeros(Wn, stride, 3, **f32)   # time-independent
             self.op, self.g_op = torch.zeros(max(n, 1), 1, **f32), torch.zeros(Wn, stride, 1, **f32)
             self.d_m2 = torch.zeros(Wn, stride, 3, **f32)
-            self.d_sh = torch.zeros(Wn, stride, self.K * 3, **f32)
             self.views = torch.zeros(Wn, 16, **f32)
             self.d_views = torch.zeros(Wn, 16, **f32)
             self.d_bases = torch.zeros(Wn, T + 1, 16, 7, **f32)
@@ -252,8 +251,9 @@ class ShardedDynamicScene:
         return self.loss3[0]
 
     def phase_owner_backward(self) -> None:
-        """Gradient rows of MY Gaussians from every camera have arrived in ``row_own``: per-Gaussian backward per
-        camera, sum over cameras into the flat gradient bucket, MLP + pose gradients into the small bucket (partial
+        """Gradient rows of MY Gaussians from every camera have arrived in ``row_own``: per-Gaussian backward over all
+        cameras (two launches; every parameter gradient leaves its kernel already summed over the cameras, straight
+        into the flat gradient bucket), MLP + pose gradients into the small bucket (partial
         sums over my slice -- the caller all-reduces ``sp.flat_grad``)."""
         L, Wn, T, n, dev, fp = _lib.lib(), self.world, self.T, self.n, self.device, self.fp
         with torch.cuda.device(dev):
@@ -262,7 +262,7 @@ class ShardedDynamicScene:
                 C.byref(self.cs_own), Wn, self.stride, _lib.ptr(self.m3), _lib.ptr(fp["features"]), _lib.ptr(self.op),
                 _lib.ptr(self.sc), _lib.ptr(self.ro), _lib.ptr(self.views), _lib.ptr(self.proj_t),
                 _lib.ptr(self.radii_own), _lib.ptr(self.geom_own), _lib.ptr(self.grad_own), _lib.ptr(self.g_m3),
-                _lib.ptr(self.d_m2), _lib.ptr(self.d_sh), _lib.ptr(self.g_op), _lib.ptr(self.g_sc), _lib.ptr(self.g_ro),
+                _lib.ptr(self.d_m2), _lib.ptr(fp["features"].grad), _lib.ptr(self.g_op), _lib.ptr(self.g_sc), _lib.ptr(self.g_ro),
                 _lib.ptr(self.d_views), st), "rdg_preprocess_backward_views")
             b = self._bases_all.detach()
             if n:
@@ -277,7 +277,6 @@ class ShardedDynamicScene:
                     _lib.ptr(fp["rotation"].grad), _lib.ptr(fp["opacity"].grad), _lib.ptr(fp["motion_coeff"].grad),
                     _lib.ptr(self.d_bases), _lib.ptr(order), _lib.ptr(inv), _lib.ptr(self.sorted_ws), st),
                     "rdg_dyn_getter_views_backward")
-                torch.sum(self.d_sh[:, :n], dim=0, out=fp["features"].grad.view(n, -1))
             else:
                 self.d_bases.zero_()
             self._bases_all.backward(self.d_bases)          # MLP backward: overwrites its ten sinks in sp.flat_grad

@@ -944,7 +944,7 @@ def test_overlapped_exchange_path_equals_single_launch_path():
         dp_losses = [float(ds.train_step(s_, 0, 2, perm=[1, 2])) for s_ in range(3)]
         torch.cuda.synchronize()
     finally:
-        BucketedAllReduce.active = real
+        BucketedAllReduce.active = staticmethod(real)
         dist.destroy_process_group()
     assert all(np.isfinite(dp_losses)) and ds.fp.step_count == step1 + 3 and ds.sp.step_count == step1 + 3
     assert float((ds.fp.flat - before).abs().max()) > 0
@@ -1214,7 +1214,9 @@ def test_sharded_step_matches_replicated_frame_dp(P, world):
         sh.phase_update()
     fused_adam_(ds.fp, row_lr=ds.row_lr, extra=(ds.sp,))
     for k in ds.fp.names:
-        assert torch.equal(torch.cat([sh.fp[k].detach() for sh in shards]), ds.fp[k].detach()), k
+        got, want = torch.cat([sh.fp[k].detach() for sh in shards]), ds.fp[k].detach()
+        assert torch.equal(got, want), (k, int((got != want).sum()), float((got - want).abs().max()),
+                                        (got != want).reshape(got.shape[0], -1).any(1).nonzero().flatten()[:8].tolist())
     for sh in shards:
         assert torch.equal(sh.sp.flat, ds.sp.flat)
 
