@@ -232,7 +232,9 @@ _ORDER_CACHE = {}
 
 def _birth_order(time_ind: torch.Tensor):
     """(order, inverse): int32 permutation sorting the Gaussians by birth index and its inverse; cached until
-    time_ind changes (it only does at densification), so the sort is not part of the step."""
+    time_ind changes (it only does at densification), so the sort is not part of the step.  The key is the tensor's
+    address / version / length: code that REPLACES a birth-index tensor (densification does) calls
+    ``invalidate_birth_order_cache()`` so that a new tensor reusing a freed address cannot inherit a stale permutation."""
     key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device))
     o = _ORDER_CACHE.get(key)
     if o is None:
@@ -244,6 +246,10 @@ def _birth_order(time_ind: torch.Tensor):
         o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous())
         _ORDER_CACHE[key] = o
     return o
+
+
+def invalidate_birth_order_cache() -> None:
+    _ORDER_CACHE.clear()
 
 
 def _identity_order(P: int, dev) -> torch.Tensor:

@@ -154,6 +154,8 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
                                                          _lib.ptr(fp["rotation"].detach()), _lib.ptr(zz), _lib.ptr(xo),
                                                          _lib.ptr(so_), _lib.stream_ptr()), "rdg_split_children")
         new_pp = {k: v[src] for k, v in per_point.items()}
+        from .deform import invalidate_birth_order_cache
+        invalidate_birth_order_cache()       # the per-point tensors (birth indices) are new objects from here on
         n_new = int(src.numel())
         return DensifyResult(out, DensifyStats.zeros(n_new, dev), new_pp, n_clone, n_sel,
                              int(prune.sum()) + n_sel)

@@ -82,8 +82,7 @@ class ShardedDynamicScene:
         per, stride = shard_rows(ds.P, world)
         lo, hi = min(rank * per, ds.P), min((rank + 1) * per, ds.P)
         n = hi - lo
-        self.lo, self.n, self.per, self.stride = lo, n, per, stride
-        self.rows = world * stride
+        self.lo, self.n, self.per = lo, n, per
         # ---- my slice of the parameters (+ fresh Adam moments copied from the replica's)
         spec = {k: ((n, *ds.fp.shapes[k][1:]), ds.fp.lr[k]) for k in ds.fp.names}
         fp = FlatParams(spec, dev)
@@ -112,10 +111,18 @@ class ShardedDynamicScene:
         self.proj_t, self.bg = ds.proj_t, ds.bg
         self.gt = ds.gt
         self._rows_cache = {}
-        # ---- persistent buffers: owner side (my Gaussians x all cameras) and camera side (all Gaussians x my camera)
+        self.stats = None                # DensifyStats of my slice once track_densification() is called
+        self._alloc(stride)
+        self.frames: List[int] = []
+
+    def _alloc(self, stride: int) -> None:
+        """Persistent buffers for ``self.n`` Gaussians of mine and a shard row stride of ``stride`` (the same on every
+        rank): owner side = my Gaussians x all cameras, camera side = all Gaussians x my camera."""
+        L, dev, Wn, n, T = _lib.lib(), self.device, self.world, self.n, self.T
+        self.stride, self.rows = stride, Wn * stride
         u8 = dict(dtype=torch.uint8, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
-        Wn, R = world, self.rows
+        R = self.rows
         with torch.cuda.device(dev):
             self.geom_own = torch.zeros(L.rdg_geom_bytes(R), **u8)      # records of unused rows stay zero = invisible
             self.geom_cam = torch.zeros(L.rdg_geom_bytes(R), **u8)
@@ -138,14 +145,15 @@ class ShardedDynamicScene:
             self.d_views = torch.zeros(Wn, 16, **f32)
             self.d_bases = torch.zeros(Wn, T + 1, 16, 7, **f32)
             self.sorted_ws = torch.empty(L.rdg_deform_sorted_views_ws_bytes(max(n, 1), Wn), **u8)
-            self.image_ws = torch.empty(L.rdg_image_bytes(self.H, self.W), **u8)
-            self.color = torch.empty(3, self.H, self.W, **f32)
-            self.depth = torch.empty(1, self.H, self.W, **f32)
-            self.normal = torch.empty(3, self.H, self.W, **f32)
-            self.alpha = torch.empty(1, self.H, self.W, **f32)
-            self.d_img = torch.empty(3, self.H, self.W, **f32)
-            self.loss_ws = torch.empty(L.rdg_loss_ws_bytes(3, self.H, self.W), **u8)
-            self.loss3 = torch.zeros(3, **f32)
+            if getattr(self, "image_ws", None) is None:
+                self.image_ws = torch.empty(L.rdg_image_bytes(self.H, self.W), **u8)
+                self.color = torch.empty(3, self.H, self.W, **f32)
+                self.depth = torch.empty(1, self.H, self.W, **f32)
+                self.normal = torch.empty(3, self.H, self.W, **f32)
+                self.alpha = torch.empty(1, self.H, self.W, **f32)
+                self.d_img = torch.empty(3, self.H, self.W, **f32)
+                self.loss_ws = torch.empty(L.rdg_loss_ws_bytes(3, self.H, self.W), **u8)
+                self.loss3 = torch.zeros(3, **f32)
         self._binning = None
         self._capacity = 0
         rs = GaussianRasterizationSettings(self.H, self.W, self.tanfovx, self.tanfovy, self.bg, 1.0, self.proj_t,
@@ -153,7 +161,6 @@ class ShardedDynamicScene:
         self.cs_own = _c_settings(rs, n, self.K)        # per-Gaussian stages: my n Gaussians (per camera)
         self.cs_cam = _c_settings(rs, R, self.K)        # compositing stages: every row of the gathered records
         self.key = (R, self.H, self.W)
-        self.frames: List[int] = []
 
     # ---- the four local phases of a step; the collectives sit between them -------------------------------------------
     def _emb_rows(self, frames: Sequence[int]) -> torch.Tensor:
@@ -199,7 +206,7 @@ class ShardedDynamicScene:
         L, dev = _lib.lib(), self.device
         n_tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         hint = rasterizer._CAPACITY_HINT
-        cap = max(int(hint.get(self.key, 0) * 1.25) + 4096, 4 * self.P_total + 4096)
+        cap = max(int(hint.get(self.key, 0) * 1.5) + 4096, 4 * self.P_total + 4096)   # every step is another camera
         deferred = rasterizer.DEFERRED_OVERFLOW_CHECK and self.key in hint
         if deferred:
             rasterizer.poll_overflow(block=False)
@@ -224,7 +231,7 @@ class ShardedDynamicScene:
             hint[self.key] = D
             if D <= cap:
                 break
-            cap = int(D * 1.25) + 4096
+            cap = int(D * 1.5) + 4096
         rasterizer._LAST_IMAGE_WS[0] = (self.image_ws, self.H, self.W)
 
     def phase_camera(self) -> torch.Tensor:
@@ -264,6 +271,15 @@ class ShardedDynamicScene:
                 _lib.ptr(self.radii_own), _lib.ptr(self.geom_own), _lib.ptr(self.grad_own), _lib.ptr(self.g_m3),
                 _lib.ptr(self.d_m2), _lib.ptr(fp["features"].grad), _lib.ptr(self.g_op), _lib.ptr(self.g_sc), _lib.ptr(self.g_ro),
                 _lib.ptr(self.d_views), st), "rdg_preprocess_backward_views")
+            if self.stats is not None and n:
+                # add_densification_stats (rodygs.py:319-341) for each camera of the step: the screen-space gradient norm
+                # and the radius of my Gaussians where they were visible -- all local, no collective
+                vis = self.radii_own.view(Wn, self.stride)[:, :n] > 0
+                g2 = torch.norm(self.d_m2[:, :n, :2], dim=-1)
+                self.stats.xyz_gradient_accum += (g2 * vis).sum(0).unsqueeze(1)
+                self.stats.denom += vis.sum(0).unsqueeze(1).to(self.stats.denom.dtype)
+                rad = (self.radii_own.view(Wn, self.stride)[:, :n] * vis).max(0).values.to(self.stats.max_radii2D.dtype)
+                self.stats.max_radii2D = torch.maximum(self.stats.max_radii2D, rad)
             b = self._bases_all.detach()
             if n:
                 order, inv = _birth_order(self.time_ind)
@@ -301,21 +317,70 @@ class ShardedDynamicScene:
         self.phase_update()
         return loss.detach()
 
+    # ---- densification (rodygs.py:319-362 / rodygs_static.py:170-319) on the slices -------------------------------------
+    def track_densification(self) -> None:
+        from .densify import DensifyStats
+        self.stats = DensifyStats.zeros(self.n, self.device)
+
+    def densify_local(self, max_grad: float = 0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
+                      max_screen_size=None, percent_dense: float = 0.01) -> dict:
+        """densify_and_prune on MY slice only: every Gaussian has one owner, and its statistics were gathered there
+        over all cameras, so no rank needs another rank's decisions.  Call ``reshard`` (collective) afterwards."""
+        from .densify import densify_and_prune
+        if self.stats is None:
+            raise RuntimeError("call track_densification() first")
+        res = densify_and_prune(self.fp, self.stats, {"time_ind": self.time_ind}, max_grad, min_opacity,
+                                extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense)
+        self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
+        self.n = self.fp.shapes["xyz"][0]
+        return {"n": self.n, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned}
+
+    def reshard(self, n_max: int, p_total: int) -> None:
+        """New common row stride after the slices changed size (slices stay where they are: a rank's Gaussians are
+        rows [rank*stride, rank*stride + n) of the gathered buffers, whatever n the other ranks have)."""
+        self.per, self.P_total = int(n_max), int(p_total)
+        self._alloc((int(n_max) + 255) // 256 * 256)
+
+    def densify(self, **kw) -> dict:
+        info = self.densify_local(**kw)
+        t = torch.tensor([self.n], dtype=torch.int64, device=self.device)
+        mx, sm = t.clone(), t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        self.reshard(int(mx.item()), int(sm.item()))
+        info["P"] = self.P_total
+        return info
+
     # ---- inspection ---------------------------------------------------------------------------------------------------
     def visible_count(self) -> int:
         return int((self.radii_cam > 0).sum().item())
 
     def gather_params(self) -> Optional[dict]:
-        """{name: full [P,...] tensor} assembled from all ranks (checkpointing, tests); collective."""
+        """{name: full [P,...] tensor} assembled from all ranks in rank order (checkpointing, tests); collective."""
+        cnt = torch.tensor([self.n], dtype=torch.int64, device=self.device)
+        counts = [torch.empty_like(cnt) for _ in range(self.world)]
+        dist.all_gather(counts, cnt)
+        counts = [int(c.item()) for c in counts]
+        width = max(counts)
         out = {}
         for k in self.fp.names:
             mine = self.fp[k].detach()
-            pad = torch.zeros(self.per, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
+            pad = torch.zeros(width, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
             pad[:self.n] = mine
             parts = [torch.empty_like(pad) for _ in range(self.world)]
             dist.all_gather(parts, pad)
-            out[k] = torch.cat(parts)[:self.P_total]
+            out[k] = torch.cat([p[:c] for p, c in zip(parts, counts)])
         return out
+
+
+def run_virtual_densify(scenes: Sequence["ShardedDynamicScene"], **kw) -> List[dict]:
+    """``densify`` for virtual ranks in one process (the two scalar all-reduces done by hand)."""
+    infos = [s.densify_local(**kw) for s in scenes]
+    n_max, p_total = max(s.n for s in scenes), sum(s.n for s in scenes)
+    for s, info in zip(scenes, infos):
+        s.reshard(n_max, p_total)
+        info["P"] = p_total
+    return infos
 
 
 def run_virtual_step(scenes: Sequence[ShardedDynamicScene], step: int, perm: Sequence[int]) -> List[torch.Tensor]:

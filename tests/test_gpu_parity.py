@@ -1237,6 +1237,40 @@ def test_sharded_training_reduces_loss_like_replicated():
     assert shards[0].visible_count() > 0
 
 
+def test_sharded_training_with_densification():
+    """Densify-and-prune inside the sharded loop: every rank gathers the screen-space statistics of ITS Gaussians over
+    all cameras of each step (no collective), densifies its own slice, and the ranks only agree on the new row stride.
+    The statistics equal what the replicated trainer accumulates over the same cameras; training carries on."""
+    from rodygs_amd.losses import fused_photometric_loss
+    from rodygs_amd.sharded import run_virtual_densify, run_virtual_step
+    frames, world = 8, 4
+    ds, shards = _replica_and_shards(12000, 256, 192, frames, world, seed=51)
+    perm = list(range(frames))
+    for sh in shards:
+        sh.track_densification()
+    ds.track_densification()
+    # one step on both formulations, statistics compared before any parameter moves apart
+    for r in range(world):
+        f = perm[(1 * world + r) % frames]
+        out, m2 = ds.render(f)
+        fused_photometric_loss(out[0], ds.gt[f], 0.2).backward()
+        ds.stats.add(ds.m2.grad, ds._last_radii > 0, ds._last_radii)
+    run_virtual_step(shards, 1, perm)
+    for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
+        got = torch.cat([getattr(sh.stats, name) for sh in shards])
+        rel_ok(got, getattr(ds.stats, name), tol=2e-4, what="sharded densify stats " + name)
+    hist = [np.mean([float(x) for x in run_virtual_step(shards, s_, perm)]) for s_ in range(2, 20)]
+    infos = run_virtual_densify(shards, max_grad=2e-5, min_opacity=0.05, percent_dense=0.002)
+    assert sum(i["cloned"] for i in infos) > 0 and sum(i["split"] for i in infos) > 0
+    assert len({sh.stride for sh in shards}) == 1 and shards[0].stride % 256 == 0
+    assert infos[0]["P"] == sum(sh.n for sh in shards) != 12000 and max(sh.n for sh in shards) <= shards[0].stride
+    assert all(sh.time_ind.shape[0] == sh.n == sh.fp.shapes["xyz"][0] for sh in shards)
+    assert all(float(sh.stats.denom.sum()) == 0.0 for sh in shards)
+    hist += [np.mean([float(x) for x in run_virtual_step(shards, s_, perm)]) for s_ in range(20, 44)]
+    assert all(np.isfinite(hist)) and np.mean(hist[-6:]) < np.mean(hist[:6])
+    assert all(float(sh.fp["xyz"].grad.abs().sum()) > 0 for sh in shards)
+
+
 def test_sharded_step_over_a_process_group():
     """`train_step` with the real collectives (all_to_all_single x2 + all_reduce over RCCL) on a 1-rank group: the
     exchange is then the identity and the step must equal the virtual single-rank step."""
@@ -1257,6 +1291,12 @@ def test_sharded_step_over_a_process_group():
         rel_ok(b.fp.flat_grad, a.fp.flat_grad, tol=2e-4, what="1-rank group gradients")
         full = b.gather_params()
         assert torch.equal(full["xyz"], b.fp["xyz"].detach())
+        b.track_densification()
+        for s_ in range(3, 9):
+            b.train_step(s_, list(range(6)))
+        info = b.densify(max_grad=2e-5, min_opacity=0.05, percent_dense=0.002)
+        assert info["P"] == b.n == b.P_total and b.stride >= b.n
+        assert np.isfinite(float(b.train_step(9, list(range(6)))))
     finally:
         dist.destroy_process_group()
 
