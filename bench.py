@@ -116,7 +116,7 @@ def main():
     gt_frames = sorted(set(gt_frames))
     ds.make_ground_truth(target, gt_frames)
     perm = gt_frames
-    sharded = (world > 1 or force_shard) and args.dp_mode == "shard" and not args.full_losses
+    sharded = (world > 1 or force_shard) and args.dp_mode == "shard"
     if sharded:
         from rodygs_amd.sharded import ShardedDynamicScene
         ss = ShardedDynamicScene.from_replica(ds, rank, world)

@@ -46,6 +46,12 @@ class DistExchange:
     def all_reduce(self, t: torch.Tensor) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
+    def all_gather(self, out: torch.Tensor, mine: torch.Tensor) -> None:
+        dist.all_gather_into_tensor(out, mine)
+
+    def reduce_scatter(self, out: torch.Tensor, full: torch.Tensor) -> None:
+        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
+
 
 def shard_rows(P: int, world: int):
     """(per, stride): Gaussians per rank (the last rank may hold fewer) and the 256-aligned row stride of a shard in
@@ -66,8 +72,16 @@ class ShardedDynamicScene:
         from .trainstep import _MLP_SINK_ORDER, bind_module_to_flat
         if not 1 <= world <= 16:
             raise ValueError("world must be 1..16 (RDG_MAX_VIEWS)")
-        if ds.full_losses:
-            raise NotImplementedError("the sharded step covers the photometric train step only")
+        # full_losses: the config-5 loss set of trainstep.DynamicScene (photometric + Pearson depth on the camera rank,
+        # motion L1 / sparsity on the owner's slice, basis regulariser on the replicated table, rigidity every 5th step
+        # on a gathered copy of the cloud)
+        self.full_losses = bool(ds.full_losses)
+        if self.full_losses:
+            self.loss_terms, self.depth_terms, self.rigidity = ds.loss_terms, ds.depth_terms, ds.rigidity
+            if "coeff" in self.rigidity[2].mode:
+                raise NotImplementedError("RigidityLoss mode 'coeff' needs the DC colours of the whole cloud")
+            self.gt_depth = ds.gt_depth
+        self._rng_state = None
         T = ds.T
         L = _lib.lib()
         if not L.rdg_dyn_getter_views_supported(16, T, world):
@@ -112,6 +126,8 @@ class ShardedDynamicScene:
         self.gt = ds.gt
         self._rows_cache = {}
         self.stats = None                # DensifyStats of my slice once track_densification() is called
+        self.counts = [min(per, max(ds.P - r * per, 0)) for r in range(world)]      # slice sizes of all ranks
+        self._time_ind_full = None
         self._alloc(stride)
         self.frames: List[int] = []
 
@@ -184,6 +200,7 @@ class ShardedDynamicScene:
             st = _lib.stream_ptr()
             # ONE pass of the MLP over the T birth-time rows + the W frame times
             allb = self.net.motion_basis(self._emb_rows(self.frames))                   # [T+W,16,7]
+            self._allb = allb
             self._bases_all = torch.cat([allb[:T].unsqueeze(0).expand(Wn, -1, -1, -1), allb[T:].unsqueeze(1)], dim=1)
             b = self._bases_all.detach()
             # my Gaussians at the times of all W cameras: parameters read once, one launch
@@ -234,6 +251,33 @@ class ShardedDynamicScene:
             cap = int(D * 1.5) + 4096
         rasterizer._LAST_IMAGE_WS[0] = (self.image_ws, self.H, self.W)
 
+    # private random stream of this rank (Pearson boxes, rigidity sample): lets several virtual ranks in one process draw
+    # exactly what they would draw in their own processes
+    def seed_rng(self, seed: int) -> None:
+        keep = (torch.get_rng_state(), torch.cuda.get_rng_state(self.device))
+        torch.manual_seed(seed)
+        self._rng_state = (torch.get_rng_state(), torch.cuda.get_rng_state(self.device))
+        torch.set_rng_state(keep[0])
+        torch.cuda.set_rng_state(keep[1], self.device)
+
+    class _Rng:
+        def __init__(self, scene):
+            self.s = scene
+
+        def __enter__(self):
+            s = self.s
+            if s._rng_state is not None:
+                self.keep = (torch.get_rng_state(), torch.cuda.get_rng_state(s.device))
+                torch.set_rng_state(s._rng_state[0])
+                torch.cuda.set_rng_state(s._rng_state[1], s.device)
+
+        def __exit__(self, *a):
+            s = self.s
+            if s._rng_state is not None:
+                s._rng_state = (torch.get_rng_state(), torch.cuda.get_rng_state(s.device))
+                torch.set_rng_state(self.keep[0])
+                torch.cuda.set_rng_state(self.keep[1], s.device)
+
     def phase_camera(self) -> torch.Tensor:
         """Records of MY camera have arrived in ``rec_cam``: bin, composite, loss, compositing backward ->
         ``row_cam`` (one gradient row per Gaussian of the whole cloud).  Returns the camera's loss."""
@@ -251,11 +295,18 @@ class ShardedDynamicScene:
             _lib.check(L.rdg_photometric_loss_backward(3, self.H, self.W, _lib.ptr(self.color), _lib.ptr(gt), 0.2,
                                                        _lib.ptr(self.loss_ws), None, _lib.ptr(self.d_img), st),
                        "rdg_photometric_loss_backward")
+            g_depth, loss = None, self.loss3[0]
+            if self.full_losses:
+                with self._Rng(self):
+                    depth_leaf = self.depth.detach().requires_grad_(True)
+                    ld = sum(w * mod(depth_leaf, self.gt_depth[frame]) for w, mod in self.depth_terms)
+                    ld.backward()
+                g_depth, loss = depth_leaf.grad.contiguous(), loss + ld.detach()
             _lib.check(L.rdg_composite_backward(C.byref(self.cs_cam), _lib.ptr(self.bg), _lib.ptr(self.geom_cam),
                                                 _lib.ptr(self._binning), self._capacity, _lib.ptr(self.image_ws),
-                                                _lib.ptr(self.d_img), None, None, _lib.ptr(self.grad_cam), st),
-                       "rdg_composite_backward")
-        return self.loss3[0]
+                                                _lib.ptr(self.d_img), _lib.ptr(g_depth), None, _lib.ptr(self.grad_cam),
+                                                st), "rdg_composite_backward")
+        return loss
 
     def phase_owner_backward(self) -> None:
         """Gradient rows of MY Gaussians from every camera have arrived in ``row_own``: per-Gaussian backward over all
@@ -295,12 +346,109 @@ class ShardedDynamicScene:
                     "rdg_dyn_getter_views_backward")
             else:
                 self.d_bases.zero_()
-            self._bases_all.backward(self.d_bases)          # MLP backward: overwrites its ten sinks in sp.flat_grad
-            self._bases_all = None
+            self._loss_owner = None
+            if self.full_losses and n:
+                # motion L1 / sparsity (means over ALL P x 16 coefficients): my slice's share, times the N cameras of
+                # the step (every rank adds these terms in the replicated formulation); accumulates on top of the
+                # getter's gradient
+                class _Local:
+                    _motion_coeff = fp["motion_coeff"]
+                share = float(Wn) * n / float(self.P_total)
+                lm = share * sum(w * mod(_Local) for k, (w, mod) in self.loss_terms.items() if k != "motion_basis_reg")
+                lm.backward()
+                self._loss_owner = lm.detach()
+
+    def rigidity_due(self, step: int) -> bool:
+        return self.full_losses and step % self.rigidity[1] == 0
+
+    def pack_for_rigidity(self) -> torch.Tensor:
+        """[per,19] = (xyz, motion coefficients) of my slice, zero rows after the first n: my part of the all-gather."""
+        n = self.n
+        buf = torch.zeros(self.per, 19, dtype=torch.float32, device=self.device)
+        buf[:n, :3] = self.fp["xyz"].detach()
+        buf[:n, 3:] = self.fp["motion_coeff"].detach().reshape(n, 16)
+        return buf
+
+    def pack_time_ind(self) -> torch.Tensor:
+        buf = torch.zeros(self.per, dtype=torch.int64, device=self.device)
+        buf[:self.n] = self.time_ind
+        return buf
+
+    def _valid_rows(self, padded: torch.Tensor) -> torch.Tensor:
+        """[W*per, ...] gathered layout -> [P, ...] without the padding rows of short slices."""
+        if all(c == self.per for c in self.counts):
+            return padded
+        return torch.cat([padded[r * self.per:r * self.per + c] for r, c in enumerate(self.counts)])
+
+    def phase_small_backward(self, step: int, gathered: Optional[torch.Tensor] = None,
+                             time_ind_gathered: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """What remains of backward after the per-Gaussian kernels: (on rigidity steps) RigidityLoss of MY camera's time
+        on the gathered cloud, the basis regulariser, then ONE pass of the MLP backward for everything that reached the
+        motion bases, and the pose backward.  Returns the [W*per,19] gradient of the gathered cloud for the
+        reduce-scatter (rigidity steps) or None."""
+        L, Wn, T, dev = _lib.lib(), self.world, self.T, self.device
+        roots, root_grads, full_grad = [self._bases_all], [self.d_bases], None
+        extra = None
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr()
+            if self.full_losses:
+                allb, scene = self._allb, self
+
+                class _Model:                                    # what the reference's loss modules read
+                    unique_times = list(range(T))
+
+                    @staticmethod
+                    def get_total_motion_table():
+                        return allb[:T]
+
+                    @staticmethod
+                    def get_motion_for_times(timesteps, time_indices=None):
+                        return allb[:T][time_indices.to(allb.device)]
+
+                w, mod = self.loss_terms["motion_basis_reg"]
+                extra = w * mod(_Model)
+                leaves = None
+                if gathered is not None:
+                    from .deform import gaussian_deformation_packed
+                    if time_ind_gathered is not None:
+                        self._time_ind_full = self._valid_rows(time_ind_gathered).contiguous()
+                    full = self._valid_rows(gathered)
+                    xyz_full = full[:, :3].contiguous().requires_grad_(True)
+                    coeff_full = full[:, 3:].contiguous().requires_grad_(True)
+                    leaves = (xyz_full, coeff_full)
+                    dxyz, _ = gaussian_deformation_packed(coeff_full, self._time_ind_full, self._bases_all[self.rank],
+                                                          self.spatial_lr_scale)
+                    _Model._xyz, _Model._motion_coeff = xyz_full, coeff_full.view(-1, 1, 16)
+                    _Model._features_dc = torch.zeros(1, 1, 3, device=dev).expand(full.shape[0], 1, 3)
+                    wr, _, rig = self.rigidity
+                    with self._Rng(self):
+                        extra = extra + wr * rig(_Model, dxyz)
+                roots.append(extra)
+                root_grads.append(None)
+            torch.autograd.backward(roots, root_grads)      # MLP backward: overwrites its ten sinks in sp.flat_grad
+            if self.full_losses and gathered is not None:
+                g = torch.cat([leaves[0].grad, leaves[1].grad], dim=1)
+                if all(c == self.per for c in self.counts):
+                    full_grad = g.contiguous()
+                else:
+                    full_grad = torch.zeros(Wn * self.per, 19, dtype=torch.float32, device=dev)
+                    o = 0
+                    for r, c in enumerate(self.counts):
+                        full_grad[r * self.per:r * self.per + c] = g[o:o + c]
+                        o += c
+            self._bases_all = self._allb = None
             sp = self.sp
             _lib.check(L.rdg_pose_views_backward(T, Wn, self._frames_c, _lib.ptr(sp["cam_q"]), _lib.ptr(sp["cam_t"]),
                                                  _lib.ptr(self.d_views), _lib.ptr(sp["cam_q"].grad),
                                                  _lib.ptr(sp["cam_t"].grad), st), "rdg_pose_views_backward")
+        self._loss_small = None if extra is None else extra.detach()
+        return full_grad
+
+    def add_rigidity_grads(self, mine: torch.Tensor) -> None:
+        """[per,19] = my rows of the rigidity gradient summed over the ranks (reduce-scatter result)."""
+        n = self.n
+        self.fp["xyz"].grad += mine[:n, :3]
+        self.fp["motion_coeff"].grad.view(n, 16).add_(mine[:n, 3:])
 
     def phase_update(self) -> None:
         from .trainstep import fused_adam_
@@ -313,9 +461,30 @@ class ShardedDynamicScene:
         loss = self.phase_camera()
         self.ex.all_to_all(self.row_own, self.row_cam)
         self.phase_owner_backward()
+        gathered = tig = None
+        if self.rigidity_due(step):
+            gathered = torch.empty(self.world * self.per, 19, dtype=torch.float32, device=self.device)
+            self.ex.all_gather(gathered, self.pack_for_rigidity())
+            if self._time_ind_full is None:
+                tig = torch.empty(self.world * self.per, dtype=torch.int64, device=self.device)
+                self.ex.all_gather(tig, self.pack_time_ind())
+        full_grad = self.phase_small_backward(step, gathered, tig)
+        if full_grad is not None:
+            mine = torch.empty(self.per, 19, dtype=torch.float32, device=self.device)
+            self.ex.reduce_scatter(mine, full_grad)
+            self.add_rigidity_grads(mine)
         self.ex.all_reduce(self.sp.flat_grad)
         self.phase_update()
-        return loss.detach()
+        return self.step_loss(loss)
+
+    def step_loss(self, camera_loss: torch.Tensor) -> torch.Tensor:
+        """This rank's summand of the step loss: its camera's terms + the replicated terms + its slice's share of the
+        per-Gaussian regularisers (the sum over ranks equals the sum over ranks of the replicated formulation)."""
+        out = camera_loss.detach()
+        for t in (getattr(self, "_loss_owner", None), getattr(self, "_loss_small", None)):
+            if t is not None:
+                out = out + t
+        return out
 
     # ---- densification (rodygs.py:319-362 / rodygs_static.py:170-319) on the slices -------------------------------------
     def track_densification(self) -> None:
@@ -335,19 +504,20 @@ class ShardedDynamicScene:
         self.n = self.fp.shapes["xyz"][0]
         return {"n": self.n, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned}
 
-    def reshard(self, n_max: int, p_total: int) -> None:
+    def reshard(self, counts: Sequence[int]) -> None:
         """New common row stride after the slices changed size (slices stay where they are: a rank's Gaussians are
         rows [rank*stride, rank*stride + n) of the gathered buffers, whatever n the other ranks have)."""
-        self.per, self.P_total = int(n_max), int(p_total)
-        self._alloc((int(n_max) + 255) // 256 * 256)
+        self.counts = [int(c) for c in counts]
+        self.per, self.P_total = max(self.counts), sum(self.counts)
+        self._time_ind_full = None
+        self._alloc((self.per + 255) // 256 * 256)
 
     def densify(self, **kw) -> dict:
         info = self.densify_local(**kw)
-        t = torch.tensor([self.n], dtype=torch.int64, device=self.device)
-        mx, sm = t.clone(), t.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        self.reshard(int(mx.item()), int(sm.item()))
+        cnt = torch.tensor([self.n], dtype=torch.int64, device=self.device)
+        counts = [torch.empty_like(cnt) for _ in range(self.world)]
+        dist.all_gather(counts, cnt)
+        self.reshard([int(c.item()) for c in counts])
         info["P"] = self.P_total
         return info
 
@@ -357,11 +527,7 @@ class ShardedDynamicScene:
 
     def gather_params(self) -> Optional[dict]:
         """{name: full [P,...] tensor} assembled from all ranks in rank order (checkpointing, tests); collective."""
-        cnt = torch.tensor([self.n], dtype=torch.int64, device=self.device)
-        counts = [torch.empty_like(cnt) for _ in range(self.world)]
-        dist.all_gather(counts, cnt)
-        counts = [int(c.item()) for c in counts]
-        width = max(counts)
+        counts, width = self.counts, self.per
         out = {}
         for k in self.fp.names:
             mine = self.fp[k].detach()
@@ -376,10 +542,10 @@ class ShardedDynamicScene:
 def run_virtual_densify(scenes: Sequence["ShardedDynamicScene"], **kw) -> List[dict]:
     """``densify`` for virtual ranks in one process (the two scalar all-reduces done by hand)."""
     infos = [s.densify_local(**kw) for s in scenes]
-    n_max, p_total = max(s.n for s in scenes), sum(s.n for s in scenes)
+    counts = [s.n for s in scenes]
     for s, info in zip(scenes, infos):
-        s.reshard(n_max, p_total)
-        info["P"] = p_total
+        s.reshard(counts)
+        info["P"] = sum(counts)
     return infos
 
 
@@ -398,8 +564,19 @@ def run_virtual_step(scenes: Sequence[ShardedDynamicScene], step: int, perm: Seq
             scenes[s].row_own.view(Wn, -1)[c].copy_(scenes[c].row_cam.view(Wn, -1)[s])
     for s in scenes:
         s.phase_owner_backward()
+    gathered = tig = None
+    if scenes[0].rigidity_due(step):
+        gathered = torch.cat([s.pack_for_rigidity() for s in scenes])
+        if scenes[0]._time_ind_full is None:
+            tig = torch.cat([s.pack_time_ind() for s in scenes])
+    full_grads = [s.phase_small_backward(step, gathered, tig) for s in scenes]
+    if full_grads[0] is not None:
+        total = torch.stack(full_grads).sum(0)
+        per = scenes[0].per
+        for r, s in enumerate(scenes):
+            s.add_rigidity_grads(total[r * per:(r + 1) * per])
     total = torch.stack([s.sp.flat_grad for s in scenes]).sum(0)
     for s in scenes:
         s.sp.flat_grad.copy_(total)
         s.phase_update()
-    return [x.detach().clone() for x in losses]
+    return [s.step_loss(x).clone() for s, x in zip(scenes, losses)]

@@ -75,7 +75,7 @@ def main():
             for c in range(W):
                 shards[s].row_own.view(W, -1)[c].copy_(shards[c].row_cam.view(W, -1)[s])
         for i, s in enumerate(shards):
-            timed("owner_bwd", s.phase_owner_backward, rec and i == 0)
+            timed("owner_bwd", lambda s=s: (s.phase_owner_backward(), s.phase_small_backward(step)), rec and i == 0)
         total = torch.stack([s.sp.flat_grad for s in shards]).sum(0)
         for i, s in enumerate(shards):
             s.sp.flat_grad.copy_(total)

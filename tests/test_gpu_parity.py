@@ -1237,6 +1237,48 @@ def test_sharded_training_reduces_loss_like_replicated():
     assert shards[0].visible_count() > 0
 
 
+@pytest.mark.parametrize("step", [5, 6])
+def test_sharded_full_loss_step_matches_replicated(step):
+    """The config-5 loss set inside the sharded step (3 virtual ranks): Pearson depth on the camera rank, motion L1 /
+    sparsity on the owner's slice, the basis regulariser on the replicated table and -- on step 5 -- RigidityLoss on an
+    all-gathered copy of the cloud with its gradient reduce-scattered back.  With every rank drawing from its own
+    seeded random stream the summed gradients must equal those of the replicated trainer over the same cameras."""
+    from rodygs_amd.sharded import ShardedDynamicScene, run_virtual_step
+    from rodygs_amd import sharded as S
+    from rodygs_amd.trainstep import DynamicScene
+    P, world, frames = 9001, 3, 6
+    sc = O.synthetic_scene(P, 320, 256, 3, seed=61)
+    tgt = O.synthetic_scene(2500, 320, 256, 3, seed=62)
+    ds = DynamicScene(sc, num_frames=frames, device=DEV, full_losses=True)
+    ds.make_ground_truth(tgt, range(frames))
+    ds.train_step(1, perm=[1])
+    shards = [ShardedDynamicScene.from_replica(ds, r, world, exchange=object()) for r in range(world)]
+    perm = list(range(frames))
+    acc, acc_sp, ref_losses = torch.zeros_like(ds.fp.flat_grad), torch.zeros_like(ds.sp.flat_grad), []
+    for r in range(world):
+        torch.manual_seed(100 + r)
+        loss = ds._full_loss(step, perm[(step * world + r) % frames])
+        loss.backward()
+        ref_losses.append(float(loss.detach()))
+        acc += ds.fp.flat_grad
+        acc_sp += ds.sp.flat_grad
+    for r, sh in enumerate(shards):
+        sh.seed_rng(100 + r)
+    real_update = S.ShardedDynamicScene.phase_update
+    S.ShardedDynamicScene.phase_update = lambda self: None
+    try:
+        losses = run_virtual_step(shards, step, perm)
+    finally:
+        S.ShardedDynamicScene.phase_update = real_update
+    assert abs(sum(float(x) for x in losses) - sum(ref_losses)) <= 2e-5 * abs(sum(ref_losses))
+    for k in ds.fp.names:
+        o, m = ds.fp.offsets[k]
+        rel_ok(torch.cat([sh.fp[k].grad for sh in shards]), acc[o:o + m].view(ds.fp.shapes[k]), tol=5e-4,
+               what=f"sharded full-loss d_{k} (step {step})")
+    for sh in shards:
+        rel_ok(sh.sp.flat_grad, acc_sp, tol=5e-4, what="sharded full-loss small bucket")
+
+
 def test_sharded_training_with_densification():
     """Densify-and-prune inside the sharded loop: every rank gathers the screen-space statistics of ITS Gaussians over
     all cameras of each step (no collective), densifies its own slice, and the ranks only agree on the new row stride.
@@ -1297,6 +1339,15 @@ def test_sharded_step_over_a_process_group():
         info = b.densify(max_grad=2e-5, min_opacity=0.05, percent_dense=0.002)
         assert info["P"] == b.n == b.P_total and b.stride >= b.n
         assert np.isfinite(float(b.train_step(9, list(range(6)))))
+        # config-5 loss set through the real all_gather / reduce_scatter (rigidity on step 10)
+        from rodygs_amd.trainstep import DynamicScene
+        sc = O.synthetic_scene(6000, 256, 192, 3, seed=43)
+        dsf = DynamicScene(sc, num_frames=6, device=DEV, full_losses=True)
+        dsf.make_ground_truth(O.synthetic_scene(1500, 256, 192, 3, seed=44), range(6))
+        c = ShardedDynamicScene.from_replica(dsf, 0, 1, exchange=DistExchange())
+        vals = [float(c.train_step(s_, list(range(6)))) for s_ in range(9, 13)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(vals)) and float(c.fp["motion_coeff"].grad.abs().sum()) > 0
     finally:
         dist.destroy_process_group()
 
