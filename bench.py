@@ -211,7 +211,8 @@ def main():
             "render_bwd": alg_bytes,
             "preprocess_bwd": P * (44 + 12 * K) * 2 + V * 48,
             "deform_fwd": P * 96, "deform_bwd": P * 96,
-            "adam": 28 * (59 + 16) * P,
+            # Gaussian-sharded frame-DP: a rank's optimiser state covers its slice only
+            "adam": 28 * (59 + 16) * (P // world if sharded else P),
         }
         sms = dict(per_stage)
         sms["binning"] = per_stage["scan_dup"] + per_stage["sort"] + per_stage["ranges"]
