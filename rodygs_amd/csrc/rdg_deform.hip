@@ -944,12 +944,12 @@ int rdg_dyn_getter_views_backward(int32_t P, int32_t Tu, int32_t nviews, int32_t
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
                            (const int*)inv_order, (float4*)sorted_ws);
         const int npair = (nviews + 1) / 2;
-        // ~256 birth-sorted Gaussians per wave: fewer leaves the gathers latency-bound, more multiplies the flush
-        // atomics (measured at 125 k Gaussians x 8 views: 128 workgroups 20 % faster than 512)
+        // ~128 birth-sorted Gaussians per wave (rocprofv3 at 125 k Gaussians x 8 views: 128 workgroups 98 us, 256: 52 us,
+        // 1024: 57 us -- fewer leaves the gathers latency-bound, more multiplies the flush atomics)
         static int accv_grid = -1;
         if (accv_grid < 0) { const char* ev = getenv("RDG_ACCV_GRID"); accv_grid = ev ? atoi(ev) : 0; }
-        int accv = accv_grid > 0 ? accv_grid : (P + 1023) / 1024;
-        if (accv_grid <= 0) accv = accv < 128 ? 128 : (accv > 2048 ? 2048 : accv);
+        int accv = accv_grid > 0 ? accv_grid : (P + 511) / 512;
+        if (accv_grid <= 0) accv = accv < 256 ? 256 : (accv > 2048 ? 2048 : accv);
         const dim3 grid(accv), block(256);
         if (npair <= 1)
             hipLaunchKernelGGL(rdg_deform_bwd_acc_views_kernel<1>, grid, block, 0, st, P, nviews, Tu, coeff,
