@@ -53,6 +53,33 @@ class DistExchange:
         dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM)
 
 
+class HostStagedExchange(DistExchange):
+    """The same five collectives staged through host memory, for process groups whose backend cannot move device
+    tensors (gloo): lets the real multi-process ``train_step`` run with several ranks sharing ONE GPU
+    (tests/test_gpu_parity.py) -- a debugging / test transport, not a performance path."""
+
+    def all_to_all(self, recv, send):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu())
+        recv.copy_(r)
+
+    def all_reduce(self, t):
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        t.copy_(c)
+
+    def all_gather(self, out, mine):
+        parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine.cpu())
+        out.copy_(torch.cat(parts).view(out.shape))
+
+    def reduce_scatter(self, out, full):
+        c = full.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n = out.shape[0]
+        out.copy_(c[dist.get_rank() * n:(dist.get_rank() + 1) * n])
+
+
 def shard_rows(P: int, world: int):
     """(per, stride): Gaussians per rank (the last rank may hold fewer) and the 256-aligned row stride of a shard in
     the exchanged buffers."""
@@ -125,6 +152,15 @@ class ShardedDynamicScene:
         self.proj_t, self.bg = ds.proj_t, ds.bg
         self.gt = ds.gt
         self._rows_cache = {}
+        if isinstance(self.ex, DistExchange) and world > 1:
+            # the small bucket is REPLICATED state: refuse to start from replicas that differ (e.g. a model initialised
+            # from an unseeded random stream on every rank)
+            chk = self.sp.flat.double().sum().reshape(1)
+            allc = torch.empty(world, dtype=torch.float64, device=dev)
+            self.ex.all_gather(allc, chk)
+            if float(allc.max() - allc.min()) != 0.0:
+                raise RuntimeError("ShardedDynamicScene: the replicated MLP / pose parameters differ between ranks "
+                                   f"(checksums {allc.tolist()}); build the replica with the same seed on every rank")
         self.stats = None                # DensifyStats of my slice once track_densification() is called
         self.counts = [min(per, max(ds.P - r * per, 0)) for r in range(world)]      # slice sizes of all ranks
         self._time_ind_full = None
@@ -515,9 +551,9 @@ class ShardedDynamicScene:
     def densify(self, **kw) -> dict:
         info = self.densify_local(**kw)
         cnt = torch.tensor([self.n], dtype=torch.int64, device=self.device)
-        counts = [torch.empty_like(cnt) for _ in range(self.world)]
-        dist.all_gather(counts, cnt)
-        self.reshard([int(c.item()) for c in counts])
+        counts = torch.empty(self.world, dtype=torch.int64, device=self.device)
+        self.ex.all_gather(counts, cnt)
+        self.reshard(counts.tolist())
         info["P"] = self.P_total
         return info
 
@@ -533,9 +569,9 @@ class ShardedDynamicScene:
             mine = self.fp[k].detach()
             pad = torch.zeros(width, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
             pad[:self.n] = mine
-            parts = [torch.empty_like(pad) for _ in range(self.world)]
-            dist.all_gather(parts, pad)
-            out[k] = torch.cat([p[:c] for p, c in zip(parts, counts)])
+            full = torch.empty(self.world * width, *mine.shape[1:], dtype=mine.dtype, device=mine.device)
+            self.ex.all_gather(full, pad)
+            out[k] = self._valid_rows(full)
         return out
 
 

@@ -148,7 +148,12 @@ class DynamicScene:
         self.fp = fp
         self.row_lr = {"features": (K * 3, 3, 0.0025 / 20.0)}
         self.time_ind = torch.randint(0, num_frames, (P,), generator=g).to(dev)
-        self.net = MLPBasisNetwork(128, 16, 26, False).to(dev)
+        # the MLP initialises from the GLOBAL random stream: pin it to the scene seed (without disturbing the caller's
+        # stream) so that every rank of a frame-DP job builds the same network
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed + 2)
+            self.net = MLPBasisNetwork(128, 16, 26, False)
+        self.net = self.net.to(dev)
         self.times = torch.arange(num_frames, dtype=torch.float32) / num_frames
         self.time_batch_embeddings = self.net.batch_embedding(self.times.to(dev))
         self.frame_embeddings = self.time_batch_embeddings  # frame i is rendered at time i/T (same rows)

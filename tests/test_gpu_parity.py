@@ -1352,6 +1352,75 @@ def test_sharded_step_over_a_process_group():
         dist.destroy_process_group()
 
 
+def _two_process_worker(rank, world, port, outdir):
+    """One rank of a REAL multi-process sharded run: both processes share cuda:0, the process group is gloo and the
+    exchange is staged through host memory (HostStagedExchange)."""
+    import os as _os
+    import torch.distributed as dist
+    _os.environ["MASTER_ADDR"], _os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import rasterizer_oracle as Or
+    from rodygs_amd.sharded import HostStagedExchange, ShardedDynamicScene
+    from rodygs_amd.trainstep import DynamicScene
+    torch.cuda.set_device(0)
+    out = {}
+    for full in (False, True):
+        sc = Or.synthetic_scene(6001, 256, 192, 3, seed=71)
+        ds = DynamicScene(sc, num_frames=6, device="cuda", full_losses=full)
+        ds.make_ground_truth(Or.synthetic_scene(1500, 256, 192, 3, seed=72), range(6))
+        ss = ShardedDynamicScene.from_replica(ds, rank, world, exchange=HostStagedExchange())
+        ss.seed_rng(500 + rank)
+        losses = [float(ss.train_step(s_, list(range(6)))) for s_ in range(4, 7)]      # step 5: rigidity (full)
+        out[full] = {"losses": losses, "params": {k: v.cpu() for k, v in ss.gather_params().items()},
+                     "sp": ss.sp.flat.cpu()}
+        if not full:
+            ss.track_densification()
+            for s_ in range(7, 13):
+                ss.train_step(s_, list(range(6)))
+            info = ss.densify(max_grad=2e-5, min_opacity=0.05, percent_dense=0.002)
+            out["densify"] = (info, ss.n, ss.stride, ss.counts, float(ss.train_step(13, list(range(6)))))
+    torch.save(out, _os.path.join(outdir, f"p{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_step_in_two_real_processes():
+    """The sharded `train_step` as two operating-system processes (one rank each, sharing this GPU, gloo group, exchange
+    staged through the host) against the same two ranks run as virtual ranks in this process: identical first-step
+    losses, the same parameters up to float-atomics noise after three steps (photometric and config-5 loss sets), and a
+    collective densification that leaves both ranks with the same stride and slice table."""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    from rodygs_amd.sharded import ShardedDynamicScene, run_virtual_step
+    from rodygs_amd.trainstep import DynamicScene
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_two_process_worker, args=(2, port, d), nprocs=2, join=True)
+        got = [torch.load(f"{d}/p{r}.pt", weights_only=False) for r in range(2)]
+    for full in (False, True):
+        sc = O.synthetic_scene(6001, 256, 192, 3, seed=71)
+        ds = DynamicScene(sc, num_frames=6, device=DEV, full_losses=full)
+        ds.make_ground_truth(O.synthetic_scene(1500, 256, 192, 3, seed=72), range(6))
+        shards = [ShardedDynamicScene.from_replica(ds, r, 2, exchange=object()) for r in range(2)]
+        for r, sh in enumerate(shards):
+            sh.seed_rng(500 + r)
+        want = [[float(x) for x in run_virtual_step(shards, s_, list(range(6)))] for s_ in range(4, 7)]
+        for r in range(2):
+            # same forward, same draws (the loss reduction itself sums with float atomics: last-bit differences)
+            assert abs(got[r][full]["losses"][0] - want[0][r]) <= 1e-6 * abs(want[0][r]), (full, r)
+            assert np.allclose(got[r][full]["losses"], [w[r] for w in want], rtol=2e-3), (full, r)
+            assert torch.equal(got[0][full]["sp"], got[r][full]["sp"])               # replicated bucket stays in step
+        for k, v in got[0][full]["params"].items():
+            ref = torch.cat([sh.fp[k].detach() for sh in shards]).cpu()
+            assert v.shape == ref.shape and torch.equal(v, got[1][full]["params"][k])
+            dlt = (v - ref).abs()
+            assert float(dlt.mean()) <= 2e-4 * (float(ref.abs().mean()) + 1e-3), (full, k, float(dlt.mean()))
+    i0, i1 = got[0]["densify"], got[1]["densify"]
+    assert i0[2] == i1[2] and i0[3] == i1[3] and i0[3] == [i0[1], i1[1]] and i0[0]["P"] == i0[1] + i1[1]
+    assert np.isfinite(i0[4]) and np.isfinite(i1[4])
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
