@@ -93,6 +93,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rodygs_amd hot path has no CPU fallback")
+    # functional checks of the N > 1 flow on a 1-GPU box: RDG_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # RDG_DIST_BACKEND=gloo moves the collectives through the host (RCCL refuses two ranks on one device)
+    backend = os.environ.get("RDG_DIST_BACKEND", "nccl")
+    if os.environ.get("RDG_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # RDG_FORCE_SHARD=1: run the sharded step on a 1-rank group too (single-GPU check of the collective path)
@@ -100,7 +105,10 @@ def main():
     if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from oracle import rasterizer_oracle as O          # synthetic-scene generator + cpu_baseline only
     from rodygs_amd import _lib
@@ -118,8 +126,8 @@ def main():
     perm = gt_frames
     sharded = (world > 1 or force_shard) and args.dp_mode == "shard"
     if sharded:
-        from rodygs_amd.sharded import ShardedDynamicScene
-        ss = ShardedDynamicScene.from_replica(ds, rank, world)
+        from rodygs_amd.sharded import HostStagedExchange, ShardedDynamicScene
+        ss = ShardedDynamicScene.from_replica(ds, rank, world, None if backend == "nccl" else HostStagedExchange())
         ds.fp = ds.sync = ds.m2 = None           # the replica's full-size buffers are not needed any more
         torch.cuda.empty_cache()
         train_step = lambda st_: ss.train_step(st_, perm)                       # noqa: E731
