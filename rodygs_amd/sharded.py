@@ -259,7 +259,8 @@ class ShardedDynamicScene:
         L, dev = _lib.lib(), self.device
         n_tiles = ((self.W + 15) // 16) * ((self.H + 15) // 16)
         hint = rasterizer._CAPACITY_HINT
-        cap = max(int(hint.get(self.key, 0) * 1.5) + 4096, 4 * self.P_total + 4096)   # every step is another camera
+        # every step is another camera: 1.5x the last instance count, and the workspace only ever grows
+        cap = max(int(hint.get(self.key, 0) * 1.5) + 4096, 4 * self.P_total + 4096, self._capacity)
         deferred = rasterizer.DEFERRED_OVERFLOW_CHECK and self.key in hint
         if deferred:
             rasterizer.poll_overflow(block=False)
