@@ -192,6 +192,50 @@ __device__ __forceinline__ void rdg_diff16_to_lds(float* sm, int Tu, const float
     }
 }
 
+// Single-camera forward (the 1-GPU train step): the difference table sits in LDS, so a Gaussian costs 28 row reads and
+// nothing else.  Same operations in the same order as rdg_dyn_getter_views_fwd_kernel: the results are bit-identical.
+__global__ void __launch_bounds__(1024)
+rdg_dyn_getter_fwd_kernel(int P, int Tu, const float* __restrict__ coeff, const long long* __restrict__ time_ind,
+                          const float* __restrict__ bases, float scale, const float* __restrict__ xyz,
+                          const float* __restrict__ scaling, const float* __restrict__ rotation,
+                          const float* __restrict__ opacity, float* __restrict__ means3D, float* __restrict__ scales,
+                          float* __restrict__ rots, float* __restrict__ opac) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dg[];
+    rdg_diff16_to_lds(smem_dg, Tu, bases);
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int u = (int)time_ind[p];
+        const float4* c4 = reinterpret_cast<const float4*>(coeff + (size_t)p * 16);
+        float c[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t = c4[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
+        float acc[RDG_DEF_K];
+#pragma unroll
+        for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 28; ++j) {
+            const float4 v = r4[j];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const int e = 4 * j + e4;          // compile-time: e = b * 7 + k
+                acc[e % 7] = __fmaf_rn(c[e / 7], vv[e4], acc[e % 7]);   // written out: same bits as the views kernel
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            means3D[3 * p + k] = __fmaf_rn(acc[k], scale, xyz[3 * p + k]);
+            scales[3 * p + k] = __expf(scaling[3 * p + k]);
+        }
+        const float4 q = reinterpret_cast<const float4*>(rotation)[p];
+        const float inv = 1.0f / fmaxf(sqrtf(__fmaf_rn(q.w, q.w, __fmaf_rn(q.z, q.z, __fmaf_rn(q.y, q.y, q.x * q.x)))), 1e-12f);
+        reinterpret_cast<float4*>(rots)[p] = make_float4(__fmaf_rn(q.x, inv, acc[3]), __fmaf_rn(q.y, inv, acc[4]),
+                                                         __fmaf_rn(q.z, inv, acc[5]), __fmaf_rn(q.w, inv, acc[6]));
+        opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
+    }
+}
+
 __global__ void __launch_bounds__(1024)
 rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind, const float* __restrict__ bases,
                           float scale, const float* __restrict__ scaling, const float* __restrict__ rotation,
@@ -386,10 +430,11 @@ __device__ __forceinline__ void rdg_views_to_lds(float* sm, int Tu, int NV, cons
     }
 }
 
-// Forward: c . (B(t_v) - table[birth]) is evaluated as c . B(t_v) - c . table[birth] with f64 accumulators: the table
-// row of a lane (the expensive LDS operand, 64 different rows per instruction) is then read once for all views instead
-// of once per view (that form was LDS-bound: 137 us for 125 k Gaussians x 8 views).  The single-view getter runs this same kernel with
-// NV = 1, so both frame-DP modes produce the same bits.
+// The table row of a lane is the expensive LDS operand (64 different rows per instruction): both kernels read it once
+// per Gaussian into registers and reuse it for every view (re-reading it per view was LDS-bound: 137 us for 125 k
+// Gaussians x 8 views); B(t_v) is a broadcast read.  The arithmetic is the reference's -- differences first, then the
+// dot product (evaluating c.B(t_v) - c.table[birth] instead loses digits when the motion basis is smooth in time) --
+// and the single-view getter performs the same operations in the same order, so both frame-DP modes produce the same bits.
 __global__ void __launch_bounds__(512)
 rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* __restrict__ coeff,
                                 const long long* __restrict__ time_ind, const float* __restrict__ bases_all,
@@ -414,44 +459,29 @@ rdg_dyn_getter_views_fwd_kernel(int P, int Tu, int NV, int stride, const float* 
 #pragma unroll
         for (int k = 0; k < 3; ++k) scales[3 * p + k] = __expf(scaling[3 * p + k]);
         opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
-        // c . table[birth]: the expensive LDS operand (64 different rows per instruction), once for all views.
-        // Both dot products accumulate in f64: B(t_v) and the birth row are close for a smooth motion basis, and the
-        // difference of two f32 dot products would lose the digits the reference keeps by subtracting first.
-        double cd[16];
+        // the birth row is the expensive LDS operand (64 different rows per instruction): read ONCE, kept in registers
+        // for all views; B(t_v) is a broadcast read.  Arithmetic = the reference's: differences first, then the dot.
+        float4 trow[28];
 #pragma unroll
-        for (int b = 0; b < 16; ++b) cd[b] = (double)c[b];
-        double tdot[RDG_DEF_K];
-#pragma unroll
-        for (int k = 0; k < RDG_DEF_K; ++k) tdot[k] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 28; ++j) {
-            const float4 t = r4[j];
-            const float vv[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const int e = 4 * j + e4;
-                tdot[e % 7] = fma(cd[e / 7], (double)vv[e4], tdot[e % 7]);
-            }
-        }
+        for (int j = 0; j < 28; ++j) trow[j] = r4[j];
         for (int v = 0; v < NV; ++v) {
-            // c . B(t_v): broadcast reads (one address for the whole wave)
             const float4* b4 = reinterpret_cast<const float4*>(sbt + v * 112);
-            double accd[RDG_DEF_K];
+            float acc[RDG_DEF_K];
 #pragma unroll
-            for (int k = 0; k < RDG_DEF_K; ++k) accd[k] = 0.0;
+            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = 0.0f;
 #pragma unroll
             for (int j = 0; j < 28; ++j) {
-                const float4 bb = b4[j];
-                const float vv[4] = {bb.x, bb.y, bb.z, bb.w};
+                const float4 t = trow[j], bb = b4[j];
+                const float vv[4] = {bb.x - t.x, bb.y - t.y, bb.z - t.z, bb.w - t.w};
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int e = 4 * j + e4;
-                    accd[e % 7] = fma(cd[e / 7], (double)vv[e4], accd[e % 7]);
+                    acc[e % 7] = __fmaf_rn(c[e / 7], vv[e4], acc[e % 7]);
                 }
+                // compiler barrier: without it all 28 broadcast reads of a view are hoisted (112 more live registers
+                // on top of the 112 of the row) and the kernel spills
+                asm volatile("" ::: "memory");
             }
-            float acc[RDG_DEF_K];
-#pragma unroll
-            for (int k = 0; k < RDG_DEF_K; ++k) acc[k] = (float)(accd[k] - tdot[k]);
             const size_t row = (size_t)v * stride + p;
             means3D[3 * row] = __fmaf_rn(acc[0], scale, x0);
             means3D[3 * row + 1] = __fmaf_rn(acc[1], scale, x1);
@@ -481,9 +511,14 @@ rdg_dyn_getter_views_bwd_kernel(int P, int Tu, int NV, int stride, const long lo
         const size_t sidx = (size_t)inv_order[p];
         float gsum[RDG_DEF_K] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float sm3[3] = {0.f, 0.f, 0.f}, ssc[3] = {0.f, 0.f, 0.f}, sop = 0.f;
-        double sacc[16];           // f64: sum_v g_v . B(t_v) and (sum_v g_v) . table[birth] nearly cancel (see forward)
+        float sacc[16];
 #pragma unroll
-        for (int b = 0; b < 16; ++b) sacc[b] = 0.0;
+        for (int b = 0; b < 16; ++b) sacc[b] = 0.0f;
+        // birth row of the table: read once, kept in registers for all views (as in the forward kernel)
+        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
+        float4 trow[28];
+#pragma unroll
+        for (int j = 0; j < 28; ++j) trow[j] = r4[j];
         for (int v = 0; v < NV; ++v) {
             const size_t row = (size_t)v * stride + p;
             const float m0 = g_means3D[3 * row], m1 = g_means3D[3 * row + 1], m2 = g_means3D[3 * row + 2];
@@ -501,31 +536,21 @@ rdg_dyn_getter_views_bwd_kernel(int P, int Tu, int NV, int stride, const long lo
             const float4* b4 = reinterpret_cast<const float4*>(sbt + v * 112);
 #pragma unroll
             for (int j = 0; j < 28; ++j) {
-                const float4 b = b4[j];
-                const float vv[4] = {b.x, b.y, b.z, b.w};
+                const float4 b = b4[j], t = trow[j];
+                // dL/dcoeff += g_v . (B(t_v) - table[birth]): differences first, as the reference (and the single-view
+                // kernel) evaluate it
+                const float vv[4] = {b.x - t.x, b.y - t.y, b.z - t.z, b.w - t.w};
 #pragma unroll
                 for (int e4 = 0; e4 < 4; ++e4) {
                     const int e = 4 * j + e4;
-                    sacc[e / 7] = fma((double)g[e % 7], (double)vv[e4], sacc[e / 7]);
+                    sacc[e / 7] = __fmaf_rn(g[e % 7], vv[e4], sacc[e / 7]);
                 }
-            }
-        }
-        // dL/dcoeff = sum_v g_v . B(t_v)  -  (sum_v g_v) . table[birth]
-        const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
-#pragma unroll
-        for (int j = 0; j < 28; ++j) {
-            const float4 t = r4[j];
-            const float vv[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-                const int e = 4 * j + e4;
-                sacc[e / 7] = fma(-(double)gsum[e % 7], (double)vv[e4], sacc[e / 7]);
+                asm volatile("" ::: "memory");     // keep the broadcast reads next to their use (register pressure)
             }
         }
         float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            dc[q] = make_float4((float)sacc[4 * q], (float)sacc[4 * q + 1], (float)sacc[4 * q + 2], (float)sacc[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) dc[q] = make_float4(sacc[4 * q], sacc[4 * q + 1], sacc[4 * q + 2], sacc[4 * q + 3]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             d_xyz[3 * p + k] = sm3[k];
@@ -847,12 +872,12 @@ int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int6
     if ((((uintptr_t)coeff | (uintptr_t)rotation | (uintptr_t)rots)) & 15) return rdg_set_error("dyn_getter: 16-B alignment");
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    int nb = (P + 511) / 512;
-    if (nb > 768) nb = 768;
+    int nb = (P + 1023) / 1024;
+    if (nb > 256) nb = 256;
     rdg_stage_begin(RDG_STAGE_DEFORM_FWD, st);
-    hipLaunchKernelGGL(rdg_dyn_getter_views_fwd_kernel, dim3(nb), dim3(512), ((size_t)Tu * RDG_DC_STRIDE + 112) * 4, st, P,
-                       Tu, 1, P, coeff, (const long long*)time_ind, bases, spatial_scale, xyz, scaling, rotation, opacity,
-                       means3D, scales, rots, opac);
+    hipLaunchKernelGGL(rdg_dyn_getter_fwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu, coeff,
+                       (const long long*)time_ind, bases, spatial_scale, xyz, scaling, rotation, opacity, means3D, scales,
+                       rots, opac);
     rdg_stage_end(RDG_STAGE_DEFORM_FWD, st);
     return rdg_check_hip(hipGetLastError(), "dyn_getter_fwd launch");
 }
