@@ -19,7 +19,8 @@ Gaussians -- parameters, Adam moments, gradients -- are SHARDED over the ranks a
 The two row formats and the *_views entry points are described in include/rodygs_hip.h.  Every collective is an
 equal-split ``all_to_all_single`` / ``all_reduce`` of ``torch.distributed`` (RCCL on the GPUs, gloo in the CPU
 tests of the exchange pattern); ``run_virtual_step`` drives several ranks inside one process for the single-GPU
-parity tests.  The reference has no distributed code: this is the build's own capability.
+parity tests, ``HostStagedExchange`` lets real processes share one GPU over gloo.  Densification runs per slice
+(``densify``), and the config-5 loss set (depth, motion regularisers, rigidity) is supported (``full_losses``).  The reference has no distributed code: this is the build's own capability.
 """
 from __future__ import annotations
 
@@ -38,7 +39,8 @@ _ROW = 16          # floats per splat record / gradient row (64 bytes)
 
 
 class DistExchange:
-    """The three collectives of a sharded step over the default process group."""
+    """The collectives of a sharded step over the default process group: the two equal-split all-to-alls and the small
+    all-reduce of every step, plus the all-gather / reduce-scatter pair of a rigidity step."""
 
     def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
         dist.all_to_all_single(recv, send)
