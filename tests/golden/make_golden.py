@@ -22,6 +22,10 @@ What is pinned: the pieces of the hot path that exist as import
                    (``... make_golden.py depth``)
   G9 motion reg  : MotionL1Loss, MotionSparsityLoss, MotionBasisRegularizaiton (src/trainer/losses.py:363-525; the
                    constructor's ``.cuda()`` is neutralised for the call), value and gradients (``... motion``)
+  G10 eval pose : matrix_to_quaternion (src/utils/graphic_utils.py:116-159), search_nearest_two
+                   (src/evaluator/utils.py:15-26), l2_loss (src/utils/loss_utils.py:23-24) and the world-view matrix a
+                   LearnableCamera builds from its (quaternion, translation) parameters (src/data/utils.py:173-232)
+                   -- the importable pieces of the evaluator's test-time pose optimisation (``... make_golden.py pose``)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -267,12 +271,39 @@ def motion_reg_golden():
     np.savez_compressed(os.path.join(OUT, "motion_reg_golden.npz"), **out)
 
 
+def eval_pose_golden():
+    from src.utils import graphic_utils as GU
+    from src.utils.loss_utils import l2_loss
+    from src.evaluator.utils import search_nearest_two
+    from src.data.utils import LearnableCamera
+    g = torch.Generator().manual_seed(1010)
+    q = torch.randn(64, 4, generator=g)
+    q[5] = torch.tensor([1e-3, 1.0, 0.0, 0.0]); q[6] = torch.tensor([0.0, 0.0, 1.0, 1e-4]); q[7] = torch.tensor([0.0, 0.0, 0.0, -1.0])
+    R = GU.quaternion_to_matrix(q)
+    out = dict(R=R.numpy(), quat=GU.matrix_to_quaternion(R).numpy())
+    poses = torch.eye(4).repeat(12, 1, 1)
+    poses[:, :3, 3] = 3.0 * torch.randn(12, 3, generator=g)
+    query = torch.eye(4)
+    query[:3, 3] = torch.randn(3, generator=g)
+    out.update(db_poses=poses.numpy(), query_pose=query.numpy(), nearest=search_nearest_two(query, poses).numpy())
+    a, b = torch.rand(3, 7, 9, generator=g), torch.rand(3, 7, 9, generator=g)
+    out.update(l2_a=a.numpy(), l2_b=b.numpy(), l2=l2_loss(a, b).numpy())
+    # LearnableCamera: W2C rotation/translation in -> (R_c2w_quat, T_c2w) parameters -> world_view_transform
+    Rw2c = GU.quaternion_to_matrix(torch.nn.functional.normalize(torch.randn(4, generator=g), dim=0)).numpy().astype(np.float64)
+    Tw2c = torch.randn(3, generator=g).numpy().astype(np.float64)
+    cam = LearnableCamera(Rw2c, Tw2c, 0.9, 0.6, torch.zeros(3, 8, 10), "x", 0.0, None, None, None, 0)
+    out.update(cam_R_w2c=Rw2c, cam_T_w2c=Tw2c, cam_quat=cam.R_c2w_quat.detach().numpy(),
+               cam_t=cam.T_c2w.detach().numpy(), cam_w2c=cam.world_view_transform.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "eval_pose_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose"):
         sys.dont_write_bytecode = True
         _stub_modules()
         sys.path.insert(0, REF)
-        {"rigidity": rigidity_golden, "depth": depth_loss_golden, "motion": motion_reg_golden}[sys.argv[1]]()
+        {"rigidity": rigidity_golden, "depth": depth_loss_golden, "motion": motion_reg_golden,
+         "pose": eval_pose_golden}[sys.argv[1]]()
         print(sys.argv[1], "golden written to", OUT)
     else:
         main()

@@ -174,3 +174,23 @@ def test_checkpoint_wire_format_round_trip_and_torch_adam_compat(tmp_path):
     b = a + 0.1
     assert abs(float(CK.psnr(a, b)) - 20.0) < 1e-4
     assert abs(float(CK.psnr(a, a + 2.0)) - float(10 * torch.log10(torch.tensor(1 / 0.25)))) < 1e-5   # clipped to 1
+
+
+def test_eval_pose_helpers_against_reference_golden():
+    """Host pieces of the evaluator's test-time pose optimisation (rodygs_amd/pose_optimizer.py) against values produced
+    by the imported reference (tests/golden/make_golden.py pose): matrix_to_quaternion incl. near-degenerate pivots,
+    search_nearest_two, l2_loss, and the LearnableCamera parameterisation + its world-view matrix."""
+    import numpy as np
+    import torch
+    from rodygs_amd.pose_optimizer import LearnablePose, l2_loss, matrix_to_quaternion, search_nearest_two
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_pose_golden.npz"))
+    q = matrix_to_quaternion(torch.from_numpy(g["R"]))
+    assert torch.allclose(q, torch.from_numpy(g["quat"]), rtol=0, atol=2e-6)
+    assert matrix_to_quaternion(torch.from_numpy(g["R"]).reshape(8, 8, 3, 3)).shape == (8, 8, 4)
+    near = search_nearest_two(torch.from_numpy(g["query_pose"]), torch.from_numpy(g["db_poses"]))
+    assert near.tolist() == g["nearest"].tolist()
+    assert abs(float(l2_loss(torch.from_numpy(g["l2_a"]), torch.from_numpy(g["l2_b"]))) - float(g["l2"])) < 1e-7
+    cam = LearnablePose(torch.from_numpy(g["cam_R_w2c"]), torch.from_numpy(g["cam_T_w2c"]))
+    assert torch.allclose(cam.R_c2w_quat.detach(), torch.from_numpy(g["cam_quat"]), atol=1e-6)
+    assert torch.allclose(cam.T_c2w.detach(), torch.from_numpy(g["cam_t"]), atol=1e-6)
+    assert torch.allclose(cam.world_view_transform.detach(), torch.from_numpy(g["cam_w2c"]), atol=1e-6)

@@ -1467,6 +1467,50 @@ def test_allreduce_frame_dp_in_two_real_processes():
         assert float(dlt.mean()) <= 2e-4 * (float(ref.abs().mean()) + 1e-3), (k, float(dlt.mean()))
 
 
+def test_test_time_pose_optimisation_recovers_camera():
+    """The evaluator's PoseOptimizer (eval.py:342-420) on the HIP rasterizer: frozen Gaussians, a held-out camera whose
+    pose is only known approximately (initialised from the calibrated pose of the nearest train frame), Adam on the
+    camera-to-world quaternion + translation through dL/dviewmatrix.  The pose error must shrink and the PSNR rise."""
+    import math
+    from rodygs_amd.checkpoint import psnr
+    from rodygs_amd.pose_optimizer import PoseOptimizer
+    from rodygs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    sc = O.synthetic_scene(4000, 192, 144, 3, seed=81)
+    dev = torch.device(DEV)
+    gs = {k: sc[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    rs = GaussianRasterizationSettings(144, 192, sc["tanfovx"], sc["tanfovy"], torch.zeros(3, device=dev), 1.0,
+                                       sc["projmatrix"].to(dev), 3, False, False, True, True)
+
+    def render(vm):
+        return GaussianRasterizer(rs)(means3D=gs["means3D"], means2D=torch.zeros_like(gs["means3D"]), shs=gs["shs"],
+                                      opacities=gs["opacities"], scales=gs["scales"], rotations=gs["rotations"],
+                                      viewmatrix=vm)[0]
+
+    def c2w(angle, shift):
+        c, s_ = math.cos(angle), math.sin(angle)
+        m = torch.eye(4)
+        m[:3, :3] = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]])
+        m[:3, 3] = torch.tensor(shift)
+        return m
+
+    train_gt = torch.stack([c2w(0.02 * i, [0.15 * i, 0.0, 0.0]) for i in range(-3, 4)])
+    calibrated = train_gt.clone()                     # the trained poses of those frames (here: exact)
+    test_gt = c2w(0.031, [0.21, 0.03, -0.02])         # between train frames 1 and 2 of the right half
+    with torch.no_grad():
+        rgb = render(torch.inverse(test_gt).t().contiguous().to(dev))
+    po = PoseOptimizer(calibrated.to(dev), train_gt.to(dev), render, camera_lr=2e-3, num_opts=200)
+    cam = po(test_gt.to(dev), rgb)
+    with torch.no_grad():
+        w2c0 = torch.inverse(calibrated[4]).to(dev)                    # the start: nearest train frame (index 4)
+        p0 = float(psnr(rgb, render(w2c0.t().contiguous())))
+        p1 = float(psnr(rgb, render(cam.viewmatrix())))
+        est = torch.inverse(cam.world_view_transform).cpu()
+    e0 = float(torch.norm(calibrated[4][:3, 3] - test_gt[:3, 3]))
+    e1 = float(torch.norm(est[:3, 3] - test_gt[:3, 3]))
+    assert float(po.history[-1]) < 0.05 * float(po.history[0]), (float(po.history[0]), float(po.history[-1]))
+    assert p1 > p0 + 8.0 and e1 < 0.25 * e0, (p0, p1, e0, e1)
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
