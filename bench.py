@@ -241,7 +241,11 @@ def main():
                        "frames": args.frames,
                        "parallelism": (f"frame-dp{world}, Gaussian-sharded (records/gradient rows all-to-all)" if sharded
                                        else f"frame-dp{world}" + (", replicated + bucketed all-reduce" if world > 1 else "")), "num_rendered_D": D, "visible_V": V,
-                       "losses": "full (config 5 set)" if args.full_losses else "photometric"},
+                       "losses": "full (config 5 set)" if args.full_losses else "photometric",
+                       # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH
+                       # features itself (RDG_FUSE_SH_ADAM=0 restores the separate launch; same bits either way)
+                       "sh_adam_in_backward": bool(world == 1 and not sharded and not args.full_losses
+                                                   and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")},
             "gaussians_per_s": fps * P,
             "loss": float(loss.item()),
             "stage_ms": per_stage,

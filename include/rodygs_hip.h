@@ -145,6 +145,19 @@ int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3
                             float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                             float* dL_dviewmatrix, void* stream);
 
+/* rdg_preprocess_backward with the optimiser step of the SH features folded in ("optimizer in backward"): the kernel
+ * holds a wave's 64 gradient rows of dL/dshs in LDS; instead of writing them out for rdg_adam_step_* to read back, it
+ * applies the Adam update to shs [P,M,3] (IN PLACE), sh_exp_avg and sh_exp_avg_sq right there -- same arithmetic, same
+ * bits as rdg_adam_step_multi on a segment (row_len = 3M, head_len, lr_head, lr_tail) fed the gradient it would have written;
+ * dL/dshs itself is never materialised.  The other outputs are those of rdg_preprocess_backward.                      */
+int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* means3D, float* shs,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+                                 const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
+                                 float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dviewmatrix,
+                                 float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len, float lr_head, float lr_tail,
+                                 float beta1, float beta2, float eps, int32_t step, void* stream);
+
 /* The per-Gaussian halves for the nviews (<= RDG_MAX_VIEWS) cameras of one step over the SAME P Gaussians (s_host->P),
  * whose time-dependent inputs are stacked with a row stride of stride_rows (multiple of 256, >= P): means3D
  * [nviews,stride,3], rotations [nviews,stride,4]; shs [P,M,3], scales [P,3] and opacities [P] are shared;

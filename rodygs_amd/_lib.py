@@ -54,6 +54,8 @@ _SIGS = {
     "rdg_composite_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, _vp, C.c_int64] + [_vp] * 7),
     "rdg_composite_backward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6),
     "rdg_preprocess_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 22),
+    "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 5 +
+                                     [C.c_int32, _vp]),
     "rdg_preprocess_forward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 10),
     "rdg_preprocess_backward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 18),
     "rdg_geom_export": (C.c_int, [C.c_int32] + [_vp] * 8),

@@ -159,6 +159,15 @@ int rdg_check_hip(hipError_t e, const char* what);
 void rdg_stage_begin(int stage, hipStream_t s);
 void rdg_stage_end(int stage, hipStream_t s);
 
+// Adam state of the SH-feature segment handed to the per-Gaussian backward kernel ("optimizer in backward",
+// rdg_preprocess_backward_adam): the kernel has a wave's 64 gradient rows in LDS -- instead of writing them out for
+// the optimizer to read back, it applies the update right there.  m == nullptr: off.
+struct RdgShAdam {
+    float* m; float* v;
+    float step_head, step_tail, b1, b2, eps, bc2_sqrt;
+    int head_len;
+};
+
 // ---- kernel launchers (one per .hip file) ----------------------------------------------------------------
 int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
@@ -182,7 +191,7 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                               const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
                               const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
                               float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
-                              float* dview, hipStream_t s);
+                              float* dview, hipStream_t s, const RdgShAdam* sh_adam = nullptr);
 
 int rdg_launch_preprocess_fwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
                                     const float* shs, const float* opac, const float* scales, const float* rots,
@@ -311,6 +320,60 @@ __device__ __forceinline__ void rdg_lds_acc_rows(float* __restrict__ g, long lon
                 const int gi = (int)(((float)idx + 0.5f) * inv_row);
                 const float val = S[gi * stride + (idx - gi * row)];
                 g[e] = ACC ? g[e] + val : val;
+            }
+        }
+    }
+}
+// One element of the update, with the fused multiply-adds written out: the float4 body and the scalar tail of a segment
+// must round identically, or a parameter's value would depend on where its segment happens to end (sharded vs
+// replicated layouts of the same cloud differed by one ulp on the tail elements).
+__device__ __forceinline__ void rdg_adam_elem(float& p, float g, float& m, float& v, float st, float b1, float b2,
+                                              float eps, float bc2_sqrt) {
+    m = __fmaf_rn(b1, m, (1.0f - b1) * g);
+    v = __fmaf_rn(b2, v, ((1.0f - b2) * g) * g);
+    p = __fmaf_rn(-st, m / (sqrtf(v) / bc2_sqrt + eps), p);
+}
+
+
+// p[rows] <- Adam(p, g = S): the update form of rdg_lds_to_rows (same chunking; head_len leading floats of a row take
+// step_head, the rest step_tail)
+__device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const RdgShAdam ad, long long first_row,
+                                                  long long n_rows, int row, int stride, const float* S, int lane) {
+    const long long base = first_row * row, total = n_rows * row;
+    const float inv_row = 1.0f / (float)row;
+    typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
+    if ((row & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)ad.m) | ((uintptr_t)ad.v)) & 15) == 0) {
+        for (int v = lane; v < 16 * row; v += 64) {
+            const long long e = base + 4ll * v;
+            if (e < total) {
+                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                const int col = 4 * v - gi * row;
+                const float* src = S + gi * stride + col;
+                rdg_nt4 pp = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(p + e));
+                rdg_nt4 mm = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.m + e));
+                rdg_nt4 vv = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.v + e));
+                float P4[4] = {pp.x, pp.y, pp.z, pp.w}, M4[4] = {mm.x, mm.y, mm.z, mm.w}, V4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    rdg_adam_elem(P4[c], src[c], M4[c], V4[c], (col + c) < ad.head_len ? ad.step_head : ad.step_tail,
+                                  ad.b1, ad.b2, ad.eps, ad.bc2_sqrt);
+                pp = rdg_nt4{P4[0], P4[1], P4[2], P4[3]}; mm = rdg_nt4{M4[0], M4[1], M4[2], M4[3]};
+                vv = rdg_nt4{V4[0], V4[1], V4[2], V4[3]};
+                __builtin_nontemporal_store(pp, reinterpret_cast<rdg_nt4*>(p + e));
+                __builtin_nontemporal_store(mm, reinterpret_cast<rdg_nt4*>(ad.m + e));
+                __builtin_nontemporal_store(vv, reinterpret_cast<rdg_nt4*>(ad.v + e));
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * row; idx += 64) {
+            const long long e = base + idx;
+            if (e < total) {
+                const int gi = (int)(((float)idx + 0.5f) * inv_row);
+                const int col = idx - gi * row;
+                float pi = p[e], mi = ad.m[e], vi = ad.v[e];
+                rdg_adam_elem(pi, S[gi * stride + col], mi, vi, col < ad.head_len ? ad.step_head : ad.step_tail, ad.b1,
+                              ad.b2, ad.eps, ad.bc2_sqrt);
+                p[e] = pi; ad.m[e] = mi; ad.v[e] = vi;
             }
         }
     }

@@ -709,16 +709,6 @@ __device__ __forceinline__ void rdg_st4(float* base, long long i, float4 v) {
     }
 }
 
-// One element of the update, with the fused multiply-adds written out: the float4 body and the scalar tail of a segment
-// must round identically, or a parameter's value would depend on where its segment happens to end (sharded vs
-// replicated layouts of the same cloud differed by one ulp on the tail elements).
-__device__ __forceinline__ void rdg_adam_elem(float& p, float g, float& m, float& v, float st, float b1, float b2,
-                                              float eps, float bc2_sqrt) {
-    m = __fmaf_rn(b1, m, (1.0f - b1) * g);
-    v = __fmaf_rn(b2, v, ((1.0f - b2) * g) * g);
-    p = __fmaf_rn(-st, m / (sqrtf(v) / bc2_sqrt + eps), p);
-}
-
 template <int VAR>
 __device__ __forceinline__ void
 rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

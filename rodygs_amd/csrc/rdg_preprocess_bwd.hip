@@ -30,7 +30,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                           float* __restrict__ posebuf_b, float* __restrict__ dmeans3D_b, float* __restrict__ dmeans2D_b,
                           float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac_b,
                           float* __restrict__ dscales_b, float* __restrict__ drots_b, float* __restrict__ dcov3D,
-                          int nviews_arg, int vstride_arg) {
+                          int nviews_arg, int vstride_arg, RdgShAdam sh_adam) {
     const int nviews = MULTI ? nviews_arg : 1, vstride = MULTI ? vstride_arg : 0;   // MULTI = false: the single-camera kernel
     // nviews > 1 (sharded frame-DP owner stage): the same Gaussians under the cameras of a whole step; per-camera
     // inputs / outputs are stacked with a row stride of vstride, SH rows, scales and opacities are shared, and dL/dshs
@@ -346,8 +346,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
     }
     if (shs && wave_first < d.P && vw == nviews - 1) {
         rdg_wave_lds_sync();
-        rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, MULTI ? sGR[threadIdx.x >> 6] : sSH[threadIdx.x >> 6],
-                        threadIdx.x & 63);
+        const float* tile = MULTI ? sGR[threadIdx.x >> 6] : sSH[threadIdx.x >> 6];
+        if (!MULTI && sh_adam.m)       // optimizer in backward: the SH parameters are updated from the LDS tile
+            rdg_lds_adam_rows(const_cast<float*>(shs), sh_adam, wave_first, d.P, sh_row, sh_stride, tile, threadIdx.x & 63);
+        else
+            rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, tile, threadIdx.x & 63);
     }
     // pose-gradient reduction: DPP wave sums -> LDS -> ONE partial row per workgroup (no atomics: 16 k waves
     // hammering the same 19 addresses ran 20x slower than the rest of the kernel, and this form is deterministic)
@@ -433,13 +436,14 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                               const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
                               const float* grow, float* posebuf, float* dmeans3D, float* dmeans2D, float* dshs,
                               float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
-                              float* dview, hipStream_t s) {
+                              float* dview, hipStream_t s, const RdgShAdam* sh_adam) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const int nblk = (d.P + 255) / 256;
     if (d.P > 0) {
         hipLaunchKernelGGL(rdg_preprocess_bwd_kernel<false>, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs, colors,
                            opac, scales, rots, cov3D, radii, (const uint8_t*)((const char*)geom_ws + G.clamped),
-                           grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D, 1, 0);
+                           grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D, 1, 0,
+                           sh_adam ? *sh_adam : RdgShAdam{});
     }
     // second-level rows live behind the per-workgroup rows (rdg_grad_bytes reserves them)
     float* part = (float*)((char*)posebuf + rdg_align_up((size_t)(nblk > 0 ? nblk : 1) * RDG_POSE_N * 4, 256));
@@ -460,7 +464,7 @@ int rdg_launch_preprocess_bwd_views(const RdgDev& d, int32_t nviews, int32_t str
         hipLaunchKernelGGL(rdg_preprocess_bwd_kernel<true>, dim3(nblk), dim3(128), 0, s, d, views, proj, means3D, shs,
                            (const float*)nullptr, opac, scales, rots, (const float*)nullptr, radii,
                            (const uint8_t*)((const char*)geom_ws + G.clamped), grow, posebuf, dmeans3D, dmeans2D, dshs,
-                           (float*)nullptr, dopac, dscales, drots, (float*)nullptr, nviews, stride);
+                           (float*)nullptr, dopac, dscales, drots, (float*)nullptr, nviews, stride, RdgShAdam{});
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd views launch");
 }
 

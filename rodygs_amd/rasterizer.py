@@ -241,6 +241,28 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_ro = torch.empty_like(ro) if ro is not None else None
             d_cov = torch.empty_like(cov) if cov is not None else None
             d_vm = torch.empty(4, 4, **f32)
+            fused = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs_adam")
+            if fused is not None:
+                # optimizer in backward for the SH features: dL/dshs never leaves the kernel's LDS tile; the kernel
+                # updates `param` (which must BE the tensor passed as shs), exp_avg and exp_avg_sq in place
+                if shs is None or col is not None or cov is not None or sc is None:
+                    raise RuntimeError("grad_sinks['shs_adam'] needs shs + scales/rotations inputs")
+                prm = fused["param"]
+                if prm.data_ptr() != shs.data_ptr() or prm.numel() != shs.numel():
+                    raise RuntimeError("grad_sinks['shs_adam']['param'] must be the storage passed to the rasterizer as shs")
+                step = fused["step"]() if callable(fused["step"]) else int(fused["step"])
+                _lib.check(L.rdg_composite_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
+                                                    ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
+                                                    _lib.ptr(g_alpha), _lib.ptr(gws), _lib.stream_ptr()),
+                           "rdg_composite_backward")
+                _lib.check(L.rdg_preprocess_backward_adam(
+                    C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(vm),
+                    _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(gws), _lib.ptr(d_m3), _lib.ptr(d_m2),
+                    _lib.ptr(d_op), _lib.ptr(d_sc), _lib.ptr(d_ro), _lib.ptr(d_vm), _lib.ptr(fused["exp_avg"]),
+                    _lib.ptr(fused["exp_avg_sq"]), int(fused["head_len"]), float(fused["lr_head"]),
+                    float(fused["lr_tail"]), float(fused["betas"][0]), float(fused["betas"][1]), float(fused["eps"]),
+                    step, _lib.stream_ptr()), "rdg_preprocess_backward_adam")
+                return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None
             rc = L.rdg_rasterize_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col),
                                           _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm),
                                           _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning),

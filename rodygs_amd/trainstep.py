@@ -11,6 +11,7 @@ One step = what /root/reference/src/trainer/rodygs.py:198-369 does for a dynamic
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -87,6 +88,8 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
     _lib.check(L.rdg_adam_step_multi(len(entries), segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
                "rdg_adam_step_multi")
 
+
+_FUSE_SH_ADAM = os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0"
 
 _MLP_SINK_ORDER = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias", "timenet.4.weight",
                    "timenet.4.bias", "head_w1", "head_b1", "head_w2", "head_b2")
@@ -195,6 +198,9 @@ class DynamicScene:
         # global and local Pearson depth + rigidity every 5th step.  Several losses then feed the same parameters, so
         # only the SH features keep an overwriting gradient sink; the other segments are zeroed and accumulated.
         self.full_losses = full_losses
+        # optimizer-in-backward for the SH features (see render()); train_step switches it on for the single-GPU
+        # photometric step only -- gradient exchange, densification statistics and extra losses need the plain path
+        self.fuse_sh_adam = False
         if full_losses:
             from .depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
             from .motion_losses import MotionBasisRegularizaiton, MotionL1Loss, MotionSparsityLoss
@@ -239,12 +245,20 @@ class DynamicScene:
         vm = pose_view_matrix(self.cam_q, self.cam_t, frame, grad_sinks=self.pose_sinks)
         m2 = self.m2
         m2.grad = None
+        sinks = {"shs": self.fp["features"].grad,
+                 # frame-DP: the SH gradient goes on the wire while the rest of backward is still running
+                 "on_shs_ready": lambda: self.sync.ready("features")}
+        if self.fuse_sh_adam and torch.is_grad_enabled():
+            # single GPU, photometric step: nothing else needs dL/dshs, so the per-Gaussian backward kernel applies the
+            # Adam update of the SH features itself (64 % of all optimiser bytes never make the round trip)
+            o, n = self.fp.offsets["features"]
+            row, head, lr_tail = self.row_lr["features"]
+            sinks = {"shs_adam": {"param": self.fp["features"], "exp_avg": self.fp.exp_avg[o:o + n],
+                                  "exp_avg_sq": self.fp.exp_avg_sq[o:o + n], "head_len": head,
+                                  "lr_head": self.fp.lr["features"], "lr_tail": lr_tail, "betas": (0.9, 0.999),
+                                  "eps": 1e-15, "step": lambda: self.fp.step_count + 1}}
         out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
-                                                  rotations=rot, viewmatrix=vm,
-                                                  grad_sinks={"shs": self.fp["features"].grad,
-                                                              # frame-DP: the SH gradient goes on the wire while the
-                                                              # rest of backward is still running
-                                                              "on_shs_ready": lambda: self.sync.ready("features")})
+                                                  rotations=rot, viewmatrix=vm, grad_sinks=sinks)
         self._last_radii = out[4]
         return out, m2
 
@@ -323,7 +337,11 @@ class DynamicScene:
             loss = self._full_loss(step, frame)
         else:
             # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
-            out, _ = self.render(frame)
+            self.fuse_sh_adam = fuse = world == 1 and _FUSE_SH_ADAM
+            try:
+                out, _ = self.render(frame)
+            finally:
+                self.fuse_sh_adam = False
             loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
         if self.stats is not None:
@@ -339,6 +357,9 @@ class DynamicScene:
                 else:
                     fused_adam_(self.fp, row_lr=self.row_lr, names=names, advance=first)
                 first = False
+        elif not self.full_losses and fuse:
+            # the SH features were stepped inside backward; everything else in the usual single launch
+            fused_adam_(self.fp, names=[k for k in self.fp.names if k != "features"], extra=(self.sp,))
         else:
             fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,))
         return loss.detach()

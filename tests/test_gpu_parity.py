@@ -1511,6 +1511,74 @@ def test_test_time_pose_optimisation_recovers_camera():
     assert p1 > p0 + 8.0 and e1 < 0.25 * e0, (p0, p1, e0, e1)
 
 
+def test_sh_adam_in_backward_equals_separate_optimiser_step():
+    """rdg_preprocess_backward_adam (the SH features stepped inside the per-Gaussian backward kernel, dL/dshs never
+    written) against rdg_preprocess_backward + rdg_adam_step_multi on the gradient it writes, from the SAME gradient rows:
+    parameters and both moments bit for bit, every other output identical."""
+    from rodygs_amd import _lib
+    from rodygs_amd.rasterizer import GaussianRasterizationSettings, _c_settings
+    L = _lib.lib()
+    P, W, H, K = 5003, 256, 176, 16
+    sc = O.synthetic_scene(P, W, H, 3, seed=91)
+    dev = torch.device(DEV)
+    t = {k: sc[k].to(dev).contiguous() for k in ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix",
+                                                   "projmatrix")}
+    rs = GaussianRasterizationSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3, device=dev), 1.0,
+                                       t["projmatrix"], 3, False, False, True, True)
+    cs = _c_settings(rs, P, K)
+    u8, f32 = dict(dtype=torch.uint8, device=dev), dict(dtype=torch.float32, device=dev)
+    n_tiles, cap = ((W + 15) // 16) * ((H + 15) // 16), 40 * P
+    geom = torch.empty(L.rdg_geom_bytes(P), **u8)
+    binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), **u8)
+    image = torch.empty(L.rdg_image_bytes(H, W), **u8)
+    outs = [torch.empty(c, H, W, **f32) for c in (3, 1, 3, 1)]
+    radii, nren = torch.empty(P, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    bg, st = torch.zeros(3, **f32), _lib.stream_ptr()
+    _lib.check(L.rdg_rasterize_forward(C.byref(cs), bg.data_ptr(), t["means3D"].data_ptr(), t["shs"].data_ptr(), None,
+                                       t["opacities"].data_ptr(), t["scales"].data_ptr(), t["rotations"].data_ptr(), None,
+                                       t["viewmatrix"].data_ptr(), t["projmatrix"].data_ptr(), geom.data_ptr(),
+                                       binning.data_ptr(), cap, image.data_ptr(), *[o.data_ptr() for o in outs],
+                                       radii.data_ptr(), nren.data_ptr(), st), "fwd")
+    assert 0 < int(nren.item()) <= cap
+    g_color = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    gws = torch.empty(L.rdg_grad_bytes(P), **u8)
+    _lib.check(L.rdg_composite_backward(C.byref(cs), bg.data_ptr(), geom.data_ptr(), binning.data_ptr(), cap,
+                                        image.data_ptr(), g_color.data_ptr(), None, None, gws.data_ptr(), st), "cbwd")
+
+    def outputs():
+        return {k: torch.zeros(*shp, **f32) for k, shp in (("m3", (P, 3)), ("m2", (P, 3)), ("op", (P, 1)), ("sc", (P, 3)),
+                                                           ("ro", (P, 4)), ("vm", (4, 4)))}
+
+    a, d_sh = outputs(), torch.zeros(P, K, 3, **f32)
+    _lib.check(L.rdg_preprocess_backward(C.byref(cs), t["means3D"].data_ptr(), t["shs"].data_ptr(), None,
+                                         t["opacities"].data_ptr(), t["scales"].data_ptr(), t["rotations"].data_ptr(), None,
+                                         t["viewmatrix"].data_ptr(), t["projmatrix"].data_ptr(), radii.data_ptr(),
+                                         geom.data_ptr(), gws.data_ptr(), a["m3"].data_ptr(), a["m2"].data_ptr(),
+                                         d_sh.data_ptr(), None, a["op"].data_ptr(), a["sc"].data_ptr(), a["ro"].data_ptr(),
+                                         None, a["vm"].data_ptr(), st), "pbwd")
+    assert float(d_sh.abs().sum()) > 0
+    gen = torch.Generator().manual_seed(2)
+    m0, v0 = (0.01 * torch.randn(P, K, 3, generator=gen)).to(dev), (1e-4 * torch.rand(P, K, 3, generator=gen)).to(dev)
+    for step in (1, 7):
+        pa, ma, va = t["shs"].clone(), m0.clone(), v0.clone()
+        seg = (_lib.RdgAdamSeg * 1)()            # the launch the train step uses for its parameter groups
+        seg[0].n, seg[0].param, seg[0].grad = pa.numel(), pa.data_ptr(), d_sh.data_ptr()
+        seg[0].exp_avg, seg[0].exp_avg_sq = ma.data_ptr(), va.data_ptr()
+        seg[0].lr_head, seg[0].lr_tail, seg[0].row_len, seg[0].head_len = 2.5e-3, 2.5e-3 / 20, K * 3, 3
+        _lib.check(L.rdg_adam_step_multi(1, seg, 0.9, 0.999, 1e-15, step, st), "adam multi")
+        pb, mb, vb, b = t["shs"].clone(), m0.clone(), v0.clone(), outputs()
+        _lib.check(L.rdg_preprocess_backward_adam(
+            C.byref(cs), t["means3D"].data_ptr(), pb.data_ptr(), t["opacities"].data_ptr(), t["scales"].data_ptr(),
+            t["rotations"].data_ptr(), t["viewmatrix"].data_ptr(), t["projmatrix"].data_ptr(), radii.data_ptr(),
+            geom.data_ptr(), gws.data_ptr(), b["m3"].data_ptr(), b["m2"].data_ptr(), b["op"].data_ptr(), b["sc"].data_ptr(),
+            b["ro"].data_ptr(), b["vm"].data_ptr(), mb.data_ptr(), vb.data_ptr(), 3, 2.5e-3, 2.5e-3 / 20, 0.9, 0.999, 1e-15,
+            step, st), "pbwd adam")
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), step
+        assert not torch.equal(pb, t["shs"])
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
