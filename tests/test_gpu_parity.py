@@ -1100,7 +1100,7 @@ def test_fused_adam_rows_matches_two_torch_groups():
     rel_ok(pd - feats.to(DEV), want - feats, tol=1e-5, what="adam rows update")
 
 
-@pytest.mark.parametrize("NV", [1, 3, 8])
+@pytest.mark.parametrize("NV", [1, 3, 5, 8, 16])
 def test_multi_view_getter_matches_single_view_getter(NV):
     """rdg_dyn_getter_views_* (one launch for the camera times of a whole step) against the single-view fused getter
     run once per view: forward bit for bit, backward = the sum over the views."""
