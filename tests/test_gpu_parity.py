@@ -1162,7 +1162,7 @@ def _replica_and_shards(P, W_img, H_img, frames, world, seed=21):
     return ds, shards
 
 
-@pytest.mark.parametrize("P,world", [(20000, 4), (5003, 3), (9000, 8)])
+@pytest.mark.parametrize("P,world", [(20000, 4), (5003, 3), (9000, 8), (4100, 16)])
 def test_sharded_step_matches_replicated_frame_dp(P, world):
     """Gaussian-sharded frame-DP (rodygs_amd/sharded.py) against the replicated all-reduce formulation it replaces:
     `world` virtual ranks inside this process, each owning a slice of the cloud and rendering one camera.  The
