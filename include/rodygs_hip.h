@@ -324,6 +324,14 @@ int rdg_pearson_depth_backward(int32_t H, int32_t W, int32_t n_boxes, int32_t bh
                                const int64_t* col0, const float* pred, const float* gt, const uint8_t* mask,
                                const void* ws, const float* g_loss, float* d_pred, void* stream);
 
+/* ---- motion L1 + sparsity regularisers (MotionL1Loss, MotionSparsityLoss, /root/reference/src/trainer/losses.py:363-384) ----
+ * coeff [P,1,B] (B = 16).  Forward: sums2[0] = sum |c|, sums2[1] = sum_p sum_b |c_pb| / (max_b |c_pb| + 1e-7) (f64; the
+ * losses are these divided by P*B).  Backward: d_coeff (+)= g_loss[0] * d/dcoeff (w_l1 * L1 + w_sparsity * sparsity);
+ * accumulate != 0 adds to d_coeff, 0 overwrites it; g_loss may be NULL (= 1).                                       */
+int rdg_motion_reg_forward(int64_t P, int32_t B, const float* coeff, double* sums2, void* stream);
+int rdg_motion_reg_backward(int64_t P, int32_t B, const float* coeff, const float* g_loss, float w_l1, float w_sparsity,
+                            float* d_coeff, int32_t accumulate, void* stream);
+
 /* ---- pytorch3d.ops.knn_points / knn_gather (RigidityLoss, /root/reference/src/trainer/losses.py:235-331) ---- */
 /* K nearest targets of every query: dists[Pq,K] squared Euclidean, ascending; idx[Pq,K] int64 target indices.
  * tmp_ws: rdg_knn_tmp_bytes(Pt).  queries == targets (same pointer, Pq == Pt) is the self query the reference

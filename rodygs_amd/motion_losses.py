@@ -93,3 +93,46 @@ class MotionBasisRegularizaiton(nn.Module):
         if self.degree["rot"] < 0:
             r_norm = 0
         return t_norm + r_norm
+
+
+class _FusedL1Sparsity(torch.autograd.Function):
+    """w_l1 * MotionL1Loss + w_sparsity * MotionSparsityLoss over coeff [P,1,16] in one HIP pass each way
+    (csrc/rdg_motionreg.hip)."""
+
+    @staticmethod
+    def forward(ctx, coeff, w_l1, w_sparsity, grad_sink):
+        from . import _lib
+        L = _lib.lib()
+        if not coeff.is_cuda:
+            raise RuntimeError("rodygs_amd.fused_motion_l1_sparsity: tensors must be on the GPU (no CPU fallback exists)")
+        c = coeff.detach().to(torch.float32).contiguous()
+        P, B = c.shape[0], c.shape[-1]
+        sums = torch.empty(2, dtype=torch.float64, device=c.device)
+        with torch.cuda.device(c.device):
+            _lib.check(L.rdg_motion_reg_forward(P, B, _lib.ptr(c), _lib.ptr(sums), _lib.stream_ptr()), "rdg_motion_reg_forward")
+        ctx.save_for_backward(c)
+        ctx.w, ctx.sink, ctx.shape = (float(w_l1), float(w_sparsity)), grad_sink, coeff.shape
+        return ((w_l1 * sums[0] + w_sparsity * sums[1]) / float(max(P * B, 1))).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        L = _lib.lib()
+        (c,) = ctx.saved_tensors
+        P, B = c.shape[0], c.shape[-1]
+        gl = g.detach().to(torch.float32).reshape(1).contiguous()
+        sink = ctx.sink
+        if sink is not None and (sink.numel() != c.numel() or not sink.is_contiguous() or sink.dtype != torch.float32):
+            raise RuntimeError("fused_motion_l1_sparsity grad_sink must be a contiguous float32 tensor shaped like coeff")
+        d = sink if sink is not None else torch.empty_like(c)
+        with torch.cuda.device(c.device):
+            _lib.check(L.rdg_motion_reg_backward(P, B, _lib.ptr(c), _lib.ptr(gl), ctx.w[0], ctx.w[1], _lib.ptr(d),
+                                                 1 if sink is not None else 0, _lib.stream_ptr()), "rdg_motion_reg_backward")
+        return (None if sink is not None else d.view(ctx.shape)), None, None, None
+
+
+def fused_motion_l1_sparsity(coeff: torch.Tensor, w_l1: float, w_sparsity: float, grad_sink=None) -> torch.Tensor:
+    """``w_l1 * MotionL1Loss()(model) + w_sparsity * MotionSparsityLoss()(model)`` for ``model._motion_coeff = coeff``
+    [P,1,16].  ``grad_sink``: a tensor shaped like coeff that the backward ADDS the gradient into (e.g. the flat gradient
+    bucket's segment) instead of returning it through autograd."""
+    return _FusedL1Sparsity.apply(coeff, w_l1, w_sparsity, grad_sink)

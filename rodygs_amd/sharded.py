@@ -390,10 +390,11 @@ class ShardedDynamicScene:
                 # motion L1 / sparsity (means over ALL P x 16 coefficients): my slice's share, times the N cameras of
                 # the step (every rank adds these terms in the replicated formulation); accumulates on top of the
                 # getter's gradient
-                class _Local:
-                    _motion_coeff = fp["motion_coeff"]
+                from .motion_losses import fused_motion_l1_sparsity
                 share = float(Wn) * n / float(self.P_total)
-                lm = share * sum(w * mod(_Local) for k, (w, mod) in self.loss_terms.items() if k != "motion_basis_reg")
+                lm = share * fused_motion_l1_sparsity(fp["motion_coeff"], self.loss_terms["motion_l1"][0],
+                                                      self.loss_terms["motion_sparsity"][0],
+                                                      grad_sink=fp["motion_coeff"].grad)
                 lm.backward()
                 self._loss_owner = lm.detach()
 

@@ -321,8 +321,13 @@ class DynamicScene:
                 return allb[:-1][time_indices.to(allb.device)]
 
         loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
-        for w, mod in self.loss_terms.values():
-            loss = loss + w * mod(_Model)
+        # motion L1 + sparsity: one HIP pass each way, gradient added straight into the flat bucket; the basis
+        # regulariser (on the small motion table) stays the host mirror
+        from .motion_losses import fused_motion_l1_sparsity
+        loss = loss + fused_motion_l1_sparsity(fp["motion_coeff"], self.loss_terms["motion_l1"][0],
+                                               self.loss_terms["motion_sparsity"][0], grad_sink=fp["motion_coeff"].grad)
+        w, mod = self.loss_terms["motion_basis_reg"]
+        loss = loss + w * mod(_Model)
         for w, mod in self.depth_terms:
             loss = loss + w * mod(out[1], self.gt_depth[frame])
         w, freq, mod = self.rigidity

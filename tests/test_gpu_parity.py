@@ -1579,6 +1579,28 @@ def test_sh_adam_in_backward_equals_separate_optimiser_step():
             assert torch.equal(a[k], b[k]), k
 
 
+def test_fused_motion_l1_sparsity_matches_reference_golden():
+    """csrc/rdg_motionreg.hip against the values and gradients the imported reference produced for MotionL1Loss and
+    MotionSparsityLoss (tests/golden/motion_reg_golden.npz), separately and combined, returned and accumulated."""
+    from rodygs_amd.motion_losses import fused_motion_l1_sparsity
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "motion_reg_golden.npz"))
+    coeff = torch.from_numpy(g["coeff"]).to(DEV)
+    for w1, w2 in ((1.0, 0.0), (0.0, 1.0), (0.01, 0.002)):
+        c = coeff.clone().requires_grad_(True)
+        loss = fused_motion_l1_sparsity(c, w1, w2)
+        loss.backward()
+        want = w1 * float(g["l1.loss"]) + w2 * float(g["sparsity.loss"])
+        assert abs(float(loss) - want) <= 2e-6 * abs(want) + 1e-9
+        wg = w1 * torch.from_numpy(g["l1.d_coeff"]) + w2 * torch.from_numpy(g["sparsity.d_coeff"])
+        rel_ok(c.grad, wg, tol=1e-5, what=f"motion reg d_coeff ({w1}, {w2})")
+        sink = torch.zeros_like(coeff)
+        for rep in (1, 2):                                   # the sink ACCUMULATES
+            c2 = coeff.clone().requires_grad_(True)
+            (3.0 * fused_motion_l1_sparsity(c2, w1, w2, grad_sink=sink)).backward()
+            assert c2.grad is None
+            rel_ok(sink, 3.0 * rep * wg, tol=2e-5, what="motion reg sink")
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
