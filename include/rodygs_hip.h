@@ -332,6 +332,14 @@ int rdg_motion_reg_forward(int64_t P, int32_t B, const float* coeff, double* sum
 int rdg_motion_reg_backward(int64_t P, int32_t B, const float* coeff, const float* g_loss, float w_l1, float w_sparsity,
                             float* d_coeff, int32_t accumulate, void* stream);
 
+/* MotionBasisRegularizaiton (/root/reference/src/trainer/losses.py:386-525) of the motion table [Tu,16,7], value AND gradient
+ * in three tiny launches: loss[0] (f64) = mean_{t,b} w_b ||d^k transl|| + mean_{t,b} w_b ||I - d^k R(q)||_F with
+ * k = degree + 1 forward differences over the time axis (degree < 0 drops that term; degrees 0..2), d_table [Tu,16,7]
+ * = its gradient (overwritten).  w_host: the 16 per-basis weights (HOST array).  ws: rdg_basis_reg_ws_bytes(Tu).   */
+size_t rdg_basis_reg_ws_bytes(int32_t Tu);
+int rdg_basis_reg(int32_t Tu, int32_t B, int32_t transl_degree, int32_t rot_degree, const float* w_host,
+                  const float* table, void* ws, double* loss, float* d_table, void* stream);
+
 /* ---- pytorch3d.ops.knn_points / knn_gather (RigidityLoss, /root/reference/src/trainer/losses.py:235-331) ---- */
 /* K nearest targets of every query: dists[Pq,K] squared Euclidean, ascending; idx[Pq,K] int64 target indices.
  * tmp_ws: rdg_knn_tmp_bytes(Pt).  queries == targets (same pointer, Pq == Pt) is the self query the reference

@@ -78,6 +78,8 @@ _SIGS = {
     "rdg_rigidity_dp_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32] + [_vp] * 6 + [C.c_float] + [_vp] * 4),
     "rdg_motion_reg_forward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "rdg_motion_reg_backward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_float, _vp, C.c_int32, _vp]),
+    "rdg_basis_reg_ws_bytes": (C.c_size_t, [C.c_int32]),
+    "rdg_basis_reg": (C.c_int, [C.c_int32] * 4 + [C.POINTER(C.c_float), _vp, _vp, _vp, _vp, _vp]),
     "rdg_pearson_ws_bytes": (C.c_size_t, [C.c_int32]),
     "rdg_pearson_depth_forward": (C.c_int, [C.c_int32] * 5 + [_vp] * 5 + [C.c_float, C.c_float, _vp, _vp, _vp]),
     "rdg_pearson_depth_backward": (C.c_int, [C.c_int32] * 5 + [_vp] * 9),

@@ -81,6 +81,12 @@ class MotionBasisRegularizaiton(nn.Module):
 
     def forward(self, model, **kwargs):
         table = model.get_total_motion_table()                                   # [Tu,B,7]
+        if table.is_cuda and table.shape[1] == 16 and max(self.degree.values()) <= 2:
+            # GPU tensors: value and gradient in three tiny HIP launches (csrc/rdg_motionreg.hip) instead of ~160
+            # framework launches over a tensor of a few thousand floats; the torch expression below is the same
+            # arithmetic and serves CPU tensors (golden tests)
+            return _FusedBasisReg.apply(table, tuple(float(x) for x in self.reg_coeff.tolist()),
+                                        self.degree["transl"], self.degree["rot"])
         w = self.reg_coeff.to(table.device)
         transl, rot = table[..., :3], table[..., 3:]
         rot_m = quaternion_to_matrix(rot.reshape(-1, 4)).reshape(*table.shape[:-1], 3, 3)
@@ -136,3 +142,29 @@ def fused_motion_l1_sparsity(coeff: torch.Tensor, w_l1: float, w_sparsity: float
     [P,1,16].  ``grad_sink``: a tensor shaped like coeff that the backward ADDS the gradient into (e.g. the flat gradient
     bucket's segment) instead of returning it through autograd."""
     return _FusedL1Sparsity.apply(coeff, w_l1, w_sparsity, grad_sink)
+
+
+class _FusedBasisReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, w, transl_degree, rot_degree):
+        import ctypes as C
+        from . import _lib
+        L = _lib.lib()
+        t = table.detach().to(torch.float32).contiguous()
+        Tu, B = t.shape[0], t.shape[1]
+        dev = t.device
+        wa = (C.c_float * 16)(*w)
+        with torch.cuda.device(dev):
+            ws = torch.empty(L.rdg_basis_reg_ws_bytes(Tu), dtype=torch.uint8, device=dev)
+            loss = torch.empty(1, dtype=torch.float64, device=dev)
+            d_table = torch.empty_like(t)
+            _lib.check(L.rdg_basis_reg(Tu, B, int(transl_degree), int(rot_degree), wa, _lib.ptr(t), _lib.ptr(ws),
+                                       _lib.ptr(loss), _lib.ptr(d_table), _lib.stream_ptr()), "rdg_basis_reg")
+        ctx.save_for_backward(d_table)
+        ctx.shape = table.shape
+        return loss[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_table,) = ctx.saved_tensors
+        return (d_table * g).view(ctx.shape), None, None, None

@@ -1601,6 +1601,38 @@ def test_fused_motion_l1_sparsity_matches_reference_golden():
             rel_ok(sink, 3.0 * rep * wg, tol=2e-5, what="motion reg sink")
 
 
+def test_fused_basis_regulariser_matches_reference_golden():
+    """rdg_basis_reg (value + gradient of MotionBasisRegularizaiton in three launches) against the imported reference's
+    value and d_table for degree 0 ("vanilla" weights) and degree 1 with the "gaussian" frequency weights, and against
+    the torch host mirror for degree 2 / a disabled term."""
+    from rodygs_amd import motion_losses as ML
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "motion_reg_golden.npz"))
+
+    def run(mod, table):
+        class M:
+            @staticmethod
+            def get_total_motion_table():
+                return table
+        return mod(M)
+
+    cases = {"basis_d0": ML.MotionBasisRegularizaiton(transl_degree=0),
+             "basis_d1_gauss": ML.MotionBasisRegularizaiton(transl_degree=1, rot_degree=1, freq_div_mode="gaussian")}
+    for name, mod in cases.items():
+        t = torch.from_numpy(g["table"]).to(DEV).requires_grad_(True)
+        v = run(mod, t)
+        (2.0 * v).backward()
+        assert abs(float(v) - float(g[name + ".loss"])) <= 5e-6 * abs(float(g[name + ".loss"]))
+        rel_ok(t.grad, 2.0 * torch.from_numpy(g[name + ".d_table"]), tol=2e-5, what=name + " d_table")
+    for mod in (ML.MotionBasisRegularizaiton(transl_degree=2, rot_degree=2, freq_div_mode="sigmoid"),
+                ML.MotionBasisRegularizaiton(transl_degree=-1, rot_degree=0)):
+        tg = torch.from_numpy(g["table"]).to(DEV).requires_grad_(True)
+        tc = torch.from_numpy(g["table"]).requires_grad_(True)
+        vg, vc = run(mod, tg), run(mod, tc)
+        vg.backward(); vc.backward()
+        assert abs(float(vg) - float(vc)) <= 5e-6 * abs(float(vc))
+        rel_ok(tg.grad, tc.grad, tol=5e-5, what="basis reg vs host mirror")
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
