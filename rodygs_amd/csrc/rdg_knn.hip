@@ -504,12 +504,14 @@ int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const
 // pos_t = canon + own(tau) and the gradient G_t are laid out [nt][n] float4, one 16-B gather per edge end.
 // Outputs are the SUM of the terms and its unscaled gradients: G_t (w.r.t. pos_t) and d_d2 [n*K].
 // ---------------------------------------------------------------------------------------------------------
+template <int KT>      // KT > 0: K known at compile time -- the K neighbour loads of a thread are issued together
 __global__ void __launch_bounds__(256)
-rdg_rigidity_dp_kernel(long long n, int K, int nt, const float4* __restrict__ pos_t, const long long* __restrict__ nn_idx,
+rdg_rigidity_dp_kernel(long long n, int K_rt, int nt, const float4* __restrict__ pos_t, const long long* __restrict__ nn_idx,
                        const float* __restrict__ d2, const long long* __restrict__ rev_off,
                        const long long* __restrict__ rev_edge, const long long* __restrict__ orig, float eps2,
                        double* __restrict__ loss_sum, float4* __restrict__ G_t, float* __restrict__ d_d2) {
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int K = KT > 0 ? KT : K_rt;
     double local = 0.0;
     if (tid < n * nt) {
         const long long tau = tid / n, i = tid - tau * n;
@@ -522,7 +524,8 @@ rdg_rigidity_dp_kernel(long long n, int K, int nt, const float4* __restrict__ po
         // (1) edges leaving i: the loss terms themselves, -u on this end, the d2 gradient
         long long row_prev = -1;
         float row_acc = 0.f;
-        for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
             const float4 q = slab[nn_idx[i * K + k]];
             const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
             const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -577,8 +580,13 @@ extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const f
     if (e == hipSuccess) e = hipMemsetAsync(d_d2, 0, (size_t)n * K * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "rigidity_dp memset");
     const long long total = n * nt;
-    hipLaunchKernelGGL(rdg_rigidity_dp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K, nt,
-                       (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
-                       (const long long*)rev_edge, (const long long*)orig, eps * eps, loss_sum, (float4*)G_t4, d_d2);
+    if (K == 8)
+        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K,
+                           nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
+                           (const long long*)rev_edge, (const long long*)orig, eps * eps, loss_sum, (float4*)G_t4, d_d2);
+    else
+        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K,
+                           nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
+                           (const long long*)rev_edge, (const long long*)orig, eps * eps, loss_sum, (float4*)G_t4, d_d2);
     return rdg_check_hip(hipGetLastError(), "rigidity_dp launch");
 }
