@@ -90,6 +90,7 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
 
 
 _FUSE_SH_ADAM = os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0"
+_PLAIN_FULL_FAST = os.environ.get("RDG_PLAIN_FULL_FAST", "1") != "0"   # 0: every full-loss step on the general path
 
 _MLP_SINK_ORDER = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias", "timenet.4.weight",
                    "timenet.4.bias", "head_w1", "head_b1", "head_w2", "head_b2")
@@ -201,6 +202,7 @@ class DynamicScene:
         # optimizer-in-backward for the SH features (see render()); train_step switches it on for the single-GPU
         # photometric step only -- gradient exchange, densification statistics and extra losses need the plain path
         self.fuse_sh_adam = False
+        self._plain_full = False     # full_losses on a step without rigidity: the photometric step's fused kernels
         if full_losses:
             from .depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
             from .motion_losses import MotionBasisRegularizaiton, MotionL1Loss, MotionSparsityLoss
@@ -221,7 +223,8 @@ class DynamicScene:
         fp, net = self.fp, self.net
         # ONE pass of the MLP over the T birth-time rows + the frame's own time (row T)
         allb = net.motion_basis(self.emb_rows[frame])                     # [T+1,16,7]: table rows, then B(t)
-        if not self.full_losses and dynamic_getter_supported(allb.shape[1], allb.shape[0] - 1):
+        self._last_allb = allb
+        if (not self.full_losses or self._plain_full) and dynamic_getter_supported(allb.shape[1], allb.shape[0] - 1):
             # deformation + activations in ONE kernel each way; all five parameter gradients go straight to the bucket
             sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
             sinks["coeff"] = fp["motion_coeff"].grad
@@ -335,10 +338,48 @@ class DynamicScene:
             loss = loss + w * mod(_Model, dxyz)
         return loss
 
+    def _full_loss_plain(self, frame: int, fuse: bool):
+        """The config-5 loss set on a step WITHOUT rigidity (4 of 5): nothing then needs the deformation as a tensor,
+        so the step runs on the photometric step's fused kernels (deformation + activations in one kernel each way,
+        gradients overwritten in the flat bucket, SH Adam in backward) with the depth terms on the rendered depth and
+        the basis regulariser on the motion table joining the same backward pass.  Returns (main loss, callable that
+        adds the per-Gaussian motion regularisers AFTER the main backward: their gradient is accumulated on top of
+        the kernels' overwriting writes, so it must come second)."""
+        from .motion_losses import fused_motion_l1_sparsity
+        fp = self.fp
+        self._plain_full, self.fuse_sh_adam = True, fuse
+        try:
+            out, _ = self.render(frame)
+        finally:
+            self._plain_full, self.fuse_sh_adam = False, False
+        allb = self._last_allb
+
+        class _Model:
+            @staticmethod
+            def get_total_motion_table():
+                return allb[:-1]
+
+        loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
+        w, mod = self.loss_terms["motion_basis_reg"]
+        loss = loss + w * mod(_Model)
+        for w, mod in self.depth_terms:
+            loss = loss + w * mod(out[1], self.gt_depth[frame])
+
+        def after():
+            reg = fused_motion_l1_sparsity(fp["motion_coeff"], self.loss_terms["motion_l1"][0],
+                                           self.loss_terms["motion_sparsity"][0], grad_sink=fp["motion_coeff"].grad)
+            reg.backward()
+            return reg.detach()
+        return loss, after
+
     def train_step(self, step: int, rank: int = 0, world: int = 1, perm=None) -> torch.Tensor:
         perm = perm if perm is not None else list(self.gt.keys())
         frame = frame_for(step, rank, world, perm)
-        if self.full_losses:
+        after = None
+        if self.full_losses and step % self.rigidity[1] != 0 and _PLAIN_FULL_FAST:
+            fuse = world == 1 and _FUSE_SH_ADAM
+            loss, after = self._full_loss_plain(frame, fuse)
+        elif self.full_losses:
             loss = self._full_loss(step, frame)
         else:
             # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
@@ -349,6 +390,8 @@ class DynamicScene:
                 self.fuse_sh_adam = False
             loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
         loss.backward()
+        if after is not None:
+            loss = loss.detach() + after()
         if self.stats is not None:
             # add_densification_stats: screen-space gradient norm of the Gaussians visible in this frame
             self.stats.add(self.m2.grad, self._last_radii > 0, self._last_radii)
@@ -362,7 +405,7 @@ class DynamicScene:
                 else:
                     fused_adam_(self.fp, row_lr=self.row_lr, names=names, advance=first)
                 first = False
-        elif not self.full_losses and fuse:
+        elif (not self.full_losses or after is not None) and fuse:
             # the SH features were stepped inside backward; everything else in the usual single launch
             fused_adam_(self.fp, names=[k for k in self.fp.names if k != "features"], extra=(self.sp,))
         else:

@@ -1633,6 +1633,34 @@ def test_fused_basis_regulariser_matches_reference_golden():
         rel_ok(tg.grad, tc.grad, tol=5e-5, what="basis reg vs host mirror")
 
 
+def test_plain_full_loss_fast_path_equals_general_path():
+    """A config-5 step without rigidity runs on the photometric step's fused kernels (fused getter with overwriting
+    sinks, per-Gaussian regularisers added after the main backward); its gradients must equal those of the general
+    accumulate-everything path from the same state and the same random boxes."""
+    from rodygs_amd.trainstep import DynamicScene
+    sc = O.synthetic_scene(9001, 320, 256, 3, seed=95)
+    ds = DynamicScene(sc, num_frames=6, device=DEV, full_losses=True)
+    ds.make_ground_truth(O.synthetic_scene(2500, 320, 256, 3, seed=96), range(6))
+    ds.train_step(1, perm=[1])
+    ds.train_step(5, perm=[2])                                  # one rigidity step, general path
+    torch.manual_seed(7)
+    la = ds._full_loss(6, 3)
+    la.backward()
+    ga, gsa = ds.fp.flat_grad.clone(), ds.sp.flat_grad.clone()
+    ds.fp.flat_grad.fill_(123.0)                                # the fast path must overwrite everything it owns
+    torch.manual_seed(7)
+    lb, after = ds._full_loss_plain(3, False)
+    lb.backward()
+    lb = lb.detach() + after()
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(la))
+    for k in ds.fp.names:
+        o, m = ds.fp.offsets[k]
+        rel_ok(ds.fp.flat_grad[o:o + m], ga[o:o + m], tol=2e-4, what="plain full-loss d_" + k)
+    rel_ok(ds.sp.flat_grad, gsa, tol=2e-4, what="plain full-loss small bucket")
+    hist = [float(ds.train_step(s_, perm=list(range(6)))) for s_ in range(6, 30)]
+    assert all(np.isfinite(hist))
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
