@@ -80,9 +80,11 @@ class _FusedDistancePreserving(torch.autograd.Function):
             p4[..., :3] = pos_t.detach()[:, order]
             # reverse adjacency of the K-NN graph: edge ids (i*K + k) grouped by their destination
             flat = ii.reshape(-1)
-            rev_edge = torch.argsort(flat, stable=True).contiguous()
-            rev_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-            rev_off[1:] = torch.cumsum(torch.bincount(flat, minlength=n), dim=0)
+            srt, rev_edge = torch.sort(flat, stable=True)
+            rev_edge = rev_edge.contiguous()
+            # offsets of every destination in the sorted edge list (searchsorted instead of bincount + cumsum:
+            # bincount reads its output size back to the host and stalls the stream of launches)
+            rev_off = torch.searchsorted(srt, torch.arange(n + 1, device=dev)).contiguous()
             loss = torch.empty(1, dtype=torch.float64, device=dev)
             G4 = torch.empty_like(p4)
             d_d2 = torch.empty_like(dd)

@@ -12,7 +12,7 @@ ds.make_ground_truth(O.synthetic_scene(P // 4, W, H, 3, seed=1234), fr)
 for s in range(6):
     ds.train_step(s, 0, 1, fr)
 out = []
-for s in range(10, 60):
+for s in range(10, 20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ds.train_step(s, 0, 1, fr)
     th = time.perf_counter() - t0
