@@ -174,7 +174,18 @@ class RigidityLoss(nn.Module):
             # broadcast matmul ([n,1,1,B] @ [t,B,3], losses.py:305-306), which the BLAS sees as n*t batched 1xB
             # products (50 M batches at config-5 size: it faulted there); one [n,B] x [B,3t] product is the same sum
             bmat = basis_xyz.permute(1, 0, 2).reshape(basis_xyz.shape[1], nt * 3)
-            own = (coeffs.reshape(n, -1) @ bmat).reshape(n, nt, 3)
+            c2 = coeffs.reshape(n, -1)
+            if c2.is_cuda and n >= 65536:
+                # the same product in 1024 row blocks (batched): its gradient w.r.t. the bases is then 1024 partial
+                # [B x n/1024]·[n/1024 x 3t] products summed, instead of ONE product with a 2 M-long inner dimension
+                # that the BLAS runs in a handful of workgroups (2.7 ms at n = 2 M)
+                nb = 1024
+                pad = (-n) % nb
+                cp = F.pad(c2, (0, 0, 0, pad)) if pad else c2
+                own = torch.bmm(cp.view(nb, -1, c2.shape[1]), bmat.unsqueeze(0).expand(nb, -1, -1))
+                own = own.view(-1, nt * 3)[:n].reshape(n, nt, 3)
+            else:
+                own = (c2 @ bmat).reshape(n, nt, 3)
             if self.fused_dp and own.is_cuda:
                 pos_t = own.permute(1, 0, 2) + canon[pick][None]                       # [t,n,3]: one slab per time
                 dp_sum = _FusedDistancePreserving.apply(pos_t, nn_idx[0], d2[0], 1e-6)
