@@ -140,7 +140,11 @@ class RigidityLoss(nn.Module):
             pick = torch.randperm(n_all, device=moved.device)[:int(n_all * frac)]
         else:
             pick = torch.tensor(random.sample(range(n_all), int(n_all * frac)))      # losses.py:225-229
-        pts, coeffs, colors = moved[pick], coeff_all[pick], model._features_dc[pick]
+        # row gathers as index_select: the sample has no repeated rows, and index_select's backward is a plain
+        # index_add, where advanced indexing sorts the indices first (0.6 ms per tensor at 2 M rows)
+        pick = pick.to(moved.device)
+        pts, coeffs = moved.index_select(0, pick), coeff_all.index_select(0, pick)
+        colors = model._features_dc.index_select(0, pick) if "coeff" in self.mode else None
         n = pts.shape[0]
         res = self._knn_points(pts[None], pts[None], K=self.K)                        # losses.py:235
         d2, nn_idx = res.dists, res.idx                                               # [1,n,K] squared, [1,n,K]
@@ -187,12 +191,12 @@ class RigidityLoss(nn.Module):
             else:
                 own = (c2 @ bmat).reshape(n, nt, 3)
             if self.fused_dp and own.is_cuda:
-                pos_t = own.permute(1, 0, 2) + canon[pick][None]                       # [t,n,3]: one slab per time
+                pos_t = own.permute(1, 0, 2) + canon.index_select(0, pick)[None]        # [t,n,3]: one slab per time
                 dp_sum = _FusedDistancePreserving.apply(pos_t, nn_idx[0], d2[0], 1e-6)
                 return total + dp_sum / (n * self.K * nt)
             nb = self._knn_gather(own[None].reshape(1, n, -1), nn_idx).reshape(1, n, self.K, own.shape[1], 3)
             nb = nb.squeeze().permute(2, 0, 1, 3)                                     # [t,n,K,3]
-            canon_s = canon[pick]
+            canon_s = canon.index_select(0, pick)
             nb_loc = nb + self._neighbours(canon_s, nn_idx)[None]                     # [t,n,K,3]
             own_loc = own.transpose(0, 1)[None, :] + canon_s[None, None]              # [1,t,n,3]
             gap = torch.norm(nb_loc[None] - own_loc[:, :, :, None], dim=-1)           # [1,t,n,K]
