@@ -152,6 +152,12 @@ def main():
     # stream gap); the per-stage table is taken from a few extra steps afterwards.
     _lib.timing_enable(True, stages=["render_bwd"])
     _lib.timing_reset()
+    # the interpreter's cyclic collector runs a full (generation-2) pass once the start-up garbage has piled up -- a
+    # 40 ms host stall that would land somewhere in a 20-step window: collect now, and keep the survivors out of later
+    # passes
+    import gc
+    gc.collect()
+    gc.freeze()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
