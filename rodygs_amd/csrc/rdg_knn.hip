@@ -504,81 +504,61 @@ int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const
 // pos_t = canon + own(tau) and the gradient G_t are laid out [nt][n] float4, one 16-B gather per edge end.
 // Outputs are the SUM of the terms and its unscaled gradients: G_t (w.r.t. pos_t) and d_d2 [n*K].
 // ---------------------------------------------------------------------------------------------------------
-// One thread per (Gaussian i, chunk of RDG_DP_TC drawn times): the neighbour lists, the reverse adjacency and the
-// original-order indices do not depend on the time, so they are loaded once per chunk instead of once per time (26 of
-// the ~60 loads of a (time, Gaussian) pair).  KT > 0: K known at compile time.
-#define RDG_DP_TC 5
-template <int KT>
+template <int KT>      // KT > 0: K known at compile time -- the K neighbour loads of a thread are issued together
 __global__ void __launch_bounds__(256)
 rdg_rigidity_dp_kernel(long long n, int K_rt, int nt, const float4* __restrict__ pos_t, const long long* __restrict__ nn_idx,
                        const float* __restrict__ d2, const long long* __restrict__ rev_off,
                        const long long* __restrict__ rev_edge, const long long* __restrict__ orig, float eps2,
                        double* __restrict__ loss_sum, float4* __restrict__ G_t, float* __restrict__ d_d2) {
-    const int K = KT > 0 ? KT : K_rt;
-    const int nchunk = (nt + RDG_DP_TC - 1) / RDG_DP_TC;
     const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int K = KT > 0 ? KT : K_rt;
     double local = 0.0;
-    if (tid < n * nchunk) {
-        const int chunk = (int)(tid / n);
-        const long long i = tid - (long long)chunk * n;
-        const int t0 = chunk * RDG_DP_TC, tc = min(RDG_DP_TC, nt - t0);
+    if (tid < n * nt) {
+        const long long tau = tid / n, i = tid - tau * n;
+        const float4* slab = pos_t + tau * n;          // positions of all sampled Gaussians at this time, 16 B each
+        const float4 p = slab[i];
         // `orig` (optional): the sample is stored in a cache-friendly order (neighbours close in memory); the
         // reference's pairing of gaps with d2 entries is defined on the ORIGINAL sample order, so rows use orig[]
         const long long i_row = orig ? orig[i] : i;
-        float4 p[RDG_DP_TC];
-        float gx[RDG_DP_TC], gy[RDG_DP_TC], gz[RDG_DP_TC];            // d/d(pos_i(tau))
-#pragma unroll
-        for (int u = 0; u < RDG_DP_TC; ++u) {
-            p[u] = pos_t[(long long)min(t0 + u, nt - 1) * n + i];
-            gx[u] = gy[u] = gz[u] = 0.f;
-        }
+        float gx = 0.f, gy = 0.f, gz = 0.f;            // d/d(pos_i(tau))
         // (1) edges leaving i: the loss terms themselves, -u on this end, the d2 gradient
+        long long row_prev = -1;
+        float row_acc = 0.f;
 #pragma unroll
         for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
-            const long long j = nn_idx[i * K + k];
-#pragma unroll
-            for (int u = 0; u < RDG_DP_TC; ++u) {
-                if (u < tc) {
-                    const long long tau = t0 + u;
-                    const float4 q = pos_t[tau * n + j];
-                    const float dx = q.x - p[u].x, dy = q.y - p[u].y, dz = q.z - p[u].z;
-                    const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-                    const long long row = ((tau * n + i_row) * K + k) / nt;
-                    const float diff = gap - d2[row];
-                    const float term = sqrtf(diff * diff + eps2);
-                    local += (double)term;
-                    const float s = diff / term;             // d term / d gap ;  d term / d y = -s
-                    atomicAdd(&d_d2[row], -s);
-                    const float ig = gap > 0.f ? s / gap : 0.f;  // torch.norm backward is 0 at the origin
-                    gx[u] -= ig * dx; gy[u] -= ig * dy; gz[u] -= ig * dz;
-                }
+            const float4 q = slab[nn_idx[i * K + k]];
+            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+            const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+            const long long row = ((tau * n + i_row) * K + k) / nt;
+            const float diff = gap - d2[row];
+            const float term = sqrtf(diff * diff + eps2);
+            local += (double)term;
+            const float s = diff / term;                 // d term / d gap ;  d term / d y = -s
+            if (row != row_prev) {
+                if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
+                row_prev = row; row_acc = 0.f;
             }
+            row_acc -= s;
+            const float ig = gap > 0.f ? s / gap : 0.f;  // torch.norm backward is 0 at the origin
+            gx -= ig * dx; gy -= ig * dy; gz -= ig * dz;
         }
+        if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
         // (2) edges arriving at i (reverse adjacency): the same terms recomputed, +u on this end -- instead of three
         // scattered float atomics per (tau, edge), which ran at the 4-byte-atomic rate (13 ms at n = 500 k)
         for (long long e = rev_off[i]; e < rev_off[i + 1]; ++e) {
             const long long edge = rev_edge[e];
             const long long src = edge / K;
             const int k = (int)(edge - src * K);
-            const long long src_row = orig ? orig[src] : src;
-#pragma unroll
-            for (int u = 0; u < RDG_DP_TC; ++u) {
-                if (u < tc) {
-                    const long long tau = t0 + u;
-                    const float4 q = pos_t[tau * n + src];
-                    const float dx = p[u].x - q.x, dy = p[u].y - q.y, dz = p[u].z - q.z;
-                    const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-                    const long long row = ((tau * n + src_row) * K + k) / nt;
-                    const float diff = gap - d2[row];
-                    const float s = diff / sqrtf(diff * diff + eps2);
-                    const float ig = gap > 0.f ? s / gap : 0.f;
-                    gx[u] += ig * dx; gy[u] += ig * dy; gz[u] += ig * dz;
-                }
-            }
+            const float4 q = slab[src];
+            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+            const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+            const long long row = ((tau * n + (orig ? orig[src] : src)) * K + k) / nt;
+            const float diff = gap - d2[row];
+            const float s = diff / sqrtf(diff * diff + eps2);
+            const float ig = gap > 0.f ? s / gap : 0.f;
+            gx += ig * dx; gy += ig * dy; gz += ig * dz;
         }
-#pragma unroll
-        for (int u = 0; u < RDG_DP_TC; ++u)
-            if (u < tc) G_t[(long long)(t0 + u) * n + i] = make_float4(gx[u], gy[u], gz[u], 0.f);
+        G_t[tau * n + i] = make_float4(gx, gy, gz, 0.f);
     }
     // block sum of the terms (f64)
     __shared__ double sh[4];
@@ -599,7 +579,7 @@ extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const f
     hipError_t e = hipMemsetAsync(loss_sum, 0, 8, st);
     if (e == hipSuccess) e = hipMemsetAsync(d_d2, 0, (size_t)n * K * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "rigidity_dp memset");
-    const long long total = n * ((nt + RDG_DP_TC - 1) / RDG_DP_TC);
+    const long long total = n * nt;
     if (K == 8)
         hipLaunchKernelGGL(rdg_rigidity_dp_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K,
                            nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
