@@ -228,7 +228,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_m3 = torch.empty(P, 3, **f32)
             d_m2 = torch.empty(P, 3, **f32)
             d_op = torch.empty_like(op)
-            d_sh = torch.empty_like(shs) if shs is not None else None
+            fused_adam = ctx.grad_sinks is not None and ctx.grad_sinks.get("shs_adam") is not None
+            d_sh = torch.empty_like(shs) if (shs is not None and not fused_adam) else None
             sink_sh = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs")
             if sink_sh is not None and shs is not None:
                 # the kernel overwrites every element of dL/dshs: let it write straight into the caller's buffer
