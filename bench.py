@@ -127,7 +127,15 @@ def main():
     sharded = (world > 1 or force_shard) and args.dp_mode == "shard"
     if sharded:
         from rodygs_amd.sharded import HostStagedExchange, ShardedDynamicScene
-        ss = ShardedDynamicScene.from_replica(ds, rank, world, None if backend == "nccl" else HostStagedExchange())
+        try:
+            ss = ShardedDynamicScene.from_replica(ds, rank, world, None if backend == "nccl" else HostStagedExchange())
+        except (NotImplementedError, ValueError) as e:
+            # a configuration the sharded step does not cover (decided from sizes every rank shares, so all ranks take
+            # this branch together): the replicated formulation runs instead
+            if rank == 0:
+                print(f"bench.py: sharded frame-DP unavailable ({e}); using --dp-mode allreduce", file=sys.stderr)
+            sharded = False
+    if sharded:
         ds.fp = ds.sync = ds.m2 = None           # the replica's full-size buffers are not needed any more
         torch.cuda.empty_cache()
         train_step = lambda st_: ss.train_step(st_, perm)                       # noqa: E731
