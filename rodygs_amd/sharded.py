@@ -565,6 +565,40 @@ class ShardedDynamicScene:
     def visible_count(self) -> int:
         return int((self.radii_cam > 0).sum().item())
 
+    def gather_flat(self) -> FlatParams:
+        """The whole cloud as ONE FlatParams on every rank (parameters and both Adam moments, rank order); collective."""
+        P = self.P_total
+        spec = {k: ((P, *self.fp.shapes[k][1:]), self.fp.lr[k]) for k in self.fp.names}
+        full = FlatParams(spec, self.device)
+        full.step_count = self.fp.step_count
+        with torch.no_grad():
+            for k in self.fp.names:
+                o, m = self.fp.offsets[k]
+                fo, fm = full.offsets[k]
+                shape = self.fp.shapes[k]
+                for src, dst in ((self.fp.flat, full.flat), (self.fp.exp_avg, full.exp_avg),
+                                 (self.fp.exp_avg_sq, full.exp_avg_sq)):
+                    pad = torch.zeros(self.per, *shape[1:], dtype=torch.float32, device=self.device)
+                    pad[:self.n] = src[o:o + m].view(shape)
+                    got = torch.empty(self.world * self.per, *shape[1:], dtype=torch.float32, device=self.device)
+                    self.ex.all_gather(got, pad)
+                    dst[fo:fo + fm].copy_(self._valid_rows(got).reshape(-1))
+        return full
+
+    def export_state_dict(self, iteration: int) -> dict:
+        """The reference's checkpoint dictionary (rodygs_amd.checkpoint.export_state_dict) of the gathered cloud, with the
+        deformation network, the birth time of every Gaussian and the camera tables; collective, identical on all ranks."""
+        from .checkpoint import export_state_dict
+        full = self.gather_flat()
+        ti = torch.zeros(self.per, dtype=torch.int64, device=self.device)
+        ti[:self.n] = self.time_ind
+        got = torch.empty(self.world * self.per, dtype=torch.int64, device=self.device)
+        self.ex.all_gather(got, ti)
+        times = (torch.arange(self.T, dtype=torch.float32, device=self.device) / self.T)[self._valid_rows(got)]
+        return export_state_dict(full, iteration, self.sh_degree, self.spatial_lr_scale, deform_network=self.net,
+                                 gaussian_to_time=times, cameras=(self.sp["cam_q"].detach(), self.sp["cam_t"].detach()),
+                                 feature_lr_rest=self.row_lr["features"][2])
+
     def gather_params(self) -> Optional[dict]:
         """{name: full [P,...] tensor} assembled from all ranks in rank order (checkpointing, tests); collective."""
         counts, width = self.counts, self.per

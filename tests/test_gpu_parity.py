@@ -1333,6 +1333,18 @@ def test_sharded_step_over_a_process_group():
         rel_ok(b.fp.flat_grad, a.fp.flat_grad, tol=2e-4, what="1-rank group gradients")
         full = b.gather_params()
         assert torch.equal(full["xyz"], b.fp["xyz"].detach())
+        from rodygs_amd.checkpoint import export_state_dict, flat_params_from_state_dict
+        sd = b.export_state_dict(iteration=3)                          # reference checkpoint layout of the whole cloud
+        want = export_state_dict(b.fp, 3, b.sh_degree, b.spatial_lr_scale, deform_network=b.net,
+                                 feature_lr_rest=b.row_lr["features"][2])
+        for k in want["model"]:
+            if k != "_deform_network":
+                assert torch.equal(sd["model"][k], want["model"][k]), k
+        assert sd["model"]["_timestep"].shape[0] == b.P_total and sd["camera"]["R_c2ws_quat"].shape == (6, 4)
+        st0, st1 = sd["optim"]["optimizer"]["state"], want["optim"]["optimizer"]["state"]
+        assert all(torch.equal(st0[i]["exp_avg_sq"], st1[i]["exp_avg_sq"]) for i in st1)
+        back = flat_params_from_state_dict(sd, {k: b.fp.lr[k] for k in b.fp.names}, DEV)
+        assert torch.equal(back["motion_coeff"].detach(), b.fp["motion_coeff"].detach())
         b.track_densification()
         for s_ in range(3, 9):
             b.train_step(s_, list(range(6)))
@@ -1371,8 +1383,10 @@ def _two_process_worker(rank, world, port, outdir):
         ss = ShardedDynamicScene.from_replica(ds, rank, world, exchange=HostStagedExchange())
         ss.seed_rng(500 + rank)
         losses = [float(ss.train_step(s_, list(range(6)))) for s_ in range(4, 7)]      # step 5: rigidity (full)
+        sd = ss.export_state_dict(iteration=7)
         out[full] = {"losses": losses, "params": {k: v.cpu() for k, v in ss.gather_params().items()},
-                     "sp": ss.sp.flat.cpu()}
+                     "sp": ss.sp.flat.cpu(), "ckpt_xyz": sd["model"]["_xyz"].cpu(),
+                     "ckpt_m": sd["optim"]["optimizer"]["state"][0]["exp_avg"].cpu()}
         if not full:
             ss.track_densification()
             for s_ in range(7, 13):
@@ -1414,6 +1428,9 @@ def test_sharded_step_in_two_real_processes():
         for k, v in got[0][full]["params"].items():
             ref = torch.cat([sh.fp[k].detach() for sh in shards]).cpu()
             assert v.shape == ref.shape and torch.equal(v, got[1][full]["params"][k])
+            if k == "xyz":                                      # the exported checkpoint holds the same gathered cloud
+                assert torch.equal(got[0][full]["ckpt_xyz"], v) and torch.equal(got[1][full]["ckpt_xyz"], v)
+                assert torch.equal(got[0][full]["ckpt_m"], got[1][full]["ckpt_m"]) and got[0][full]["ckpt_m"].shape == v.shape
             dlt = (v - ref).abs()
             assert float(dlt.mean()) <= 2e-4 * (float(ref.abs().mean()) + 1e-3), (full, k, float(dlt.mean()))
     i0, i1 = got[0]["densify"], got[1]["densify"]
