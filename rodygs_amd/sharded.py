@@ -241,6 +241,8 @@ class ShardedDynamicScene:
             self._allb = allb
             self._bases_all = torch.cat([allb[:T].unsqueeze(0).expand(Wn, -1, -1, -1), allb[T:].unsqueeze(1)], dim=1)
             b = self._bases_all.detach()
+            if n == 0:                  # an empty slice (fewer Gaussians than ranks): its record rows stay zero
+                return
             # my Gaussians at the times of all W cameras: parameters read once, one launch
             _lib.check(L.rdg_dyn_getter_views_forward(n, T, Wn, self.stride, _lib.ptr(fp["motion_coeff"]),
                                                       _lib.ptr(self.time_ind), _lib.ptr(b), float(self.spatial_lr_scale),
@@ -355,6 +357,11 @@ class ShardedDynamicScene:
         L, Wn, T, n, dev, fp = _lib.lib(), self.world, self.T, self.n, self.device, self.fp
         with torch.cuda.device(dev):
             st = _lib.stream_ptr()
+            self._loss_owner = None
+            if n == 0:                  # empty slice: no parameter gradients; no contribution to bases or poses
+                self.d_bases.zero_()
+                self.d_views.zero_()
+                return
             _lib.check(L.rdg_preprocess_backward_views(
                 C.byref(self.cs_own), Wn, self.stride, _lib.ptr(self.m3), _lib.ptr(fp["features"]), _lib.ptr(self.op),
                 _lib.ptr(self.sc), _lib.ptr(self.ro), _lib.ptr(self.views), _lib.ptr(self.proj_t),

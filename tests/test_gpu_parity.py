@@ -1162,7 +1162,7 @@ def _replica_and_shards(P, W_img, H_img, frames, world, seed=21):
     return ds, shards
 
 
-@pytest.mark.parametrize("P,world", [(20000, 4), (5003, 3), (9000, 8), (4100, 16)])
+@pytest.mark.parametrize("P,world", [(20000, 4), (5003, 3), (9000, 8), (4100, 16), (37, 8), (5, 8)])
 def test_sharded_step_matches_replicated_frame_dp(P, world):
     """Gaussian-sharded frame-DP (rodygs_amd/sharded.py) against the replicated all-reduce formulation it replaces:
     `world` virtual ranks inside this process, each owning a slice of the cloud and rendering one camera.  The
@@ -1203,7 +1203,7 @@ def test_sharded_step_matches_replicated_frame_dp(P, world):
         rel_ok(got, want, tol=2e-4, what="sharded d_" + k)
     for sh in shards:
         rel_ok(sh.sp.flat_grad, acc_sp, tol=2e-4, what="sharded small bucket")
-        assert sh.lo == sh.rank * per and sh.n == min(per, max(P - sh.lo, 0))
+        assert sh.lo == min(sh.rank * per, P) and sh.n == min(per, max(P - sh.lo, 0))      # (5, 8): three empty slices
     # Adam on the slices == Adam on the replica when fed the same gradients
     ds.fp.flat_grad.copy_(acc)
     ds.sp.flat_grad.copy_(shards[0].sp.flat_grad)
