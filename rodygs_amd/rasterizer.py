@@ -318,7 +318,11 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3Ds_precomp=None, viewmatrix=None, extra_attrs=None, grad_sinks=None):
         """Reference call signature (renderer.py:87-101).  ``grad_sinks`` is an extension outside the reference
-        surface: {"shs": tensor} makes backward write dL/dshs into that tensor instead of returning it."""
+        surface: {"shs": tensor} makes backward write dL/dshs into that tensor instead of returning it;
+        {"shs_adam": {param, exp_avg, exp_avg_sq, head_len, lr_head, lr_tail, betas, eps, step}} makes backward apply
+        the Adam step of the SH features itself (``rdg_preprocess_backward_adam``) -- the parameters change DURING
+        backward, so use it only where backward runs exactly once per optimiser step and nothing else needs dL/dshs
+        (rodygs_amd/trainstep.py does, for the single-GPU photometric step)."""
         if extra_attrs is not None:
             raise NotImplementedError("extra_attrs is not used by RoDyGS and is not implemented")
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
