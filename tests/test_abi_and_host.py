@@ -194,3 +194,21 @@ def test_eval_pose_helpers_against_reference_golden():
     assert torch.allclose(cam.R_c2w_quat.detach(), torch.from_numpy(g["cam_quat"]), atol=1e-6)
     assert torch.allclose(cam.T_c2w.detach(), torch.from_numpy(g["cam_t"]), atol=1e-6)
     assert torch.allclose(cam.world_view_transform.detach(), torch.from_numpy(g["cam_w2c"]), atol=1e-6)
+
+
+def test_committed_bench_line_honours_the_contract():
+    """The bench line committed under profiles/ (printed by `python bench.py` on the GPU box) carries every field of
+    the measurement contract: the driver's keys, `roofline` for the dominant kernel and `cpu_baseline`."""
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r01_v10_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
