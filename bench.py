@@ -33,39 +33,121 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: FP32 vector peak
+PMC_FILE = "r02_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
 
 
-def cpu_baseline(scene, sh_degree, sample_tiles=96, max_seconds=40.0):
-    """Oracle (kind "port") on a bounded sample: full per-Gaussian stage + binning for the frame, then forward +
-    backward compositing of `sample_tiles` evenly spaced tiles, extrapolated to the whole image."""
+def workload_label(P, W, H, frames, full_losses, world):
+    """Name the workload from the arguments (BASELINE.json configs by shape), never from a hard-coded string."""
+    base = f"{P} dynamic Gaussians + deformation MLP, {W}x{H}, SH3, {frames}-frame synthetic video"
+    if (P, W, H) == (1000000, 1920, 1080) and not full_losses:
+        return base + (" (BASELINE configs[2])" if world == 1 else f" (BASELINE configs[3] shape on {world} GPUs)")
+    if (P, W, H) == (4000000, 3840, 2160) and full_losses:
+        return base + " + depth and motion-regularisation losses (BASELINE configs[4] shape)"
+    if (P, W, H) == (100000, 1920, 1080):
+        return base + " (BASELINE configs[1] size, run as a dynamic train step)"
+    return base + " (not a BASELINE config)"
+
+
+def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=False, radix_binning=False):
+    """ALGORITHMIC HBM bytes per stage and step (SURVEY.md §8d formulas, adjusted to the algorithm that actually runs
+    -- DESIGN.md §4 'Roofline accounting'):
+      * binning: bucket binning moves, per tile instance, a 4-B rank (written by the count pass, read by the scatter
+        pass), an 8-B (depth, id) composite (written by the scatter, read by the per-tile sort) and the 4-B sorted id
+        = 28 B, plus two passes over 40 B of per-Gaussian geometry and the per-tile counters / ranges; the survey's
+        6-pass radix formula applies only under RDG_BIN_MODE=radix;
+      * optimizer in backward: the SH features' Adam step happens inside the per-Gaussian backward kernel -- their
+        28 B/float leave the Adam launch; the kernel no longer writes dL/dshs (-12K B) and instead reads and writes the
+        parameter and both moments (24 B/float) of those 3K floats."""
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    n_pass = (32 + max(tiles - 1, 1).bit_length() + 7) // 8
+    n_adam = 59 + 16                                    # floats per Gaussian: 11 geometry + 3K SH (K=16) + 16 coeff
+    own = P // world if sharded else P                  # Gaussian-sharded frame-DP: a rank steps its slice only
+    sb = {
+        "preprocess": P * (44 + 12 * K) + V * 48 + P * 8,
+        "binning": (D * 12 + D * 24 * n_pass + D * 8 + tiles * 8) if radix_binning else (D * 28 + P * 80 + tiles * 16),
+        "render_fwd": D * 44 + H * W * 40,
+        "render_bwd": D * 44 + H * W * 40 + V * 40,
+        "preprocess_bwd": P * (44 + 12 * K) * 2 + V * 48,
+        "deform_fwd": P * 96, "deform_bwd": P * 96,
+        "adam": 28 * n_adam * own,
+    }
+    if sh_adam_in_backward:
+        sb["adam"] -= 28 * 3 * K * own
+        sb["preprocess_bwd"] += (24 * 3 * K - 12 * K) * P
+    return sb
+
+
+def _cpu_train_step(scene, P, W, H, sh_degree, budget_s):
+    """One CPU train step of the bench workload's shape built from the oracle (kind "port"): activations ->
+    oracle rasterizer forward -> 0.8 L1 + 0.2 D-SSIM (torch) -> backward -> torch.optim.Adam (eps 1e-15) over every
+    Gaussian parameter.  The compositing runs over interleaved eighths of the tile grid until `budget_s` is spent;
+    if tiles remain, their share is extrapolated by splat instances and the returned dict says so."""
     from oracle import rasterizer_oracle as O   # checker / baseline only -- never on the product path
-    P, H, W = scene["means3D"].shape[0], scene["H"], scene["W"]
+    from rodygs_amd.losses import photometric_loss     # torch expression (host mirror pinned by golden G6)
     st = O.OracleSettings(H, W, scene["tanfovx"], scene["tanfovy"], torch.zeros(3), 1.0, scene["projmatrix"], sh_degree)
-    names = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
-    ins = {k: scene[k].clone().requires_grad_(True) for k in names}
+    op0 = scene["opacities"].clamp(1e-4, 1 - 1e-4)
+    params = {"xyz": scene["means3D"].clone(), "features": scene["shs"].clone(), "scaling": torch.log(scene["scales"]),
+              "rotation": scene["rotations"].clone(), "opacity": torch.log(op0 / (1 - op0))}
+    params = {k: v.requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.Adam([{"params": [v], "lr": 1e-3} for v in params.values()], lr=0.0, eps=1e-15)
+    vm = scene["viewmatrix"].clone().requires_grad_(True)
     m2 = torch.zeros(P, 3, requires_grad=True)
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1))
     t0 = time.perf_counter()
-    geom = O.preprocess(ins["means3D"], m2, ins["opacities"], ins["viewmatrix"], st, shs=ins["shs"],
-                        scales=ins["scales"], rotations=ins["rotations"])
+    rot = torch.nn.functional.normalize(params["rotation"], dim=1)
+    geom = O.preprocess(params["xyz"], m2, torch.sigmoid(params["opacity"]), vm, st, shs=params["features"],
+                        scales=torch.exp(params["scaling"]), rotations=rot)
     binning = O.bin_and_sort(geom)
     t_pre = time.perf_counter() - t0
     gx, gy = geom["grid"]
     n_tiles = gx * gy
-    stride = max(1, n_tiles // sample_tiles)
-    subset = list(range(stride // 2, n_tiles, stride))[:sample_tiles]
+    ranges = binning["ranges"].astype("int64")
+    total_pairs = int(binning["num_rendered"])
+    color = torch.zeros(3, H, W)
+    done_tiles, done_pairs = 0, 0
     t1 = time.perf_counter()
-    img = O.render_tiles(geom, binning, st.bg, H, W, tile_subset=subset)
-    loss = img["color"].sum() + 0.1 * img["depth"].sum()
+    for c in range(8):
+        subset = list(range(c, n_tiles, 8))
+        color = color + O.render_tiles(geom, binning, st.bg, H, W, tile_subset=subset)["color"]
+        done_tiles += len(subset)
+        done_pairs += int((ranges[subset, 1] - ranges[subset, 0]).sum())
+        if time.perf_counter() - t1 > 0.4 * budget_s:     # backward costs about as much again
+            break
+    loss = photometric_loss(color, gt, 0.2)
     loss.backward()
     t_tiles = time.perf_counter() - t1
-    pairs = int(sum((binning["ranges"][t, 1] - binning["ranges"][t, 0]) for t in subset))
-    total_pairs = int(binning["num_rendered"])
-    # tile time scales with the splat instances in the tile, not with the tile count
-    est = t_pre + t_tiles * (total_pairs / max(pairs, 1))
-    return {"value": 1.0 / est, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fwd+bwd of one frame: full preprocess+binning of {P} Gaussians ({t_pre:.1f}s) + "
-                      f"{len(subset)}/{n_tiles} tiles holding {pairs}/{total_pairs} splat instances ({t_tiles:.1f}s), "
-                      f"extrapolated by instances; rasterizer only (no MLP/loss/Adam)"}
+    t2 = time.perf_counter()
+    opt.step()
+    t_adam = time.perf_counter() - t2
+    scale = total_pairs / max(done_pairs, 1)
+    return {"seconds": t_pre + t_tiles * scale + t_adam, "t_pre": t_pre, "t_tiles": t_tiles, "t_adam": t_adam,
+            "tiles_done": done_tiles, "n_tiles": n_tiles, "pairs_done": done_pairs, "pairs": total_pairs,
+            "extrapolated": done_tiles < n_tiles}
+
+
+def cpu_baseline(scene, sh_degree, budget_s=60.0):
+    """cpu_baseline leg (N = 1, rank 0): the oracle-built CPU train step on this box's host cores.
+      value    : the bench workload itself (the scene the GPU was timed on), one full step; compositing over as many
+                 interleaved eighths of the tile grid as fit in `budget_s` (all of them on a box with enough cores --
+                 then nothing is extrapolated; otherwise by splat instances, and `sample` says so);
+      c2_full  : BASELINE configs[1] size (100 k Gaussians, 1080p, SH3) timed IN FULL, forward + backward + Adam,
+                 median of 3 -- no extrapolation."""
+    from rodygs_amd.synthetic import synthetic_scene
+    P, H, W = scene["means3D"].shape[0], scene["H"], scene["W"]
+    cores = torch.get_num_threads()
+    r = _cpu_train_step(scene, P, W, H, sh_degree, budget_s)
+    how = ("every tile composited: no extrapolation" if not r["extrapolated"] else
+           f"{r['tiles_done']}/{r['n_tiles']} tiles holding {r['pairs_done']}/{r['pairs']} splat instances composited, "
+           f"the rest extrapolated by instances")
+    c2 = synthetic_scene(100000, 1920, 1080, 3, seed=777)
+    runs = sorted(_cpu_train_step(c2, 100000, 1920, 1080, sh_degree, 1e9)["seconds"] for _ in range(3))
+    return {"value": 1.0 / r["seconds"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle train step (activations + rasterizer fwd/bwd + 0.8 L1 + 0.2 D-SSIM + torch Adam eps 1e-15; "
+                      f"no deformation MLP) of the bench frame, {P} Gaussians {W}x{H}: per-Gaussian stage + binning "
+                      f"{r['t_pre']:.1f}s, compositing fwd+bwd {r['t_tiles']:.1f}s ({how}), Adam {r['t_adam']:.1f}s",
+            "c2_full": {"value": 1.0 / runs[1], "unit": "frames/s", "seconds_median_of_3": runs[1], "runs_s": runs,
+                        "workload": "100000 Gaussians, 1920x1080, SH3 (BASELINE configs[1] size), every tile, "
+                                    "fwd + bwd + Adam, no extrapolation"}}
 
 
 def main():
@@ -79,6 +161,9 @@ def main():
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--gt-frames", type=int, default=16, help="distinct frames with ground truth resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=60.0,
+                    help="seconds of CPU compositing the cpu_baseline leg may spend on the bench frame before it "
+                         "extrapolates the remaining tiles")
     ap.add_argument("--full-losses", action="store_true",
                     help="config-5 loss set (depth, motion regularisers, rigidity every 5th step) instead of the "
                          "photometric-only step the headline metric is quoted on")
@@ -110,14 +195,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from oracle import rasterizer_oracle as O          # synthetic-scene generator + cpu_baseline only
+    from rodygs_amd.synthetic import synthetic_scene
     from rodygs_amd import _lib
     from rodygs_amd.trainstep import DynamicScene
     _lib.lib()
 
     P, W, H = args.points, args.width, args.height
-    scene = O.synthetic_scene(P, W, H, 3, seed=777)
-    target = O.synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
+    scene = synthetic_scene(P, W, H, 3, seed=777)
+    target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
     ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, full_losses=args.full_losses)
     n_gt = min(args.gt_frames * world, args.frames)
     gt_frames = [int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)]
@@ -212,30 +297,24 @@ def main():
         # --pmc WRITE_SIZE in separate runs, gfx950 correction applied); only valid for the workload it was taken on
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             wl = pmc["workload"]
             if (wl["points"], wl["width"], wl["height"]) == (P, W, H):
                 traffic = pmc["kernels"]["rdg_render_bwd_kernel"]["hbm_bytes_corrected"]
         except Exception:
             traffic = None
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # whole-step and per-stage algorithmic bytes (the survey's own formula, radix-sort term and
-        # all, so the number is comparable across builds) and the FP32-VALU fraction of the two compositing kernels
+        # whole-step and per-stage algorithmic bytes for the algorithm that actually ran
+        # (stage_bytes), and the FP32-VALU fraction of the two compositing kernels
         with torch.no_grad():
             _, n_contrib = rasterizer.last_compositing_state()
             S = int(n_contrib.sum(dtype=torch.int64).item())
-        K, tiles = 16, ((W + 15) // 16) * ((H + 15) // 16)
-        n_pass = (32 + max(tiles - 1, 1).bit_length() + 7) // 8
-        sb = {
-            "preprocess": P * (44 + 12 * K) + V * 48 + P * 8,
-            "binning": D * 12 + D * 24 * n_pass + D * 8 + tiles * 8,
-            "render_fwd": D * 44 + H * W * 40,
-            "render_bwd": alg_bytes,
-            "preprocess_bwd": P * (44 + 12 * K) * 2 + V * 48,
-            "deform_fwd": P * 96, "deform_bwd": P * 96,
-            # Gaussian-sharded frame-DP: a rank's optimiser state covers its slice only
-            "adam": 28 * (59 + 16) * (P // world if sharded else P),
-        }
+        K = 16
+        sh_adam_in_backward = bool(world == 1 and not sharded and not args.full_losses
+                                   and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")
+        radix_binning = os.environ.get("RDG_BIN_MODE", "")[:1] == "r"
+        sb = stage_bytes(P, K, V, D, H, W, world=world, sharded=sharded, sh_adam_in_backward=sh_adam_in_backward,
+                         radix_binning=radix_binning)
         sms = dict(per_stage)
         sms["binning"] = per_stage["scan_dup"] + per_stage["sort"] + per_stage["ranges"]
         stage_roofline = {k: {"algorithmic_bytes": b, "ms": sms[k],
@@ -250,16 +329,16 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{P} dynamic Gaussians + deformation MLP, {W}x{H}, SH3, {args.frames}-frame "
-                                   f"synthetic video (BASELINE configs[2])", "points": P, "width": W, "height": H,
+            "config": {"workload": workload_label(P, W, H, args.frames, args.full_losses, world), "points": P,
+                       "width": W, "height": H,
                        "frames": args.frames,
                        "parallelism": (f"frame-dp{world}, Gaussian-sharded (records/gradient rows all-to-all)" if sharded
                                        else f"frame-dp{world}" + (", replicated + bucketed all-reduce" if world > 1 else "")), "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",
                        # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH
                        # features itself (RDG_FUSE_SH_ADAM=0 restores the separate launch; same bits either way)
-                       "sh_adam_in_backward": bool(world == 1 and not sharded and not args.full_losses
-                                                   and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")},
+                       "sh_adam_in_backward": sh_adam_in_backward,
+                       "binning": "radix" if radix_binning else "bucket"},
             "gaussians_per_s": fps * P,
             "loss": float(loss.item()),
             "stage_ms": per_stage,
@@ -277,7 +356,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # contract: the CPU leg runs at N = 1 only
             try:
-                res["cpu_baseline"] = cpu_baseline(scene, 3)
+                res["cpu_baseline"] = cpu_baseline(scene, 3, budget_s=args.cpu_budget)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}

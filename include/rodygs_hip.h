@@ -296,6 +296,13 @@ int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const fl
 int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float* xyz, const float* scaling,
                        const float* rotation, const float* z, float* xyz_out, float* scaling_out, void* stream);
 
+/* ThreeDGSTrainer.reset_opacity (/root/reference/src/trainer/rodygs_static.py:151-160) with the optimizer surgery of
+ * replace_tensor_to_optimizer (/root/reference/src/trainer/utils.py:15-32), in place on a flat-bucket segment:
+ * opacity_logit[i] = inverse_sigmoid(min(sigmoid(opacity_logit[i]), max_opacity)) (reference: 0.01), and both Adam
+ * moments of the segment zeroed; the optimiser's step counter is kept, as the reference keeps state["step"].       */
+int rdg_reset_opacity(int64_t n, float max_opacity, float* opacity_logit, float* exp_avg, float* exp_avg_sq,
+                      void* stream);
+
 /* Distance-preserving term of RigidityLoss (/root/reference/src/trainer/losses.py:293-358) without the [t,n,K,3]
  * intermediates: pos_t4 [nt,n,4] = position (canonical + translation, w unused) of every sampled Gaussian at the
  * drawn times, nn_idx [n,K] (indices into the sample), d2 [n,K] squared neighbour distances, and the reverse

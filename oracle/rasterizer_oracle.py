@@ -306,57 +306,104 @@ def bin_and_sort(geom):
                 keys_sorted=keys_sorted, vals_sorted=vals_sorted, ranges=ranges)
 
 
-def render_tiles(geom, binning, bg, H, W, tile_subset=None):
-    """Per-tile front-to-back compositing, vectorised over [splats, 256 pixels]."""
+def _composite_group(a, pixx, pixy, bgc):
+    """Front-to-back compositing of G tiles at once.  a [G,L,13] = (px, py, conic a b c, opacity, 7 features) per list
+    slot (padding slots: all zero -> alpha 0 -> never blended), pixx / pixy [G,256] pixel coordinates.
+    Returns (values [G,8,256] = colour(+bg) 3, depth 1, normal 3, alpha 1;  final_T [G,256];  n_contrib [G,256])."""
+    dt = a.dtype
+    dx = a[:, :, 0:1] - pixx.unsqueeze(1)
+    dy = a[:, :, 1:2] - pixy.unsqueeze(1)
+    power = -0.5 * (a[:, :, 2:3] * dx * dx + a[:, :, 4:5] * dy * dy) - a[:, :, 3:4] * dx * dy
+    ok = power <= 0
+    G = torch.exp(torch.where(ok, power, torch.zeros_like(power)))
+    alpha = _ste_min(a[:, :, 5:6] * G, ALPHA_CAP)
+    ok = ok & (alpha >= ALPHA_MIN)
+    a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
+    cum = torch.cumprod(1.0 - a_eff, dim=1)
+    inc = ok & (cum >= T_STOP)
+    T_before = torch.cat([torch.ones(cum.shape[0], 1, cum.shape[2], dtype=dt), cum[:, :-1]], dim=1)
+    wgt = torch.where(inc, a_eff * T_before, torch.zeros_like(a_eff))
+    acc = torch.einsum("gnp,gnc->gcp", wgt, a[:, :, 6:])
+    Tf = torch.prod(torch.where(inc, 1.0 - a_eff, torch.ones_like(a_eff)), dim=1)
+    vals = torch.cat([acc[:, 0:3] + Tf.unsqueeze(1) * bgc.view(1, 3, 1), acc[:, 3:], (1.0 - Tf).unsqueeze(1)], dim=1)
+    with torch.no_grad():
+        idx = torch.arange(1, inc.shape[1] + 1, dtype=torch.int32).view(1, -1, 1)
+        ncon = (inc.to(torch.int32) * idx).max(dim=1).values
+    return vals, Tf.detach(), ncon
+
+
+def render_tiles(geom, binning, bg, H, W, tile_subset=None, rows_per_group=8192):
+    """Per-tile front-to-back compositing, vectorised over [tiles, list slots, 256 pixels].
+
+    Tiles are processed in groups of similar list length (padded with all-zero slots to the group's longest list,
+    at most ``rows_per_group`` slots per group); the per-instance attributes are gathered once per group and every
+    group runs under activation checkpointing, so the autograd graph of a 1080p frame holds the gathered rows only
+    (a per-tile Python loop that kept every [L,256] intermediate alive needed ~20 GB at 100 k Gaussians / 1080p and
+    spent its time in per-tile framework overhead).  Pixels of ragged border tiles outside the image are computed
+    and dropped."""
+    from torch.utils.checkpoint import checkpoint
     dt = geom["px"].dtype
     gx, gy = geom["grid"]
-    feats = torch.cat([geom["rgb"], geom["depth"].unsqueeze(1), geom["normal"]], dim=1)  # [P,7]
-    C = feats.shape[1]
-    out = torch.zeros(C, H, W, dtype=dt)
-    alpha_img = torch.zeros(1, H, W, dtype=dt)
-    final_T = torch.ones(H, W, dtype=dt)
-    n_contrib = torch.zeros(H, W, dtype=torch.int32)
-    vals = torch.from_numpy(binning["vals_sorted"].astype(np.int64))
+    P = geom["px"].shape[0]
+    vals = binning["vals_sorted"].astype(np.int64)
     ranges = binning["ranges"].astype(np.int64)
     bgc = bg.to(dt).reshape(3)
-    ly, lx = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
-    tiles_iter = range(gx * gy) if tile_subset is None else tile_subset
-    for t in tiles_iter:
-        tyi, txi = divmod(t, gx)
-        x0, y0 = txi * TILE, tyi * TILE
-        x1, y1 = min(x0 + TILE, W), min(y0 + TILE, H)
-        tw, th = x1 - x0, y1 - y0
-        s, e = int(ranges[t, 0]), int(ranges[t, 1])
-        if e <= s:
-            out[0:3, y0:y1, x0:x1] = bgc.view(3, 1, 1).expand(3, th, tw)
-            continue
-        ids = vals[s:e]
-        pixx = (x0 + lx[:th, :tw]).reshape(-1).to(dt)
-        pixy = (y0 + ly[:th, :tw]).reshape(-1).to(dt)
-        dx = geom["px"][ids].unsqueeze(1) - pixx.unsqueeze(0)
-        dy = geom["py"][ids].unsqueeze(1) - pixy.unsqueeze(0)
-        con = geom["conic"][ids]
-        power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
-        ok = power <= 0
-        G = torch.exp(torch.where(ok, power, torch.zeros_like(power)))
-        alpha = _ste_min(geom["opacity"][ids].unsqueeze(1) * G, ALPHA_CAP)
-        ok = ok & (alpha >= ALPHA_MIN)
-        a_eff = torch.where(ok, alpha, torch.zeros_like(alpha))
-        cum = torch.cumprod(1.0 - a_eff, dim=0)
-        inc = ok & (cum >= T_STOP)
-        T_before = torch.cat([torch.ones(1, cum.shape[1], dtype=dt), cum[:-1]], dim=0)
-        wgt = torch.where(inc, a_eff * T_before, torch.zeros_like(a_eff))
-        acc = torch.einsum("np,nc->cp", wgt, feats[ids])
-        Tf = torch.prod(torch.where(inc, 1.0 - a_eff, torch.ones_like(a_eff)), dim=0)
-        acc = torch.cat([acc[0:3] + Tf.unsqueeze(0) * bgc.view(3, 1), acc[3:]], dim=0)
-        out[:, y0:y1, x0:x1] = acc.reshape(C, th, tw)
-        alpha_img[0, y0:y1, x0:x1] = (1.0 - Tf).reshape(th, tw)
-        with torch.no_grad():
-            final_T[y0:y1, x0:x1] = Tf.reshape(th, tw)
-            idx = torch.arange(1, inc.shape[0] + 1, dtype=torch.int32).unsqueeze(1)
-            n_contrib[y0:y1, x0:x1] = (inc.to(torch.int32) * idx).max(dim=0).values.reshape(th, tw)
-    return dict(color=out[0:3], depth=out[3:4], normal=out[4:7], alpha=alpha_img, final_T=final_T,
-                n_contrib=n_contrib)
+    tiles = np.asarray(list(range(gx * gy) if tile_subset is None else tile_subset), dtype=np.int64)
+    out = torch.zeros(8, H * W, dtype=dt)
+    final_T = torch.ones(H * W, dtype=dt)
+    n_contrib = torch.zeros(H * W, dtype=torch.int32)
+    if len(tiles):
+        lens = ranges[tiles, 1] - ranges[tiles, 0]
+        ly, lx = np.divmod(np.arange(256, dtype=np.int64), 16)
+        py_all = (tiles // gx)[:, None] * TILE + ly[None, :]
+        px_all = (tiles % gx)[:, None] * TILE + lx[None, :]
+        # empty tiles: background colour, alpha 0 (one vectorised write)
+        emp = lens == 0
+        if emp.any():
+            inside = (px_all[emp] < W) & (py_all[emp] < H)
+            flat = torch.from_numpy((py_all[emp] * W + px_all[emp])[inside])
+            bgv = torch.zeros(8, flat.numel(), dtype=dt)
+            bgv[0:3] = bgc.view(3, 1)
+            out = out.index_copy(1, flat, bgv)
+        attrs = torch.cat([geom["px"].unsqueeze(1), geom["py"].unsqueeze(1), geom["conic"],
+                           geom["opacity"].unsqueeze(1), geom["rgb"], geom["depth"].unsqueeze(1), geom["normal"],
+                           ], dim=1)                                                        # [P, 6 + 7]
+        attrs = torch.cat([attrs, torch.zeros(1, attrs.shape[1], dtype=dt)], dim=0)        # row P = padding slot
+        order = np.argsort(lens, kind="stable")
+        order = order[lens[order] > 0]
+        pix_idx, pix_val = [], []
+        i = 0
+        while i < len(order):
+            # the group's longest list is its last (sorted by length): grow while (tiles x longest list) fits
+            j = i + 1
+            while j < len(order) and (j + 1 - i) * int(lens[order[j]]) <= rows_per_group:
+                j += 1
+            sel = order[i:j]
+            L = int(lens[sel].max())
+            idx = np.full((len(sel), L), P, dtype=np.int64)
+            for r, k in enumerate(sel):
+                s0 = int(ranges[tiles[k], 0])
+                idx[r, :lens[k]] = vals[s0:s0 + lens[k]]
+            a = attrs[torch.from_numpy(idx)]                                                # [G, L, 13]
+            pxx = torch.from_numpy(px_all[sel]).to(dt)
+            pyy = torch.from_numpy(py_all[sel]).to(dt)
+            if a.requires_grad:
+                v, Tf, nc = checkpoint(_composite_group, a, pxx, pyy, bgc, use_reentrant=False)
+            else:
+                v, Tf, nc = _composite_group(a, pxx, pyy, bgc)
+            inside = torch.from_numpy((px_all[sel] < W) & (py_all[sel] < H))
+            flat = torch.from_numpy(py_all[sel] * W + px_all[sel])[inside]
+            pix_idx.append(flat)
+            pix_val.append(v.permute(1, 0, 2)[:, inside])                                  # [8, n_inside]
+            with torch.no_grad():
+                final_T[flat] = Tf[inside]
+                n_contrib[flat] = nc[inside]
+            i = j
+        if pix_idx:
+            out = out.index_copy(1, torch.cat(pix_idx), torch.cat(pix_val, dim=1))
+    out = out.reshape(8, H, W)
+    return dict(color=out[0:3], depth=out[3:4], normal=out[4:7], alpha=out[7:8], final_T=final_T.reshape(H, W),
+                n_contrib=n_contrib.reshape(H, W))
 
 
 def rasterize(means3D, means2D, opacities, viewmatrix, settings: OracleSettings, shs=None, colors_precomp=None,
@@ -371,46 +418,6 @@ def rasterize(means3D, means2D, opacities, viewmatrix, settings: OracleSettings,
     return img["color"], img["depth"], img["normal"], img["alpha"], geom["radii"], aux
 
 
-# ---- synthetic scene generator shared by tests / bench ---------------------------------------
-
-def projection_matrix(znear, zfar, fovx, fovy):
-    """Restatement of /root/reference/src/utils/graphic_utils.py:43-63 (pinned by tests/golden)."""
-    tx, ty = math.tan(fovx / 2), math.tan(fovy / 2)
-    top, right = ty * znear, tx * znear
-    Pm = torch.zeros(4, 4)
-    Pm[0, 0] = 2.0 * znear / (2 * right)
-    Pm[1, 1] = 2.0 * znear / (2 * top)
-    Pm[3, 2] = 1.0
-    Pm[2, 2] = zfar / (zfar - znear)
-    Pm[2, 3] = -(zfar * znear) / (zfar - znear)
-    return Pm
-
-
-def synthetic_scene(P: int, W: int, H: int, sh_degree_max: int = 3, seed: int = 777, fovx_deg: float = 50.0,
-                    device="cpu"):
-    """Seeded synthetic cloud + camera of SURVEY.md §8d (uniform in the frustum slab z in [2,20])."""
-    g = torch.Generator().manual_seed(seed)
-    fovx = math.radians(fovx_deg)
-    focal = W / (2 * math.tan(fovx / 2))
-    fovy = 2 * math.atan(H / (2 * focal))
-    tanx, tany = math.tan(fovx / 2), math.tan(fovy / 2)
-    z = 2.0 + 18.0 * torch.rand(P, generator=g)
-    x = (2 * torch.rand(P, generator=g) - 1) * 1.1 * z * tanx
-    y = (2 * torch.rand(P, generator=g) - 1) * 1.1 * z * tany
-    xyz = torch.stack([x, y, z], dim=1)
-    sigma_px = min(max(2.0 * (1e6 / P) ** (1.0 / 3.0) * (W / 1920.0), 0.7), 8.0)
-    scales = (sigma_px * z / focal).unsqueeze(1) * torch.exp(0.5 * torch.randn(P, 3, generator=g))
-    q = torch.randn(P, 4, generator=g)
-    q = q / q.norm(dim=1, keepdim=True)
-    opac = torch.sigmoid(2.0 * torch.randn(P, 1, generator=g))
-    K = (sh_degree_max + 1) ** 2
-    shs = torch.zeros(P, K, 3)
-    shs[:, 0] = (torch.rand(P, 3, generator=g) - 0.5) / SH_C0
-    if K > 1:
-        shs[:, 1:] = 0.05 * torch.randn(P, K - 1, 3, generator=g)
-    view = torch.eye(4)  # identity pose looking down +z
-    proj = projection_matrix(0.01, 100.0, fovx, fovy)
-    scene = dict(means3D=xyz, scales=scales, rotations=q, opacities=opac, shs=shs,
-                 viewmatrix=view.t().contiguous(), projmatrix=proj.t().contiguous(),
-                 tanfovx=tanx, tanfovy=tany, W=W, H=H, fovx=fovx, fovy=fovy)
-    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in scene.items()}
+# ---- synthetic scene generators live in the product package (bench.py's inputs must not come from
+# test infrastructure); re-exported here so the tests keep one import ---------------------------------------------
+from rodygs_amd.synthetic import projection_matrix, skewed_scene, synthetic_scene  # noqa: E402,F401

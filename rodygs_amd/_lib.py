@@ -75,6 +75,7 @@ _SIGS = {
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_gather_rows": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),
     "rdg_split_children": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
+    "rdg_reset_opacity": (C.c_int, [C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "rdg_rigidity_dp_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32] + [_vp] * 6 + [C.c_float] + [_vp] * 4),
     "rdg_motion_reg_forward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "rdg_motion_reg_backward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_float, _vp, C.c_int32, _vp]),

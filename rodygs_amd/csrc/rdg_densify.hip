@@ -42,7 +42,30 @@ __global__ void rdg_split_children_kernel(long long n, const long long* __restri
     scaling_out[3 * i + 2] = logf(s2 * inv_shrink);
 }
 
+// reset_opacity (/root/reference/src/trainer/rodygs_static.py:151-160 + replace_tensor_to_optimizer,
+// src/trainer/utils.py:15-32): logit <- inverse_sigmoid(min(sigmoid(logit), cap)), both Adam moments <- 0.
+__global__ void rdg_reset_opacity_kernel(long long n, float cap, float* __restrict__ logit, float* __restrict__ m,
+                                         float* __restrict__ v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float o = 1.0f / (1.0f + expf(-logit[i]));
+    const float c = fminf(o, cap);
+    logit[i] = logf(c / (1.0f - c));
+    m[i] = 0.0f;
+    v[i] = 0.0f;
+}
+
 extern "C" {
+
+int rdg_reset_opacity(int64_t n, float max_opacity, float* opacity_logit, float* exp_avg, float* exp_avg_sq,
+                      void* stream) {
+    if (n <= 0) return 0;
+    if (!(max_opacity > 0.0f && max_opacity < 1.0f)) return rdg_set_error("reset_opacity: max_opacity must be in (0, 1)");
+    if (!opacity_logit || !exp_avg || !exp_avg_sq) return rdg_set_error("reset_opacity: NULL buffer");
+    hipLaunchKernelGGL(rdg_reset_opacity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long long)n, max_opacity, opacity_logit, exp_avg, exp_avg_sq);
+    return rdg_check_hip(hipGetLastError(), "reset_opacity launch");
+}
 
 int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const float* src, float* dst, void* stream) {
     if (n_new <= 0 || row_len <= 0) return 0;

@@ -159,3 +159,18 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         n_new = int(src.numel())
         return DensifyResult(out, DensifyStats.zeros(n_new, dev), new_pp, n_clone, n_sel,
                              int(prune.sum()) + n_sel)
+
+
+def reset_opacity_(fp: FlatParams, name: str = "opacity", max_opacity: float = 0.01) -> None:
+    """ThreeDGSTrainer.reset_opacity (/root/reference/src/trainer/rodygs_static.py:151-160) on the flat bucket, in
+    place: opacity logits become inverse_sigmoid(min(sigmoid(logit), 0.01)) and -- as replace_tensor_to_optimizer
+    does (/root/reference/src/trainer/utils.py:15-32) -- both Adam moments of that segment are zeroed while the step
+    counter is kept.  One HIP launch (rdg_reset_opacity); the Parameter object, its .grad view and every other
+    segment are untouched, so nothing that points into the bucket needs re-binding."""
+    if not fp.flat.is_cuda:
+        raise RuntimeError("reset_opacity_: the flat bucket must live on the GPU (no CPU fallback exists)")
+    o, n = fp.offsets[name]
+    with torch.cuda.device(fp.flat.device):
+        _lib.check(_lib.lib().rdg_reset_opacity(n, float(max_opacity), fp.flat.data_ptr() + 4 * o,
+                                                fp.exp_avg.data_ptr() + 4 * o, fp.exp_avg_sq.data_ptr() + 4 * o,
+                                                _lib.stream_ptr()), "rdg_reset_opacity")

@@ -211,6 +211,12 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_normal, g_alpha, g_radii, g_extra):
+        if g_normal is not None:
+            # rendered_normal is composited from per-Gaussian normals that are constants of the graph, and no reference
+            # caller differentiates it (src/trainer/rodygs.py:272-309): its backward is not built.  A silent zero would
+            # be the wrong failure mode.
+            raise RuntimeError("rodygs_amd rasterizer: rendered_normal received an upstream gradient, but its backward "
+                               "is not implemented (no RoDyGS loss reads it); detach it before using it in a loss")
         if ctx.empty_cloud or (g_color is None and g_depth is None and g_alpha is None):
             return (None,) * 11
         L = _lib.lib()
@@ -245,7 +251,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             fused = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs_adam")
             if fused is not None:
                 # optimizer in backward for the SH features: dL/dshs never leaves the kernel's LDS tile; the kernel
-                # updates `param` (which must BE the tensor passed as shs), exp_avg and exp_avg_sq in place
+                # updates `param` (which must BE the tensor passed as shs), exp_avg and exp_avg_sq in place.
+                # The saved shs shares that storage (no autograd version bump), so a second backward through this
+                # node -- loss.backward(retain_graph=True) twice, /root/reference/src/trainer/rodygs.py:310 -- would
+                # differentiate at already-stepped parameters and step them again: one shot only.
+                if getattr(ctx, "shs_adam_consumed", False):
+                    raise RuntimeError("grad_sinks['shs_adam']: this forward's backward already applied the SH Adam "
+                                       "step; a second backward through the same graph is not allowed with the "
+                                       "optimizer-in-backward sink (use grad_sinks['shs'] or no sink for retain_graph)")
+                ctx.shs_adam_consumed = True
                 if shs is None or col is not None or cov is not None or sc is None:
                     raise RuntimeError("grad_sinks['shs_adam'] needs shs + scales/rotations inputs")
                 prm = fused["param"]

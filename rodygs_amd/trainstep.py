@@ -45,9 +45,26 @@ def world_view_transform(q_c2w: torch.Tensor, t_c2w: torch.Tensor) -> torch.Tens
     return torch.cat([top, bottom], dim=0)
 
 
+def expon_lr(step: int, lr_init: float, lr_final: float, lr_delay_steps: int = 0, lr_delay_mult: float = 1.0,
+             max_steps: int = 1000000) -> float:
+    """The xyz learning-rate schedule of the reference (get_expon_lr_func,
+    /root/reference/src/utils/general_utils.py:40-73; used by update_learning_rate,
+    /root/reference/src/trainer/rodygs_static.py:143-149): log-linear from lr_init to lr_final over max_steps, with the
+    optional reverse-cosine warm-up.  Feed the value to ``fused_adam_(..., lr_override={"xyz": lr})``."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    delay = 1.0
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * min(max(step / lr_delay_steps, 0.0), 1.0))
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
 def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None, extra=(),
-                names=None, advance: bool = True) -> None:
+                names=None, advance: bool = True, lr_override=None) -> None:
     """ONE fused HIP launch for all parameter groups of the flat buffers (rdg_adam_step_multi).
+    lr_override: {segment name: lr} for THIS step only (the reference re-sets the xyz group's lr every iteration,
+    rodygs_static.py:143-149); segments not named keep ``fp.lr``.
     row_lr: {name: (row_len, head_len, lr_tail)} for segments whose rows mix two learning rates.
     extra: further FlatParams stepped by the same launch (e.g. the MLP + camera-pose bucket); neighbouring
     segments of one buffer with the same learning rate are merged (their alignment padding has zero gradients).
@@ -64,12 +81,13 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
                 entries.append(None)      # a gap: the neighbours must not be merged across it
                 continue
             o, n = f.offsets[k]
-            row_len, head_len, lr_tail = ((row_lr or {}).get(k, (1, 1, f.lr[k])) if f is fp else (1, 1, f.lr[k]))
+            lr_k = float(lr_override[k]) if (f is fp and lr_override and k in lr_override) else f.lr[k]
+            row_len, head_len, lr_tail = ((row_lr or {}).get(k, (1, 1, lr_k)) if f is fp else (1, 1, lr_k))
             last = entries[-1] if entries else None
-            if last is not None and last[0] is f and last[4] == 1 and row_len == 1 and last[3] == f.lr[k]:
+            if last is not None and last[0] is f and last[4] == 1 and row_len == 1 and last[3] == lr_k:
                 entries[-1] = (f, last[1], o + n - last[1], last[3], 1, 1, last[6])
             else:
-                entries.append((f, o, n, f.lr[k], row_len, head_len, lr_tail))
+                entries.append((f, o, n, lr_k, row_len, head_len, lr_tail))
     entries = [e for e in entries if e is not None]
     if not entries:
         return

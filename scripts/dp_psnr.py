@@ -31,12 +31,13 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from oracle import rasterizer_oracle as O                       # synthetic-scene generator only
+    from rodygs_amd.synthetic import synthetic_scene
     from rodygs_amd.checkpoint import psnr
     from rodygs_amd.sharded import ShardedDynamicScene, run_virtual_step
     from rodygs_amd.trainstep import DynamicScene
     dev = torch.device("cuda", 0)
-    sc = O.synthetic_scene(a.points, a.width, a.height, 3, seed=777)
-    tgt = O.synthetic_scene(a.points // 3, a.width, a.height, 3, seed=1234)
+    sc = synthetic_scene(a.points, a.width, a.height, 3, seed=777)
+    tgt = synthetic_scene(a.points // 3, a.width, a.height, 3, seed=1234)
     perm = list(range(a.frames))
 
     def fresh():

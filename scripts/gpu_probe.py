@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import rasterizer_oracle as O  # noqa: E402
+from rodygs_amd.synthetic import synthetic_scene
 from oracle import deform_oracle as DO  # noqa: E402
 from oracle import knn_oracle as KO  # noqa: E402
 import hip_stages as HS  # noqa: E402
@@ -31,7 +32,7 @@ def stats(name, a, b):
 
 def probe_stages(P, W, H, deg, seed=1):
     print(f"== stages P={P} {W}x{H} deg={deg}")
-    sc = O.synthetic_scene(P, W, H, 3, seed=seed)
+    sc = synthetic_scene(P, W, H, 3, seed=seed)
     hs = HS.run_stages(sc, deg)
     st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], deg)
     with torch.no_grad():
@@ -70,7 +71,7 @@ def probe_stages(P, W, H, deg, seed=1):
 
 def probe_full(P, W, H, deg, seed=2, bg=(0.1, 0.2, 0.3)):
     print(f"== full fwd/bwd P={P} {W}x{H} deg={deg}")
-    sc = O.synthetic_scene(P, W, H, 3, seed=seed)
+    sc = synthetic_scene(P, W, H, 3, seed=seed)
     bgt = torch.tensor(bg)
     names = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
     ins = {k: sc[k].clone().to(dev).requires_grad_(True) for k in names}
@@ -158,7 +159,7 @@ def probe_misc():
 
 def probe_speed(P=1000000, W=1920, H=1080, deg=3, iters=5):
     print(f"== speed P={P} {W}x{H}")
-    sc = O.synthetic_scene(P, W, H, 3, seed=777)
+    sc = synthetic_scene(P, W, H, 3, seed=777)
     names = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
     ins = {k: sc[k].clone().to(dev).requires_grad_(True) for k in names}
     rs = HS.make_settings(sc, deg)

@@ -19,6 +19,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
 from oracle import rasterizer_oracle as O                                  # noqa: E402  (checker side of the experiment)
+from rodygs_amd.synthetic import synthetic_scene
 from rodygs_amd.checkpoint import psnr                                     # noqa: E402
 from rodygs_amd.losses import photometric_loss                             # noqa: E402  (torch restatement, both runs)
 
@@ -49,8 +50,8 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     W = H = a.size
-    sc = O.synthetic_scene(a.points, W, H, 3, seed=3)
-    tgt = O.synthetic_scene(a.points, W, H, 3, seed=4)
+    sc = synthetic_scene(a.points, W, H, 3, seed=3)
+    tgt = synthetic_scene(a.points, W, H, 3, seed=4)
     st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 3)
     with torch.no_grad():
         gt = O.rasterize(tgt["means3D"], torch.zeros(a.points, 3), tgt["opacities"], tgt["viewmatrix"], st, shs=tgt["shs"],

@@ -25,11 +25,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     a = ap.parse_args()
     from oracle import rasterizer_oracle as O
+    from rodygs_amd.synthetic import synthetic_scene
     from rodygs_amd.sharded import ShardedDynamicScene
     from rodygs_amd.trainstep import DynamicScene
     dev = torch.device("cuda", 0)
-    sc = O.synthetic_scene(a.points, a.width, a.height, 3, seed=777)
-    tgt = O.synthetic_scene(max(a.points // 4, 1000), a.width, a.height, 3, seed=1234)
+    sc = synthetic_scene(a.points, a.width, a.height, 3, seed=777)
+    tgt = synthetic_scene(max(a.points // 4, 1000), a.width, a.height, 3, seed=1234)
     ds = DynamicScene(sc, num_frames=100, device=dev)
     frames = list(range(0, 100, 6))
     ds.make_ground_truth(tgt, frames)

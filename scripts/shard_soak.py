@@ -3,12 +3,13 @@ import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rasterizer_oracle as O
+from rodygs_amd.synthetic import synthetic_scene
 from rodygs_amd.sharded import ShardedDynamicScene, run_virtual_densify, run_virtual_step
 from rodygs_amd.trainstep import DynamicScene
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-sc = O.synthetic_scene(40000, 480, 272, 3, seed=5)
+sc = synthetic_scene(40000, 480, 272, 3, seed=5)
 ds = DynamicScene(sc, num_frames=24, device="cuda")
-ds.make_ground_truth(O.synthetic_scene(12000, 480, 272, 3, seed=6), range(24))
+ds.make_ground_truth(synthetic_scene(12000, 480, 272, 3, seed=6), range(24))
 sh = [ShardedDynamicScene.from_replica(ds, r, W, exchange=object()) for r in range(W)]
 for s in sh:
     s.track_densification()

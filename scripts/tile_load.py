@@ -3,11 +3,12 @@ import ctypes as C, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rasterizer_oracle as O
+from rodygs_amd.synthetic import synthetic_scene
 from rodygs_amd import _lib
 from rodygs_amd.rasterizer import GaussianRasterizationSettings, _c_settings
 L = _lib.lib()
 P, W, H, K = 1000000, 1920, 1080, 16
-sc = O.synthetic_scene(P, W, H, 3, seed=777)
+sc = synthetic_scene(P, W, H, 3, seed=777)
 dev = torch.device("cuda")
 t = {k: sc[k].to(dev).contiguous() for k in ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix", "projmatrix")}
 rs = GaussianRasterizationSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3, device=dev), 1.0, t["projmatrix"], 3, False, False, True, True)

@@ -26,6 +26,9 @@ What is pinned: the pieces of the hot path that exist as import
                    (src/evaluator/utils.py:15-26), l2_loss (src/utils/loss_utils.py:23-24) and the world-view matrix a
                    LearnableCamera builds from its (quaternion, translation) parameters (src/data/utils.py:173-232)
                    -- the importable pieces of the evaluator's test-time pose optimisation (``... make_golden.py pose``)
+  G11 optimizer : get_expon_lr_func (src/utils/general_utils.py:40-73) and reset_opacity + replace_tensor_to_optimizer
+                   (src/trainer/rodygs_static.py:151-160, src/trainer/utils.py:15-32) on a real torch.optim.Adam state,
+                   plus the Adam step that follows (``... make_golden.py optimizer``)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -297,13 +300,54 @@ def eval_pose_golden():
     np.savez_compressed(os.path.join(OUT, "eval_pose_golden.npz"), **out)
 
 
+def optimizer_golden():
+    """G11: the two optimiser-side pieces of the training loop that touch the flat bucket between steps --
+    get_expon_lr_func (src/utils/general_utils.py:40-73; xyz schedule of rodygs_static.py:143-149) and the
+    reset_opacity arithmetic (rodygs_static.py:151-160: inverse_sigmoid(min(sigmoid(logit), 0.01)), with
+    replace_tensor_to_optimizer zeroing both Adam moments, src/trainer/utils.py:15-32, run here on a real
+    torch.optim.Adam so the stored state is the reference's own)."""
+    from src.utils.general_utils import get_expon_lr_func, inverse_sigmoid
+    from src.trainer.utils import replace_tensor_to_optimizer
+    steps = np.array([0, 1, 10, 100, 999, 1000, 15000, 29999, 30000, 40000], dtype=np.int64)
+    out = dict(lr_steps=steps)
+    for tag, kw in (("a", dict(lr_init=0.00016 * 5.0, lr_final=0.0000016 * 5.0, lr_delay_mult=0.01, max_steps=30000)),
+                    ("b", dict(lr_init=1e-3, lr_final=1e-5, lr_delay_steps=500, lr_delay_mult=0.1, max_steps=2000))):
+        fn = get_expon_lr_func(**kw)
+        out["lr_" + tag] = np.array([fn(int(s)) for s in steps], dtype=np.float64)
+        out["lr_kw_" + tag] = np.array([kw["lr_init"], kw["lr_final"], kw.get("lr_delay_steps", 0), kw["lr_delay_mult"],
+                                        kw["max_steps"]], dtype=np.float64)
+    g = torch.Generator().manual_seed(1111)
+    logit = torch.nn.Parameter(4.0 * torch.randn(4097, 1, generator=g))
+    opt = torch.optim.Adam([{"params": [logit], "lr": 0.05, "name": "opacity"}], lr=0.0, eps=1e-15)
+    for _ in range(3):                       # give the state non-zero moments and a step count
+        opt.zero_grad()
+        (torch.sigmoid(logit) * torch.linspace(-1, 1, 4097).unsqueeze(1)).sum().backward()
+        opt.step()
+    before = logit.detach().clone()
+    st = opt.state[logit]
+    out.update(reset_logit_in=before.numpy(), reset_m_in=st["exp_avg"].numpy().copy(),
+               reset_v_in=st["exp_avg_sq"].numpy().copy(), reset_step=np.int64(int(st["step"])))
+    get_opacity = torch.sigmoid(before)
+    new = inverse_sigmoid(torch.min(get_opacity, torch.ones_like(get_opacity) * 0.01))
+    res = replace_tensor_to_optimizer(opt, new, "opacity")["opacity"]
+    st2 = opt.state[res]
+    out.update(reset_logit_out=res.detach().numpy(), reset_m_out=st2["exp_avg"].numpy(),
+               reset_v_out=st2["exp_avg_sq"].numpy(), reset_step_out=np.int64(int(st2["step"])))
+    # one more Adam step from the reset state: what the bucket must look like after the next optimiser step
+    res.grad = torch.linspace(1, -1, 4097).unsqueeze(1) * 0.3
+    opt.step()
+    out.update(next_grad=res.grad.numpy(), next_logit=res.detach().numpy(), next_m=st2["exp_avg"].numpy(),
+               next_v=st2["exp_avg_sq"].numpy())
+    np.savez_compressed(os.path.join(OUT, "optimizer_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose", "optimizer"):
         sys.dont_write_bytecode = True
         _stub_modules()
         sys.path.insert(0, REF)
         {"rigidity": rigidity_golden, "depth": depth_loss_golden, "motion": motion_reg_golden,
-         "pose": eval_pose_golden}[sys.argv[1]]()
+         "pose": eval_pose_golden, "optimizer": optimizer_golden}[sys.argv[1]]()
         print(sys.argv[1], "golden written to", OUT)
     else:
         main()

@@ -212,3 +212,24 @@ def test_committed_bench_line_honours_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+
+
+def test_bench_accounting_follows_the_algorithm_that_runs():
+    """bench.stage_bytes: optimizer-in-backward moves the SH share of the Adam bytes into the per-Gaussian backward
+    kernel (and removes the dL/dshs write), bucket binning is not priced with the radix formula, sharding shrinks only
+    the optimiser; bench.workload_label is derived from the arguments."""
+    import bench
+    P, K, V, D, H, W = 1000000, 16, 854412, 3475218, 1080, 1920
+    plain = bench.stage_bytes(P, K, V, D, H, W)
+    fused = bench.stage_bytes(P, K, V, D, H, W, sh_adam_in_backward=True)
+    assert plain["adam"] == 28 * 75 * P and fused["adam"] == 28 * 27 * P
+    assert fused["preprocess_bwd"] - plain["preprocess_bwd"] == (24 * 48 - 12 * 16) * P
+    # the step's total falls by exactly the gradient round trip that no longer happens (write 4 B + read 4 B per float)
+    assert sum(plain.values()) - sum(fused.values()) == 8 * 48 * P
+    radix = bench.stage_bytes(P, K, V, D, H, W, radix_binning=True)
+    assert plain["binning"] == D * 28 + P * 80 + 8160 * 16 and radix["binning"] > 3 * plain["binning"]
+    assert bench.stage_bytes(P, K, V, D, H, W, world=8, sharded=True)["adam"] == 28 * 75 * (P // 8)
+    assert "configs[2]" in bench.workload_label(1000000, 1920, 1080, 100, False, 1)
+    assert "configs[4]" in bench.workload_label(4000000, 3840, 2160, 100, True, 1)
+    assert "configs[2]" not in bench.workload_label(4000000, 3840, 2160, 100, True, 1)
+    assert "not a BASELINE config" in bench.workload_label(5000, 640, 480, 10, False, 1)

@@ -274,26 +274,127 @@ def test_capacity_overflow_retries_and_retain_graph():
 
 
 def test_render_wrapper_returns_reference_dict():
-    """render() mirror of /root/reference/src/trainer/renderer.py:17-114: keys, shapes, viewspace grad."""
+    """render() mirror of /root/reference/src/trainer/renderer.py:17-114: keys, shapes, and every VALUE of the dict
+    (plus the gradients that flow back through it) against the oracle rendering the same camera."""
     from rodygs_amd import render
     sc = O.synthetic_scene(2000, 160, 120, 3, seed=13)
+    sc["viewmatrix"] = orbit_view(3.0, -2.0, (0.1, 0.05, 0.2))
+    bg = torch.tensor([0.2, 0.4, 0.1])
 
     class Cam:
         FoVx, FoVy = sc["fovx"], sc["fovy"]
         image_height, image_width = 120, 160
         projection_matrix = sc["projmatrix"].t().contiguous().to(DEV)      # un-transposed P, as FixedCameraTorch
-        world_view_transform = sc["viewmatrix"].t().contiguous().to(DEV)
+        world_view_transform = sc["viewmatrix"].t().contiguous().to(DEV).requires_grad_(True)
 
     xyz = sc["means3D"].to(DEV).requires_grad_(True)
-    pkg = render(xyz, 3, sc["opacities"].to(DEV), sc["scales"].to(DEV), sc["rotations"].to(DEV), sc["shs"].to(DEV),
-                 Cam, torch.zeros(3, device=DEV), enable_sh_grad=True, enable_cov_grad=True)
+    shs = sc["shs"].to(DEV).requires_grad_(True)
+    pkg = render(xyz, 3, sc["opacities"].to(DEV), sc["scales"].to(DEV), sc["rotations"].to(DEV), shs,
+                 Cam, bg.to(DEV), enable_sh_grad=True, enable_cov_grad=True)
     assert set(pkg) == {"rendered_image", "rendered_depth", "rendered_normal", "rendered_alpha", "viewspace_points",
                         "visibility_filter", "radii", "extra"}
     assert pkg["rendered_image"].shape == (3, 120, 160) and pkg["rendered_depth"].shape == (1, 120, 160)
     assert pkg["visibility_filter"].dtype == torch.bool and pkg["visibility_filter"].shape == (2000,)
-    pkg["rendered_image"].sum().backward()
-    assert pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].grad.shape == (2000, 3)
-    assert float(pkg["viewspace_points"].grad[:, :2].abs().sum()) > 0 and xyz.grad is not None
+    g = torch.Generator().manual_seed(5)
+    wc, wd = torch.rand(3, 120, 160, generator=g), torch.rand(1, 120, 160, generator=g)
+    ((pkg["rendered_image"] * wc.to(DEV)).sum() + 0.1 * (pkg["rendered_depth"] * wd.to(DEV)).sum()).backward()
+    # oracle with the arguments the reference's render() builds (renderer.py:50-101)
+    oi = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+    om2 = torch.zeros(2000, 3, requires_grad=True)
+    st = O.OracleSettings(120, 160, math.tan(sc["fovx"] * 0.5), math.tan(sc["fovy"] * 0.5), bg, 1.0, sc["projmatrix"], 3)
+    oc, od, on, oa, orad, _ = O.rasterize(oi["means3D"], om2, oi["opacities"], oi["viewmatrix"], st, shs=oi["shs"],
+                                          scales=oi["scales"], rotations=oi["rotations"])
+    ((oc * wc).sum() + 0.1 * (od * wd).sum()).backward()
+    for key, ref in (("rendered_image", oc), ("rendered_depth", od), ("rendered_normal", on), ("rendered_alpha", oa)):
+        rel_ok(pkg[key], ref, outliers=OUTLIER_FRAC, what=key)
+    assert torch.equal(pkg["radii"].cpu(), orad) and torch.equal(pkg["visibility_filter"].cpu(), orad > 0)
+    assert pkg["extra"].numel() == 0
+    rel_ok(pkg["viewspace_points"].grad, om2.grad, outliers=OUTLIER_FRAC, what="viewspace_points.grad")
+    rel_ok(xyz.grad, oi["means3D"].grad, outliers=OUTLIER_FRAC, what="d_xyz through render()")
+    rel_ok(shs.grad, oi["shs"].grad, outliers=OUTLIER_FRAC, what="d_shs through render()")
+    # the camera's world_view_transform is W2C; the rasterizer saw its transpose
+    rel_ok(Cam.world_view_transform.grad, oi["viewmatrix"].grad.t(), outliers=OUTLIER_FRAC, what="d_world_view_transform")
+
+
+# ---- the committed rasterizer fixture (SURVEY.md §8c G4) and the long-list paths ---------------------------------
+
+def _fixture_scene(name):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"rasterizer_golden_{name}.npz"))
+    sc = {k: torch.from_numpy(g["in_" + k]) for k in NAMES}
+    sc.update(projmatrix=torch.from_numpy(g["in_projmatrix"]), tanfovx=float(g["in_tanfovx"]),
+              tanfovy=float(g["in_tanfovy"]), W=int(g["in_W"]), H=int(g["in_H"]))
+    return g, sc, int(g["in_sh_degree"]), torch.from_numpy(g["in_bg"])
+
+
+@pytest.mark.parametrize("scene", ["c1", "skewed"])
+def test_hip_matches_committed_rasterizer_fixture(scene):
+    """HIP path against tests/golden/rasterizer_golden_*.npz (oracle output frozen by make_rasterizer_golden.py):
+    binning integers bit for bit, images / per-pixel state / every gradient to 1e-4."""
+    import importlib.util
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    from rodygs_amd.rasterizer import last_compositing_state
+    spec = importlib.util.spec_from_file_location(
+        "make_rasterizer_golden", os.path.join(os.path.dirname(__file__), "golden", "make_rasterizer_golden.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    g, sc, deg, bg = _fixture_scene(scene)
+    P = sc["means3D"].shape[0]
+    hs = HS.run_stages(sc, deg)
+    assert hs["D"] == int(g["num_rendered"])
+    assert np.array_equal(hs["radii"], g["radii"])
+    assert np.array_equal(hs["tiles_touched"], g["tiles_touched"].astype(np.uint32))
+    for k in ("keys_unsorted", "vals_unsorted", "keys_sorted", "vals_sorted", "ranges"):
+        assert np.array_equal(hs[k], g[k]), k
+    hi = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+    m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(HS.make_settings(sc, deg, bg=bg))(
+        means3D=hi["means3D"], means2D=m2, shs=hi["shs"], opacities=hi["opacities"], scales=hi["scales"],
+        rotations=hi["rotations"], viewmatrix=hi["viewmatrix"])
+    fT, nc = last_compositing_state()
+    M.fixture_loss(out[0], out[1], out[3]).backward()
+    assert np.array_equal(out[4].cpu().numpy(), g["radii"])
+    for i_, k in ((0, "color"), (1, "depth"), (2, "normal"), (3, "alpha")):
+        rel_ok(out[i_], g[k], outliers=OUTLIER_FRAC, what="fixture " + k)
+    rel_ok(fT, g["final_T"], outliers=OUTLIER_FRAC, what="fixture final_T")
+    assert (nc.cpu().numpy() != g["n_contrib"]).mean() <= OUTLIER_FRAC
+    for k in NAMES:
+        rel_ok(hi[k].grad, g["grad_" + k], outliers=OUTLIER_FRAC, what="fixture d_" + k)
+    rel_ok(m2.grad, g["grad_means2D"], outliers=OUTLIER_FRAC, what="fixture d_means2D")
+
+
+def _tile_counts(ranges):
+    r = ranges.astype(np.int64)
+    return np.sort(r[:, 1] - r[:, 0])
+
+
+@pytest.mark.parametrize("heavy", [23000, 70000])
+def test_skewed_scene_long_tile_lists(heavy):
+    """Densified scenes are not uniform (configs/train/train_kubric_mrig.yaml:168-173): one tile holding `heavy`
+    instances (the multi-workgroup merge path of the per-tile sort), tiles at 2-8 k (its LDS path), a few at 1-2 k,
+    depth ties, and compositing thousands of splats deep.  Keys / order / ranges bit-exact, image + every gradient
+    <= 1e-4 against the oracle."""
+    import hip_stages as HS
+    W, H = 320, 240
+    sc = O.skewed_scene(W, H, [(5, 6, heavy), (14, 3, 7900), (9, 11, 4200), (2, 2, 2500), (17, 12, 1300)],
+                        background=3000, sh_degree_max=3, seed=77, equal_depth_every=5)
+    sc["viewmatrix"] = orbit_view(1.0, -0.7, (0.04, -0.02, 0.08))
+    P = sc["means3D"].shape[0]
+    hs = HS.run_stages(sc, 3)
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 3)
+    with torch.no_grad():
+        g = O.preprocess(sc["means3D"], torch.zeros(P, 3), sc["opacities"], sc["viewmatrix"], st, shs=sc["shs"],
+                         scales=sc["scales"], rotations=sc["rotations"])
+    b = O.bin_and_sort(g)
+    n = _tile_counts(b["ranges"])
+    assert n[-1] > max(8192, heavy * 0.9) and ((n > 2048) & (n <= 8192)).sum() >= 2 and ((n > 1024) & (n <= 2048)).sum() >= 1
+    assert (b["keys_sorted"][1:] == b["keys_sorted"][:-1]).sum() > 1000
+    assert hs["D"] == b["num_rendered"]
+    for k in ("keys_unsorted", "vals_unsorted", "keys_sorted", "vals_sorted", "ranges"):
+        assert np.array_equal(hs[k], b[k]), k
+    res = run_pair(sc, 3, (0.1, 0.2, 0.3))
+    check_pair(res, NAMES)
+    assert int(res[5][5]["n_contrib"].max()) > 8192      # compositing really walked the long list
 
 
 # ---- full-size properties (BASELINE config 3 shape: 1 M Gaussians, 1080p) --------------------------------------
@@ -338,7 +439,8 @@ def test_full_size_properties_1m_1080p():
     rel_ok(g2, 2.5 * g1, tol=2e-5, what="backward linearity")      # float atomics: order-dependent rounding only
 
 
-@pytest.mark.parametrize("P,W,H,n_sample", [(1000000, 1920, 1080, 20),      # BASELINE configs[2..3]
+@pytest.mark.parametrize("P,W,H,n_sample", [(100000, 1920, 1080, 20),       # BASELINE configs[1]
+                                            (1000000, 1920, 1080, 20),      # configs[2..3]
                                             (4000000, 3840, 2160, 10)])     # configs[4]: the largest size
 def test_full_size_sampled_tiles_against_oracle(P, W, H, n_sample):
     """BASELINE's full sizes (the frames bench.py renders): the oracle is affordable on a SAMPLE of tiles (its
@@ -1594,6 +1696,107 @@ def test_sh_adam_in_backward_equals_separate_optimiser_step():
         assert not torch.equal(pb, t["shs"])
         for k in a:
             assert torch.equal(a[k], b[k]), k
+
+
+def test_sh_adam_sink_is_one_shot_and_normal_gradient_raises():
+    """The optimizer-in-backward sink updates a saved tensor in place: a second backward through the same graph
+    (loss.backward(retain_graph=True) twice, /root/reference/src/trainer/rodygs.py:310) must raise instead of stepping
+    already-stepped parameters; and an upstream gradient on rendered_normal (backward not built) must raise, not
+    silently vanish."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    P = 1500
+    sc = O.synthetic_scene(P, 128, 96, 3, seed=14)
+    rs = HS.make_settings(sc, 3)
+    ins = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+    shs = sc["shs"].clone().to(DEV)                         # the "parameter" the kernel steps in place
+    m, v = torch.zeros_like(shs), torch.zeros_like(shs)
+    sink = {"shs_adam": {"param": shs, "exp_avg": m, "exp_avg_sq": v, "head_len": 3, "lr_head": 2.5e-3,
+                         "lr_tail": 2.5e-3 / 20, "betas": (0.9, 0.999), "eps": 1e-15, "step": 1}}
+    m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=shs.requires_grad_(True),
+                                 opacities=ins["opacities"], scales=ins["scales"], rotations=ins["rotations"],
+                                 viewmatrix=ins["viewmatrix"], grad_sinks=sink)
+    before = shs.detach().clone()
+    loss = out[0].sum()
+    loss.backward(retain_graph=True)
+    after = shs.detach().clone()
+    assert not torch.equal(before, after) and shs.grad is None
+    with pytest.raises(RuntimeError, match="already applied the SH Adam step"):
+        loss.backward()
+    assert torch.equal(shs.detach(), after)                 # nothing was stepped twice
+    # rendered_normal: no backward
+    out = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                 scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+    with pytest.raises(RuntimeError, match="rendered_normal received an upstream gradient"):
+        (out[0].sum() + out[2].sum()).backward()
+    (out[0].sum() + out[2].detach().sum()).backward()       # detached: fine
+
+
+def test_reset_opacity_matches_reference_golden():
+    """rdg_reset_opacity on a flat-bucket segment against what the imported reference produced on a real
+    torch.optim.Adam (golden G11: reset_opacity + replace_tensor_to_optimizer, then the next Adam step)."""
+    from rodygs_amd.densify import reset_opacity_
+    from rodygs_amd.dp import FlatParams
+    from rodygs_amd.trainstep import fused_adam_
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "optimizer_golden.npz"))
+    n = g["reset_logit_in"].shape[0]
+    fp = FlatParams({"xyz": ((n, 3), 1e-3), "opacity": ((n, 1), 0.05), "scaling": ((n, 3), 1e-3)}, torch.device(DEV))
+    o, cnt = fp.offsets["opacity"]
+    with torch.no_grad():
+        fp["opacity"].copy_(torch.from_numpy(g["reset_logit_in"]))
+        fp.exp_avg[o:o + cnt].copy_(torch.from_numpy(g["reset_m_in"]).reshape(-1))
+        fp.exp_avg_sq[o:o + cnt].copy_(torch.from_numpy(g["reset_v_in"]).reshape(-1))
+        fp.exp_avg[:o].fill_(0.25)
+        fp.exp_avg_sq[o + cnt:].fill_(0.5)
+        fp["xyz"].fill_(1.0)
+    fp.step_count = int(g["reset_step"])
+    p_obj, grad_obj = fp["opacity"], fp["opacity"].grad
+    reset_opacity_(fp)
+    assert fp["opacity"] is p_obj and fp["opacity"].grad is grad_obj        # nothing re-bound
+    rel_ok(fp["opacity"], g["reset_logit_out"], tol=2e-6, what="reset logits")
+    assert float(fp.exp_avg[o:o + cnt].abs().max()) == 0.0 and float(fp.exp_avg_sq[o:o + cnt].abs().max()) == 0.0
+    assert float(fp.exp_avg[:o].min()) == 0.25 and float(fp.exp_avg_sq[o + cnt:].min()) == 0.5   # neighbours untouched
+    assert float(fp["xyz"].min()) == 1.0 and fp.step_count == int(g["reset_step_out"])
+    # the optimiser step that follows: moments restart from zero, the step counter (bias correction) continues
+    with torch.no_grad():
+        fp.flat_grad.zero_()
+        fp["opacity"].grad.copy_(torch.from_numpy(g["next_grad"]))
+    fused_adam_(fp, names=["opacity"])
+    rel_ok(fp["opacity"], g["next_logit"], tol=1e-5, what="logits after the next Adam step")
+    rel_ok(fp.exp_avg[o:o + cnt].view(n, 1), g["next_m"], tol=1e-6, what="exp_avg")
+    rel_ok(fp.exp_avg_sq[o:o + cnt].view(n, 1), g["next_v"], tol=1e-6, what="exp_avg_sq")
+
+
+def test_adam_lr_override_is_per_segment_and_per_step():
+    """The reference re-sets the xyz group's learning rate every iteration (rodygs_static.py:143-149): lr_override
+    changes that segment for that launch only; torch.optim.Adam with the same per-group lr is the reference."""
+    from rodygs_amd.dp import FlatParams
+    from rodygs_amd.trainstep import expon_lr, fused_adam_
+    n = 3001
+    dev = torch.device(DEV)
+    fp = FlatParams({"xyz": ((n, 3), 8e-4), "scaling": ((n, 3), 1e-3), "opacity": ((n, 1), 0.05)}, dev)
+    gen = torch.Generator().manual_seed(3)
+    ref = {k: torch.nn.Parameter(torch.randn(*fp.shapes[k], generator=gen).to(dev)) for k in fp.names}
+    with torch.no_grad():
+        for k in fp.names:
+            fp[k].copy_(ref[k])
+    opt = torch.optim.Adam([{"params": [ref[k]], "lr": fp.lr[k], "name": k} for k in fp.names], lr=0.0, eps=1e-15)
+    for it in range(1, 5):
+        lr_xyz = expon_lr(it * 5000, 8e-4, 8e-6, 0, 0.01, 30000)
+        for grp in opt.param_groups:
+            if grp["name"] == "xyz":
+                grp["lr"] = lr_xyz
+        for k in fp.names:
+            gk = torch.randn(*fp.shapes[k], generator=gen).to(dev)
+            ref[k].grad = gk.clone()
+            with torch.no_grad():
+                fp[k].grad.copy_(gk)
+        opt.step()
+        fused_adam_(fp, lr_override={"xyz": lr_xyz})
+        for k in fp.names:
+            rel_ok(fp[k], ref[k], tol=2e-6, what=f"{k} after step {it}")
+    assert fp.lr["xyz"] == 8e-4                                   # the override never sticks
 
 
 def test_fused_motion_l1_sparsity_matches_reference_golden():
