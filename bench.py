@@ -125,7 +125,7 @@ def _cpu_train_step(scene, P, W, H, sh_degree, budget_s):
             "extrapolated": done_tiles < n_tiles}
 
 
-def cpu_baseline(scene, sh_degree, budget_s=60.0):
+def cpu_baseline(scene, sh_degree, budget_s=60.0, threads=16):
     """cpu_baseline leg (N = 1, rank 0): the oracle-built CPU train step on this box's host cores.
       value    : the bench workload itself (the scene the GPU was timed on), one full step; compositing over as many
                  interleaved eighths of the tile grid as fit in `budget_s` (all of them on a box with enough cores --
@@ -134,7 +134,10 @@ def cpu_baseline(scene, sh_degree, budget_s=60.0):
                  median of 3 -- no extrapolation."""
     from rodygs_amd.synthetic import synthetic_scene
     P, H, W = scene["means3D"].shape[0], scene["H"], scene["W"]
-    cores = torch.get_num_threads()
+    # the oracle's tensors are a few hundred KB each: beyond ~16 threads torch's intra-op fork/join costs more than it
+    # buys (measured on the 128-core GPU box); `cores` reports the threads actually used
+    cores = max(1, min(torch.get_num_threads(), int(threads)))
+    torch.set_num_threads(cores)
     r = _cpu_train_step(scene, P, W, H, sh_degree, budget_s)
     how = ("every tile composited: no extrapolation" if not r["extrapolated"] else
            f"{r['tiles_done']}/{r['n_tiles']} tiles holding {r['pairs_done']}/{r['pairs']} splat instances composited, "
@@ -161,6 +164,7 @@ def main():
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--gt-frames", type=int, default=16, help="distinct frames with ground truth resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads of the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=60.0,
                     help="seconds of CPU compositing the cpu_baseline leg may spend on the bench frame before it "
                          "extrapolates the remaining tiles")
@@ -203,7 +207,10 @@ def main():
     P, W, H = args.points, args.width, args.height
     scene = synthetic_scene(P, W, H, 3, seed=777)
     target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
-    ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, full_losses=args.full_losses)
+    # rows of the cloud along the Z curve of their positions (RDG_SPATIAL_ORDER=0: the generator's random order)
+    spatial_order = os.environ.get("RDG_SPATIAL_ORDER", "1") != "0"
+    ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, full_losses=args.full_losses,
+                      spatial_order=spatial_order)
     n_gt = min(args.gt_frames * world, args.frames)
     gt_frames = [int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)]
     gt_frames = sorted(set(gt_frames))
@@ -338,7 +345,8 @@ def main():
                        # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH
                        # features itself (RDG_FUSE_SH_ADAM=0 restores the separate launch; same bits either way)
                        "sh_adam_in_backward": sh_adam_in_backward,
-                       "binning": "radix" if radix_binning else "bucket"},
+                       "binning": "radix" if radix_binning else "bucket",
+                       "row_order": "z-curve of the canonical positions" if spatial_order else "generator (random)"},
             "gaussians_per_s": fps * P,
             "loss": float(loss.item()),
             "stage_ms": per_stage,
@@ -356,7 +364,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # contract: the CPU leg runs at N = 1 only
             try:
-                res["cpu_baseline"] = cpu_baseline(scene, 3, budget_s=args.cpu_budget)
+                res["cpu_baseline"] = cpu_baseline(scene, 3, budget_s=args.cpu_budget, threads=args.cpu_threads)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(),
                                        "kind": "port", "sample": f"failed: {e}"}

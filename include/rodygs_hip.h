@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RDG_ABI_VERSION 1
+#define RDG_ABI_VERSION 2
 #define RDG_MAX_VIEWS 16   /* cameras per step in the *_views entry points */
 
 /* Mirror of GaussianRasterizationSettings (renderer.py:50-63) + sizes. Host struct, passed by pointer. */
@@ -156,7 +156,7 @@ int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* m
                                  const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
                                  float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dviewmatrix,
                                  float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len, float lr_head, float lr_tail,
-                                 float beta1, float beta2, float eps, int32_t step, void* stream);
+                                 double beta1, double beta2, float eps, int32_t step, void* stream);
 
 /* The per-Gaussian halves for the nviews (<= RDG_MAX_VIEWS) cameras of one step over the SAME P Gaussians (s_host->P),
  * whose time-dependent inputs are stacked with a row stride of stride_rows (multiple of 256, >= P): means3D
@@ -363,14 +363,16 @@ int rdg_knn_gather_forward(int64_t n_rows, int32_t U, const float* x, const int6
 int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const float* g, const int64_t* idx, float* d_x,
                             void* stream);
 
-/* ---- fused Adam over a flat f32 parameter (used by bench.py's train step) ---------- */
+/* ---- fused Adam over a flat f32 parameter (used by bench.py's train step) ----------
+ * torch.optim.Adam semantics; beta1 / beta2 are DOUBLES, as the Python floats torch receives: 1 - beta is formed in
+ * double and rounded once (1 - float(0.999) is off by 4.7e-5 relative, which would bias exp_avg_sq).           */
 int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
-                  float beta1, float beta2, float eps, int32_t step, void* stream);
+                  double beta1, double beta2, float eps, int32_t step, void* stream);
 /* Same, for a segment made of rows of row_len floats whose first head_len floats use lr_head and the rest lr_tail
  * (the SH features [P,16,3] kept as ONE tensor: DC at feature_lr, the rest at feature_lr/20, as the parameter
  * groups f_dc / f_rest of /root/reference/src/trainer/rodygs_static.py:106-141).                               */
 int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                       int32_t row_len, int32_t head_len, float lr_head, float lr_tail, float beta1, float beta2,
+                       int32_t row_len, int32_t head_len, float lr_head, float lr_tail, double beta1, double beta2,
                        float eps, int32_t step, void* stream);
 
 /* All parameter groups in ONE launch (the reference steps ~8 groups per sub-step, rodygs_static.py:106-141).     */
@@ -384,7 +386,7 @@ typedef struct RdgAdamSeg {
     float lr_head, lr_tail; /* lr of the first head_len floats of every row / of the rest */
     int32_t row_len, head_len;   /* row_len <= 1: uniform lr_head                          */
 } RdgAdamSeg;
-int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, float beta2, float eps, int32_t step,
+int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps, int32_t step,
                         void* stream);
 
 /* ---- fused photometric loss -------------------------------------------------------------

@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "librodygs_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _lock = threading.Lock()
@@ -54,8 +54,8 @@ _SIGS = {
     "rdg_composite_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, _vp, C.c_int64] + [_vp] * 7),
     "rdg_composite_backward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6),
     "rdg_preprocess_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 22),
-    "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 5 +
-                                     [C.c_int32, _vp]),
+    "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 2 +
+                                     [C.c_double, C.c_double, C.c_float, C.c_int32, _vp]),
     "rdg_preprocess_forward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 10),
     "rdg_preprocess_backward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 18),
     "rdg_geom_export": (C.c_int, [C.c_int32] + [_vp] * 8),
@@ -88,11 +88,11 @@ _SIGS = {
     "rdg_knn_points_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_vp] * 7),
     "rdg_knn_gather_forward": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),
     "rdg_knn_gather_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int64] + [_vp] * 4),
-    "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_float, C.c_float, C.c_float,
+    "rdg_adam_step": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float,
                                 C.c_int32, _vp]),
     "rdg_adam_step_rows": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_float, C.c_float,
-                                     C.c_float, C.c_float, C.c_float, C.c_int32, _vp]),
-    "rdg_adam_step_multi": (C.c_int, [C.c_int32, C.POINTER(RdgAdamSeg), C.c_float, C.c_float, C.c_float, C.c_int32,
+                                     C.c_double, C.c_double, C.c_float, C.c_int32, _vp]),
+    "rdg_adam_step_multi": (C.c_int, [C.c_int32, C.POINTER(RdgAdamSeg), C.c_double, C.c_double, C.c_float, C.c_int32,
                                       _vp]),
     "rdg_loss_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "rdg_photometric_loss_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, C.c_float, _vp, _vp, _vp]),

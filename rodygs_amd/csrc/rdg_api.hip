@@ -211,7 +211,7 @@ int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* m
                                  const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
                                  float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dviewmatrix,
                                  float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len, float lr_head, float lr_tail,
-                                 float beta1, float beta2, float eps, int32_t step, void* stream) {
+                                 double beta1, double beta2, float eps, int32_t step, void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
     if (!shs || !scales || !rotations || !sh_exp_avg || !sh_exp_avg_sq)
@@ -221,14 +221,15 @@ int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* m
     hipStream_t st = (hipStream_t)stream;
     const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
     float* posebuf = (float*)((char*)grad_ws + grow_bytes);
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     RdgShAdam ad;
     ad.m = sh_exp_avg; ad.v = sh_exp_avg_sq;
     // the same scalars rdg_adam_step_multi hands its kernel (float(lr) * float(1 / bc1)), so that the fused update and
     // the separate launch produce the same bits
     const float inv_bc1 = (float)(1.0 / bc1);
     ad.step_head = lr_head * inv_bc1; ad.step_tail = lr_tail * inv_bc1;
-    ad.b1 = beta1; ad.b2 = beta2; ad.eps = eps; ad.bc2_sqrt = (float)sqrt(bc2);
+    ad.b1 = (float)beta1; ad.b2 = (float)beta2; ad.omb1 = (float)(1.0 - beta1); ad.omb2 = (float)(1.0 - beta2);
+    ad.eps = eps; ad.bc2_sqrt = (float)sqrt(bc2);
     ad.head_len = head_len;
     rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
     int rc = rdg_launch_preprocess_bwd(d, means3D, shs, nullptr, opacities, scales, rotations, nullptr, viewmatrix,

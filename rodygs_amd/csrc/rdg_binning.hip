@@ -311,11 +311,8 @@ __global__ void rdg_copy_pairs_kernel(const uint64_t* __restrict__ k, const uint
 //   4. sort    : ... and is fixed by a per-tile bitonic sort of the composites in LDS.  Composites are unique,
 //                so the result is deterministic and identical to the stable sort on (tile | depth): equal depths
 //                come out in increasing Gaussian index = emission order.  Bit-exact against the oracle.
-// Tiles with more than RDG_TSORT_LDS instances are sorted in place in global memory by the same network.
+// Tiles with more than RDG_TSORT_LDS instances go through a multi-workgroup chunk sort + merge tree (below).
 // ---------------------------------------------------------------------------------------------------------
-#define RDG_TSORT_SMALL 1024
-#define RDG_TSORT_LDS 8192
-
 // position of tile (x, y) on the Z curve of the counter array (rdg_cnt_entries)
 __device__ __forceinline__ uint32_t rdg_zidx(uint32_t x, uint32_t y) {
     x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u;
@@ -325,9 +322,15 @@ __device__ __forceinline__ uint32_t rdg_zidx(uint32_t x, uint32_t y) {
     return x | (y << 1);
 }
 
+// Count pass, wave-aggregated: the 64 instance slots a wave handles per step are grouped by tile with a ballot
+// "match" over the bits of the counter index (the same idiom as the radix scatter); the lowest lane of every group
+// adds the group's size with ONE returning atomic and the others take (base + their position in the group).  The
+// rank an instance keeps is therefore exactly what a per-instance atomic would have handed out, with as many atomics
+// as there are DISTINCT tiles among the wave's 64 slots: spatially coherent clouds (Morton-ordered scenes, densified
+// clusters, one tile holding 200 k instances) issue a fraction of the atomics and no longer serialise on one address.
 template <int MODE>  // 0 = count, 1 = scatter
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
+rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restrict__ rec,
                        const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
                        const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_cnt,
                        const uint2* __restrict__ ranges, uint32_t* __restrict__ rank_buf,
@@ -361,40 +364,67 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
     __syncthreads();
     const uint32_t first = block_sums[blockIdx.x];
     const uint32_t total = block_sums[blockIdx.x + 1] - first;
-    for (uint32_t k = tid; k < total; k += RDG_PRE_BLOCK) {
-        int lo = 0, hi = RDG_PRE_BLOCK - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (sOff[mid] <= k) lo = mid; else hi = mid - 1;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t k0 = 0; k0 < total; k0 += RDG_PRE_BLOCK) {     // block-uniform trip count: the ballots need every lane
+        const uint32_t k = k0 + tid;
+        const bool act = k < total;
+        int lo = 0;
+        uint32_t tx = 0, ty = 0;
+        if (act) {
+            int hi = RDG_PRE_BLOCK - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (sOff[mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            const uint32_t j = k - sOff[lo];
+            const uint32_t wd = sW[lo];
+            const uint32_t ry = j / wd, rx = j - ry * wd;
+            tx = (uint32_t)sX0[lo] + rx; ty = (uint32_t)sY0[lo] + ry;
         }
-        const uint32_t j = k - sOff[lo];
-        const uint32_t wd = sW[lo];
-        const uint32_t ry = j / wd, rx = j - ry * wd;
-        const uint32_t tile = (uint32_t)(sY0[lo] + ry) * (uint32_t)gx + (uint32_t)(sX0[lo] + rx);
         if (MODE == 0) {
-            // the counting atomic already hands every instance a unique rank inside its tile: keep it (coalesced
-            // 4-B store in emission order), and the scatter pass needs no second round of atomics
-            rank_buf[first + k] = atomicAdd(&tile_cnt[rdg_zidx((uint32_t)(sX0[lo] + rx), (uint32_t)(sY0[lo] + ry))], 1u);
-        } else {
+            const uint32_t z = rdg_zidx(tx, ty);
+            unsigned long long m = __ballot(act);
+            if (m == 0ull) continue;
+            for (int bit = 0; bit < zbits; ++bit) {
+                const bool bset = (z >> bit) & 1u;
+                const unsigned long long bal = __ballot(act && bset);
+                m &= bset ? bal : ~bal;
+            }
+            const uint32_t below = (uint32_t)__popcll(m & lt_mask);
+            uint32_t base = 0;
+            if (act && below == 0) base = atomicAdd(&tile_cnt[z], (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, act ? __ffsll((long long)m) - 1 : 0);
+            // coalesced 4-B store in emission order; the scatter pass needs no second round of atomics
+            if (act) rank_buf[first + k] = base + below;
+        } else if (act) {
+            const uint32_t tile = ty * (uint32_t)gx + tx;
             const uint32_t pos = ranges[tile].x + rank_buf[first + k];
             comp[pos] = ((uint64_t)sDepth[lo] << 32) | (uint64_t)(blockIdx.x * RDG_PRE_BLOCK + lo);
         }
     }
 }
 
-// exclusive scan of tile_cnt -> ranges (untouched tiles stay (0,0), as identifyTileRanges leaves them); clears cursors
+// exclusive scan of tile_cnt -> ranges (untouched tiles stay (0,0), as identifyTileRanges leaves them); clears cursors.
+// Tiles with more than RDG_TSORT_LDS instances are entered in the heavy work list (one work item per chunk of
+// RDG_TSORT_LDS instances) for the multi-workgroup sort; the arrival counters of their merge trees are zeroed here.
 __global__ void __launch_bounds__(1024)
 rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
-                     uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered) {
+                     uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered,
+                     uint32_t* __restrict__ hv_header, RdgHeavyDesc* __restrict__ hv_desc, uint2* __restrict__ hv_work,
+                     uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_work) {
     if ((long long)(*num_rendered) > capacity) {
         // capacity overflow: leave EVERY tile empty, so the compositing kernels (forward and backward) see a valid,
         // empty scene (background image, zero gradients) instead of stale ranges; the host detects D > capacity
         for (int i = threadIdx.x; i < n_tiles; i += 1024) { ranges[i] = make_uint2(0u, 0u); tile_fill[i] = 0u; }
+        if (threadIdx.x == 0) { hv_header[0] = 0u; hv_header[1] = 0u; }
         return;
     }
     // every thread owns a run of consecutive tiles (local sums), ONE block-level scan of the 1024 run totals, then the
     // runs are written out: two barriers in all instead of two per 1024 tiles
     __shared__ uint32_t wtot[16];
+    __shared__ uint32_t sHeavy, sWork;
+    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; }
+    for (uint32_t i = threadIdx.x; i < 2u * max_work; i += 1024) hv_nodes[i] = 0u;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (n_tiles + 1023) / 1024;
     const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
@@ -409,8 +439,22 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
         const uint32_t v = tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))];
         ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
         tile_fill[i] = 0u;
+        if (v > RDG_TSORT_LDS) {
+            const uint32_t nch = (v + RDG_TSORT_LDS - 1) / RDG_TSORT_LDS;
+            const uint32_t h = atomicAdd(&sHeavy, 1u);
+            const uint32_t wb = atomicAdd(&sWork, nch);
+            // sized by construction (rdg_heavy_layout): h < max_heavy and wb + nch <= max_work always hold
+            if (h < max_heavy && wb + nch <= max_work) {
+                RdgHeavyDesc d; d.start = run; d.n = v; d.nchunks = nch; d.node_base = 2u * wb; d.tile = (uint32_t)i;
+                d.pad0 = d.pad1 = d.pad2 = 0u;
+                hv_desc[h] = d;
+                for (uint32_t c = 0; c < nch; ++c) hv_work[wb + c] = make_uint2(h, c);
+            }
+        }
         run += v;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { hv_header[0] = min(sWork, max_work); hv_header[1] = min(sHeavy, max_heavy); }
 }
 
 // ascending compare-exchange network without directions (virtual +inf padding: partners >= n are skipped)
@@ -440,38 +484,157 @@ __device__ __forceinline__ void rdg_bitonic_sort(ARR a, uint32_t n, uint32_t N2,
     }
 }
 
+// ---- heavy tiles: chunk sort + merge tree over several workgroups --------------------------------------------
+// A tile with n > RDG_TSORT_LDS instances is cut into chunks of RDG_TSORT_LDS; one workgroup sorts each chunk in LDS,
+// then the chunks are merged pairwise up a binary tree.  The tree is climbed WITHOUT waiting: every finished run
+// bumps the arrival counter of its parent node; the workgroup whose bump finds the sibling already there does the
+// parent's merge (and climbs on), the other one exits.  Nothing ever spins, so no residency assumption is made.
+// Runs alternate between the composite buffer and the spare key buffer (`alt`); hand-offs between workgroups follow
+// the producer / consumer recipe for non-coherent L2s: every wave drains its stores, workgroup barrier, one lane
+// releases at agent scope and bumps the counter; the merging workgroup acquires at agent scope before its first load.
+// A merge streams its two runs through LDS in output blocks of RDG_MERGE_OB elements: the block boundaries come from
+// a merge-path search over the two runs in global memory (one thread per boundary), each thread then merges
+// RDG_MERGE_PER consecutive outputs from LDS (odd stride: conflict-free starts), and the block is written coalesced.
+#define RDG_MERGE_OB 4096
+#define RDG_MERGE_PER 17
+
+// number of elements of A among the first d outputs of merge(A, B); keys are unique
+template <typename PA, typename PB>
+__device__ __forceinline__ uint32_t rdg_merge_path(PA A, uint32_t nA, PB B, uint32_t nB, uint32_t d) {
+    uint32_t lo = d > nB ? d - nB : 0u, hi = min(d, nA);
+    while (lo < hi) {
+        const uint32_t m = (lo + hi) >> 1;
+        if (A[m] < B[d - 1 - m]) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
+__device__ void rdg_merge_runs(const uint64_t* __restrict__ A, uint32_t nA, const uint64_t* __restrict__ B, uint32_t nB,
+                               uint64_t* __restrict__ O, uint64_t* sIn, uint64_t* sOut, uint32_t* sSplit, uint32_t tid) {
+    const uint32_t n = nA + nB;
+    const uint32_t nblk = (n + RDG_MERGE_OB - 1) / RDG_MERGE_OB;
+    for (uint32_t sb = 0; sb < nblk; sb += 256) {
+        const uint32_t nb = min(256u, nblk - sb);
+        for (uint32_t t = tid; t <= nb; t += 256) {
+            const uint32_t d = min((sb + t) * RDG_MERGE_OB, n);
+            sSplit[t] = rdg_merge_path(A, nA, B, nB, d);
+        }
+        __syncthreads();
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t d0 = min((sb + b) * RDG_MERGE_OB, n), d1 = min((sb + b + 1) * RDG_MERGE_OB, n);
+            const uint32_t a0 = sSplit[b], a1 = sSplit[b + 1];
+            const uint32_t b0 = d0 - a0, b1 = d1 - a1;
+            const uint32_t la = a1 - a0, lb = b1 - b0, lt = la + lb;
+            for (uint32_t i = tid; i < la; i += 256) sIn[i] = A[a0 + i];
+            for (uint32_t i = tid; i < lb; i += 256) sIn[la + i] = B[b0 + i];
+            __syncthreads();
+            const uint32_t o0 = tid * RDG_MERGE_PER;
+            if (o0 < lt) {
+                uint32_t ia = rdg_merge_path(sIn, la, sIn + la, lb, o0), ib = o0 - ia;
+                uint64_t va = ia < la ? sIn[ia] : ~0ull, vb = ib < lb ? sIn[la + ib] : ~0ull;
+                const uint32_t o1 = min(o0 + RDG_MERGE_PER, lt);
+                for (uint32_t o = o0; o < o1; ++o) {
+                    if (va < vb) { sOut[o] = va; ++ia; va = ia < la ? sIn[ia] : ~0ull; }
+                    else         { sOut[o] = vb; ++ib; vb = ib < lb ? sIn[la + ib] : ~0ull; }
+                }
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < lt; i += 256) O[d0 + i] = sOut[i];
+            __syncthreads();
+        }
+    }
+}
+
 template <int LDS_N, bool LARGE>
 __global__ void __launch_bounds__(256)
 rdg_tile_sort_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __restrict__ comp,
                      uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out, long long capacity,
-                     const int32_t* __restrict__ num_rendered) {
+                     const int32_t* __restrict__ num_rendered, uint64_t* __restrict__ alt,
+                     const uint32_t* __restrict__ hv_header, const RdgHeavyDesc* __restrict__ hv_desc,
+                     const uint2* __restrict__ hv_work, uint32_t* __restrict__ hv_nodes) {
     if ((long long)(*num_rendered) > capacity) return;
-    const int tile = blockIdx.x;
-    const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    if (LARGE ? (n <= RDG_TSORT_SMALL) : (n == 0 || n > RDG_TSORT_SMALL)) return;
     __shared__ uint64_t sK[LDS_N];
-    uint32_t N2 = 2;
-    while (N2 < n) N2 <<= 1;
-    uint64_t* g = comp + rg.x;
     const uint32_t tid = threadIdx.x;
-    if (n <= (uint32_t)LDS_N) {
+    if (!LARGE || (int)blockIdx.x < n_tiles) {
+        const int tile = blockIdx.x;
+        const uint2 rg = ranges[tile];
+        const uint32_t n = rg.y - rg.x;
+        if (LARGE ? (n <= RDG_TSORT_SMALL || n > (uint32_t)LDS_N) : (n == 0 || n > RDG_TSORT_SMALL)) return;
+        uint32_t N2 = 2;
+        while (N2 < n) N2 <<= 1;
+        const uint64_t* g = comp + rg.x;
         for (uint32_t i = tid; i < n; i += 256) sK[i] = g[i];
         __syncthreads();
         if (n > 1) rdg_bitonic_sort(sK, n, N2, tid, 256u);
         for (uint32_t i = tid; i < n; i += 256) {
             const uint64_t k = sK[i];
-            g[i] = k;
             vals_out[rg.x + i] = (uint32_t)k;
             if (keys_full_out) keys_full_out[rg.x + i] = ((uint64_t)tile << 32) | (k >> 32);
         }
-    } else {
-        // oversized tile: same network, in place in global memory (workgroup-scope visibility via the barriers)
-        rdg_bitonic_sort(g, n, N2, tid, 256u);
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t k = g[i];
-            vals_out[rg.x + i] = (uint32_t)k;
-            if (keys_full_out) keys_full_out[rg.x + i] = ((uint64_t)tile << 32) | (k >> 32);
+        return;
+    }
+    if constexpr (LARGE) {
+        // ---- heavy work item: chunk c of heavy tile h ------------------------------------------------------
+        __shared__ uint32_t sSplit[257];
+        __shared__ uint32_t sOld;
+        const uint32_t wi = blockIdx.x - (uint32_t)n_tiles;
+        if (wi >= hv_header[0]) return;
+        const uint2 item = hv_work[wi];
+        const RdgHeavyDesc d = hv_desc[item.x];
+        uint64_t* src = comp + d.start;
+        uint64_t* dst = alt + d.start;
+        {   // leaf: sort my chunk in LDS, in place
+            const uint32_t lo = item.y * (uint32_t)LDS_N;
+            const uint32_t nc = min((uint32_t)LDS_N, d.n - lo);
+            uint32_t N2 = 2;
+            while (N2 < nc) N2 <<= 1;
+            for (uint32_t i = tid; i < nc; i += 256) sK[i] = src[lo + i];
+            __syncthreads();
+            if (nc > 1) rdg_bitonic_sort(sK, nc, N2, tid, 256u);
+            for (uint32_t i = tid; i < nc; i += 256) src[lo + i] = sK[i];
+        }
+        uint32_t idx = item.y;            // my run's index at the current level
+        uint32_t nrun = d.nchunks;        // runs at the current level
+        uint32_t len = (uint32_t)LDS_N;   // nominal run length at the current level
+        uint32_t* cnt = hv_nodes + d.node_base;   // counters of the next level's nodes
+        while (nrun > 1) {
+            const uint32_t parent = idx >> 1;
+            const uint32_t lo = parent * 2u * len;
+            const uint32_t mid = min(lo + len, d.n), hi = min(lo + 2u * len, d.n);
+            if ((idx ^ 1u) < nrun) {
+                // publish my run, then see whether the sibling is already there
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    sOld = atomicAdd(&cnt[parent], 1u);
+                }
+                __syncthreads();
+                if (sOld == 0u) return;   // first of the two: the sibling's workgroup merges
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                rdg_merge_runs(src + lo, mid - lo, src + mid, hi - mid, dst + lo, sK, sK + RDG_MERGE_OB, sSplit, tid);
+            } else {
+                // no sibling at this level: carry the run over to the other buffer
+                for (uint32_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
+            }
+            uint64_t* t = src; src = dst; dst = t;
+            cnt += (nrun + 1u) >> 1;
+            idx = parent;
+            nrun = (nrun + 1u) >> 1;
+            len <<= 1;
+        }
+        // the whole tile is one sorted run in `src`, written by this workgroup: its own stores are visible to it
+        __syncthreads();
+        for (uint32_t i = tid; i < d.n; i += 256) {
+            const uint64_t k = src[i];
+            vals_out[d.start + i] = (uint32_t)k;
+            // keys_full_out may BE the spare buffer the runs alternate through: element i is read before it is written
+            if (keys_full_out) keys_full_out[d.start + i] = ((uint64_t)d.tile << 32) | (k >> 32);
         }
     }
 }
@@ -513,17 +676,26 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                                vals_unsorted_copy, (long long)capacity, num_rendered);
         }
         rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
+        int zbits = 0;
+        while (((size_t)1 << zbits) < rdg_cnt_entries(d.gx, d.gy)) ++zbits;
         hipError_t em = hipMemsetAsync(tile_cnt, 0, rdg_cnt_entries(d.gx, d.gy) * 4, s);
         if (em != hipSuccess) return rdg_check_hip(em, "tile_cnt memset");
         if (d.P > 0)
-            hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+            hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered);
+        const RdgHeavyLayout HL = rdg_heavy_layout(capacity);
+        char* hv = b + B.heavy;
+        uint32_t* hv_header = (uint32_t*)(hv + HL.header);
+        RdgHeavyDesc* hv_desc = (RdgHeavyDesc*)(hv + HL.desc);
+        uint2* hv_work = (uint2*)(hv + HL.work);
+        uint32_t* hv_nodes = (uint32_t*)(hv + HL.nodes);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
-                           (long long)capacity, num_rendered);
+                           (long long)capacity, num_rendered, hv_header, hv_desc, hv_work, hv_nodes, HL.max_heavy,
+                           HL.max_work);
         if (d.P > 0)
-            hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
+            hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered);
@@ -531,9 +703,13 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         rdg_stage_begin(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
         hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_SMALL, false>), dim3(n_tiles), dim3(256), 0, s, n_tiles, ranges,
-                           comp, vals_out, kfull, (long long)capacity, num_rendered);
-        hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_LDS, true>), dim3(n_tiles), dim3(256), 0, s, n_tiles, ranges,
-                           comp, vals_out, kfull, (long long)capacity, num_rendered);
+                           comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header, hv_desc,
+                           hv_work, hv_nodes);
+        // tiles of 1025 .. 8192 instances (one workgroup each, LDS) + the work items of heavier tiles (chunk sort +
+        // merge tree over several workgroups); the grid is sized by the capacity, surplus workgroups exit at once
+        hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_LDS, true>), dim3(n_tiles + HL.max_work), dim3(256), 0, s,
+                           n_tiles, ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header,
+                           hv_desc, hv_work, hv_nodes);
         rdg_stage_end(RDG_STAGE_SORT, s);
         return rdg_check_hip(hipGetLastError(), "bucket bin launch");
     }

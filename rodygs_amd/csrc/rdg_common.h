@@ -81,11 +81,40 @@ static inline RdgSortLayout rdg_sort_layout(int64_t capacity) {
     return L;
 }
 
+// ---- heavy tiles (bucket binning): tiles with more than RDG_TSORT_LDS instances are sorted by several workgroups
+// (chunk sort in LDS + a merge tree, rdg_binning.hip).  Everything is sized by the capacity alone: a heavy tile has
+// > RDG_TSORT_LDS instances, so there are < cap / RDG_TSORT_LDS of them and < 2 cap / RDG_TSORT_LDS chunks in all.
+#define RDG_TSORT_SMALL 1024
+#define RDG_TSORT_LDS 8192
+struct RdgHeavyDesc { uint32_t start, n, nchunks, node_base, tile, pad0, pad1, pad2; };
+struct RdgHeavyLayout {
+    size_t header;   // uint32[64]: [0] = number of work items (chunks), [1] = number of heavy tiles
+    size_t desc;     // RdgHeavyDesc[max_heavy]
+    size_t work;     // uint2[max_work]  (heavy tile index, chunk index)
+    size_t nodes;    // uint32[2 * max_work]  arrival counters of the merge-tree nodes
+    size_t total;
+    uint32_t max_heavy, max_work;
+};
+static inline RdgHeavyLayout rdg_heavy_layout(int64_t capacity) {
+    RdgHeavyLayout L;
+    const size_t cap = (size_t)(capacity > 0 ? capacity : 1);
+    L.max_heavy = (uint32_t)(cap / RDG_TSORT_LDS + 1);
+    L.max_work = 2 * L.max_heavy;
+    size_t o = 0;
+    L.header = o;  o = rdg_align_up(o + 256, 256);
+    L.desc = o;    o = rdg_align_up(o + (size_t)L.max_heavy * sizeof(RdgHeavyDesc), 256);
+    L.work = o;    o = rdg_align_up(o + (size_t)L.max_work * 8, 256);
+    L.nodes = o;   o = rdg_align_up(o + (size_t)L.max_work * 2 * 4, 256);
+    L.total = o;
+    return L;
+}
+
 // ---- binning workspace layout ----------------------------------------------------------------------------
 struct RdgBinLayout {
     size_t keys_a, keys_b;  // uint64[cap]
     size_t vals_a, vals_b;  // uint32[cap]
     size_t sort_tmp;        // RdgSortLayout
+    size_t heavy;           // RdgHeavyLayout: work list of the multi-workgroup sort of tiles > RDG_TSORT_LDS instances
     size_t hit;             // uint64[cap/64 + n_tiles + 2][4]: per 64 list slots of a tile, per quadrant, "the forward
                             // had a pixel that could blend this splat" (lets the backward skip the other visits)
     size_t total;
@@ -99,6 +128,7 @@ static inline RdgBinLayout rdg_bin_layout(int64_t capacity, int32_t n_tiles = 0)
     L.vals_a = o;  o = rdg_align_up(o + cap * 4, 256);
     L.vals_b = o;  o = rdg_align_up(o + cap * 4, 256);
     L.sort_tmp = o; o = rdg_align_up(o + rdg_sort_layout(capacity).total, 256);
+    L.heavy = o;   o = rdg_align_up(o + rdg_heavy_layout(capacity).total, 256);
     L.hit = o;     o = rdg_align_up(o + (cap / 64 + (size_t)(n_tiles > 0 ? n_tiles : 262144) + 2) * 32, 256);
     L.total = o;
     return L;
@@ -164,7 +194,7 @@ void rdg_stage_end(int stage, hipStream_t s);
 // the optimizer to read back, it applies the update right there.  m == nullptr: off.
 struct RdgShAdam {
     float* m; float* v;
-    float step_head, step_tail, b1, b2, eps, bc2_sqrt;
+    float step_head, step_tail, b1, b2, omb1, omb2, eps, bc2_sqrt;   // omb = 1 - beta, rounded from double
     int head_len;
 };
 
@@ -327,10 +357,12 @@ __device__ __forceinline__ void rdg_lds_acc_rows(float* __restrict__ g, long lon
 // One element of the update, with the fused multiply-adds written out: the float4 body and the scalar tail of a segment
 // must round identically, or a parameter's value would depend on where its segment happens to end (sharded vs
 // replicated layouts of the same cloud differed by one ulp on the tail elements).
+// omb1 / omb2 = 1 - beta evaluated in double on the host and rounded once (torch.optim.Adam takes Python doubles:
+// 1 - float(0.999) would be off by 4.7e-5 relative, a systematic difference in exp_avg_sq).
 __device__ __forceinline__ void rdg_adam_elem(float& p, float g, float& m, float& v, float st, float b1, float b2,
-                                              float eps, float bc2_sqrt) {
-    m = __fmaf_rn(b1, m, (1.0f - b1) * g);
-    v = __fmaf_rn(b2, v, ((1.0f - b2) * g) * g);
+                                              float omb1, float omb2, float eps, float bc2_sqrt) {
+    m = __fmaf_rn(b1, m, omb1 * g);
+    v = __fmaf_rn(b2, v, (omb2 * g) * g);
     p = __fmaf_rn(-st, m / (sqrtf(v) / bc2_sqrt + eps), p);
 }
 
@@ -356,7 +388,7 @@ __device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const R
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     rdg_adam_elem(P4[c], src[c], M4[c], V4[c], (col + c) < ad.head_len ? ad.step_head : ad.step_tail,
-                                  ad.b1, ad.b2, ad.eps, ad.bc2_sqrt);
+                                  ad.b1, ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
                 pp = rdg_nt4{P4[0], P4[1], P4[2], P4[3]}; mm = rdg_nt4{M4[0], M4[1], M4[2], M4[3]};
                 vv = rdg_nt4{V4[0], V4[1], V4[2], V4[3]};
                 __builtin_nontemporal_store(pp, reinterpret_cast<rdg_nt4*>(p + e));
@@ -372,7 +404,7 @@ __device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const R
                 const int col = idx - gi * row;
                 float pi = p[e], mi = ad.m[e], vi = ad.v[e];
                 rdg_adam_elem(pi, S[gi * stride + col], mi, vi, col < ad.head_len ? ad.step_head : ad.step_tail, ad.b1,
-                              ad.b2, ad.eps, ad.bc2_sqrt);
+                              ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
                 p[e] = pi; ad.m[e] = mi; ad.v[e] = vi;
             }
         }

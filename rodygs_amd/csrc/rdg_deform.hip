@@ -712,7 +712,7 @@ __device__ __forceinline__ void rdg_st4(float* base, long long i, float4 v) {
 template <int VAR>
 __device__ __forceinline__ void
 rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                 float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
+                 float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2, float omb1, float omb2,
                  float eps, float bc2_sqrt) {
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -730,7 +730,7 @@ rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g
         } else {
             s0 = s1 = s2 = s3 = step_head;
         }
-#define RDG_ADAM1(c, st) rdg_adam_elem(pp.c, gg.c, mm.c, vv.c, st, b1, b2, eps, bc2_sqrt);
+#define RDG_ADAM1(c, st) rdg_adam_elem(pp.c, gg.c, mm.c, vv.c, st, b1, b2, omb1, omb2, eps, bc2_sqrt);
         RDG_ADAM1(x, s0) RDG_ADAM1(y, s1) RDG_ADAM1(z, s2) RDG_ADAM1(w, s3)
         rdg_st4<VAR>(p, i, pp);
         rdg_st4<VAR>(m, i, mm);
@@ -742,26 +742,27 @@ rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g
     if (i < n) {
         const float st = (row_len > 1) ? ((int)(i % row_len) < head_len ? step_head : step_tail) : step_head;
         float pi = p[i], mi = m[i], vi = v[i];
-        rdg_adam_elem(pi, g[i], mi, vi, st, b1, b2, eps, bc2_sqrt);
+        rdg_adam_elem(pi, g[i], mi, vi, st, b1, b2, omb1, omb2, eps, bc2_sqrt);
         m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 
 __global__ void __launch_bounds__(256)
 rdg_adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2,
+                float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2, float omb1, float omb2,
                 float eps, float bc2_sqrt) {
-    rdg_adam_segment<0>(n, p, g, m, v, step_head, step_tail, row_len, head_len, b1, b2, eps, bc2_sqrt);
+    rdg_adam_segment<0>(n, p, g, m, v, step_head, step_tail, row_len, head_len, b1, b2, omb1, omb2, eps, bc2_sqrt);
 }
 
 // all parameter groups of a model in ONE launch: blockIdx.y selects the segment
 struct RdgAdamSegs { RdgAdamSeg s[RDG_ADAM_MAX_SEGS]; };
 template <int VAR>
 __global__ void __launch_bounds__(256)
-rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float eps, float bc2_sqrt) {
+rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float omb1, float omb2, float eps,
+                      float bc2_sqrt) {
     const RdgAdamSeg sg = segs.s[blockIdx.y];
     rdg_adam_segment<VAR>(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, sg.lr_head * inv_bc1, sg.lr_tail * inv_bc1,
-                     sg.row_len, sg.head_len, b1, b2, eps, bc2_sqrt);
+                     sg.row_len, sg.head_len, b1, b2, omb1, omb2, eps, bc2_sqrt);
 }
 
 extern "C" {
@@ -985,30 +986,31 @@ int rdg_dyn_getter_views_backward(int32_t P, int32_t Tu, int32_t nviews, int32_t
 }
 
 static int rdg_adam_launch(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int row_len,
-                           int head_len, float lr_head, float lr_tail, float beta1, float beta2, float eps, int32_t step,
+                           int head_len, float lr_head, float lr_tail, double beta1, double beta2, float eps, int32_t step,
                            void* stream) {
     if (n <= 0) return 0;
     if (step < 1) return rdg_set_error("adam: step must be >= 1");
     hipStream_t st = (hipStream_t)stream;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     long long blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     rdg_stage_begin(RDG_STAGE_ADAM, st);
     hipLaunchKernelGGL(rdg_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n, param, grad, exp_avg,
-                       exp_avg_sq, (float)(lr_head / bc1), (float)(lr_tail / bc1), row_len, head_len, beta1, beta2, eps,
+                       exp_avg_sq, (float)(lr_head / bc1), (float)(lr_tail / bc1), row_len, head_len, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
                        (float)sqrt(bc2));
     rdg_stage_end(RDG_STAGE_ADAM, st);
     return rdg_check_hip(hipGetLastError(), "adam launch");
 }
 
-int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                  float beta2, float eps, int32_t step, void* stream) {
+int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
+                  double beta2, float eps, int32_t step, void* stream) {
     return rdg_adam_launch(n, param, grad, exp_avg, exp_avg_sq, 1, 1, lr, lr, beta1, beta2, eps, step, stream);
 }
 
-int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, float beta2, float eps, int32_t step,
+int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps, int32_t step,
                         void* stream) {
     if (nseg <= 0) return 0;
     if (nseg > RDG_ADAM_MAX_SEGS) return rdg_set_error("adam: at most %d segments per launch", RDG_ADAM_MAX_SEGS);
@@ -1021,8 +1023,8 @@ int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, 
         if (segs.s[i].row_len < 1) segs.s[i].row_len = 1;
         if (segs.s[i].n > nmax) nmax = segs.s[i].n;
     }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     // measured at 75 M parameters (scripts/adam_probe.py): streaming (nontemporal) loads/stores + 16 k workgroups per
     // segment 367 us = 5.7 TB/s; cached accesses + 2 k workgroups 416 us.  RDG_ADAM_VAR=0 / RDG_ADAM_BLOCKS override.
     static int var = -1, cap = 16384;
@@ -1036,16 +1038,18 @@ int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, float beta1, 
     rdg_stage_begin(RDG_STAGE_ADAM, st);
     if (var & 1)
         hipLaunchKernelGGL(rdg_adam_multi_kernel<1>, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs,
-                           (float)(1.0 / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+                           (float)(1.0 / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
+                           (float)sqrt(bc2));
     else
         hipLaunchKernelGGL(rdg_adam_multi_kernel<0>, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs,
-                           (float)(1.0 / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+                           (float)(1.0 / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
+                           (float)sqrt(bc2));
     rdg_stage_end(RDG_STAGE_ADAM, st);
     return rdg_check_hip(hipGetLastError(), "adam multi launch");
 }
 
 int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t row_len,
-                       int32_t head_len, float lr_head, float lr_tail, float beta1, float beta2, float eps, int32_t step,
+                       int32_t head_len, float lr_head, float lr_tail, double beta1, double beta2, float eps, int32_t step,
                        void* stream) {
     if (row_len < 1 || head_len < 0 || head_len > row_len) return rdg_set_error("adam: bad row structure");
     return rdg_adam_launch(n, param, grad, exp_avg, exp_avg_sq, row_len, head_len, lr_head, lr_tail, beta1, beta2, eps,

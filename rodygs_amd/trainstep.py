@@ -136,9 +136,18 @@ class DynamicScene:
     SURVEY.md §8d (seeded), replicated on every rank."""
 
     def __init__(self, scene: dict, num_frames: int = 100, sh_degree: int = 3, device="cuda", seed: int = 777,
-                 spatial_lr_scale: float = 5.0, orbit_deg: float = 15.0, full_losses: bool = False):
+                 spatial_lr_scale: float = 5.0, orbit_deg: float = 15.0, full_losses: bool = False,
+                 spatial_order: bool = False):
         g = torch.Generator().manual_seed(seed + 1)
         dev = torch.device(device)
+        if spatial_order:
+            # rows along the Z curve of the canonical positions (rodygs_amd/layout.py): same cloud, coherent memory
+            from .layout import morton_order
+            perm = morton_order(scene["means3D"])
+            scene = dict(scene)
+            for k in ("means3D", "shs", "scales", "rotations", "opacities"):
+                scene[k] = scene[k][perm].contiguous()
+        self.spatial_order = bool(spatial_order)
         self.device = dev
         self.W, self.H = scene["W"], scene["H"]
         self.tanfovx, self.tanfovy = scene["tanfovx"], scene["tanfovy"]

@@ -1,0 +1,68 @@
+"""Binning time of a frame with ONE tile holding `--heavy` instances (default 200 k), on the GPU box.
+
+    python scripts/heavy_tile_probe.py [--heavy 200000] > gpurun_out/heavy_tile.json
+
+Real RoDyGS scenes densify every 100 iterations (/root/reference/configs/train/train_kubric_mrig.yaml:168-173) and
+concentrate Gaussians; the per-tile sort must not fall off a cliff there.  Prints one JSON object: the stage times of
+the binning kernels (hipEvents around the launches, mean of --reps forwards), the tile-occupancy profile, and whether
+the sorted (key, value) stream equals numpy's stable sort of the emitted stream (bit-exact)."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--heavy", type=int, default=200000)
+    ap.add_argument("--background", type=int, default=300000)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer, _lib
+    from rodygs_amd.synthetic import skewed_scene
+    W, H = 1920, 1080
+    sc = skewed_scene(W, H, [(60, 34, args.heavy), (20, 10, 30000), (90, 50, 7000), (100, 20, 3000)],
+                      background=args.background, sh_degree_max=3, seed=5, equal_depth_every=9)
+    P = sc["means3D"].shape[0]
+    hs = HS.run_stages(sc, 3)
+    order = np.argsort(hs["keys_unsorted"], kind="stable")
+    exact = bool(np.array_equal(hs["keys_sorted"], hs["keys_unsorted"][order]) and
+                 np.array_equal(hs["vals_sorted"], hs["vals_unsorted"][order]))
+    r = hs["ranges"].astype(np.int64)
+    n = np.sort(r[:, 1] - r[:, 0])[::-1]
+    dev = "cuda"
+    ins = {k: sc[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")}
+    rs = HS.make_settings(sc, 3)
+    m2 = torch.zeros(P, 3, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            return GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                          scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+    for _ in range(3):
+        fwd()
+    torch.cuda.synchronize()
+    _lib.timing_enable(True)
+    _lib.timing_reset()
+    for _ in range(args.reps):
+        fwd()
+    torch.cuda.synchronize()
+    st = {k: (ms / c if c else 0.0) for k, (ms, c) in _lib.stage_times().items()}
+    _lib.timing_enable(False)
+    print(json.dumps({"workload": f"{P} Gaussians, {W}x{H}: one tile with {int(n[0])} instances, next {n[1:6].tolist()}",
+                      "num_rendered_D": int(hs["D"]), "largest_tiles": n[:8].tolist(), "sorted_stream_bit_exact": exact,
+                      "binning_ms": st["scan_dup"] + st["sort"] + st["ranges"],
+                      "stage_ms": {k: st[k] for k in ("preprocess", "scan_dup", "sort", "render_fwd")},
+                      "reps": args.reps, "bin_mode": os.environ.get("RDG_BIN_MODE", "bucket")}))
+
+
+if __name__ == "__main__":
+    main()

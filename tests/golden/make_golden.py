@@ -331,13 +331,14 @@ def optimizer_golden():
     new = inverse_sigmoid(torch.min(get_opacity, torch.ones_like(get_opacity) * 0.01))
     res = replace_tensor_to_optimizer(opt, new, "opacity")["opacity"]
     st2 = opt.state[res]
-    out.update(reset_logit_out=res.detach().numpy(), reset_m_out=st2["exp_avg"].numpy(),
-               reset_v_out=st2["exp_avg_sq"].numpy(), reset_step_out=np.int64(int(st2["step"])))
+    # .copy(): the arrays would otherwise alias tensors that the optimiser step below updates in place
+    out.update(reset_logit_out=res.detach().numpy().copy(), reset_m_out=st2["exp_avg"].numpy().copy(),
+               reset_v_out=st2["exp_avg_sq"].numpy().copy(), reset_step_out=np.int64(int(st2["step"])))
     # one more Adam step from the reset state: what the bucket must look like after the next optimiser step
     res.grad = torch.linspace(1, -1, 4097).unsqueeze(1) * 0.3
     opt.step()
-    out.update(next_grad=res.grad.numpy(), next_logit=res.detach().numpy(), next_m=st2["exp_avg"].numpy(),
-               next_v=st2["exp_avg_sq"].numpy())
+    out.update(next_grad=res.grad.numpy().copy(), next_logit=res.detach().numpy().copy(),
+               next_m=st2["exp_avg"].numpy().copy(), next_v=st2["exp_avg_sq"].numpy().copy())
     np.savez_compressed(os.path.join(OUT, "optimizer_golden.npz"), **out)
 
 

@@ -1921,3 +1921,34 @@ def test_sharded_step_full_size_1m_1080p_8_ranks():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_row_order_does_not_change_the_image():
+    """Z-curve ordering of the cloud (rodygs_amd/layout.py) is a memory-layout choice: the rendered image and the
+    gradients (un-permuted) must equal those of the generator's order -- only summation order differs."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    from rodygs_amd.layout import morton_order
+    P = 30000
+    sc = O.synthetic_scene(P, 480, 272, 3, seed=19)
+    perm = morton_order(sc["means3D"])
+    assert sorted(perm.tolist()) == list(range(P))
+    rs = HS.make_settings(sc, 3, bg=torch.tensor([0.3, 0.1, 0.2]))
+    w = torch.rand(3, 272, 480, generator=torch.Generator().manual_seed(2)).to(DEV)
+    outs = []
+    for order in (None, perm):
+        ins = {}
+        for k in NAMES:
+            t = sc[k] if (order is None or k == "viewmatrix") else sc[k][order]
+            ins[k] = t.clone().contiguous().to(DEV).requires_grad_(True)
+        m2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                     scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+        (out[0] * w).sum().backward()
+        outs.append((out, ins))
+    (oa, ia), (ob, ib) = outs
+    rel_ok(ob[0], oa[0], tol=2e-5, outliers=OUTLIER_FRAC, what="image under row permutation")
+    assert torch.equal(ob[4].cpu(), oa[4].cpu()[perm])
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        rel_ok(ib[k].grad, ia[k].grad[perm.to(DEV)], tol=1e-4, outliers=OUTLIER_FRAC, what="d_" + k + " under row permutation")
+    rel_ok(ib["viewmatrix"].grad, ia["viewmatrix"].grad, tol=1e-4, what="d_viewmatrix under row permutation")
