@@ -8,10 +8,11 @@ Workload (BASELINE.json configs[2], the one the metric is quoted on): 1 M dynami
 MLP, 1920x1080, SH degree 3, 100-frame synthetic video (SURVEY.md §8d generator, seed 777).  A "step" is one
 full train step on one camera per GPU: deformation -> rasterize forward -> 0.8 L1 + 0.2 D-SSIM -> backward ->
 fused Adam over every parameter.  Inputs are resident in HBM before the timed region.  Weak scaling: every GPU
-renders its own frame, value = frames (train steps x GPUs) per second.  N > 1 (--dp-mode): "shard" (default) keeps
-the Gaussians sharded over the ranks and exchanges 64-byte splat records / gradient rows with two all-to-alls per
-step (rodygs_amd/sharded.py); "allreduce" replicates the cloud and all-reduces the flat gradient bucket (RCCL,
-overlapped with backward and Adam).
+renders its own frame, value = frames (train steps x GPUs) per second.  N > 1 (--dp-mode): "allreduce" is the
+BASELINE north_star formulation -- replicated cloud, RCCL all-reduce of the flat gradient bucket, overlapped with
+backward and Adam; "shard" keeps the Gaussians sharded over the ranks and exchanges 64-byte splat records / gradient
+rows with two all-to-alls per step (rodygs_amd/sharded.py); the default "both" times exactly K steps of each, back to
+back, prints the faster one as `value` (its name in config.parallelism) and both under `dp_modes`.
 
 The JSON line also carries
   roofline     : the dominant kernel (render backward) -- ALGORITHMIC bytes per launch / its average duration,
@@ -153,70 +154,22 @@ def cpu_baseline(scene, sh_degree, budget_s=60.0, threads=16):
                                     "fwd + bwd + Adam, no extrapolation"}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--points", type=int, default=1000000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--gt-frames", type=int, default=16, help="distinct frames with ground truth resident in HBM")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads of the cpu_baseline leg")
-    ap.add_argument("--cpu-budget", type=float, default=60.0,
-                    help="seconds of CPU compositing the cpu_baseline leg may spend on the bench frame before it "
-                         "extrapolates the remaining tiles")
-    ap.add_argument("--full-losses", action="store_true",
-                    help="config-5 loss set (depth, motion regularisers, rigidity every 5th step) instead of the "
-                         "photometric-only step the headline metric is quoted on")
-    ap.add_argument("--dp-mode", choices=["shard", "allreduce"], default=os.environ.get("RDG_DP_MODE", "shard"),
-                    help="N > 1: 'shard' = Gaussians sharded over the ranks, splat records / gradient rows exchanged "
-                         "with two all-to-alls (rodygs_amd/sharded.py); 'allreduce' = replicated cloud, overlapped "
-                         "bucketed all-reduce of the 75-float-per-Gaussian gradient")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the rodygs_amd hot path has no CPU fallback")
-    # functional checks of the N > 1 flow on a 1-GPU box: RDG_ONE_DEVICE=1 puts every rank on cuda:0 and
-    # RDG_DIST_BACKEND=gloo moves the collectives through the host (RCCL refuses two ranks on one device)
-    backend = os.environ.get("RDG_DIST_BACKEND", "nccl")
-    if os.environ.get("RDG_ONE_DEVICE"):
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # RDG_FORCE_SHARD=1: run the sharded step on a 1-rank group too (single-GPU check of the collective path)
-    force_shard = bool(os.environ.get("RDG_FORCE_SHARD")) and world == 1
-    if world > 1 or force_shard:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from rodygs_amd.synthetic import synthetic_scene
-    from rodygs_amd import _lib
+def run_mode(args, mode, rank, world, dev, backend, scene, target):
+    """Build the scene for one N > 1 formulation ("allreduce" | "shard"; "single" at N = 1), warm up, time EXACTLY
+    args.steps steps between barriers, and collect the per-stage table from a few extra steps.  Returns a dict of raw
+    measurements (every rank; dt is the MAX over ranks)."""
+    from rodygs_amd import _lib, rasterizer
     from rodygs_amd.trainstep import DynamicScene
-    _lib.lib()
-
     P, W, H = args.points, args.width, args.height
-    scene = synthetic_scene(P, W, H, 3, seed=777)
-    target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
     # rows of the cloud along the Z curve of their positions (RDG_SPATIAL_ORDER=0: the generator's random order)
     spatial_order = os.environ.get("RDG_SPATIAL_ORDER", "1") != "0"
     ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, full_losses=args.full_losses,
                       spatial_order=spatial_order)
     n_gt = min(args.gt_frames * world, args.frames)
-    gt_frames = [int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)]
-    gt_frames = sorted(set(gt_frames))
-    ds.make_ground_truth(target, gt_frames)
-    perm = gt_frames
-    sharded = (world > 1 or force_shard) and args.dp_mode == "shard"
+    perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
+    ds.make_ground_truth(target, perm)
+    sharded = mode == "shard"
+    ss = None
     if sharded:
         from rodygs_amd.sharded import HostStagedExchange, ShardedDynamicScene
         try:
@@ -225,7 +178,7 @@ def main():
             # a configuration the sharded step does not cover (decided from sizes every rank shares, so all ranks take
             # this branch together): the replicated formulation runs instead
             if rank == 0:
-                print(f"bench.py: sharded frame-DP unavailable ({e}); using --dp-mode allreduce", file=sys.stderr)
+                print(f"bench.py: sharded frame-DP unavailable ({e}); using the replicated formulation", file=sys.stderr)
             sharded = False
     if sharded:
         ds.fp = ds.sync = ds.m2 = None           # the replica's full-size buffers are not needed any more
@@ -239,11 +192,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rasterizer.DEFERRED_OVERFLOW_CHECK = False
     step = 0
     for _ in range(args.warmup):
         train_step(step)
         step += 1
-    from rodygs_amd import rasterizer
     # After the warm-up the instance count D of every frame is known to within a few percent: stop reading it back
     # inside the forward (no host wait in the step).  Capacity is 1.25x the last D; an overflow would render that
     # frame empty and raise RasterizerCapacityOverflow at the next forward / at the final poll below.
@@ -282,18 +235,95 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-
+    out = {"mode": mode, "sharded": sharded, "dt": dt, "loss": float(loss.item()), "spatial_order": spatial_order,
+           "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
         if sharded:
-            D = int(rasterizer._CAPACITY_HINT.get(ss.key, 0))
-            V = ss.visible_count()
+            out["D"] = int(rasterizer._CAPACITY_HINT.get(ss.key, 0))
+            out["V"] = ss.visible_count()
         else:
-            D = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
+            out["D"] = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
             with torch.no_grad():
-                out, _ = ds.render(perm[0])
-                V = int((out[4] > 0).sum().item())
+                o, _ = ds.render(perm[0])
+                out["V"] = int((o[4] > 0).sum().item())
+        with torch.no_grad():
+            _, n_contrib = rasterizer.last_compositing_state()
+            out["S"] = int(n_contrib.sum(dtype=torch.int64).item())
+    del ds, ss, train_step
+    gc.unfreeze()
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=1000000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--gt-frames", type=int, default=16, help="distinct frames with ground truth resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads of the cpu_baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=60.0,
+                    help="seconds of CPU compositing the cpu_baseline leg may spend on the bench frame before it "
+                         "extrapolates the remaining tiles")
+    ap.add_argument("--full-losses", action="store_true",
+                    help="config-5 loss set (depth, motion regularisers, rigidity every 5th step) instead of the "
+                         "photometric-only step the headline metric is quoted on")
+    ap.add_argument("--dp-mode", choices=["both", "allreduce", "shard"], default=os.environ.get("RDG_DP_MODE", "both"),
+                    help="N > 1 formulation: 'allreduce' = BASELINE north_star: replicated cloud, frames over the GPUs, "
+                         "RCCL all-reduce of the Gaussian / pose gradients (bucketed, overlapped with backward and Adam); "
+                         "'shard' = Gaussians sharded over the ranks, 64-byte splat records / gradient rows exchanged "
+                         "with two all-to-alls (rodygs_amd/sharded.py); 'both' (default) times EXACTLY --steps steps of "
+                         "each, back to back, reports the faster one as `value` and both under `dp_modes`")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rodygs_amd hot path has no CPU fallback")
+    # functional checks of the N > 1 flow on a 1-GPU box: RDG_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # RDG_DIST_BACKEND=gloo moves the collectives through the host (RCCL refuses two ranks on one device)
+    backend = os.environ.get("RDG_DIST_BACKEND", "nccl")
+    if os.environ.get("RDG_ONE_DEVICE"):
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # RDG_FORCE_SHARD=1: run the sharded step on a 1-rank group too (single-GPU check of the collective path)
+    force_shard = bool(os.environ.get("RDG_FORCE_SHARD")) and world == 1
+    if world > 1 or force_shard:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    from rodygs_amd.synthetic import synthetic_scene
+    from rodygs_amd import _lib
+    _lib.lib()
+
+    P, W, H = args.points, args.width, args.height
+    scene = synthetic_scene(P, W, H, 3, seed=777)
+    target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
+    if force_shard:
+        modes = ["shard"]
+    elif world == 1:
+        modes = ["single"]
+    else:
+        modes = ["allreduce", "shard"] if args.dp_mode == "both" else [args.dp_mode]
+    runs = [run_mode(args, m, rank, world, dev, backend, scene, target) for m in modes]
+
+    if rank == 0:
+        best = min(runs, key=lambda r: r["dt"])
+        sharded, dt, per_stage = best["sharded"], best["dt"], best["per_stage"]
+        D, V, S, spatial_order = best["D"], best["V"], best["S"], best["spatial_order"]
         fps = args.steps * world / dt
-        per_stage = {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}
         # dominant kernel: render backward.  Algorithmic bytes per launch (DESIGN.md §5 / SURVEY.md §8d):
         #   D*44 (sorted id + 40-B splat features) + H*W*40 (5 upstream-gradient channels, final_T, n_contrib, +pad
         #   as in the survey formula) + V*40 (10 accumulated floats per visible Gaussian)
@@ -313,9 +343,6 @@ def main():
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # whole-step and per-stage algorithmic bytes for the algorithm that actually ran
         # (stage_bytes), and the FP32-VALU fraction of the two compositing kernels
-        with torch.no_grad():
-            _, n_contrib = rasterizer.last_compositing_state()
-            S = int(n_contrib.sum(dtype=torch.int64).item())
         K = 16
         sh_adam_in_backward = bool(world == 1 and not sharded and not args.full_losses
                                    and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")
@@ -331,6 +358,13 @@ def main():
         valu = {k: {"flops": S * f, "tflops": S * f / (per_stage[k] * 1e-3) / 1e12,
                     "frac_of_fp32_vector_peak": S * f / (per_stage[k] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
                 for k, f in (("render_fwd", 22), ("render_bwd", 60)) if per_stage[k] > 0}
+        if world == 1:
+            parallelism = "single GPU (frame-dp1)"
+        elif sharded:
+            parallelism = f"frame-dp{world}, Gaussian-sharded: splat records / gradient rows all-to-all (DESIGN.md §6)"
+        else:
+            parallelism = (f"frame-dp{world}, replicated cloud + RCCL all-reduce of Gaussian / pose gradients "
+                           f"(BASELINE north_star formulation)")
         res = {
             "metric": "train-step fps at 1M dynamic Gaussians / 1080p (fwd+bwd+Adam, one camera per GPU per step)",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -339,8 +373,7 @@ def main():
             "config": {"workload": workload_label(P, W, H, args.frames, args.full_losses, world), "points": P,
                        "width": W, "height": H,
                        "frames": args.frames,
-                       "parallelism": (f"frame-dp{world}, Gaussian-sharded (records/gradient rows all-to-all)" if sharded
-                                       else f"frame-dp{world}" + (", replicated + bucketed all-reduce" if world > 1 else "")), "num_rendered_D": D, "visible_V": V,
+                       "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",
                        # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH
                        # features itself (RDG_FUSE_SH_ADAM=0 restores the separate launch; same bits either way)
@@ -348,7 +381,7 @@ def main():
                        "binning": "radix" if radix_binning else "bucket",
                        "row_order": "z-curve of the canonical positions" if spatial_order else "generator (random)"},
             "gaussians_per_s": fps * P,
-            "loss": float(loss.item()),
+            "loss": best["loss"],
             "stage_ms": per_stage,
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": b_step * fps / world / 1e9,
                               "frac_of_8TBps": b_step * fps / world / 1e9 / HBM_PEAK_GBPS,
@@ -362,6 +395,11 @@ def main():
                          "note": "compositing kernels are VALU/exp/LDS-bound (SURVEY.md §8d); the HBM fraction is "
                                  "reported because north_star asks for it"},
         }
+        if world > 1:
+            # every formulation that was timed (each EXACTLY --steps steps between barriers, max over ranks)
+            res["dp_modes"] = {r["mode"] + ("" if r["sharded"] == (r["mode"] == "shard") else " (fell back to replicated)"):
+                               {"value": args.steps * world / r["dt"], "unit": "frames/s",
+                                "ms_per_step": r["dt"] / args.steps * 1e3} for r in runs}
         if not args.no_cpu_baseline and world == 1:      # contract: the CPU leg runs at N = 1 only
             try:
                 res["cpu_baseline"] = cpu_baseline(scene, 3, budget_s=args.cpu_budget, threads=args.cpu_threads)

@@ -58,7 +58,14 @@ typedef struct RdgRasterSettings {
     int32_t enable_cov_grad; /* pose-gradient gates (SURVEY.md §7 open question 4)           */
     int32_t enable_sh_grad;
     int32_t render_normal;   /* 1: composite the normal channels (default); 0: leave them zero */
-    int32_t reserved[3];
+    int32_t bin_mode;        /* tile binning algorithm of THIS forward: 0 = bucket binning (default; RDG_BIN_MODE=radix in the
+                              * environment overrides), 1 = stable LSD radix sort of (tile | depth) keys.  Same result bit
+                              * for bit; bucket binning is faster on ordinary frames, the radix sort has no atomics and no
+                              * per-tile work, so its time does not depend on how the instances are spread over the tiles
+                              * (a tile holding 200 k instances).  Callers pick it from num_rendered[1] of the previous frame. */
+    int32_t num_rendered_stats; /* 1: num_rendered points to int32[2] and the binning stage also writes
+                              * [1] = largest number of instances in one tile                                    */
+    int32_t reserved[1];
 } RdgRasterSettings;
 
 /* stage ids for rdg_stage_time_ms() */
@@ -129,7 +136,7 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
 int rdg_geom_from_records(const RdgRasterSettings* s_host, void* geom_ws, int32_t* radii, int32_t* num_rendered_dev,
                           void* stream);
 int rdg_composite_forward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws, const int32_t* radii,
-                          void* binning_ws, int64_t capacity, void* image_ws, const int32_t* num_rendered_dev,
+                          void* binning_ws, int64_t capacity, void* image_ws, int32_t* num_rendered_dev,
                           float* out_color, float* out_depth, float* out_normal, float* out_alpha, void* stream);
 /* zeroes the gradient rows of grad_ws, then accumulates the compositing backward into them                         */
 int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
@@ -198,7 +205,7 @@ int rdg_image_export(int32_t H, int32_t W, const void* image_ws, float* final_T,
 /* duplicateWithKeys + sort + tile ranges.  keys_unsorted/vals_unsorted/keys_sorted/vals_sorted (capacity
  * entries each) and ranges[n_tiles,2] are optional copies for the tests.                                    */
 int rdg_bin_forward(const RdgRasterSettings* s_host, const void* geom_ws, const int32_t* radii, void* binning_ws,
-                    int64_t capacity, void* image_ws, const int32_t* num_rendered_dev, uint64_t* keys_unsorted,
+                    int64_t capacity, void* image_ws, int32_t* num_rendered_dev, uint64_t* keys_unsorted,
                     uint32_t* vals_unsorted, uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
                     void* stream);
 /* Stable LSD radix sort of n (key,value) pairs on key bits [0,end_bit).  n is read from *n_dev on the device

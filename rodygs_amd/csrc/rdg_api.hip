@@ -76,6 +76,7 @@ static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     d->smod = s->scale_modifier;
     d->prefiltered = s->prefiltered; d->cov_grad = s->enable_cov_grad; d->sh_grad = s->enable_sh_grad;
     d->render_normal = s->render_normal;
+    d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats;
     return 0;
 }
 
@@ -138,7 +139,7 @@ int rdg_geom_from_records(const RdgRasterSettings* s_host, void* geom_ws, int32_
 }
 
 int rdg_composite_forward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws, const int32_t* radii,
-                          void* binning_ws, int64_t capacity, void* image_ws, const int32_t* num_rendered_dev,
+                          void* binning_ws, int64_t capacity, void* image_ws, int32_t* num_rendered_dev,
                           float* out_color, float* out_depth, float* out_normal, float* out_alpha, void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
@@ -377,7 +378,7 @@ __global__ void rdg_copy_u32_kernel(const uint32_t* __restrict__ a, uint32_t* __
 }
 
 int rdg_bin_forward(const RdgRasterSettings* s_host, const void* geom_ws, const int32_t* radii, void* binning_ws,
-                    int64_t capacity, void* image_ws, const int32_t* num_rendered_dev, uint64_t* keys_unsorted,
+                    int64_t capacity, void* image_ws, int32_t* num_rendered_dev, uint64_t* keys_unsorted,
                     uint32_t* vals_unsorted, uint64_t* keys_sorted, uint32_t* vals_sorted, uint32_t* ranges,
                     void* stream) {
     RdgDev d;

@@ -411,8 +411,10 @@ __global__ void __launch_bounds__(1024)
 rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
                      uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered,
                      uint32_t* __restrict__ hv_header, RdgHeavyDesc* __restrict__ hv_desc, uint2* __restrict__ hv_work,
-                     uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_work) {
+                     uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_work,
+                     int32_t* __restrict__ max_tile_out) {
     if ((long long)(*num_rendered) > capacity) {
+        if (threadIdx.x == 0 && max_tile_out) *max_tile_out = 0;
         // capacity overflow: leave EVERY tile empty, so the compositing kernels (forward and backward) see a valid,
         // empty scene (background image, zero gradients) instead of stale ranges; the host detects D > capacity
         for (int i = threadIdx.x; i < n_tiles; i += 1024) { ranges[i] = make_uint2(0u, 0u); tile_fill[i] = 0u; }
@@ -422,21 +424,43 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
     // every thread owns a run of consecutive tiles (local sums), ONE block-level scan of the 1024 run totals, then the
     // runs are written out: two barriers in all instead of two per 1024 tiles
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t sHeavy, sWork;
-    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; }
+    __shared__ uint32_t sHeavy, sWork, sMaxTile;
+    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; sMaxTile = 0u; }
     for (uint32_t i = threadIdx.x; i < 2u * max_work; i += 1024) hv_nodes[i] = 0u;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (n_tiles + 1023) / 1024;
     const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
-    uint32_t mine = 0;
-    for (int i = t0; i < t1; ++i) mine += tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))];
+    // the counters of a thread's run are fetched 8 at a time with independent loads (one memory latency per 8 tiles,
+    // not per tile: this single workgroup sits on the critical path of every frame)
+    uint32_t mine = 0, big = 0;
+    for (int c0 = t0; c0 < t1; c0 += 8) {
+        uint32_t vv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = c0 + q;
+            vv[q] = i < t1 ? tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mine += vv[q]; big = max(big, vv[q]); }
+    }
     const uint32_t inc = rdg_wave_scan_incl(mine);
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
+    if (max_tile_out) atomicMax(&sMaxTile, big);
     uint32_t run = inc - mine;
     for (uint32_t k = 0; k < w; ++k) run += wtot[k];
-    for (int i = t0; i < t1; ++i) {
-        const uint32_t v = tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))];
+    for (int c0 = t0; c0 < t1; c0 += 8) {
+      uint32_t vv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+          const int i = c0 + q;
+          vv[q] = i < t1 ? tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = c0 + q;
+        if (i >= t1) break;
+        const uint32_t v = vv[q];
         ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
         tile_fill[i] = 0u;
         if (v > RDG_TSORT_LDS) {
@@ -452,36 +476,101 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
             }
         }
         run += v;
+      }
     }
     __syncthreads();
-    if (threadIdx.x == 0) { hv_header[0] = min(sWork, max_work); hv_header[1] = min(sHeavy, max_heavy); }
+    if (threadIdx.x == 0) {
+        hv_header[0] = min(sWork, max_work); hv_header[1] = min(sHeavy, max_heavy);
+        if (max_tile_out) *max_tile_out = (int32_t)sMaxTile;
+    }
 }
 
-// ascending compare-exchange network without directions (virtual +inf padding: partners >= n are skipped)
+// ascending compare-exchange network without directions over N2 = 2^m slots (slots >= n must hold +inf = ~0ull, which
+// no real composite equals: depth bits of a positive float are < 0x7f800000), 256 threads,
+// comparator idx = tid + 256 m.  Most stages never leave a wave: with partner distance j <= 64 (and the mirrored first
+// step of a merge of size k <= 128) the comparators idx in [64 w + 256 m, 64 w + 256 m + 64) read and write only
+// elements [2 (64 w + 256 m), + 128) -- the same 128 for every such stage.  Between two wave-local stages the LDS
+// traffic of a wave is already ordered (one wave's LDS operations execute in program order), so the workgroup barrier is
+// needed only around the stages that do cross waves: 5 of the 45 stages of a 512-element sort, 21 of 91 at 8192.
+// (A version with the elements in registers and DPP / ds_bpermute exchanges was SLOWER, 127 vs 71 us on the bench
+// frame: every lane then evaluates its own side of each comparator, twice the compares and selects.)
+// Call with the data in place and visible (barrier after the load); ends with a barrier.
+// The whole network is generated at compile time for each power-of-two size (templates on the merge size K and the
+// partner distance J): no loop counters, no stage dispatch, index arithmetic folded to two instructions, and the two
+// elements of a half-cleaner comparator (J*8 bytes apart) move with ONE ds_read2_b64 / ds_write2_b64.  With run-time
+// loops the kernel spent 70 % of its instructions in the scalar unit (1 087 of 1 560 per wave and tile, PMC), and the
+// scalar unit is shared by the four SIMDs of a CU: that, not LDS or VALU, was what the sort was waiting for.
+template <bool PREV_LOCAL, bool LOCAL>
+__device__ __forceinline__ void rdg_stage_sync() {
+    if constexpr (PREV_LOCAL && LOCAL) rdg_wave_lds_sync(); else __syncthreads();
+}
+
+template <int J, int N2, typename ARR>
+__device__ __forceinline__ void rdg_half_stage(ARR a, uint32_t n, uint32_t tid) {
+    for (uint32_t idx = tid; idx < (uint32_t)(N2 >> 1); idx += 256) {
+        const uint32_t i = idx + (idx & ~(uint32_t)(J - 1)), p = i + J;
+        const uint64_t x = a[i], y = a[p];
+        const bool sw = x > y;            // branch-free: both slots are always rewritten (exec-mask juggling per
+        a[i] = sw ? y : x;                // comparator costs more scalar instructions than the stores it saves)
+        a[p] = sw ? x : y;
+    }
+}
+
+template <int K, int N2, typename ARR>
+__device__ __forceinline__ void rdg_flip_stage(ARR a, uint32_t n, uint32_t tid) {
+    constexpr uint32_t hk = K >> 1;
+    for (uint32_t idx = tid; idx < (uint32_t)(N2 >> 1); idx += 256) {
+        const uint32_t off = idx & (hk - 1), base = (idx - off) << 1;
+        const uint32_t i = base + off, p = base + K - 1 - off;
+        const uint64_t x = a[i], y = a[p];
+        const bool sw = x > y;
+        a[i] = sw ? y : x;
+        a[p] = sw ? x : y;
+    }
+}
+
+// half-cleaners J, J/2, ..., 1; PREV_LOCAL = the stage before was wave-local
+template <int J, int N2, bool PREV_LOCAL, typename ARR>
+__device__ __forceinline__ void rdg_half_stages(ARR a, uint32_t n, uint32_t tid) {
+    if constexpr (J >= 1) {
+        constexpr bool local = J <= 64;
+        rdg_stage_sync<PREV_LOCAL, local>();
+        rdg_half_stage<J, N2>(a, n, tid);
+        rdg_half_stages<J / 2, N2, local>(a, n, tid);
+    }
+}
+
+// merges of size K, 2K, ..., N2 (each: mirrored first step, then half-cleaners K/4 ... 1)
+template <int K, int N2, typename ARR>
+__device__ __forceinline__ void rdg_merge_stages(ARR a, uint32_t n, uint32_t tid) {
+    if constexpr (K <= N2) {
+        constexpr bool local = (K >> 1) <= 64;
+        if constexpr (K > 2) rdg_stage_sync<true, local>();     // the stage before a merge is the half-cleaner J = 1
+        rdg_flip_stage<K, N2>(a, n, tid);
+        rdg_half_stages<K / 4, N2, local>(a, n, tid);
+        rdg_merge_stages<2 * K, N2>(a, n, tid);
+    }
+}
+
 template <typename ARR>
 __device__ __forceinline__ void rdg_bitonic_sort(ARR a, uint32_t n, uint32_t N2, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t k = 2; k <= N2; k <<= 1) {
-        const uint32_t hk = k >> 1;
-        for (uint32_t idx = tid; idx < (N2 >> 1); idx += nthreads) {
-            const uint32_t base = (idx / hk) * k, off = idx & (hk - 1);
-            const uint32_t i = base + off, p = base + k - 1 - off;
-            if (p < n) {
-                const uint64_t x = a[i], y = a[p];
-                if (x > y) { a[i] = y; a[p] = x; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t idx = tid; idx < (N2 >> 1); idx += nthreads) {
-                const uint32_t i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), p = i + j;
-                if (p < n) {
-                    const uint64_t x = a[i], y = a[p];
-                    if (x > y) { a[i] = y; a[p] = x; }
-                }
-            }
-            __syncthreads();
-        }
+    (void)nthreads;   // 256 by construction (the wave-locality argument above depends on it)
+    switch (N2) {
+        case 2: rdg_merge_stages<2, 2>(a, n, tid); break;
+        case 4: rdg_merge_stages<2, 4>(a, n, tid); break;
+        case 8: rdg_merge_stages<2, 8>(a, n, tid); break;
+        case 16: rdg_merge_stages<2, 16>(a, n, tid); break;
+        case 32: rdg_merge_stages<2, 32>(a, n, tid); break;
+        case 64: rdg_merge_stages<2, 64>(a, n, tid); break;
+        case 128: rdg_merge_stages<2, 128>(a, n, tid); break;
+        case 256: rdg_merge_stages<2, 256>(a, n, tid); break;
+        case 512: rdg_merge_stages<2, 512>(a, n, tid); break;
+        case 1024: rdg_merge_stages<2, 1024>(a, n, tid); break;
+        case 2048: rdg_merge_stages<2, 2048>(a, n, tid); break;
+        case 4096: rdg_merge_stages<2, 4096>(a, n, tid); break;
+        default: rdg_merge_stages<2, 8192>(a, n, tid); break;
     }
+    __syncthreads();
 }
 
 // ---- heavy tiles: chunk sort + merge tree over several workgroups --------------------------------------------
@@ -509,6 +598,20 @@ __device__ __forceinline__ uint32_t rdg_merge_path(PA A, uint32_t nA, PB B, uint
     return lo;
 }
 
+// the 16 elements a thread brings in for one output block (elements tid + 256 r of the block's [A-part | B-part]):
+// all 16 loads are issued back to back, so a block costs ONE global-memory latency, and the next block's loads are in
+// flight while the current one is merged
+#define RDG_MERGE_LD (RDG_MERGE_OB / 256)
+__device__ __forceinline__ void rdg_merge_fetch(const uint64_t* __restrict__ A, const uint64_t* __restrict__ B,
+                                                uint32_t a0, uint32_t la, uint32_t b0, uint32_t lt, uint32_t tid,
+                                                uint64_t (&v)[RDG_MERGE_LD]) {
+#pragma unroll
+    for (int r = 0; r < RDG_MERGE_LD; ++r) {
+        const uint32_t i = tid + 256u * r;
+        v[r] = i < lt ? (i < la ? A[a0 + i] : B[b0 + (i - la)]) : ~0ull;
+    }
+}
+
 __device__ void rdg_merge_runs(const uint64_t* __restrict__ A, uint32_t nA, const uint64_t* __restrict__ B, uint32_t nB,
                                uint64_t* __restrict__ O, uint64_t* sIn, uint64_t* sOut, uint32_t* sSplit, uint32_t tid) {
     const uint32_t n = nA + nB;
@@ -520,14 +623,21 @@ __device__ void rdg_merge_runs(const uint64_t* __restrict__ A, uint32_t nA, cons
             sSplit[t] = rdg_merge_path(A, nA, B, nB, d);
         }
         __syncthreads();
+        uint64_t v[RDG_MERGE_LD];
+        {
+            const uint32_t d0 = min(sb * RDG_MERGE_OB, n), d1 = min((sb + 1) * RDG_MERGE_OB, n);
+            rdg_merge_fetch(A, B, sSplit[0], sSplit[1] - sSplit[0], d0 - sSplit[0], d1 - d0, tid, v);
+        }
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t d0 = min((sb + b) * RDG_MERGE_OB, n), d1 = min((sb + b + 1) * RDG_MERGE_OB, n);
-            const uint32_t a0 = sSplit[b], a1 = sSplit[b + 1];
-            const uint32_t b0 = d0 - a0, b1 = d1 - a1;
-            const uint32_t la = a1 - a0, lb = b1 - b0, lt = la + lb;
-            for (uint32_t i = tid; i < la; i += 256) sIn[i] = A[a0 + i];
-            for (uint32_t i = tid; i < lb; i += 256) sIn[la + i] = B[b0 + i];
+            const uint32_t la = sSplit[b + 1] - sSplit[b], lt = d1 - d0, lb = lt - la;
+#pragma unroll
+            for (int r = 0; r < RDG_MERGE_LD; ++r) sIn[tid + 256u * r] = v[r];
             __syncthreads();
+            if (b + 1 < nb) {
+                const uint32_t e0 = d1, e1 = min((sb + b + 2) * RDG_MERGE_OB, n);
+                rdg_merge_fetch(A, B, sSplit[b + 1], sSplit[b + 2] - sSplit[b + 1], e0 - sSplit[b + 1], e1 - e0, tid, v);
+            }
             const uint32_t o0 = tid * RDG_MERGE_PER;
             if (o0 < lt) {
                 uint32_t ia = rdg_merge_path(sIn, la, sIn + la, lb, o0), ib = o0 - ia;
@@ -539,9 +649,13 @@ __device__ void rdg_merge_runs(const uint64_t* __restrict__ A, uint32_t nA, cons
                 }
             }
             __syncthreads();
-            for (uint32_t i = tid; i < lt; i += 256) O[d0 + i] = sOut[i];
-            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RDG_MERGE_LD; ++r) {
+                const uint32_t i = tid + 256u * r;
+                if (i < lt) O[d0 + i] = sOut[i];
+            }
         }
+        __syncthreads();   // sSplit is rewritten by the next super-batch
     }
 }
 
@@ -563,7 +677,7 @@ rdg_tile_sort_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __
         uint32_t N2 = 2;
         while (N2 < n) N2 <<= 1;
         const uint64_t* g = comp + rg.x;
-        for (uint32_t i = tid; i < n; i += 256) sK[i] = g[i];
+        for (uint32_t i = tid; i < N2; i += 256) sK[i] = i < n ? g[i] : ~0ull;
         __syncthreads();
         if (n > 1) rdg_bitonic_sort(sK, n, N2, tid, 256u);
         for (uint32_t i = tid; i < n; i += 256) {
@@ -588,7 +702,7 @@ rdg_tile_sort_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __
             const uint32_t nc = min((uint32_t)LDS_N, d.n - lo);
             uint32_t N2 = 2;
             while (N2 < nc) N2 <<= 1;
-            for (uint32_t i = tid; i < nc; i += 256) sK[i] = src[lo + i];
+            for (uint32_t i = tid; i < N2; i += 256) sK[i] = i < nc ? src[lo + i] : ~0ull;
             __syncthreads();
             if (nc > 1) rdg_bitonic_sort(sK, nc, N2, tid, 256u);
             for (uint32_t i = tid; i < nc; i += 256) src[lo + i] = sK[i];
@@ -639,8 +753,22 @@ rdg_tile_sort_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __
     }
 }
 
+// largest tile list of the radix path (the bucket path gets it from its scan kernel): num_rendered[1]
+__global__ void __launch_bounds__(1024)
+rdg_tile_max_kernel(int n_tiles, const uint2* __restrict__ ranges, long long capacity, int32_t* __restrict__ num_rendered) {
+    __shared__ uint32_t sMax;
+    if (threadIdx.x == 0) sMax = 0u;
+    __syncthreads();
+    uint32_t m = 0;
+    if ((long long)num_rendered[0] <= capacity)
+        for (int i = threadIdx.x; i < n_tiles; i += 1024) { const uint2 r = ranges[i]; m = max(m, r.y - r.x); }
+    atomicMax(&sMax, m);
+    __syncthreads();
+    if (threadIdx.x == 0) num_rendered[1] = (int32_t)sMax;
+}
+
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
-                   void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
+                   void* image_ws, int32_t* num_rendered, uint64_t* keys_unsorted_copy,
                    uint32_t* vals_unsorted_copy, hipStream_t s, bool radix_export_keys) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const RdgBinLayout B = rdg_bin_layout(capacity);
@@ -656,7 +784,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
 
     static int radix_mode = -1;   // RDG_BIN_MODE=radix selects the LSD radix path (kept for A/B runs)
     if (radix_mode < 0) { const char* ev = getenv("RDG_BIN_MODE"); radix_mode = (ev && ev[0] == 'r') ? 1 : 0; }
-    if (!radix_mode) {
+    if (!radix_mode && d.bin_mode != 1) {
         const int npass = (rdg_key_bits(n_tiles) + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
         uint32_t* vals_out = (npass & 1) ? vals_b : vals_a;      // where the compositing kernels look
         uint64_t* keys_out = (npass & 1) ? keys_b : keys_a;      // full (tile | depth) keys, tests only
@@ -693,7 +821,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         uint32_t* hv_nodes = (uint32_t*)(hv + HL.nodes);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered, hv_header, hv_desc, hv_work, hv_nodes, HL.max_heavy,
-                           HL.max_work);
+                           HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
@@ -737,6 +865,9 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     if (e != hipSuccess) return rdg_check_hip(e, "ranges memset");
     hipLaunchKernelGGL(rdg_tile_ranges_kernel, dim3(2048), dim3(256), 0, s, in_b ? keys_b : keys_a,
                        (long long)capacity, num_rendered, ranges);
+    if (d.nren_stats)
+        hipLaunchKernelGGL(rdg_tile_max_kernel, dim3(1), dim3(1024), 0, s, n_tiles, ranges, (long long)capacity,
+                           num_rendered);
     rdg_stage_end(RDG_STAGE_RANGES, s);
     return rdg_check_hip(hipGetLastError(), "bin launch");
 }

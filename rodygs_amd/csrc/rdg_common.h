@@ -181,6 +181,7 @@ struct RdgDev {
     int32_t P, M, deg, H, W, gx, gy;
     float tanx, tany, fx, fy, smod;
     int32_t prefiltered, cov_grad, sh_grad, render_normal;
+    int32_t bin_mode, nren_stats;
 };
 
 // ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------
@@ -206,7 +207,7 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
 int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii, int32_t* num_rendered,
                                  hipStream_t s);
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
-                   void* image_ws, const int32_t* num_rendered, uint64_t* keys_unsorted_copy,
+                   void* image_ws, int32_t* num_rendered, uint64_t* keys_unsorted_copy,
                    uint32_t* vals_unsorted_copy, hipStream_t s, bool export_sorted_keys = false);
 int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
                     const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s);

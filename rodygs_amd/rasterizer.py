@@ -26,6 +26,13 @@ from . import _lib
 # module-level knobs (not part of the reference surface)
 RENDER_NORMAL = True          # composite the (unused-by-RoDyGS) normal channels
 _CAPACITY_HINT = {}           # (P, H, W) -> last num_rendered, to size the binning workspace without a sync
+_BIN_HINT = {}                # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
+# Bucket binning (count / scan / scatter + per-tile sort) is the fast path on ordinary frames, but its cost grows with
+# the longest tile list (same-address atomics in the count pass, a merge tree in the sort); the LSD radix path does not
+# care how instances are spread.  Same result bit for bit, so the choice is made per frame from the PREVIOUS frame's
+# largest tile list (it arrives with num_rendered: no extra read-back), with hysteresis.
+BIN_RADIX_ABOVE = 32768
+BIN_BUCKET_BELOW = 16384
 
 
 DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
@@ -40,7 +47,14 @@ class RasterizerCapacityOverflow(RuntimeError):
 
 
 def _pinned_slot() -> torch.Tensor:
-    return _PINNED_FREE.pop() if _PINNED_FREE else torch.empty(1, dtype=torch.int32).pin_memory()
+    return _PINNED_FREE.pop() if _PINNED_FREE else torch.empty(2, dtype=torch.int32).pin_memory()
+
+
+def _note_largest_tile(key, largest: int) -> None:
+    if largest > BIN_RADIX_ABOVE:
+        _BIN_HINT[key] = 1
+    elif largest < BIN_BUCKET_BELOW:
+        _BIN_HINT.pop(key, None)
 
 
 def poll_overflow(block: bool = False) -> None:
@@ -54,6 +68,7 @@ def poll_overflow(block: bool = False) -> None:
         _PENDING.pop(0)
         _PINNED_FREE.append(host)
         _CAPACITY_HINT[key] = max(n, int(_CAPACITY_HINT.get(key, 0) * 0.9))
+        _note_largest_tile(key, int(host[1]))
         if n > cap:
             _CAPACITY_HINT[key] = n
             raise RasterizerCapacityOverflow(
@@ -91,6 +106,8 @@ def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int) -> _lib.RdgRa
     s.enable_cov_grad = int(bool(rs.enable_cov_grad))
     s.enable_sh_grad = int(bool(rs.enable_sh_grad))
     s.render_normal = int(bool(RENDER_NORMAL))
+    s.bin_mode = 0
+    s.num_rendered_stats = 0
     return s
 
 
@@ -162,8 +179,11 @@ class _RasterizeGaussians(torch.autograd.Function):
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
             # written by the per-Gaussian stage's scan whenever there is at least one Gaussian
-            nren = (torch.zeros if P == 0 else torch.empty)(1, dtype=torch.int32, device=dev)
+            # [0] = D (instances), [1] = largest tile list, both written by the forward
+            nren = torch.zeros(2, dtype=torch.int32, device=dev)
             key = (P, H, W)
+            cs.num_rendered_stats = 1
+            cs.bin_mode = int(_BIN_HINT.get(key, 0))
             cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
             stream = _lib.stream_ptr()
             deferred = DEFERRED_OVERFLOW_CHECK and key in _CAPACITY_HINT
@@ -189,8 +209,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                     n = -1
                     break
                 # one host read AFTER the whole forward is queued (upstream stalls mid-pipeline instead)
-                n = int(nren.item())
+                n, largest = (int(v) for v in nren.tolist())
                 _CAPACITY_HINT[key] = n
+                _note_largest_tile(key, largest)
                 if n <= cap:
                     break
                 cap = int(n * 1.25) + 4096

@@ -184,7 +184,7 @@ class ShardedDynamicScene:
             self.grad_cam = torch.zeros(L.rdg_grad_bytes(R), **u8)
             self.radii_own = torch.zeros(R, dtype=torch.int32, device=dev)
             self.radii_cam = torch.zeros(R, dtype=torch.int32, device=dev)
-            self.nren = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.nren = torch.zeros(2, dtype=torch.int32, device=dev)   # [0] = D, [1] = largest tile list
             self.rec_own = self.geom_own[:R * 64].view(torch.float32)
             self.rec_cam = self.geom_cam[:R * 64].view(torch.float32)
             self.row_own = self.grad_own[:R * 64].view(torch.float32)
@@ -273,6 +273,8 @@ class ShardedDynamicScene:
             if self._binning is None or self._capacity != cap:
                 self._binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), dtype=torch.uint8, device=dev)
                 self._capacity = cap
+            self.cs_cam.num_rendered_stats = 1
+            self.cs_cam.bin_mode = int(rasterizer._BIN_HINT.get(self.key, 0))
             _lib.check(L.rdg_composite_forward(C.byref(self.cs_cam), _lib.ptr(self.bg), _lib.ptr(self.geom_cam),
                                                _lib.ptr(self.radii_cam), _lib.ptr(self._binning), cap,
                                                _lib.ptr(self.image_ws), _lib.ptr(self.nren), _lib.ptr(self.color),
@@ -285,8 +287,9 @@ class ShardedDynamicScene:
                 ev.record()
                 rasterizer._PENDING.append((ev, host, self.key, cap))
                 break
-            D = int(self.nren.item())
+            D, largest = (int(v) for v in self.nren.tolist())
             hint[self.key] = D
+            rasterizer._note_largest_tile(self.key, largest)
             if D <= cap:
                 break
             cap = int(D * 1.5) + 4096

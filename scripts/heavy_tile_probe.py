@@ -47,20 +47,33 @@ def main():
         with torch.no_grad():
             return GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
                                           scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
-    for _ in range(3):
-        fwd()
-    torch.cuda.synchronize()
-    _lib.timing_enable(True)
-    _lib.timing_reset()
-    for _ in range(args.reps):
-        fwd()
-    torch.cuda.synchronize()
-    st = {k: (ms / c if c else 0.0) for k, (ms, c) in _lib.stage_times().items()}
-    _lib.timing_enable(False)
+    from rodygs_amd import rasterizer
+
+    def timed(radix_above):
+        rasterizer.BIN_RADIX_ABOVE = radix_above
+        rasterizer._BIN_HINT.clear()
+        for _ in range(3):
+            fwd()
+        torch.cuda.synchronize()
+        _lib.timing_enable(True)
+        _lib.timing_reset()
+        for _ in range(args.reps):
+            fwd()
+        torch.cuda.synchronize()
+        t = {k: (ms / c if c else 0.0) for k, (ms, c) in _lib.stage_times().items()}
+        _lib.timing_enable(False)
+        return t, bool(rasterizer._BIN_HINT)
+
+    default_above = rasterizer.BIN_RADIX_ABOVE
+    st_b, _ = timed(1 << 40)              # hint disabled: bucket binning + merge tree on every frame
+    st, radix_hint = timed(default_above)  # as shipped: the first frame's largest tile switches the next ones to radix
     print(json.dumps({"workload": f"{P} Gaussians, {W}x{H}: one tile with {int(n[0])} instances, next {n[1:6].tolist()}",
                       "num_rendered_D": int(hs["D"]), "largest_tiles": n[:8].tolist(), "sorted_stream_bit_exact": exact,
                       "binning_ms": st["scan_dup"] + st["sort"] + st["ranges"],
-                      "stage_ms": {k: st[k] for k in ("preprocess", "scan_dup", "sort", "render_fwd")},
+                      "radix_by_hint": radix_hint,
+                      "stage_ms": {k: st[k] for k in ("preprocess", "scan_dup", "sort", "ranges", "render_fwd")},
+                      "bucket_only_binning_ms": st_b["scan_dup"] + st_b["sort"] + st_b["ranges"],
+                      "bucket_only_stage_ms": {k: st_b[k] for k in ("scan_dup", "sort")},
                       "reps": args.reps, "bin_mode": os.environ.get("RDG_BIN_MODE", "bucket")}))
 
 

@@ -4,8 +4,11 @@ f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step ends with rdg_adam_multi_kernel followed by torch small-Adam kernels; take the span between the last two adam launches
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("rdg_adam_multi_kernel")]
-a, b = idx[-2], idx[-1]
+idx = [i for i, r in enumerate(rows) if "rdg_adam_multi_kernel" in r["Kernel_Name"]]
+# bench.py: 5 warm-up steps, 20 timed steps (only the dominant kernel bracketed by events), 5 steps with every stage
+# bracketed (each bracket costs ~10 us of stream gap): show a step of the TIMED region unless told otherwise
+which = int(sys.argv[2]) if len(sys.argv) > 2 else (19 if len(idx) >= 26 else len(idx) - 2)
+a, b = idx[which], idx[which + 1]
 t0 = int(rows[a]["End_Timestamp"])
 prev_end = t0
 tot = 0

@@ -1952,3 +1952,88 @@ def test_row_order_does_not_change_the_image():
     for k in ("means3D", "shs", "opacities", "scales", "rotations"):
         rel_ok(ib[k].grad, ia[k].grad[perm.to(DEV)], tol=1e-4, outliers=OUTLIER_FRAC, what="d_" + k + " under row permutation")
     rel_ok(ib["viewmatrix"].grad, ia["viewmatrix"].grad, tol=1e-4, what="d_viewmatrix under row permutation")
+
+
+def test_bin_mode_follows_the_largest_tile_of_the_previous_frame():
+    """A frame whose largest tile list exceeds BIN_RADIX_ABOVE makes the NEXT forward of that (P, H, W) take the radix
+    path (its time does not depend on how instances are spread over tiles); same image bit for bit either way, and the
+    hint falls back once the lists are short again."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer, rasterizer
+    W, H = 320, 240
+    sc = O.skewed_scene(W, H, [(5, 6, 40000), (14, 3, 3000)], background=2000, sh_degree_max=3, seed=78)
+    P = sc["means3D"].shape[0]
+    rs = HS.make_settings(sc, 3)
+    ins = {k: sc[k].to(DEV) for k in NAMES}
+    key = (P, H, W)
+    rasterizer._BIN_HINT.pop(key, None)
+
+    def fwd(src=ins):
+        with torch.no_grad():
+            return GaussianRasterizer(rs)(means3D=src["means3D"], means2D=torch.zeros(P, 3, device=DEV), shs=src["shs"],
+                                          opacities=src["opacities"], scales=src["scales"], rotations=src["rotations"],
+                                          viewmatrix=src["viewmatrix"])
+    a = fwd()                                   # bucket binning (multi-workgroup merge for the 40 k tile)
+    assert rasterizer._BIN_HINT.get(key) == 1
+    b = fwd()                                   # radix path, chosen by the hint
+    for i_ in (0, 1, 3):
+        assert torch.equal(a[i_], b[i_])
+    assert torch.equal(a[4], b[4])
+    # lists short again (opacity irrelevant: move the cluster behind the camera) -> back to bucket binning
+    far = dict(ins)
+    m3 = ins["means3D"].clone()
+    m3[:, 2] = torch.where(ins["opacities"][:, 0] < 0.035, -torch.ones_like(m3[:, 2]), m3[:, 2])
+    far["means3D"] = m3
+    fwd(far)
+    assert key not in rasterizer._BIN_HINT
+
+
+def test_bench_runs_both_dp_formulations_the_way_the_driver_launches_it():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2` in fresh child processes
+    (two ranks sharing this one GPU: RDG_ONE_DEVICE=1, collectives through gloo): the default --dp-mode times BOTH
+    formulations -- the north_star's replicated cloud + all-reduce and the Gaussian-sharded step -- prints one JSON
+    line whose `value` is the faster one, names it in config.parallelism, and lists both under dp_modes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, RDG_ONE_DEVICE="1", RDG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--points", "20000", "--width", "320", "--height", "240", "--frames", "8", "--gt-frames", "4"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert set(d["dp_modes"]) == {"allreduce", "shard"}
+    best = max(d["dp_modes"].items(), key=lambda kv: kv[1]["value"])
+    assert abs(best[1]["value"] - d["value"]) < 1e-9 * d["value"]
+    assert ("Gaussian-sharded" in d["config"]["parallelism"]) == (best[0] == "shard")
+    assert ("all-reduce" in d["config"]["parallelism"]) == (best[0] == "allreduce")
+    assert "not a BASELINE config" in d["config"]["workload"]
+    assert all(v["hbm_frac"] is None or 0 < v["hbm_frac"] <= 1.0 for v in d["stage_roofline"].values())
+
+
+def test_psnr_delta_through_the_real_train_step():
+    """BASELINE metric "PSNR delta vs ref" (north_star: within 0.05 dB), at 20 k dynamic Gaussians, 320x240, 500
+    optimiser steps with one densification: the train step bench.py times (fused kernels, fused Adam, SH Adam inside
+    backward -- and the same with the separate Adam launch) against a CPU loop driven by the oracle rasterizer +
+    torch.optim.Adam, same initial state, frames, ground truth and split samples (scripts/psnr_delta.py).
+    PSNR per /root/reference/src/utils/eval_utils.py:36-39."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "psnr_delta", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "psnr_delta.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    res = M.run(points=20000, width=320, height=240, steps=500, frames=8)
+    for k in ("hip_fused", "hip_unfused", "oracle"):
+        assert res[k]["psnr_end_db"] > res[k]["psnr_start_db"] + 1.0, (k, res[k])     # it really trained
+        assert res[k]["densify"]["cloned"] + res[k]["densify"]["split"] > 0, (k, res[k])
+    assert abs(res["delta_db"]["hip_fused"]) <= 0.05, res
+    assert abs(res["delta_db"]["hip_unfused"]) <= 0.05, res
