@@ -62,13 +62,17 @@ def _prune(st: State, mask: torch.Tensor):
     st.per_point = {k: v[valid] for k, v in st.per_point.items()}
 
 
-def densify_and_prune(st: State, max_grad, min_opacity, extent, max_screen_size, percent_dense, N, z):
-    """rodygs_static.py:280-301; returns the number of clone / split selections."""
+def densify_and_prune(st: State, max_grad, min_opacity, extent, max_screen_size, percent_dense, N, z, decisions=None):
+    """rodygs_static.py:280-301; returns the number of clone / split selections.  ``decisions`` ({"clone", "split",
+    "prune"} boolean masks, the layout of rodygs_amd.densify.DensifyResult.decisions) replaces the three threshold
+    tests -- used by scripts/psnr_delta.py to hold the set of Gaussians fixed across runs."""
     grads = st.accum / st.denom
     grads[grads.isnan()] = 0.0
     # ---- clone (:244-277) ----
     scaling = torch.exp(st.params["scaling"])
     sel = (torch.norm(grads, dim=-1) >= max_grad) & (scaling.max(dim=1).values <= percent_dense * extent)
+    if decisions is not None:
+        sel = decisions["clone"]
     new = {k: v[sel] for k, v in st.params.items()}
     st.per_point = {k: torch.cat([v, v[sel]]) for k, v in st.per_point.items()}
     n_clone = int(sel.sum())
@@ -78,6 +82,8 @@ def densify_and_prune(st: State, max_grad, min_opacity, extent, max_screen_size,
     padded[:grads.shape[0]] = grads.squeeze()
     scaling = torch.exp(st.params["scaling"])
     sel = (padded >= max_grad) & (scaling.max(dim=1).values > percent_dense * extent)
+    if decisions is not None:
+        sel = torch.cat([decisions["split"], torch.zeros(st.P - decisions["split"].shape[0], dtype=torch.bool)])
     n_sel = int(sel.sum())
     stds = scaling[sel].repeat(N, 1)
     samples = stds * z[:stds.shape[0]]
@@ -94,5 +100,7 @@ def densify_and_prune(st: State, max_grad, min_opacity, extent, max_screen_size,
         big_vs = st.max_radii > max_screen_size
         big_ws = torch.exp(st.params["scaling"]).max(dim=1).values > 0.1 * extent
         mask = mask | big_vs | big_ws
+    if decisions is not None:
+        mask = decisions["prune"]
     _prune(st, mask)
     return n_clone, n_sel

@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librodygs_hip.so")
+# RDG_LIB_PATH: load another build of the same ABI (A/B runs of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("RDG_LIB_PATH") or os.path.join(_HERE, "csrc", "librodygs_hip.so")
 ABI_VERSION = 2
 
 _lib = None

@@ -500,14 +500,22 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
 // elements of a half-cleaner comparator (J*8 bytes apart) move with ONE ds_read2_b64 / ds_write2_b64.  With run-time
 // loops the kernel spent 70 % of its instructions in the scalar unit (1 087 of 1 560 per wave and tile, PMC), and the
 // scalar unit is shared by the four SIMDs of a CU: that, not LDS or VALU, was what the sort was waiting for.
+// THREADS = 256: a workgroup sorts one list, comparator idx = tid + 256 m (tid = thread in the workgroup).
+// What bounds this sort is the LDS WRITE path (about 80 B/clk per CU for 8-byte stores, MI355X_MICROARCH.md §LDS): 45-55
+// stages x 8 B written per element and stage = 2.6 GB of LDS stores per 1080p frame = ~55 us chip-wide, whatever the
+// instruction count -- run-time loops, the compile-time network below, barriers on every stage or only on the
+// cross-wave ones, one WAVE per tile without any barrier (THREADS = 64: 86 us, fewer waves to cover the latency) and
+// elements held in registers with DPP / ds_bpermute exchanges (127 us: every lane evaluates its own side of each
+// comparator) all landed at 70 us or worse.  Next step, not taken: 16 consecutive elements per lane so that the stages
+// with partner distance <= 8 run in registers between ONE LDS read and write (28 instead of 55 LDS round trips).
 template <bool PREV_LOCAL, bool LOCAL>
 __device__ __forceinline__ void rdg_stage_sync() {
     if constexpr (PREV_LOCAL && LOCAL) rdg_wave_lds_sync(); else __syncthreads();
 }
 
-template <int J, int N2, typename ARR>
-__device__ __forceinline__ void rdg_half_stage(ARR a, uint32_t n, uint32_t tid) {
-    for (uint32_t idx = tid; idx < (uint32_t)(N2 >> 1); idx += 256) {
+template <int J, int N2, int THREADS, typename ARR>
+__device__ __forceinline__ void rdg_half_stage(ARR a, uint32_t tid) {
+    for (uint32_t idx = tid; idx < (uint32_t)(N2 >> 1); idx += THREADS) {
         const uint32_t i = idx + (idx & ~(uint32_t)(J - 1)), p = i + J;
         const uint64_t x = a[i], y = a[p];
         const bool sw = x > y;            // branch-free: both slots are always rewritten (exec-mask juggling per
@@ -516,10 +524,10 @@ __device__ __forceinline__ void rdg_half_stage(ARR a, uint32_t n, uint32_t tid) 
     }
 }
 
-template <int K, int N2, typename ARR>
-__device__ __forceinline__ void rdg_flip_stage(ARR a, uint32_t n, uint32_t tid) {
+template <int K, int N2, int THREADS, typename ARR>
+__device__ __forceinline__ void rdg_flip_stage(ARR a, uint32_t tid) {
     constexpr uint32_t hk = K >> 1;
-    for (uint32_t idx = tid; idx < (uint32_t)(N2 >> 1); idx += 256) {
+    for (uint32_t idx = tid; idx < (uint32_t)(N2 >> 1); idx += THREADS) {
         const uint32_t off = idx & (hk - 1), base = (idx - off) << 1;
         const uint32_t i = base + off, p = base + K - 1 - off;
         const uint64_t x = a[i], y = a[p];
@@ -530,45 +538,46 @@ __device__ __forceinline__ void rdg_flip_stage(ARR a, uint32_t n, uint32_t tid) 
 }
 
 // half-cleaners J, J/2, ..., 1; PREV_LOCAL = the stage before was wave-local
-template <int J, int N2, bool PREV_LOCAL, typename ARR>
-__device__ __forceinline__ void rdg_half_stages(ARR a, uint32_t n, uint32_t tid) {
+template <int J, int N2, int THREADS, bool PREV_LOCAL, typename ARR>
+__device__ __forceinline__ void rdg_half_stages(ARR a, uint32_t tid) {
     if constexpr (J >= 1) {
-        constexpr bool local = J <= 64;
+        constexpr bool local = THREADS == 64 || J <= 64;
         rdg_stage_sync<PREV_LOCAL, local>();
-        rdg_half_stage<J, N2>(a, n, tid);
-        rdg_half_stages<J / 2, N2, local>(a, n, tid);
+        rdg_half_stage<J, N2, THREADS>(a, tid);
+        rdg_half_stages<J / 2, N2, THREADS, local>(a, tid);
     }
 }
 
 // merges of size K, 2K, ..., N2 (each: mirrored first step, then half-cleaners K/4 ... 1)
-template <int K, int N2, typename ARR>
-__device__ __forceinline__ void rdg_merge_stages(ARR a, uint32_t n, uint32_t tid) {
+template <int K, int N2, int THREADS, typename ARR>
+__device__ __forceinline__ void rdg_merge_stages(ARR a, uint32_t tid) {
     if constexpr (K <= N2) {
-        constexpr bool local = (K >> 1) <= 64;
+        constexpr bool local = THREADS == 64 || (K >> 1) <= 64;
         if constexpr (K > 2) rdg_stage_sync<true, local>();     // the stage before a merge is the half-cleaner J = 1
-        rdg_flip_stage<K, N2>(a, n, tid);
-        rdg_half_stages<K / 4, N2, local>(a, n, tid);
-        rdg_merge_stages<2 * K, N2>(a, n, tid);
+        rdg_flip_stage<K, N2, THREADS>(a, tid);
+        rdg_half_stages<K / 4, N2, THREADS, local>(a, tid);
+        rdg_merge_stages<2 * K, N2, THREADS>(a, tid);
     }
 }
 
+// workgroup version (256 threads): data in place and visible (barrier after the load); ends with a barrier
 template <typename ARR>
 __device__ __forceinline__ void rdg_bitonic_sort(ARR a, uint32_t n, uint32_t N2, uint32_t tid, uint32_t nthreads) {
-    (void)nthreads;   // 256 by construction (the wave-locality argument above depends on it)
+    (void)nthreads; (void)n;
     switch (N2) {
-        case 2: rdg_merge_stages<2, 2>(a, n, tid); break;
-        case 4: rdg_merge_stages<2, 4>(a, n, tid); break;
-        case 8: rdg_merge_stages<2, 8>(a, n, tid); break;
-        case 16: rdg_merge_stages<2, 16>(a, n, tid); break;
-        case 32: rdg_merge_stages<2, 32>(a, n, tid); break;
-        case 64: rdg_merge_stages<2, 64>(a, n, tid); break;
-        case 128: rdg_merge_stages<2, 128>(a, n, tid); break;
-        case 256: rdg_merge_stages<2, 256>(a, n, tid); break;
-        case 512: rdg_merge_stages<2, 512>(a, n, tid); break;
-        case 1024: rdg_merge_stages<2, 1024>(a, n, tid); break;
-        case 2048: rdg_merge_stages<2, 2048>(a, n, tid); break;
-        case 4096: rdg_merge_stages<2, 4096>(a, n, tid); break;
-        default: rdg_merge_stages<2, 8192>(a, n, tid); break;
+        case 2: rdg_merge_stages<2, 2, 256>(a, tid); break;
+        case 4: rdg_merge_stages<2, 4, 256>(a, tid); break;
+        case 8: rdg_merge_stages<2, 8, 256>(a, tid); break;
+        case 16: rdg_merge_stages<2, 16, 256>(a, tid); break;
+        case 32: rdg_merge_stages<2, 32, 256>(a, tid); break;
+        case 64: rdg_merge_stages<2, 64, 256>(a, tid); break;
+        case 128: rdg_merge_stages<2, 128, 256>(a, tid); break;
+        case 256: rdg_merge_stages<2, 256, 256>(a, tid); break;
+        case 512: rdg_merge_stages<2, 512, 256>(a, tid); break;
+        case 1024: rdg_merge_stages<2, 1024, 256>(a, tid); break;
+        case 2048: rdg_merge_stages<2, 2048, 256>(a, tid); break;
+        case 4096: rdg_merge_stages<2, 4096, 256>(a, tid); break;
+        default: rdg_merge_stages<2, 8192, 256>(a, tid); break;
     }
     __syncthreads();
 }

@@ -67,6 +67,7 @@ class DensifyResult:
     n_clone: int
     n_split: int
     n_pruned: int
+    decisions: Optional[Dict[str, torch.Tensor]] = None   # the clone / split / prune masks that were applied
 
 
 def _gather_rows(src_flat: torch.Tensor, row_len: int, idx: torch.Tensor, dst_flat: torch.Tensor) -> None:
@@ -99,11 +100,15 @@ def rebuild_flat_params(fp: FlatParams, src: torch.Tensor, keep_moments: torch.T
 
 def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad: float,
                       min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01, N: int = 2,
-                      z: Optional[torch.Tensor] = None) -> DensifyResult:
+                      z: Optional[torch.Tensor] = None, decisions: Optional[Dict[str, torch.Tensor]] = None) -> DensifyResult:
     """``fp`` holds at least xyz [P,3], scaling [P,3] (log), rotation [P,4] (raw), opacity [P,1] (logit); every other
     segment (SH features, motion coefficients, ...) is carried along row-wise.  ``per_point``: further [P,...]
     tensors that follow the Gaussians (gaussian_to_time, gaussian_to_time_ind).  ``z``: optional standard-normal
-    draws [N * n_split, 3] for the split children (default: torch.randn on the device)."""
+    draws [N * n_split, 3] for the split children (default: torch.randn on the device).  ``decisions``: replay the
+    masks of an earlier call ({"clone": [P], "split": [P], "prune": [rows after clone + split]}, as returned in
+    ``DensifyResult.decisions``) instead of thresholding this run's statistics -- for experiments that must hold the set
+    of Gaussians fixed across runs (scripts/psnr_delta.py: a borderline Gaussian crossing the gradient threshold in one
+    run and not in the other changes P and, from there, the whole trajectory)."""
     if not fp.flat.is_cuda:
         raise RuntimeError("rodygs_amd.densify_and_prune: buffers must be on the GPU (no CPU fallback exists)")
     if fp.shapes["scaling"][1:] != (3,):
@@ -117,6 +122,8 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         small = max_s <= percent_dense * extent
         clone_mask = (torch.norm(grads, dim=-1) >= max_grad) & small                    # rodygs_static.py:244-251
         split_mask = (grads.squeeze(-1) >= max_grad) & ~small                            # :185-193 (clones: grad 0)
+        if decisions is not None:
+            clone_mask, split_mask = decisions["clone"].to(dev), decisions["split"].to(dev)
         idx_all = torch.arange(P, device=dev)
         idx_clone = idx_all[clone_mask]
         idx_split = idx_all[split_mask]
@@ -135,6 +142,9 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         prune = opac < min_opacity
         if max_screen_size:
             prune = prune | (scale_now > 0.1 * extent)                                   # max_radii2D was just zeroed
+        if decisions is not None:
+            prune = decisions["prune"].to(dev)
+        used = {"clone": clone_mask.clone(), "split": split_mask.clone(), "prune": prune.clone()}
         keep = ~prune
         src, kind, child_no = src[keep], kind[keep], child_no[keep]
         out = rebuild_flat_params(fp, src, kind == 0)
@@ -158,7 +168,7 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         invalidate_birth_order_cache()       # the per-point tensors (birth indices) are new objects from here on
         n_new = int(src.numel())
         return DensifyResult(out, DensifyStats.zeros(n_new, dev), new_pp, n_clone, n_sel,
-                             int(prune.sum()) + n_sel)
+                             int(prune.sum()) + n_sel, used)
 
 
 def reset_opacity_(fp: FlatParams, name: str = "opacity", max_opacity: float = 0.01) -> None:

@@ -298,7 +298,8 @@ class DynamicScene:
         self.stats = DensifyStats.zeros(self.P, self.device)
 
     def densify(self, max_grad: float = 0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
-                max_screen_size=None, percent_dense: float = 0.01, z: Optional[torch.Tensor] = None) -> dict:
+                max_screen_size=None, percent_dense: float = 0.01, z: Optional[torch.Tensor] = None,
+                decisions=None) -> dict:
         """densify_and_prune over the flat bucket, then re-point everything that referred to the old buffers
         (gradient sinks live in the new bucket, birth indices follow the Gaussians, exchange object rebuilt)."""
         from .densify import allreduce_stats_, densify_and_prune
@@ -307,12 +308,13 @@ class DynamicScene:
         allreduce_stats_(self.stats)
         res = densify_and_prune(self.fp, self.stats, {"time_ind": self.time_ind}, max_grad, min_opacity,
                                 extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense,
-                                z=z)
+                                z=z, decisions=decisions)
         self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
         self.P = self.fp.shapes["xyz"][0]
         self.m2 = torch.zeros(self.P, 3, device=self.device, requires_grad=True)
         self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
-        return {"P": self.P, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned}
+        return {"P": self.P, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned,
+                "decisions": res.decisions}
 
     def make_ground_truth(self, target_scene: dict, frames):
         """GT images = HIP render of a different-seed static cloud from each frame's camera."""
