@@ -334,7 +334,14 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restric
                        const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
                        const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_cnt,
                        const uint2* __restrict__ ranges, uint32_t* __restrict__ rank_buf,
-                       uint64_t* __restrict__ comp, long long capacity, const int32_t* __restrict__ num_rendered) {
+                       uint64_t* __restrict__ comp, long long capacity, const int32_t* __restrict__ num_rendered,
+                       uint4* __restrict__ zero16, long long n_zero16) {
+    // scatter pass: also clears the compositing stage's visit record (one launch and one stream boundary less than a
+    // memset of its own); must happen on the overflow path too -- the forward then renders an empty scene
+    if (MODE == 1)
+        for (long long i = (long long)blockIdx.x * RDG_PRE_BLOCK + threadIdx.x; i < n_zero16;
+             i += (long long)gridDim.x * RDG_PRE_BLOCK)
+            zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     if ((long long)(*num_rendered) > capacity) return;
     __shared__ uint32_t sOff[RDG_PRE_BLOCK];
     __shared__ uint32_t sDepth[RDG_PRE_BLOCK];
@@ -433,15 +440,20 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
     // the counters of a thread's run are fetched 8 at a time with independent loads (one memory latency per 8 tiles,
     // not per tile: this single workgroup sits on the critical path of every frame)
     uint32_t mine = 0, big = 0;
-    for (int c0 = t0; c0 < t1; c0 += 8) {
-        uint32_t vv[8];
+    // (x, y) of the run's first tile by ONE division; the rest by stepping along the row
+    const uint32_t x_first = (uint32_t)(t0 % gx), y_first = (uint32_t)(t0 / gx);
+    {
+        uint32_t x = x_first, y = y_first;
+        for (int c0 = t0; c0 < t1; c0 += 8) {
+            uint32_t vv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int i = c0 + q;
-            vv[q] = i < t1 ? tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))] : 0u;
+            for (int q = 0; q < 8; ++q) {
+                vv[q] = c0 + q < t1 ? tile_cnt[rdg_zidx(x, y)] : 0u;
+                if (++x == (uint32_t)gx) { x = 0; ++y; }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { mine += vv[q]; big = max(big, vv[q]); }
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { mine += vv[q]; big = max(big, vv[q]); }
     }
     const uint32_t inc = rdg_wave_scan_incl(mine);
     if (lane == 63) wtot[w] = inc;
@@ -449,12 +461,13 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
     if (max_tile_out) atomicMax(&sMaxTile, big);
     uint32_t run = inc - mine;
     for (uint32_t k = 0; k < w; ++k) run += wtot[k];
+    uint32_t x2 = x_first, y2 = y_first;
     for (int c0 = t0; c0 < t1; c0 += 8) {
       uint32_t vv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-          const int i = c0 + q;
-          vv[q] = i < t1 ? tile_cnt[rdg_zidx((uint32_t)(i % gx), (uint32_t)(i / gx))] : 0u;
+          vv[q] = c0 + q < t1 ? tile_cnt[rdg_zidx(x2, y2)] : 0u;
+          if (++x2 == (uint32_t)gx) { x2 = 0; ++y2; }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -821,7 +834,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
-                               (long long)capacity, num_rendered);
+                               (long long)capacity, num_rendered, (uint4*)nullptr, 0ll);
         const RdgHeavyLayout HL = rdg_heavy_layout(capacity);
         char* hv = b + B.heavy;
         uint32_t* hv_header = (uint32_t*)(hv + HL.header);
@@ -835,7 +848,12 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
-                               (long long)capacity, num_rendered);
+                               (long long)capacity, num_rendered, (uint4*)(b + B.hit),
+                               (long long)(rdg_hit_bytes(capacity, n_tiles) / 16));
+        else {
+            hipError_t eh = hipMemsetAsync(b + B.hit, 0, rdg_hit_bytes(capacity, n_tiles), s);
+            if (eh != hipSuccess) return rdg_check_hip(eh, "hit bits memset");
+        }
         rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
         rdg_stage_begin(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
@@ -851,6 +869,10 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         return rdg_check_hip(hipGetLastError(), "bucket bin launch");
     }
 
+    {
+        hipError_t eh = hipMemsetAsync(b + B.hit, 0, rdg_hit_bytes(capacity, n_tiles), s);
+        if (eh != hipSuccess) return rdg_check_hip(eh, "hit bits memset");
+    }
     rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
     if (d.P > 0) {
         const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;

@@ -211,9 +211,8 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const uint32_t* plist = (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a));
     char* im = (char*)image_ws;
     const int nblk = ((n_tiles + 7) / 8) * 8;
+    // zeroed by the binning stage (rdg_launch_bin), which always runs before this launch
     unsigned long long* hitbits = (unsigned long long*)((char*)bin_ws + B.hit);
-    hipError_t em = hipMemsetAsync(hitbits, 0, rdg_hit_bytes(capacity, n_tiles), s);
-    if (em != hipSuccess) return rdg_check_hip(em, "hit bits memset");
     hipLaunchKernelGGL(rdg_render_fwd_kernel, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, d.render_normal,
                        bg, (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),
                        (long long)capacity, num_rendered, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),

@@ -198,20 +198,32 @@ def test_eval_pose_helpers_against_reference_golden():
 
 def test_committed_bench_line_honours_the_contract():
     """The bench line committed under profiles/ (printed by `python bench.py` on the GPU box) carries every field of
-    the measurement contract: the driver's keys, `roofline` for the dominant kernel and `cpu_baseline`."""
+    the measurement contract: the driver's keys, `roofline` for the dominant kernel and `cpu_baseline`; no stage is
+    credited with more bytes than 8 TB/s could move in its time; the workload label is derived, not hard-coded."""
     import json
-    d = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r01_v10_bench.json")))
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r02_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["points"] == 1000000
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert "no extrapolation" in c["sample"] and c["c2_full"]["value"] > 0 and len(c["c2_full"]["runs_s"]) == 3
     assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-6 * d["value"]
+    for name, st in d["stage_roofline"].items():
+        assert st["hbm_frac"] is None or 0.0 < st["hbm_frac"] <= 1.0, (name, st)
+    assert 0.0 < d["step_roofline"]["frac_of_8TBps"] <= 1.0
+    # the step's byte count is the sum of the per-stage counts bench.stage_bytes prices
+    import bench
+    cfg = d["config"]
+    sb = bench.stage_bytes(cfg["points"], 16, cfg["visible_V"], cfg["num_rendered_D"], cfg["height"], cfg["width"],
+                           sh_adam_in_backward=cfg["sh_adam_in_backward"], radix_binning=cfg["binning"] == "radix")
+    assert sum(sb.values()) == d["step_roofline"]["algorithmic_bytes_per_step"]
 
 
 def test_bench_accounting_follows_the_algorithm_that_runs():
