@@ -278,16 +278,28 @@ __device__ __forceinline__ void rdg_rows_to_lds(const float* __restrict__ g, lon
     const long long base = first_row * row, total = n_rows * row;
     const float inv_row = 1.0f / (float)row;
     if ((row & 3) == 0 && (((uintptr_t)g) & 15) == 0) {
-        for (int v = lane; v < 16 * row; v += 64) {
-            const long long e = base + 4ll * v;
-            if (e < total) {
-                typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
+        typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
+        // four 16-B loads in flight per lane before the first LDS store (the callers run at 2 waves per SIMD)
+        for (int v0 = lane; v0 < 16 * row; v0 += 256) {
+            rdg_nt4 val[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + 64 * u;
+                const long long e = base + 4ll * v;
                 // NT = false: the rows will be read again soon (another camera of the same step): keep them cached
-                const rdg_nt4 val = NT ? __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(g + e))
-                                       : *reinterpret_cast<const rdg_nt4*>(g + e);
-                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
-                float* dst = S + gi * stride + (4 * v - gi * row);
-                dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+                if (v < 16 * row && e < total)
+                    val[u] = NT ? __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(g + e))
+                                : *reinterpret_cast<const rdg_nt4*>(g + e);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int v = v0 + 64 * u;
+                const long long e = base + 4ll * v;
+                if (v < 16 * row && e < total) {
+                    const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                    float* dst = S + gi * stride + (4 * v - gi * row);
+                    dst[0] = val[u].x; dst[1] = val[u].y; dst[2] = val[u].z; dst[3] = val[u].w;
+                }
             }
         }
     } else {
@@ -376,27 +388,42 @@ __device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const R
     const float inv_row = 1.0f / (float)row;
     typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
     if ((row & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)ad.m) | ((uintptr_t)ad.v)) & 15) == 0) {
-        for (int v = lane; v < 16 * row; v += 64) {
-            const long long e = base + 4ll * v;
-            if (e < total) {
-                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
-                const int col = 4 * v - gi * row;
-                const float* src = S + gi * stride + col;
-                rdg_nt4 pp = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(p + e));
-                rdg_nt4 mm = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.m + e));
-                rdg_nt4 vv = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.v + e));
-                float P4[4] = {pp.x, pp.y, pp.z, pp.w}, M4[4] = {mm.x, mm.y, mm.z, mm.w}, V4[4] = {vv.x, vv.y, vv.z, vv.w};
+        // RDG_ADAM_UNROLL chunks per trip with every load issued before the first use: the kernel that calls this runs
+        // two waves per SIMD (186 VGPRs), so the bytes in flight per CU -- not the arithmetic -- set its rate
+#define RDG_ADAM_UNROLL 4
+        for (int v0 = lane; v0 < 16 * row; v0 += 64 * RDG_ADAM_UNROLL) {
+            rdg_nt4 pp[RDG_ADAM_UNROLL], mm[RDG_ADAM_UNROLL], vv[RDG_ADAM_UNROLL];
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    rdg_adam_elem(P4[c], src[c], M4[c], V4[c], (col + c) < ad.head_len ? ad.step_head : ad.step_tail,
-                                  ad.b1, ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
-                pp = rdg_nt4{P4[0], P4[1], P4[2], P4[3]}; mm = rdg_nt4{M4[0], M4[1], M4[2], M4[3]};
-                vv = rdg_nt4{V4[0], V4[1], V4[2], V4[3]};
-                __builtin_nontemporal_store(pp, reinterpret_cast<rdg_nt4*>(p + e));
-                __builtin_nontemporal_store(mm, reinterpret_cast<rdg_nt4*>(ad.m + e));
-                __builtin_nontemporal_store(vv, reinterpret_cast<rdg_nt4*>(ad.v + e));
+            for (int u = 0; u < RDG_ADAM_UNROLL; ++u) {
+                const int v = v0 + 64 * u;
+                const long long e = base + 4ll * v;
+                if (v < 16 * row && e < total) {
+                    pp[u] = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(p + e));
+                    mm[u] = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.m + e));
+                    vv[u] = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.v + e));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RDG_ADAM_UNROLL; ++u) {
+                const int v = v0 + 64 * u;
+                const long long e = base + 4ll * v;
+                if (v < 16 * row && e < total) {
+                    const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                    const int col = 4 * v - gi * row;
+                    const float* src = S + gi * stride + col;
+                    float P4[4] = {pp[u].x, pp[u].y, pp[u].z, pp[u].w}, M4[4] = {mm[u].x, mm[u].y, mm[u].z, mm[u].w};
+                    float V4[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        rdg_adam_elem(P4[c], src[c], M4[c], V4[c], (col + c) < ad.head_len ? ad.step_head : ad.step_tail,
+                                      ad.b1, ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
+                    __builtin_nontemporal_store(rdg_nt4{P4[0], P4[1], P4[2], P4[3]}, reinterpret_cast<rdg_nt4*>(p + e));
+                    __builtin_nontemporal_store(rdg_nt4{M4[0], M4[1], M4[2], M4[3]}, reinterpret_cast<rdg_nt4*>(ad.m + e));
+                    __builtin_nontemporal_store(rdg_nt4{V4[0], V4[1], V4[2], V4[3]}, reinterpret_cast<rdg_nt4*>(ad.v + e));
+                }
             }
         }
+#undef RDG_ADAM_UNROLL
     } else {
         for (int idx = lane; idx < 64 * row; idx += 64) {
             const long long e = base + idx;
