@@ -818,27 +818,67 @@ def test_pearson_depth_losses_match_reference_golden(mode):
     rel_ok(pred2.grad, g[f"local.{tag}.d_pred"], tol=1e-4, what="local d_pred")
 
 
-def test_pearson_depth_loss_full_hd_against_oracle():
-    """1080p, box_p 128, p_corr 0.5 (configs/train/train_kubric_mrig.yaml depth losses): 60 boxes drawn on the GPU
-    exactly as the reference draws them; value and gradient against the CPU oracle on the same corners."""
+@pytest.mark.parametrize("H,W", [(1080, 1920), (2160, 3840)])     # BASELINE configs[2..3] and configs[4] image sizes
+def test_pearson_depth_loss_full_hd_against_oracle(H, W):
+    """1080p and 4K, box_p 128, p_corr 0.5 (configs/train/train_kubric_mrig.yaml depth losses): 60 / 240 boxes drawn on
+    the GPU exactly as the reference draws them; value and gradient against the CPU oracle on the same corners."""
+    import math as _m
     from oracle import depth_loss_oracle as DL
     from rodygs_amd.depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
     g = torch.Generator().manual_seed(8)
-    H, W = 1080, 1920
+    n_box = int(0.5 * _m.floor(H / 128) * _m.floor(W / 128))
     gt = torch.rand(1, H, W, generator=g) * 15 + 2
     p0 = gt * 1.3 - 1.0 + torch.randn(1, H, W, generator=g)
     torch.manual_seed(5)
-    rows = torch.randint(0, H - 128, size=(60,), device=DEV)
-    cols = torch.randint(0, W - 128, size=(60,), device=DEV)
+    rows = torch.randint(0, H - 128, size=(n_box,), device=DEV)
+    cols = torch.randint(0, W - 128, size=(n_box,), device=DEV)
     torch.manual_seed(5)
     pred = p0.clone().to(DEV).requires_grad_(True)
     loss = LocalPearsonDepthLoss(128, 0.5)(pred, gt.to(DEV)) + GlobalPearsonDepthLoss()(pred, gt.to(DEV))
     loss.backward()
     po = p0.clone().requires_grad_(True)
-    lo = DL.local_pearson_depth_loss(po, gt, rows.cpu(), cols.cpu(), 128, 60) + DL.pearson_depth_loss(po, gt)
+    lo = DL.local_pearson_depth_loss(po, gt, rows.cpu(), cols.cpu(), 128, n_box) + DL.pearson_depth_loss(po, gt)
     lo.backward()
     assert abs(float(loss) - float(lo)) <= 1e-5 * abs(float(lo))
-    rel_ok(pred.grad, po.grad, tol=1e-4, what="d_pred 1080p")
+    rel_ok(pred.grad, po.grad, tol=1e-4, what=f"d_pred {W}x{H}")
+
+
+def test_config5_shape_full_loss_step_at_4m_4k():
+    """BASELINE configs[4] shape on one GPU: 4 M dynamic Gaussians, 3840x2160, the whole loss set of the reference's
+    dynamic sub-step (photometric + global / local Pearson depth + motion L1 / sparsity / basis regularisers + rigidity
+    on the HIP K-NN every 5th step).  Too big for the oracle as a whole (its pieces are compared at this size above and
+    in the sampled-tile test): here the step must run on the rigidity path and on the plain path, keep every parameter
+    finite, move the loss down, and the per-Gaussian motion regularisers must equal their torch expression at 4 M rows."""
+    from rodygs_amd.motion_losses import fused_motion_l1_sparsity
+    from rodygs_amd.trainstep import DynamicScene
+    P, W, H = 4000000, 3840, 2160
+    sc = O.synthetic_scene(P, W, H, 3, seed=777)
+    tgt = O.synthetic_scene(P // 4, W, H, 3, seed=1234)
+    ds = DynamicScene(sc, num_frames=100, device=DEV, full_losses=True, spatial_order=True)
+    frames = [0, 25, 50, 75]
+    ds.make_ground_truth(tgt, frames)
+    del tgt
+    losses = [float(ds.train_step(s_, perm=frames)) for s_ in range(7)]       # steps 0 and 5: rigidity path
+    assert all(np.isfinite(losses)), losses
+    assert losses[6] < losses[1] and losses[5] < losses[0], losses
+    for k in ds.fp.names:
+        assert bool(torch.isfinite(ds.fp[k]).all()), k
+    assert float(ds.fp["motion_coeff"].grad.abs().sum()) > 0 and float(ds.sp["cam_t"].grad.abs().sum()) > 0
+    # motion L1 + sparsity at 4 M rows against the reference's torch expression (losses.py:363-420)
+    c = ds.fp["motion_coeff"].detach().clone().requires_grad_(True)
+    sink = torch.zeros_like(c)
+    lf = fused_motion_l1_sparsity(c, 0.01, 0.002, grad_sink=sink)
+    lf.backward()
+    from rodygs_amd.motion_losses import MotionL1Loss, MotionSparsityLoss      # host mirrors pinned by golden G9
+    cr = c.detach().clone().requires_grad_(True)
+
+    class _M:
+        _motion_coeff = cr
+
+    lref = 0.01 * MotionL1Loss()(_M) + 0.002 * MotionSparsityLoss()(_M)
+    lref.backward()
+    assert abs(float(lf) - float(lref)) <= 2e-5 * abs(float(lref)), (float(lf), float(lref))
+    rel_ok(sink, cr.grad, tol=1e-4, what="motion regulariser gradient at 4 M")
 
 
 @pytest.mark.parametrize("max_screen_size", [None, 20])
