@@ -595,6 +595,131 @@ __device__ __forceinline__ void rdg_bitonic_sort(ARR a, uint32_t n, uint32_t N2,
     __syncthreads();
 }
 
+// ---- lists of up to 1024 instances: one WAVE per tile, E = N2 / 64 consecutive elements per LANE ------------------
+// The LDS network above moves every element through LDS once per stage (45-55 stages) and is bound by the LDS store
+// path.  Here a lane keeps E consecutive elements of the list in registers: every comparator whose partner distance is
+// below E is a register-to-register compare-exchange, and only the stages that pair different lanes go through LDS --
+// the wave writes its elements transposed (element e of lane L at [e][L]: conflict-free), and every lane reads the E
+// elements of its partner lane (L ^ mask; mirrored element order for the first step of a merge).  21 LDS round trips
+// instead of 45 (512 slots) or 55 (1024).  One wave owns the whole list, so there is no workgroup barrier at all.
+// Same ascending network (mirrored first step + half-cleaners), slots >= n hold +inf.
+__device__ __forceinline__ void rdg_cx(uint64_t& x, uint64_t& y) {     // in-register compare-exchange, min to x
+    const bool sw = x > y;
+    const uint64_t lo = sw ? y : x, hi = sw ? x : y;
+    x = lo; y = hi;
+}
+
+// merge of size K (K <= E) inside every lane: mirrored first step, then half-cleaners K/4 ... 1
+template <int K, int E>
+__device__ __forceinline__ void rdg_lane_merge_reg(uint64_t (&v)[E]) {
+#pragma unroll
+    for (int b = 0; b < E; b += K)
+#pragma unroll
+        for (int o = 0; o < K / 2; ++o) rdg_cx(v[b + o], v[b + K - 1 - o]);
+#pragma unroll
+    for (int J = K / 4; J >= 1; J >>= 1)
+#pragma unroll
+        for (int idx = 0; idx < E / 2; ++idx) {
+            const int i = idx + (idx & ~(J - 1));
+            rdg_cx(v[i], v[i + J]);
+        }
+}
+
+// half-cleaners J = JTOP ... 1 inside every lane (JTOP < E)
+template <int JTOP, int E>
+__device__ __forceinline__ void rdg_lane_halves_reg(uint64_t (&v)[E]) {
+#pragma unroll
+    for (int J = JTOP; J >= 1; J >>= 1)
+#pragma unroll
+        for (int idx = 0; idx < E / 2; ++idx) {
+            const int i = idx + (idx & ~(J - 1));
+            rdg_cx(v[i], v[i + J]);
+        }
+}
+
+// one stage that pairs lane L with lane L ^ M through LDS; MIRROR: partner element E - 1 - e (first step of a merge)
+template <int M, bool MIRROR, int E>
+__device__ __forceinline__ void rdg_lane_cross(uint64_t (&v)[E], uint64_t* a, uint32_t lane, bool lower) {
+    rdg_wave_lds_sync();                 // every lane is done reading the previous exchange
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e * 64 + lane] = v[e];
+    rdg_wave_lds_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint64_t p = a[(MIRROR ? E - 1 - e : e) * 64 + (lane ^ (uint32_t)M)];
+        const bool take = lower ? (p < v[e]) : (p > v[e]);
+        v[e] = take ? p : v[e];
+    }
+}
+
+// half-cleaners with partner distance J = JE * E >= E (lane distance JE), down to lane distance 1
+template <int JE, int E>
+__device__ __forceinline__ void rdg_lane_halves_cross(uint64_t (&v)[E], uint64_t* a, uint32_t lane) {
+    if constexpr (JE >= 1) {
+        rdg_lane_cross<JE, false, E>(v, a, lane, (lane & (uint32_t)JE) == 0u);
+        rdg_lane_halves_cross<JE / 2, E>(v, a, lane);
+    }
+}
+
+// merges whose size KE * E spans several lanes (KE = 2, 4, ..., 64)
+template <int KE, int E>
+__device__ __forceinline__ void rdg_lane_merges_cross(uint64_t (&v)[E], uint64_t* a, uint32_t lane) {
+    if constexpr (KE <= 64) {
+        rdg_lane_cross<KE - 1, true, E>(v, a, lane, (lane & (uint32_t)(KE / 2)) == 0u);
+        rdg_lane_halves_cross<KE / 4, E>(v, a, lane);
+        if constexpr (E >= 2) rdg_lane_halves_reg<E / 2, E>(v);
+        rdg_lane_merges_cross<2 * KE, E>(v, a, lane);
+    }
+}
+
+template <int K, int E>
+__device__ __forceinline__ void rdg_lane_merges_reg(uint64_t (&v)[E]) {
+    if constexpr (K <= E) {
+        rdg_lane_merge_reg<K, E>(v);
+        rdg_lane_merges_reg<2 * K, E>(v);
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void rdg_tile_sort_lanes(const uint64_t* __restrict__ g, uint32_t n, uint32_t first,
+                                                    uint32_t tile, uint64_t* a, uint32_t lane,
+                                                    uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out) {
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const uint32_t i = lane * E + e; v[e] = i < n ? g[i] : ~0ull; }
+    rdg_lane_merges_reg<2, E>(v);            // merges of 2 .. E elements: inside the lanes
+    rdg_lane_merges_cross<2, E>(v, a, lane); // merges of 2 E .. 64 E elements
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = lane * E + e;
+        if (i < n) {
+            vals_out[first + i] = (uint32_t)v[e];
+            if (keys_full_out) keys_full_out[first + i] = ((uint64_t)tile << 32) | (v[e] >> 32);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rdg_tile_sort_lanes_kernel(int n_tiles, const uint2* __restrict__ ranges, const uint64_t* __restrict__ comp,
+                           uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out, long long capacity,
+                           const int32_t* __restrict__ num_rendered) {
+    if ((long long)(*num_rendered) > capacity) return;
+    __shared__ uint64_t sA[4][RDG_TSORT_SMALL];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + (int)wv;
+    if (tile >= n_tiles) return;
+    const uint2 rg = ranges[tile];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0 || n > RDG_TSORT_SMALL) return;
+    const uint64_t* g = comp + rg.x;
+    uint64_t* a = sA[wv];
+    if (n <= 64) rdg_tile_sort_lanes<1>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+    else if (n <= 128) rdg_tile_sort_lanes<2>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+    else if (n <= 256) rdg_tile_sort_lanes<4>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+    else if (n <= 512) rdg_tile_sort_lanes<8>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+    else rdg_tile_sort_lanes<16>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+}
+
 // ---- heavy tiles: chunk sort + merge tree over several workgroups --------------------------------------------
 // A tile with n > RDG_TSORT_LDS instances is cut into chunks of RDG_TSORT_LDS; one workgroup sorts each chunk in LDS,
 // then the chunks are merged pairwise up a binary tree.  The tree is climbed WITHOUT waiting: every finished run
@@ -857,9 +982,15 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
         rdg_stage_begin(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
-        hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_SMALL, false>), dim3(n_tiles), dim3(256), 0, s, n_tiles, ranges,
-                           comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header, hv_desc,
-                           hv_work, hv_nodes);
+        static int sort_lds = -1;   // RDG_TILE_SORT=lds: the LDS network for the short lists too (A/B)
+        if (sort_lds < 0) { const char* ev = getenv("RDG_TILE_SORT"); sort_lds = (ev && ev[0] == 'l' && ev[1] == 'd') ? 1 : 0; }
+        if (sort_lds)
+            hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_SMALL, false>), dim3(n_tiles), dim3(256), 0, s, n_tiles,
+                               ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header,
+                               hv_desc, hv_work, hv_nodes);
+        else
+            hipLaunchKernelGGL(rdg_tile_sort_lanes_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, n_tiles, ranges, comp,
+                               vals_out, kfull, (long long)capacity, num_rendered);
         // tiles of 1025 .. 8192 instances (one workgroup each, LDS) + the work items of heavier tiles (chunk sort +
         // merge tree over several workgroups); the grid is sized by the capacity, surplus workgroups exit at once
         hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_LDS, true>), dim3(n_tiles + HL.max_work), dim3(256), 0, s,

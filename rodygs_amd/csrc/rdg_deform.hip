@@ -11,6 +11,14 @@
 // [Tu,16,7] table (ds_add_f32, random rows => few bank conflicts) and flushed once per workgroup with
 // contiguous global float atomics.
 #include "rdg_common.h"
+#include <stdlib.h>
+// workgroups of the single-camera getter kernels (1024 threads, the difference table in LDS: two fit a CU);
+// RDG_GETTER_GRID overrides for probes
+static int rdg_getter_grid_cap() {
+    static int cap = -1;
+    if (cap < 0) { const char* ev = getenv("RDG_GETTER_GRID"); cap = ev ? atoi(ev) : 256; if (cap < 1) cap = 256; }
+    return cap;
+}
 
 #define RDG_DEF_K 7
 #define RDG_DEF_MAXB 16
@@ -864,7 +872,7 @@ int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int6
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int nb = (P + 1023) / 1024;
-    if (nb > 256) nb = 256;
+    if (nb > rdg_getter_grid_cap()) nb = rdg_getter_grid_cap();
     rdg_stage_begin(RDG_STAGE_DEFORM_FWD, st);
     hipLaunchKernelGGL(rdg_dyn_getter_fwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu, coeff,
                        (const long long*)time_ind, bases, spatial_scale, xyz, scaling, rotation, opacity, means3D, scales,
@@ -893,7 +901,7 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
     if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_bwd memset");
     if (P > 0) {
         int nb = (P + 1023) / 1024;
-        if (nb > 256) nb = 256;
+        if (nb > rdg_getter_grid_cap()) nb = rdg_getter_grid_cap();
         hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
