@@ -21,6 +21,7 @@
 #define LH 5
 #define LWX (LTX + 2 * LH)    // 42: tile + halo
 #define LWY (LTY + 2 * LH)
+#define RDG_LOSS_NL ((LWY * LWX + 255) / 256)   // halo-tile elements per thread
 
 struct RdgWin { float w[11]; };
 
@@ -65,12 +66,26 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
     const size_t hw = (size_t)H * Wd;
     const float* X = img + c * hw;
     const float* Y = gt + c * hw;
-    for (int idx = tid; idx < LWY * LWX; idx += 256) {
-        const int r = idx / LWX, cc = idx - r * LWX;
-        const int gy = oy + r - LH, gx = ox + cc - LH;
-        float xv = 0.f, yv = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < Wd) { xv = X[(size_t)gy * Wd + gx]; yv = Y[(size_t)gy * Wd + gx]; }
-        sx[r][cc] = xv; sy[r][cc] = yv;
+    {
+        // the whole halo tile in ONE round of loads per thread (7 elements x 2 images in flight before the first LDS
+        // store): with three workgroups per CU the load phase, not the filters, set this kernel's time
+        float xv[RDG_LOSS_NL], yv[RDG_LOSS_NL];
+#pragma unroll
+        for (int it = 0; it < RDG_LOSS_NL; ++it) {
+            const int idx = tid + 256 * it;
+            const int r = idx / LWX, cc = idx - r * LWX;
+            const int gy = oy + r - LH, gx = ox + cc - LH;
+            xv[it] = 0.f; yv[it] = 0.f;
+            if (idx < LWY * LWX && gy >= 0 && gy < H && gx >= 0 && gx < Wd) {
+                xv[it] = X[(size_t)gy * Wd + gx]; yv[it] = Y[(size_t)gy * Wd + gx];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < RDG_LOSS_NL; ++it) {
+            const int idx = tid + 256 * it;
+            const int r = idx / LWX, cc = idx - r * LWX;
+            if (idx < LWY * LWX) { sx[r][cc] = xv[it]; sy[r][cc] = yv[it]; }
+        }
     }
     __syncthreads();
     // horizontal pass: LWY rows x (LTX / RB) groups of RB outputs
@@ -177,15 +192,25 @@ rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
     if (!rdg_loss_tile((Wd + LTX - 1) / LTX, (H + LTY - 1) / LTY, C, ox, oy, c, bid)) return;
     const size_t hw = (size_t)H * Wd;
     const size_t stride = (size_t)C * hw;
-    for (int idx = tid; idx < LWY * LWX; idx += 256) {
-        const int r = idx / LWX, cc = idx - r * LWX;
-        const int gy = oy + r - LH, gx = ox + cc - LH;
-        float a = 0.f, b = 0.f, d = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < Wd) {
-            const size_t p = c * hw + (size_t)gy * Wd + gx;
-            a = maps[p]; b = maps[stride + p]; d = maps[2 * stride + p];
+    {
+        float a[RDG_LOSS_NL], b[RDG_LOSS_NL], d[RDG_LOSS_NL];
+#pragma unroll
+        for (int it = 0; it < RDG_LOSS_NL; ++it) {
+            const int idx = tid + 256 * it;
+            const int r = idx / LWX, cc = idx - r * LWX;
+            const int gy = oy + r - LH, gx = ox + cc - LH;
+            a[it] = 0.f; b[it] = 0.f; d[it] = 0.f;
+            if (idx < LWY * LWX && gy >= 0 && gy < H && gx >= 0 && gx < Wd) {
+                const size_t p = c * hw + (size_t)gy * Wd + gx;
+                a[it] = maps[p]; b[it] = maps[stride + p]; d[it] = maps[2 * stride + p];
+            }
         }
-        sa[0][r][cc] = a; sa[1][r][cc] = b; sa[2][r][cc] = d;
+#pragma unroll
+        for (int it = 0; it < RDG_LOSS_NL; ++it) {
+            const int idx = tid + 256 * it;
+            const int r = idx / LWX, cc = idx - r * LWX;
+            if (idx < LWY * LWX) { sa[0][r][cc] = a[it]; sa[1][r][cc] = b[it]; sa[2][r][cc] = d[it]; }
+        }
     }
     __syncthreads();
     for (int item = tid; item < LWY * (LTX / RB); item += 256) {
