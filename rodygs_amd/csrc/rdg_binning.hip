@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(1024)
 rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt, uint2* __restrict__ ranges,
                      uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered,
                      uint32_t* __restrict__ hv_header, RdgHeavyDesc* __restrict__ hv_desc, uint2* __restrict__ hv_work,
-                     uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_work,
+                     uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_chunks, uint32_t max_work,
                      int32_t* __restrict__ max_tile_out) {
     if ((long long)(*num_rendered) > capacity) {
         if (threadIdx.x == 0 && max_tile_out) *max_tile_out = 0;
@@ -431,9 +431,9 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
     // every thread owns a run of consecutive tiles (local sums), ONE block-level scan of the 1024 run totals, then the
     // runs are written out: two barriers in all instead of two per 1024 tiles
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t sHeavy, sWork, sMaxTile;
-    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; sMaxTile = 0u; }
-    for (uint32_t i = threadIdx.x; i < 2u * max_work; i += 1024) hv_nodes[i] = 0u;
+    __shared__ uint32_t sHeavy, sWork, sChunks, sMaxTile;
+    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; sChunks = 0u; sMaxTile = 0u; }
+    for (uint32_t i = threadIdx.x; i < 2u * max_chunks; i += 1024) hv_nodes[i] = 0u;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (n_tiles + 1023) / 1024;
     const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
@@ -479,14 +479,18 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
         if (v > RDG_TSORT_LDS) {
             const uint32_t nch = (v + RDG_TSORT_LDS - 1) / RDG_TSORT_LDS;
             const uint32_t h = atomicAdd(&sHeavy, 1u);
+            const uint32_t cb = atomicAdd(&sChunks, nch);
             const uint32_t wb = atomicAdd(&sWork, nch);
-            // sized by construction (rdg_heavy_layout): h < max_heavy and wb + nch <= max_work always hold
-            if (h < max_heavy && wb + nch <= max_work) {
-                RdgHeavyDesc d; d.start = run; d.n = v; d.nchunks = nch; d.node_base = 2u * wb; d.tile = (uint32_t)i;
+            // sized by construction (rdg_heavy_layout): the three bounds always hold
+            if (h < max_heavy && cb + nch <= max_chunks && wb + nch <= max_work) {
+                RdgHeavyDesc d; d.start = run; d.n = v; d.nchunks = nch; d.node_base = 2u * cb; d.tile = (uint32_t)i;
                 d.pad0 = d.pad1 = d.pad2 = 0u;
                 hv_desc[h] = d;
                 for (uint32_t c = 0; c < nch; ++c) hv_work[wb + c] = make_uint2(h, c);
             }
+        } else if (v > RDG_TSORT_SMALL) {
+            const uint32_t wb = atomicAdd(&sWork, 1u);
+            if (wb < max_work) hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0u);
         }
         run += v;
       }
@@ -806,96 +810,103 @@ __device__ void rdg_merge_runs(const uint64_t* __restrict__ A, uint32_t nA, cons
     }
 }
 
-template <int LDS_N, bool LARGE>
-__global__ void __launch_bounds__(256)
-rdg_tile_sort_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __restrict__ comp,
-                     uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out, long long capacity,
-                     const int32_t* __restrict__ num_rendered, uint64_t* __restrict__ alt,
-                     const uint32_t* __restrict__ hv_header, const RdgHeavyDesc* __restrict__ hv_desc,
-                     const uint2* __restrict__ hv_work, uint32_t* __restrict__ hv_nodes) {
-    if ((long long)(*num_rendered) > capacity) return;
-    __shared__ uint64_t sK[LDS_N];
-    const uint32_t tid = threadIdx.x;
-    if (!LARGE || (int)blockIdx.x < n_tiles) {
-        const int tile = blockIdx.x;
-        const uint2 rg = ranges[tile];
-        const uint32_t n = rg.y - rg.x;
-        if (LARGE ? (n <= RDG_TSORT_SMALL || n > (uint32_t)LDS_N) : (n == 0 || n > RDG_TSORT_SMALL)) return;
+// one heavy work item: chunk `chunk` of heavy tile d (leaf sort, then as far up the merge tree as this workgroup gets)
+__device__ void rdg_heavy_item(const RdgHeavyDesc d, uint32_t chunk, uint64_t* __restrict__ comp, uint64_t* __restrict__ alt,
+                               uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out,
+                               uint32_t* __restrict__ hv_nodes, uint64_t* sK, uint32_t* sSplit, uint32_t* sOld,
+                               uint32_t tid) {
+    uint64_t* src = comp + d.start;
+    uint64_t* dst = alt + d.start;
+    {   // leaf: sort my chunk in LDS, in place
+        const uint32_t lo = chunk * (uint32_t)RDG_TSORT_LDS;
+        const uint32_t nc = min((uint32_t)RDG_TSORT_LDS, d.n - lo);
         uint32_t N2 = 2;
-        while (N2 < n) N2 <<= 1;
-        const uint64_t* g = comp + rg.x;
-        for (uint32_t i = tid; i < N2; i += 256) sK[i] = i < n ? g[i] : ~0ull;
+        while (N2 < nc) N2 <<= 1;
+        for (uint32_t i = tid; i < N2; i += 256) sK[i] = i < nc ? src[lo + i] : ~0ull;
         __syncthreads();
-        if (n > 1) rdg_bitonic_sort(sK, n, N2, tid, 256u);
-        for (uint32_t i = tid; i < n; i += 256) {
-            const uint64_t k = sK[i];
-            vals_out[rg.x + i] = (uint32_t)k;
-            if (keys_full_out) keys_full_out[rg.x + i] = ((uint64_t)tile << 32) | (k >> 32);
-        }
-        return;
+        if (nc > 1) rdg_bitonic_sort(sK, nc, N2, tid, 256u);
+        for (uint32_t i = tid; i < nc; i += 256) src[lo + i] = sK[i];
     }
-    if constexpr (LARGE) {
-        // ---- heavy work item: chunk c of heavy tile h ------------------------------------------------------
-        __shared__ uint32_t sSplit[257];
-        __shared__ uint32_t sOld;
-        const uint32_t wi = blockIdx.x - (uint32_t)n_tiles;
-        if (wi >= hv_header[0]) return;
-        const uint2 item = hv_work[wi];
-        const RdgHeavyDesc d = hv_desc[item.x];
-        uint64_t* src = comp + d.start;
-        uint64_t* dst = alt + d.start;
-        {   // leaf: sort my chunk in LDS, in place
-            const uint32_t lo = item.y * (uint32_t)LDS_N;
-            const uint32_t nc = min((uint32_t)LDS_N, d.n - lo);
-            uint32_t N2 = 2;
-            while (N2 < nc) N2 <<= 1;
-            for (uint32_t i = tid; i < N2; i += 256) sK[i] = i < nc ? src[lo + i] : ~0ull;
+    uint32_t idx = chunk;                     // my run's index at the current level
+    uint32_t nrun = d.nchunks;                // runs at the current level
+    uint32_t len = (uint32_t)RDG_TSORT_LDS;   // nominal run length at the current level
+    uint32_t* cnt = hv_nodes + d.node_base;   // counters of the next level's nodes
+    while (nrun > 1) {
+        const uint32_t parent = idx >> 1;
+        const uint32_t lo = parent * 2u * len;
+        const uint32_t mid = min(lo + len, d.n), hi = min(lo + 2u * len, d.n);
+        if ((idx ^ 1u) < nrun) {
+            // publish my run, then see whether the sibling is already there
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (nc > 1) rdg_bitonic_sort(sK, nc, N2, tid, 256u);
-            for (uint32_t i = tid; i < nc; i += 256) src[lo + i] = sK[i];
-        }
-        uint32_t idx = item.y;            // my run's index at the current level
-        uint32_t nrun = d.nchunks;        // runs at the current level
-        uint32_t len = (uint32_t)LDS_N;   // nominal run length at the current level
-        uint32_t* cnt = hv_nodes + d.node_base;   // counters of the next level's nodes
-        while (nrun > 1) {
-            const uint32_t parent = idx >> 1;
-            const uint32_t lo = parent * 2u * len;
-            const uint32_t mid = min(lo + len, d.n), hi = min(lo + 2u * len, d.n);
-            if ((idx ^ 1u) < nrun) {
-                // publish my run, then see whether the sibling is already there
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    sOld = atomicAdd(&cnt[parent], 1u);
-                }
-                __syncthreads();
-                if (sOld == 0u) return;   // first of the two: the sibling's workgroup merges
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __syncthreads();
-                rdg_merge_runs(src + lo, mid - lo, src + mid, hi - mid, dst + lo, sK, sK + RDG_MERGE_OB, sSplit, tid);
-            } else {
-                // no sibling at this level: carry the run over to the other buffer
-                for (uint32_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
+                *sOld = atomicAdd(&cnt[parent], 1u);
             }
-            uint64_t* t = src; src = dst; dst = t;
-            cnt += (nrun + 1u) >> 1;
-            idx = parent;
-            nrun = (nrun + 1u) >> 1;
-            len <<= 1;
+            __syncthreads();
+            if (*sOld == 0u) return;   // first of the two: the sibling's workgroup merges
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            rdg_merge_runs(src + lo, mid - lo, src + mid, hi - mid, dst + lo, sK, sK + RDG_MERGE_OB, sSplit, tid);
+        } else {
+            // no sibling at this level: carry the run over to the other buffer
+            for (uint32_t i = lo + tid; i < hi; i += 256) dst[i] = src[i];
         }
-        // the whole tile is one sorted run in `src`, written by this workgroup: its own stores are visible to it
-        __syncthreads();
-        for (uint32_t i = tid; i < d.n; i += 256) {
-            const uint64_t k = src[i];
-            vals_out[d.start + i] = (uint32_t)k;
-            // keys_full_out may BE the spare buffer the runs alternate through: element i is read before it is written
-            if (keys_full_out) keys_full_out[d.start + i] = ((uint64_t)d.tile << 32) | (k >> 32);
+        uint64_t* t = src; src = dst; dst = t;
+        cnt += (nrun + 1u) >> 1;
+        idx = parent;
+        nrun = (nrun + 1u) >> 1;
+        len <<= 1;
+    }
+    // the whole tile is one sorted run in `src`, written by this workgroup: its own stores are visible to it
+    __syncthreads();
+    for (uint32_t i = tid; i < d.n; i += 256) {
+        const uint64_t k = src[i];
+        vals_out[d.start + i] = (uint32_t)k;
+        // keys_full_out may BE the spare buffer the runs alternate through: element i is read before it is written
+        if (keys_full_out) keys_full_out[d.start + i] = ((uint64_t)d.tile << 32) | (k >> 32);
+    }
+}
+
+// Lists of more than RDG_TSORT_SMALL instances: a fixed grid of workgroups walks the device-side work list the scan
+// kernel wrote (tiles of up to RDG_TSORT_LDS instances: one LDS sort each; heavier tiles: one item per chunk, see
+// above).  On an ordinary frame the list is empty and the launch costs one load per workgroup.
+__global__ void __launch_bounds__(256)
+rdg_tile_sort_large_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ comp, uint32_t* __restrict__ vals_out,
+                           uint64_t* __restrict__ keys_full_out, long long capacity,
+                           const int32_t* __restrict__ num_rendered, uint64_t* __restrict__ alt,
+                           const uint32_t* __restrict__ hv_header, const RdgHeavyDesc* __restrict__ hv_desc,
+                           const uint2* __restrict__ hv_work, uint32_t* __restrict__ hv_nodes) {
+    if ((long long)(*num_rendered) > capacity) return;
+    __shared__ uint64_t sK[RDG_TSORT_LDS];
+    __shared__ uint32_t sSplit[257];
+    __shared__ uint32_t sOld;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_work = hv_header[0];
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        __syncthreads();                       // the previous item is done with sK / sSplit / sOld
+        const uint2 item = hv_work[wi];
+        if (item.x & 0x80000000u) {
+            const uint32_t tile = item.x & 0x7fffffffu;
+            const uint2 rg = ranges[tile];
+            const uint32_t n = rg.y - rg.x;
+            uint32_t N2 = 2;
+            while (N2 < n) N2 <<= 1;
+            const uint64_t* g = comp + rg.x;
+            for (uint32_t i = tid; i < N2; i += 256) sK[i] = i < n ? g[i] : ~0ull;
+            __syncthreads();
+            rdg_bitonic_sort(sK, n, N2, tid, 256u);
+            for (uint32_t i = tid; i < n; i += 256) {
+                const uint64_t k = sK[i];
+                vals_out[rg.x + i] = (uint32_t)k;
+                if (keys_full_out) keys_full_out[rg.x + i] = ((uint64_t)tile << 32) | (k >> 32);
+            }
+        } else {
+            rdg_heavy_item(hv_desc[item.x], item.y, comp, alt, vals_out, keys_full_out, hv_nodes, sK, sSplit, &sOld, tid);
         }
     }
 }
@@ -968,7 +979,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         uint32_t* hv_nodes = (uint32_t*)(hv + HL.nodes);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered, hv_header, hv_desc, hv_work, hv_nodes, HL.max_heavy,
-                           HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr);
+                           HL.max_chunks, HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
@@ -982,20 +993,12 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
         rdg_stage_begin(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
-        static int sort_lds = -1;   // RDG_TILE_SORT=lds: the LDS network for the short lists too (A/B)
-        if (sort_lds < 0) { const char* ev = getenv("RDG_TILE_SORT"); sort_lds = (ev && ev[0] == 'l' && ev[1] == 'd') ? 1 : 0; }
-        if (sort_lds)
-            hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_SMALL, false>), dim3(n_tiles), dim3(256), 0, s, n_tiles,
-                               ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header,
-                               hv_desc, hv_work, hv_nodes);
-        else
-            hipLaunchKernelGGL(rdg_tile_sort_lanes_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, n_tiles, ranges, comp,
-                               vals_out, kfull, (long long)capacity, num_rendered);
-        // tiles of 1025 .. 8192 instances (one workgroup each, LDS) + the work items of heavier tiles (chunk sort +
-        // merge tree over several workgroups); the grid is sized by the capacity, surplus workgroups exit at once
-        hipLaunchKernelGGL((rdg_tile_sort_kernel<RDG_TSORT_LDS, true>), dim3(n_tiles + HL.max_work), dim3(256), 0, s,
-                           n_tiles, ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header,
-                           hv_desc, hv_work, hv_nodes);
+        hipLaunchKernelGGL(rdg_tile_sort_lanes_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, n_tiles, ranges, comp,
+                           vals_out, kfull, (long long)capacity, num_rendered);
+        // lists above 1024 instances: a fixed grid walks the device-side work list (empty on an ordinary frame)
+        hipLaunchKernelGGL(rdg_tile_sort_large_kernel, dim3(HL.max_work < 1024u ? HL.max_work : 1024u), dim3(256), 0, s,
+                           ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header, hv_desc,
+                           hv_work, hv_nodes);
         rdg_stage_end(RDG_STAGE_SORT, s);
         return rdg_check_hip(hipGetLastError(), "bucket bin launch");
     }

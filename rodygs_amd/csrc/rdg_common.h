@@ -88,23 +88,25 @@ static inline RdgSortLayout rdg_sort_layout(int64_t capacity) {
 #define RDG_TSORT_LDS 8192
 struct RdgHeavyDesc { uint32_t start, n, nchunks, node_base, tile, pad0, pad1, pad2; };
 struct RdgHeavyLayout {
-    size_t header;   // uint32[64]: [0] = number of work items (chunks), [1] = number of heavy tiles
+    size_t header;   // uint32[64]: [0] = number of work items, [1] = number of heavy tiles
     size_t desc;     // RdgHeavyDesc[max_heavy]
-    size_t work;     // uint2[max_work]  (heavy tile index, chunk index)
-    size_t nodes;    // uint32[2 * max_work]  arrival counters of the merge-tree nodes
+    size_t work;     // uint2[max_work]: (heavy tile index, chunk index), or (0x80000000 | tile, 0) for a tile of
+                     //                  RDG_TSORT_SMALL + 1 .. RDG_TSORT_LDS instances (one workgroup sorts it in LDS)
+    size_t nodes;    // uint32[2 * max_chunks]  arrival counters of the merge-tree nodes
     size_t total;
-    uint32_t max_heavy, max_work;
+    uint32_t max_heavy, max_chunks, max_work;
 };
 static inline RdgHeavyLayout rdg_heavy_layout(int64_t capacity) {
     RdgHeavyLayout L;
     const size_t cap = (size_t)(capacity > 0 ? capacity : 1);
     L.max_heavy = (uint32_t)(cap / RDG_TSORT_LDS + 1);
-    L.max_work = 2 * L.max_heavy;
+    L.max_chunks = 2 * L.max_heavy;
+    L.max_work = L.max_chunks + (uint32_t)(cap / RDG_TSORT_SMALL + 1);
     size_t o = 0;
     L.header = o;  o = rdg_align_up(o + 256, 256);
     L.desc = o;    o = rdg_align_up(o + (size_t)L.max_heavy * sizeof(RdgHeavyDesc), 256);
     L.work = o;    o = rdg_align_up(o + (size_t)L.max_work * 8, 256);
-    L.nodes = o;   o = rdg_align_up(o + (size_t)L.max_work * 2 * 4, 256);
+    L.nodes = o;   o = rdg_align_up(o + (size_t)L.max_chunks * 2 * 4, 256);
     L.total = o;
     return L;
 }
