@@ -77,6 +77,7 @@ static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     d->prefiltered = s->prefiltered; d->cov_grad = s->enable_cov_grad; d->sh_grad = s->enable_sh_grad;
     d->render_normal = s->render_normal;
     d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats;
+    d->tile_cnt_zeroed = 0;
     return 0;
 }
 
@@ -159,11 +160,27 @@ int rdg_rasterize_forward(const RdgRasterSettings* s_host, const float* bg, cons
                           const float* projmatrix, void* geom_ws, void* binning_ws, int64_t capacity, void* image_ws,
                           float* out_color, float* out_depth, float* out_normal, float* out_alpha, int32_t* radii,
                           int32_t* num_rendered_dev, void* stream) {
-    int rc = rdg_preprocess_forward(s_host, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                    viewmatrix, projmatrix, geom_ws, radii, num_rendered_dev, stream);
+    // the same two stages as rdg_preprocess_forward + rdg_composite_forward, with one difference: knowing the image
+    // workspace, the per-Gaussian stage's scan kernel clears the binning counters on its way (no memset launch)
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
+    rdg_stage_begin(RDG_STAGE_PREPROCESS, st);
+    int rc = rdg_launch_preprocess_fwd(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                       viewmatrix, projmatrix, geom_ws, radii, num_rendered_dev, st,
+                                       (uint32_t*)((char*)image_ws + I.tile_cnt), rdg_cnt_entries(d.gx, d.gy));
+    rdg_stage_end(RDG_STAGE_PREPROCESS, st);
     if (rc) return rc;
-    return rdg_composite_forward(s_host, bg, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev,
-                                 out_color, out_depth, out_normal, out_alpha, stream);
+    d.tile_cnt_zeroed = 1;
+    rc = rdg_launch_bin(d, geom_ws, radii, binning_ws, capacity, image_ws, num_rendered_dev, nullptr, nullptr, st);
+    if (rc) return rc;
+    rdg_stage_begin(RDG_STAGE_RENDER_FWD, st);
+    rc = rdg_launch_render_fwd(d, bg, geom_ws, binning_ws, capacity, image_ws, num_rendered_dev, out_color, out_depth,
+                               out_normal, out_alpha, st);
+    rdg_stage_end(RDG_STAGE_RENDER_FWD, st);
+    return rc;
 }
 
 int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,

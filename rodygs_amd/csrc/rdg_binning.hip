@@ -970,8 +970,10 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
         int zbits = 0;
         while (((size_t)1 << zbits) < rdg_cnt_entries(d.gx, d.gy)) ++zbits;
-        hipError_t em = hipMemsetAsync(tile_cnt, 0, rdg_cnt_entries(d.gx, d.gy) * 4, s);
-        if (em != hipSuccess) return rdg_check_hip(em, "tile_cnt memset");
+        if (!d.tile_cnt_zeroed) {
+            hipError_t em = hipMemsetAsync(tile_cnt, 0, rdg_cnt_entries(d.gx, d.gy) * 4, s);
+            if (em != hipSuccess) return rdg_check_hip(em, "tile_cnt memset");
+        }
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,

@@ -184,6 +184,7 @@ struct RdgDev {
     float tanx, tany, fx, fy, smod;
     int32_t prefiltered, cov_grad, sh_grad, render_normal;
     int32_t bin_mode, nren_stats;
+    int32_t tile_cnt_zeroed;   // internal: the per-tile counters were cleared by the per-Gaussian stage's scan kernel
 };
 
 // ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------
@@ -205,7 +206,7 @@ struct RdgShAdam {
 int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, void* geom_ws, int32_t* radii,
-                              int32_t* num_rendered, hipStream_t s);
+                              int32_t* num_rendered, hipStream_t s, uint32_t* zero_buf = nullptr, size_t zero_words = 0);
 int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii, int32_t* num_rendered,
                                  hipStream_t s);
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,

@@ -251,8 +251,11 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
                           const float* __restrict__ g_scales, const float* __restrict__ g_rots,
                           const float* __restrict__ g_opac, float* __restrict__ d_xyz, float* __restrict__ d_scaling,
                           float* __restrict__ d_rotation, float* __restrict__ d_opacity, float* __restrict__ d_coeff,
-                          const int* __restrict__ inv_order, float4* __restrict__ gs) {
+                          const int* __restrict__ inv_order, float4* __restrict__ gs, float* __restrict__ zero_out,
+                          int n_zero) {
     extern __shared__ __attribute__((aligned(16))) float smem_dg[];
+    // the (Tu + 1) x 112 accumulator the NEXT kernel adds into is cleared here (one memset launch less)
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero; k += gridDim.x * blockDim.x) zero_out[k] = 0.0f;
     rdg_diff16_to_lds(smem_dg, Tu, bases);
     __syncthreads();
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
@@ -897,15 +900,17 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
     float* d_table = d_bases;
     float* d_basis_t = d_bases + (size_t)Tu * 112;
     rdg_stage_begin(RDG_STAGE_DEFORM_BWD, st);
-    hipError_t e = hipMemsetAsync(d_bases, 0, (size_t)(Tu + 1) * 112 * 4, st);
-    if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_bwd memset");
+    if (P <= 0) {
+        hipError_t e = hipMemsetAsync(d_bases, 0, (size_t)(Tu + 1) * 112 * 4, st);
+        if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_bwd memset");
+    }
     if (P > 0) {
         int nb = (P + 1023) / 1024;
         if (nb > rdg_getter_grid_cap()) nb = rdg_getter_grid_cap();
         hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
-                           (const int*)inv_order, (float4*)sorted_ws);
+                           (const int*)inv_order, (float4*)sorted_ws, d_bases, (Tu + 1) * 112);
         hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(2048), dim3(256), 0, st, P, coeff,
                            (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,
                            spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws);

@@ -232,7 +232,11 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
 // Exclusive scan of block_sums[0..nblk) in place by ONE 1024-thread block; block_sums[nblk] and *num_rendered
 // receive the total (D).  nblk <= 16384 at P = 4 M, i.e. <= 16 sweeps.
 __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblk,
-                                                                   int32_t* __restrict__ num_rendered) {
+                                                                   int32_t* __restrict__ num_rendered,
+                                                                   uint32_t* __restrict__ zero_buf, int zero_words) {
+    // optional: clear the binning stage's per-tile counters here (this block is otherwise idle most of its life; saves
+    // a memset launch and a stream boundary per frame)
+    for (int i = threadIdx.x; i < zero_words; i += 1024) zero_buf[i] = 0u;
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -295,14 +299,14 @@ int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii,
         hipLaunchKernelGGL(rdg_geom_from_records_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
                            (const RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), block_sums, radii);
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
-                       num_rendered);
+                       num_rendered, (uint32_t*)nullptr, 0);
     return rdg_check_hip(hipGetLastError(), "geom_from_records launch");
 }
 
 int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, void* geom_ws, int32_t* radii,
-                              int32_t* num_rendered, hipStream_t s) {
+                              int32_t* num_rendered, hipStream_t s, uint32_t* zero_buf, size_t zero_words) {
     const RdgGeomLayout L = rdg_geom_layout(d.P);
     char* g = (char*)geom_ws;
     const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
@@ -313,7 +317,7 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
                            (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0);
     }
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
-                       num_rendered);
+                       num_rendered, zero_buf, (int)zero_words);
     return rdg_check_hip(hipGetLastError(), "preprocess_fwd launch");
 }
 

@@ -229,6 +229,7 @@ class DynamicScene:
         # optimizer-in-backward for the SH features (see render()); train_step switches it on for the single-GPU
         # photometric step only -- gradient exchange, densification statistics and extra losses need the plain path
         self.fuse_sh_adam = False
+        self._grad_one = None
         self._plain_full = False     # full_losses on a step without rigidity: the photometric step's fused kernels
         if full_losses:
             from .depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
@@ -419,7 +420,10 @@ class DynamicScene:
             finally:
                 self.fuse_sh_adam = False
             loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
-        loss.backward()
+        # the seed gradient is a resident 1.0 (autograd would otherwise launch a fill kernel for ones_like(loss))
+        if self._grad_one is None or self._grad_one.device != loss.device:
+            self._grad_one = torch.ones((), dtype=torch.float32, device=loss.device)
+        loss.backward(self._grad_one)
         if after is not None:
             loss = loss.detach() + after()
         if self.stats is not None:
