@@ -90,7 +90,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
         if (live) {
             const float4* gr = reinterpret_cast<const float4*>(grow + (size_t)i * RDG_GROW);
             const float4 ga = gr[0], gb = gr[1], gc = gr[2];
-            gnx = ga.x; gny = ga.y;
+            const float m1x = ga.x, m1y = ga.y;   // first moments sum(G dL/dG dx), sum(G dL/dG dy) of the pixel offsets
             const float gca = ga.z, gcb = ga.w, gcc = gb.x;
             gop = gb.y;
             grgb[0] = gb.z; grgb[1] = gb.w; grgb[2] = gc.x;
@@ -104,18 +104,6 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
             float dvx = 0.f, dvy = 0.f, dvz = 0.f;      // common part (projection + depth)
             float evx = 0.f, evy = 0.f, evz = 0.f;      // EWA part (t in the Jacobian)
 
-            // (1) ndc path
-            {
-                const float hx = Pm[0] * vx + Pm[4] * vy + Pm[8] * vz + Pm[12];
-                const float hy = Pm[1] * vx + Pm[5] * vy + Pm[9] * vz + Pm[13];
-                const float hw = Pm[3] * vx + Pm[7] * vy + Pm[11] * vz + Pm[15];
-                const float pw = 1.0f / (hw + 1e-7f);
-                const float dhx = gnx * pw, dhy = gny * pw;
-                const float dhw = -(gnx * hx + gny * hy) * pw * pw;
-                dvx += Pm[0] * dhx + Pm[1] * dhy + Pm[3] * dhw;
-                dvy += Pm[4] * dhx + Pm[5] * dhy + Pm[7] * dhw;
-                dvz += Pm[8] * dhx + Pm[9] * dhy + Pm[11] * dhw;
-            }
             // (2) depth
             dvz += gdepth;
 
@@ -160,6 +148,25 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
             const float b = u00 * T10 + u01 * T11 + u02 * T12;
             const float c = u10 * T10 + u11 * T11 + u12 * T12 + RDG_DILATION;
             const float det = a * c - b * b;
+            // (1) ndc path.  The compositing backward hands over the FIRST MOMENTS of G dL/dG over the pixel offsets;
+            // dL/dmean2D = -(conic . moments), and the pixel -> ndc factors 0.5 W, 0.5 H are applied here, once per
+            // Gaussian, instead of per pixel-splat pair there (conic = Sigma2D^-1 = (c, -b, a) / det)
+            if (det != 0.0f) {
+                const float idet = 1.0f / det;
+                gnx = -0.5f * (float)d.W * ((c * idet) * m1x - (b * idet) * m1y);
+                gny = -0.5f * (float)d.H * ((a * idet) * m1y - (b * idet) * m1x);
+            }
+            {
+                const float hx = Pm[0] * vx + Pm[4] * vy + Pm[8] * vz + Pm[12];
+                const float hy = Pm[1] * vx + Pm[5] * vy + Pm[9] * vz + Pm[13];
+                const float hw = Pm[3] * vx + Pm[7] * vy + Pm[11] * vz + Pm[15];
+                const float pw = 1.0f / (hw + 1e-7f);
+                const float dhx = gnx * pw, dhy = gny * pw;
+                const float dhw = -(gnx * hx + gny * hy) * pw * pw;
+                dvx += Pm[0] * dhx + Pm[1] * dhy + Pm[3] * dhw;
+                dvy += Pm[4] * dhx + Pm[5] * dhy + Pm[7] * dhw;
+                dvz += Pm[8] * dhx + Pm[9] * dhy + Pm[11] * dhw;
+            }
             // (3) conic -> cov2D
             float da = 0.f, db = 0.f, dc = 0.f;
             if (det != 0.0f) {

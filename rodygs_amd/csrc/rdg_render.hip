@@ -302,9 +302,9 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
     int ring_n = 0;   // wave-uniform fill level of this wave's ring
     const int fc = lane & 15;
-    const float flush_scale = fc == 0 ? (-0.5f / RDG_NEG_LOG2E) * (float)W
-                            : fc == 1 ? (-0.5f / RDG_NEG_LOG2E) * (float)H
-                            : (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : (fc == 9 && !HAS_DEPTH) ? 0.0f : 1.0f;
+    // components 0, 1 are the raw first moments sum(G dL/dG dx), sum(G dL/dG dy): the per-Gaussian backward turns them
+    // into dL/dmean2D with the conic it has anyway (two multiplies and two fused multiply-adds per pair less here)
+    const float flush_scale = (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : (fc == 9 && !HAS_DEPTH) ? 0.0f : 1.0f;
 
     for (int r = 0; r < rounds; ++r) {
         const int kbase = kmax - 1 - r * RDG_BATCH;  // list position of slot 0 of this batch
@@ -374,16 +374,14 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 }
                 dL_dalpha = dL_dalpha * T + (T_final * inv1ma) * tail;
                 dL_dalpha = hit ? dL_dalpha : 0.0f;
-                // The constant factors of the five geometric derivatives (0.5 W / log2 e, 0.5 H / log2 e, -0.5, -1, -0.5)
-                // are applied once per flushed row total (rdg_ring_flush), not per pixel-splat pair.
+                // The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per flushed row total
+                // (rdg_ring_flush), not per pixel-splat pair.
                 const float g5 = G * dL_dalpha;
                 const float Gw = g5 * q1.y;                         // G * dL/dG
-                const float g0 = Gw * fmaf(q0.w, dy, t_);           // ~ dL/d(mean2D.x)
-                const float g1 = Gw * fmaf(q0.w, dx, v_);           // ~ dL/d(mean2D.y)
-                const float gX = Gw * dx, gY = Gw * dy;
-                const float g2 = gX * dx;                           // ~ dL/d(conic a)
-                const float g3 = gX * dy;                           // ~ dL/d(conic b)
-                const float g4 = gY * dy;                           // ~ dL/d(conic c)
+                const float g0 = Gw * dx, g1 = Gw * dy;             // first moments (-> dL/d(mean2D) per Gaussian)
+                const float g2 = g0 * dx;                           // ~ dL/d(conic a)
+                const float g3 = g0 * dy;                           // ~ dL/d(conic b)
+                const float g4 = g1 * dy;                           // ~ dL/d(conic c)
                 const float g6 = dch * dLp0, g7 = dch * dLp1, g8 = dch * dLp2, g9 = HAS_DEPTH ? dch * dLd : 0.0f;
                 // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds), fold the VALUE index into
                 // the lane index while reducing.  DPP write masks work on quads (bank_mask: 4 lanes) and rows, so the
