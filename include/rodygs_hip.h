@@ -130,7 +130,8 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
  *       (px, py, conic_a, conic_b | conic_c, opacity, depth, radius as int bits | r, g, b, - | nx, ny, nz, -);
  *   - gradient rows: the first P*64 bytes of grad_ws, one 16-float row per Gaussian
  *       (m1x, m1y = sum over pixels of G dL/dG (px - x), G dL/dG (py - y): dL/dmean2D = -conic . (m1x, m1y) is formed by
- *        rdg_preprocess_backward; dL/dconic a b c, dL/dopacity, dL/drgb, dL/ddepth, pad).
+ *        rdg_preprocess_backward; dL/dconic a b c -- these five divided by the Gaussian's opacity, which
+ *        rdg_preprocess_backward multiplies back in --, dL/dopacity, dL/drgb, dL/ddepth, pad).
  * A rank that owns a slice of the Gaussians runs the per-Gaussian halves for every camera of the step; the rank that
  * owns a camera gathers that camera's records into one geom_ws, calls rdg_geom_from_records (tile counts, radii and
  * the instance count D rebuilt from the records alone) and runs the compositing halves over all P records.        */

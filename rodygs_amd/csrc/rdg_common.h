@@ -27,7 +27,7 @@ struct __attribute__((aligned(64))) RdgRec {
 
 // 64-byte per-Gaussian gradient accumulator row (one 64-B atomic request per (tile, splat)):
 //   [0] [1] first moments sum(G dL/dG dx), sum(G dL/dG dy) of the pixel offsets (dL/dmean2D = -conic . moments,
-//   formed by the per-Gaussian backward)  [2..4] dL/dconic(a,b,c)  [5] dL/dopacity  [6..8] dL/drgb  [9] dL/ddepth
+//   formed by the per-Gaussian backward)  [2..4] dL/dconic(a,b,c) -- these five DIVIDED BY THE OPACITY  [5] dL/dopacity  [6..8] dL/drgb  [9] dL/ddepth
 #define RDG_GROW 16
 
 static inline size_t rdg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

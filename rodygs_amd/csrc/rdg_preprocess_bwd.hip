@@ -90,8 +90,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
         if (live) {
             const float4* gr = reinterpret_cast<const float4*>(grow + (size_t)i * RDG_GROW);
             const float4 ga = gr[0], gb = gr[1], gc = gr[2];
-            const float m1x = ga.x, m1y = ga.y;   // first moments sum(G dL/dG dx), sum(G dL/dG dy) of the pixel offsets
-            const float gca = ga.z, gcb = ga.w, gcc = gb.x;
+            // the five geometric sums arrive divided by the opacity (a per-splat constant the compositing backward does
+            // not multiply every pixel-splat pair with): first moments sum(G dL/dG dx), sum(G dL/dG dy), conic gradients
+            const float o_ = opac[i];
+            const float m1x = o_ * ga.x, m1y = o_ * ga.y;
+            const float gca = o_ * ga.z, gcb = o_ * ga.w, gcc = o_ * gb.x;
             gop = gb.y;
             grgb[0] = gb.z; grgb[1] = gb.w; grgb[2] = gc.x;
             const float gdepth = gc.y;

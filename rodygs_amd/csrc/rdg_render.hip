@@ -376,9 +376,9 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 dL_dalpha = hit ? dL_dalpha : 0.0f;
                 // The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per flushed row total
                 // (rdg_ring_flush), not per pixel-splat pair.
-                const float g5 = G * dL_dalpha;
-                const float Gw = g5 * q1.y;                         // G * dL/dG
-                const float g0 = Gw * dx, g1 = Gw * dy;             // first moments (-> dL/d(mean2D) per Gaussian)
+                const float g5 = G * dL_dalpha;                     // dL/dopacity; G dL/dG = opacity * g5 -- the opacity is a
+                //                                                     per-splat constant: applied by the per-Gaussian backward
+                const float g0 = g5 * dx, g1 = g5 * dy;             // first moments / opacity (-> dL/d(mean2D) per Gaussian)
                 const float g2 = g0 * dx;                           // ~ dL/d(conic a)
                 const float g3 = g0 * dy;                           // ~ dL/d(conic b)
                 const float g4 = g1 * dy;                           // ~ dL/d(conic c)
