@@ -111,7 +111,10 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
     const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
     const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
     const bool inside = pxi < W && pyi < H;
-    const float pixx = (float)pxi, pixy = (float)pyi;
+    float pixx = (float)pxi, pixy = (float)pyi;
+    // opaque to the compiler: it otherwise re-converts the integer coordinate inside the visit loop (one VALU
+    // instruction per visit to save one register)
+    asm volatile("" : "+v"(pixx), "+v"(pixy));
     const float X0 = (float)(tx * RDG_TILE), Y0 = (float)(ty * RDG_TILE);
     const uint2 range = ranges[tile];
     const int todo_total = (int)(range.y - range.x);
@@ -288,6 +291,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     }
     const float bgdot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
     const float tail = dLa - bgdot;  // d(out)/dT_final chain: alpha_out = 1 - T_final, colour += T_final*bg
+    const float Ttail = T_final * tail;   // per-pixel constant of the dL/dalpha recurrence
 
     // wave / block maxima of last_contributor: splats at list positions >= max are skipped wholesale
     int wmax = last_contributor;
@@ -372,7 +376,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     dL_dalpha += ed * dLd;
                     accd += aeff * ed;
                 }
-                dL_dalpha = dL_dalpha * T + (T_final * inv1ma) * tail;
+                dL_dalpha = fmaf(dL_dalpha, T, Ttail * inv1ma);
                 dL_dalpha = hit ? dL_dalpha : 0.0f;
                 // The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per flushed row total
                 // (rdg_ring_flush), not per pixel-splat pair.
