@@ -245,3 +245,47 @@ def test_bench_accounting_follows_the_algorithm_that_runs():
     assert "configs[4]" in bench.workload_label(4000000, 3840, 2160, 100, True, 1)
     assert "configs[2]" not in bench.workload_label(4000000, 3840, 2160, 100, True, 1)
     assert "not a BASELINE config" in bench.workload_label(5000, 640, 480, 10, False, 1)
+
+
+def test_zcurve_row_order_is_a_permutation_along_the_curve():
+    """rodygs_amd.layout: Morton codes interleave the quantised coordinates bit by bit; morton_order is a stable
+    permutation; points of one octant of the bounding box come before the next octant's."""
+    from rodygs_amd.layout import morton_codes, morton_order
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(4096, 3, generator=g) * torch.tensor([4.0, 2.0, 9.0]) - 1.0
+    codes = morton_codes(x, bits=10)
+    lo, hi = x.min(0).values.double(), x.max(0).values.double()
+    q = ((x.double() - lo) / (hi - lo) * 1023).round().long()
+
+    def interleave(a, b, c):
+        r = 0
+        for i in range(10):
+            r |= ((a >> i) & 1) << (3 * i) | ((b >> i) & 1) << (3 * i + 1) | ((c >> i) & 1) << (3 * i + 2)
+        return r
+    for i in range(0, 4096, 257):
+        assert interleave(*q[i].tolist()) == int(codes[i])
+    perm = morton_order(x, bits=10)
+    assert sorted(perm.tolist()) == list(range(4096))
+    assert bool((codes[perm][1:] >= codes[perm][:-1]).all())
+    top = (q[perm] >> 9)                                   # octant = most significant bit of every axis
+    octant = top[:, 0] + 2 * top[:, 1] + 4 * top[:, 2]
+    assert bool((octant[1:] >= octant[:-1]).all())
+    assert morton_order(torch.zeros(0, 3)).numel() == 0
+
+
+def test_bin_mode_hint_has_hysteresis():
+    """rasterizer._note_largest_tile: above BIN_RADIX_ABOVE the next frame of that (P, H, W) takes the radix path, and it
+    stays there until the largest list falls below BIN_BUCKET_BELOW (no flapping around one threshold)."""
+    from rodygs_amd import rasterizer as R
+    key = ("test", 1, 2)
+    R._BIN_HINT.pop(key, None)
+    R._note_largest_tile(key, R.BIN_RADIX_ABOVE)
+    assert key not in R._BIN_HINT
+    R._note_largest_tile(key, R.BIN_RADIX_ABOVE + 1)
+    assert R._BIN_HINT[key] == 1
+    R._note_largest_tile(key, R.BIN_BUCKET_BELOW + 5)           # between the thresholds: unchanged
+    assert R._BIN_HINT[key] == 1
+    R._note_largest_tile(key, R.BIN_BUCKET_BELOW - 1)
+    assert key not in R._BIN_HINT
+    R._note_largest_tile(key, R.BIN_BUCKET_BELOW + 5)           # between the thresholds from below: still bucket
+    assert key not in R._BIN_HINT
