@@ -103,8 +103,11 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
     // on capacity overflow the binning stage has emptied every tile range: this kernel then renders the background
     const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
+    // sQ1 = (conic c, opacity, -, -): only its first half is read; same 16-B stride as the others so that one address
+    // register serves all four arrays.  sQ2 = (r, g, b, depth).
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH], sQ3[RDG_BATCH];
     __shared__ unsigned long long sMask[4][4];  // [consumer quadrant][staging wave]
+    __shared__ unsigned long long sCap[4];      // per staging wave: splats whose opacity exceeds the alpha cap
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
@@ -133,20 +136,28 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
         if (__syncthreads_count(amin > 1.0f) == 256) break;
         const int k = r * RDG_BATCH + tid;
         uint32_t qbits = 0;
+        bool over_cap = false;
         if (k < todo_total) {
             const uint32_t id = point_list[range.x + k];
             const RdgRec* p = rec + id;
-            const float4 q0 = p->q0, q1 = p->q1;
+            const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
             sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
-            sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
-            sQ2[tid] = p->q2;
+            *(float2*)&sQ1[tid] = make_float2(RDG_NEG_LOG2E * q1.x, q1.y);
+            sQ2[tid] = make_float4(q2.x, q2.y, q2.z, q1.z);
             if (render_normal) sQ3[tid] = p->q3;
             qbits = rdg_quadrant_bits(q0, q1, X0, Y0);
+            over_cap = q1.y > RDG_ALPHA_CAP;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const unsigned long long m = __ballot((qbits >> q) & 1u);
             if (lane == 0) sMask[q][wv] = m;
+        }
+        {
+            // alpha = min(0.99, opacity * G) with G <= 1 wherever the splat blends: the min can only be active for a
+            // splat whose opacity itself exceeds the cap -- a per-splat bit, tested by the scalar unit in the walk
+            const unsigned long long m = __ballot(over_cap);
+            if (lane == 0) sCap[wv] = m;
         }
         __syncthreads();
         const uint32_t base_idx = (uint32_t)(r * RDG_BATCH);
@@ -154,35 +165,61 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
         for (int s = 0; s < 4; ++s) {
             if (rdg_all(amin > 1.0f)) break;   // once per 64 staged splats; inside the walk only after a pixel stops
             unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
+            const unsigned long long cap = rdg_uniform_u64(sCap[s]);
             unsigned long long seen = 0ull;    // splats of this 64-slot word that some pixel of the quadrant may blend
             while (mask) {
                 const int jb = __builtin_ctzll(mask);
                 const int j = s * 64 + jb;
                 mask &= mask - 1;
-                const float4 q0 = sQ0[j];
-                const float4 q1 = sQ1[j];
+                // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar
+                // for every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
+                int aj = j * 16;
+                asm volatile("" : "+v"(aj));
+                const float4 q0 = *(const float4*)((const char*)sQ0 + aj);
+                const float2 q1 = *(const float2*)((const char*)sQ1 + aj);
                 const float dx = q0.x - pixx, dy = q0.y - pixy;
                 float t_, v_;
                 const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
-                const float alpha = fminf(RDG_ALPHA_CAP, q1.y * __builtin_amdgcn_exp2f(power));
-                const bool cand = power <= 0.0f && alpha >= amin;
-                if (!rdg_any(cand)) continue;
-                seen |= 1ull << jb;
-                const float test_T = T * (1.0f - alpha);
-                const bool stop = cand && test_T < RDG_T_STOP;
-                const bool hit = cand && !stop;
-                const float wgt = hit ? alpha * T : 0.0f;
-                const float4 q2 = sQ2[j];
-                C0 += wgt * q2.x; C1 += wgt * q2.y; C2 += wgt * q2.z;
-                Dp += wgt * q1.z;
-                if (render_normal) {
-                    const float4 q3 = sQ3[j];
-                    N0 += wgt * q3.x; N1 += wgt * q3.y; N2 += wgt * q3.z;
+                float alpha = q1.y * __builtin_amdgcn_exp2f(power);
+                if ((cap >> jb) & 1ull) {
+                    asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
+                    alpha = fminf(RDG_ALPHA_CAP, alpha);
                 }
-                if (hit) { T = test_T; last_contributor = base_idx + (uint32_t)j + 1u; }
-                if (rdg_any(stop)) {
+                // lanes that may blend this splat, as a scalar mask (a ballot of the combined predicate would be
+                // materialised through a 0/1 vector)
+                const unsigned long long cand = __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= amin);
+                if (!cand) continue;
+                seen |= 1ull << jb;
+                // A lane that does not blend the splat runs the same instructions with alpha_eff = 0: T (1 - 0) = T, zero
+                // weight.  T >= RDG_T_STOP is an invariant of every lane (the update that would break it is the one that is
+                // not applied), so "T (1 - alpha_eff) < RDG_T_STOP" alone says "this pixel stops here"; the stopping lanes
+                // are repaired in the (rare) branch below.
+                float aeff;
+                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(aeff) : "v"(alpha), "s"(cand));
+                float test_T = T * (1.0f - aeff);
+                float wgt = aeff * T;
+                const float4 q2 = *(const float4*)((const char*)sQ2 + aj);
+                const uint32_t idx = base_idx + (uint32_t)j + 1u;
+                unsigned long long upd = cand;   // lanes that blend this splat
+                const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < RDG_T_STOP);
+                if (stopm) {
+                    const bool stop = test_T < RDG_T_STOP;
+                    upd &= ~stopm;
+                    wgt = stop ? 0.0f : wgt;
+                    test_T = stop ? T : test_T;
                     amin = stop ? __builtin_inff() : amin;
                     if (rdg_all(amin > 1.0f)) { mask = 0ull; }
+                }
+                T = test_T;
+                // last_contributor = upd ? idx : last_contributor as ONE vector instruction (a move under the lane mask;
+                // the select would need the scalar index copied into a VGPR first).  The walk runs with all lanes enabled.
+                asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1"
+                             : "+v"(last_contributor) : "s"(upd), "s"(idx));
+                C0 += wgt * q2.x; C1 += wgt * q2.y; C2 += wgt * q2.z;
+                Dp += wgt * q2.w;
+                if (render_normal) {
+                    const float4 q3 = *(const float4*)((const char*)sQ3 + aj);
+                    N0 += wgt * q3.x; N1 += wgt * q3.y; N2 += wgt * q3.z;
                 }
             }
             if (lane == 0 && seen) hit[(size_t)(r * 4 + s) * 4 + wv] = seen;
@@ -223,12 +260,18 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
     return rdg_check_hip(hipGetLastError(), "render_fwd launch");
 }
 
-#define RDG_RING 16
+#define RDG_RING 8
+// A ring entry holds, for each of the wave's 16 quads (quad = lane >> 2; two quads = one 8-pixel row of the quadrant),
+// six floats: see the reduction in the kernel.  Stride 6 keeps the parking stores 8-byte aligned and the 16 writer
+// lanes on 16 different banks.
+#define RDG_RING_Q 6
 // Flush a wave's ring: 16 consecutive lanes = the 64-B accumulator row of one Gaussian, 4 entries per instruction,
-// which is the access shape the global float-atomic unit runs at full rate for.
+// which is the access shape the global float-atomic unit runs at full rate for.  Lane c sums the eight pixel-row
+// partials of component c (foff = where that component sits inside a quad pair).
 // `scale` = this lane's constant factor for component (lane & 15), see the derivative block of the kernel.
-__device__ __forceinline__ void rdg_ring_flush(float (*ring)[4][12], const uint32_t* ids, int n, int lane, float scale,
-                                               float* __restrict__ grow) {
+template <bool HAS_DEPTH>
+__device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], const uint32_t* ids, int n, int lane,
+                                               float scale, int foff, float* __restrict__ grow) {
     // LDS operations of one wave execute in program order; the fences only pin the compiler's ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -236,9 +279,10 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[4][12], const uint3
     const int c = lane & 15;
     for (int e0 = 0; e0 < n; e0 += 4) {
         const int e = e0 + (lane >> 4);
-        if (e < n && c < 10) {
-            const float* r = &ring[e][0][c];
-            const float v = ((r[0] + r[12]) + (r[24] + r[36])) * scale;
+        if (e < n && c < (HAS_DEPTH ? 10 : 9)) {
+            const float* r = &ring[e][0][0] + foff;
+            constexpr int G = 2 * RDG_RING_Q;   // floats per pixel row (quad pair)
+            const float v = (((r[0] + r[G]) + (r[2 * G] + r[3 * G])) + ((r[4 * G] + r[5 * G]) + (r[6 * G] + r[7 * G]))) * scale;
             if (v != 0.0f) atomicAdd(grow + (size_t)ids[e] * RDG_GROW + c, v);
         }
     }
@@ -262,11 +306,11 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                       float* __restrict__ grow, const unsigned long long* __restrict__ hitbits) {
     const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
-    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];
-    __shared__ uint32_t sId[RDG_BATCH];
-    __shared__ float sRing[4][RDG_RING][4][12];   // per wave: [entry][16-lane row][component] partial sums
+    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
+    __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
     __shared__ uint32_t sRingId[4][RDG_RING];
     __shared__ unsigned long long sMask[4][4];
+    __shared__ unsigned long long sCap[4];   // per staging wave: splats whose opacity exceeds the alpha cap
     __shared__ int sMax[4];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -308,11 +352,14 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     const int fc = lane & 15;
     // components 0, 1 are the raw first moments sum(G dL/dG dx), sum(G dL/dG dy): the per-Gaussian backward turns them
     // into dL/dmean2D with the conic it has anyway (two multiplies and two fused multiply-adds per pair less here)
-    const float flush_scale = (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : (fc == 9 && !HAS_DEPTH) ? 0.0f : 1.0f;
+    const float flush_scale = (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : 1.0f;
+    // where component fc sits in a pixel row's two quads (A = slots 0..5, B = slots 6..11): see the reduction below
+    const int flush_off = (int)((0x5827049136ull >> (4 * fc)) & 15ull);
 
     for (int r = 0; r < rounds; ++r) {
         const int kbase = kmax - 1 - r * RDG_BATCH;  // list position of slot 0 of this batch
         uint32_t qbits = 0;
+        bool over_cap = false;
         {
             const int k = kbase - tid;
             if (k >= 0) {
@@ -328,11 +375,11 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 if (qbits) {   // nobody will look at the other slots: skip their record gathers
                     const uint32_t id = point_list[range.x + k];
                     const RdgRec* p = rec + id;
-                    const float4 q0 = p->q0, q1 = p->q1;
-                    sId[tid] = id;
+                    const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
                     sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
                     sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
-                    sQ2[tid] = p->q2;
+                    sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(id));
+                    over_cap = q1.y > RDG_ALPHA_CAP;
                 }
             }
         }
@@ -341,24 +388,40 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             const unsigned long long m = __ballot((qbits >> q) & 1u);
             if (lane == 0) sMask[q][wv] = m;
         }
+        {
+            // alpha = min(0.99, opacity * G) with G <= 1 wherever the splat blends: the min is only ever active for a
+            // splat whose opacity itself exceeds the cap -- a per-splat bit, tested by the scalar unit in the walk
+            const unsigned long long m = __ballot(over_cap);
+            if (lane == 0) sCap[wv] = m;
+        }
         __syncthreads();
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
             unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
+            const unsigned long long cap = rdg_uniform_u64(sCap[s]);
             while (mask) {
-                const int j = s * 64 + __builtin_ctzll(mask);
+                const int jb = __builtin_ctzll(mask);
+                const int j = s * 64 + jb;
                 mask &= mask - 1;
                 const int k = kbase - j;  // list position of this splat
-                const float4 q0 = sQ0[j];
-                const float4 q1 = sQ1[j];
+                // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar
+                // for every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
+                int aj = j * 16;
+                asm volatile("" : "+v"(aj));
+                const float4 q0 = *(const float4*)((const char*)sQ0 + aj);
+                const float4 q1 = *(const float4*)((const char*)sQ1 + aj);
                 const float dx = q0.x - pixx, dy = q0.y - pixy;
                 float t_, v_;
                 const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
                 const float G = __builtin_amdgcn_exp2f(power);
-                const float alpha = fminf(RDG_ALPHA_CAP, q1.y * G);
+                float alpha = q1.y * G;
+                if ((cap >> jb) & 1ull) {
+                    asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
+                    alpha = fminf(RDG_ALPHA_CAP, alpha);
+                }
                 const bool hit = (k < last_contributor) && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
                 if (!rdg_any(hit)) continue;
-                const float4 q2 = sQ2[j];
+                const float4 q2 = *(const float4*)((const char*)sQ2 + aj);
                 // Branch-free per-pixel derivatives.  A lane that does not blend this splat runs the same instructions
                 // with alpha_eff = 0, which leaves every piece of its state unchanged (T/(1-0) = T, B += 0*(c - B)) and
                 // zeroes its contributions, so no per-variable selects are needed.  B* is the colour accumulated
@@ -378,85 +441,88 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 }
                 dL_dalpha = fmaf(dL_dalpha, T, Ttail * inv1ma);
                 dL_dalpha = hit ? dL_dalpha : 0.0f;
-                // The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per flushed row total
-                // (rdg_ring_flush), not per pixel-splat pair.
-                const float g5 = G * dL_dalpha;                     // dL/dopacity; G dL/dG = opacity * g5 -- the opacity is a
-                //                                                     per-splat constant: applied by the per-Gaussian backward
-                const float g0 = g5 * dx, g1 = g5 * dy;             // first moments / opacity (-> dL/d(mean2D) per Gaussian)
-                const float g2 = g0 * dx;                           // ~ dL/d(conic a)
-                const float g3 = g0 * dy;                           // ~ dL/d(conic b)
-                const float g4 = g1 * dy;                           // ~ dL/d(conic c)
-                const float g6 = dch * dLp0, g7 = dch * dLp1, g8 = dch * dLp2, g9 = HAS_DEPTH ? dch * dLd : 0.0f;
-                // Transposed wave reduction: instead of ten 6-step butterflies (60 DPP adds), fold the VALUE index into
-                // the lane index while reducing.  DPP write masks work on quads (bank_mask: 4 lanes) and rows, so the
-                // folding steps come FIRST and act across quads: a rotate-by-8 exchange turns two values into one (the
-                // low half-row keeps the pair sum of the first value, the high half-row of the second), a half-row
-                // mirror does it again between neighbouring quads, and two plain quad butterflies finish.  Each
-                // "two values -> one" step is TWO instructions (one DPP add per bank_mask into the same register),
-                // which the compiler cannot express (it needs two selects + one DPP add), hence the hand-scheduled
-                // block: 21 VALU for the whole 10-value reduction.  DPP needs two wait states after the VALU write of
-                // the register it reads: the order below keeps at least two instructions between every producer and
-                // its DPP consumer; s_nop 1 covers the inputs.
-                // Result: every lane of quad q (h = q >> 1, p = q & 1) holds the 16-lane row total of component
-                // 2p + h (y0), 4 + 2p + h (y1), 8 + h (y2).
-                float x0, x1, x2, x3, x4, y0, y1, y2;
+                // What leaves the lane: the weight t0 = G dL/dalpha (= dL/dopacity; G dL/dG = opacity * t0, the opacity
+                // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 dx and
+                // t2 = t0 dx^2, and the colour terms.  The y-moments are NOT formed per pixel: the eight lanes of a
+                // pixel row share dy, so sum(t0 dy) = dy sum(t0), sum(t0 dx dy) = dy sum(t1), sum(t0 dy^2) = dy^2 sum(t0)
+                // are formed from the row totals (two multiplies per visit instead of three, and six values to reduce
+                // instead of nine).  The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per
+                // flushed row total (rdg_ring_flush).
+                const float t0 = G * dL_dalpha;
+                const float t1 = t0 * dx;
+                const float t2 = t1 * dx;
+                const float c0 = dch * dLp0, c1 = dch * dLp1, c2 = dch * dLp2, cd = HAS_DEPTH ? dch * dLd : 0.0f;
+                // Transposed reduction over the 8 lanes of a pixel row: DPP write masks work on quads (bank_mask), so the
+                // step across the row's two quads comes first and folds two values into one register (quad A = lanes
+                // 0-3 of the row keeps the pair sums of the first value, quad B of the second: one DPP add per bank
+                // mask into the same register, which the compiler cannot express), then two plain quad butterflies.
+                // 12 DPP adds (15 with depth) instead of 20 (21) for nine row totals over 16 lanes.  DPP needs two wait
+                // states after the VALU write of the register it reads: the order below keeps at least two instructions
+                // between every producer and its DPP consumer; s_nop 1 covers the inputs.
+                // Result, in every lane of a quad:   quad A: r0 = sum t0, r1 = sum t2, r2 = sum c1
+                //                                    quad B: r0 = sum t1, r1 = sum c0, r2 = sum c2     (r3 = sum cd)
+                float r0, r1, r2, r3 = 0.0f;
                 if (HAS_DEPTH) {
                     asm volatile(
                         "s_nop 1\n\t"
-                        "v_add_f32_dpp %[x4], %[g8], %[g8] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                        "v_add_f32_dpp %[x4], %[g9], %[g9] row_ror:8 row_mask:0xf bank_mask:0xc"
-                        : [x4] "=&v"(x4) : [g8] "v"(g8), [g9] "v"(g9));
+                        "v_add_f32_dpp %[r0], %[t0], %[t0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %[r0], %[t1], %[t1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %[r1], %[t2], %[t2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %[r1], %[c0], %[c0] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %[r2], %[c1], %[c1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %[r2], %[c2], %[c2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %[r3], %[cd], %[cd] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+                        : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [cd] "v"(cd));
                 } else {
-                    // both half-rows carry component 8 (the flush multiplies component 9 by zero)
                     asm volatile(
                         "s_nop 1\n\t"
-                        "v_add_f32_dpp %[x4], %[g8], %[g8] row_ror:8 row_mask:0xf bank_mask:0xf"
-                        : [x4] "=&v"(x4) : [g8] "v"(g8));
+                        "v_add_f32_dpp %[r0], %[t0], %[t0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %[r0], %[t1], %[t1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %[r1], %[t2], %[t2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %[r1], %[c0], %[c0] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %[r2], %[c1], %[c1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                        "v_add_f32_dpp %[r2], %[c2], %[c2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2)
+                        : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2));
                 }
-                asm volatile(
-                    "s_nop 1\n\t"
-                    "v_add_f32_dpp %[x0], %[g0], %[g0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                    "v_add_f32_dpp %[x0], %[g1], %[g1] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                    "v_add_f32_dpp %[x1], %[g2], %[g2] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                    "v_add_f32_dpp %[x1], %[g3], %[g3] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                    "v_add_f32_dpp %[x2], %[g4], %[g4] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                    "v_add_f32_dpp %[x2], %[g5], %[g5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                    "v_add_f32_dpp %[x3], %[g6], %[g6] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-                    "v_add_f32_dpp %[x3], %[g7], %[g7] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-                    "v_add_f32_dpp %[y0], %[x0], %[x0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                    "v_add_f32_dpp %[y0], %[x1], %[x1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                    "v_add_f32_dpp %[y1], %[x2], %[x2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                    "v_add_f32_dpp %[y1], %[x3], %[x3] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                    "v_add_f32_dpp %[y2], %[x4], %[x4] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %[y0], %[y0], %[y0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %[y1], %[y1], %[y1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %[y2], %[y2], %[y2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %[y0], %[y0], %[y0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %[y1], %[y1], %[y1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                    "v_add_f32_dpp %[y2], %[y2], %[y2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                    : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3),
-                      [y0] "=&v"(y0), [y1] "=&v"(y1), [y2] "=&v"(y2)
-                    : [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [g5] "v"(g5),
-                      [g6] "v"(g6), [g7] "v"(g7), [x4] "v"(x4));
+                // y-moments of the row from its totals (quad A: dy sum t0, dy^2 sum t0; quad B: dy sum t1)
+                const float m1 = r0 * dy;
+                const float m2 = m1 * dy;
                 {
-                    // One lane per quad parks the row totals in this wave's private ring with PLAIN LDS stores (LDS
-                    // float atomics into a table shared by the 4 waves cost a third of the kernel); the 4 row partials
-                    // are added when the ring is flushed.
+                    // One lane per quad parks the quad's totals in this wave's private ring with PLAIN LDS stores (LDS
+                    // float atomics into a table shared by the 4 waves cost a third of the kernel); the 8 pixel-row
+                    // partials are added when the ring is flushed.
                     if ((lane & 3) == 0) {
-                        const int par = (lane >> 2) & 1, hh = (lane >> 3) & 1;
-                        float* gr = &sRing[wv][ring_n][lane >> 4][2 * par + hh];
-                        gr[0] = y0;
-                        gr[4] = y1;
-                        if (!par) gr[8] = y2;
-                        if (lane == 0) sRingId[wv][ring_n] = sId[j];
+                        float* gr = &sRing[wv][ring_n][lane >> 2][0];
+                        gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = m1; gr[4] = m2;
+                        if (HAS_DEPTH) gr[5] = r3;
+                        if (lane == 0) sRingId[wv][ring_n] = __float_as_uint(q2.w);
                     }
-                    if (++ring_n == RDG_RING) { rdg_ring_flush(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, grow); ring_n = 0; }
+                    if (++ring_n == RDG_RING) {
+                        rdg_ring_flush<HAS_DEPTH>(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, flush_off, grow);
+                        ring_n = 0;
+                    }
                 }
             }
         }
         __syncthreads();   // every wave is done with this round's staged records
     }
-    rdg_ring_flush(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, grow);
+    rdg_ring_flush<HAS_DEPTH>(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, flush_off, grow);
 }
 
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
