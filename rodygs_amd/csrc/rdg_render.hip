@@ -71,16 +71,26 @@ __device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const flo
     return bits;
 }
 
-// Staged form of a splat's conic: (A2, B, C2) = -log2(e) * (a, b, c), so that
-//   log2(G) = 0.5 (A2 dx^2 + C2 dy^2) + B dx dy      and      G = v_exp_f32(log2 G)  with no extra multiply,
-// and the products t = A2 dx, v = C2 dy are reused by the backward (dG/ddx ~ t + B dy, dG/ddy ~ v + B dx).  Forward
-// and backward evaluate exactly this expression, so they take identical blend / skip decisions.
+// Staged form of a splat's conic.  With (A2, B, C2) = -log2(e) * (a, b, c),
+//   log2(G) = 0.5 (A2 dx^2 + C2 dy^2) + B dx dy = hA (dx + beta dy)^2 + gam dy^2,
+//   hA = 0.5 A2,  beta = B / A2,  gam = 0.5 (C2 - beta B)           (the square completed once per staged splat)
+// which is five instructions per pixel-splat pair instead of seven, both terms of one sign (a > 0 for every visible
+// splat: the conic is the inverse of a positive-definite matrix), and G = v_exp_f32(log2 G) with no extra multiply.
+// Forward and backward evaluate exactly this expression on the same staged values, so they take identical blend / skip
+// decisions.
 #define RDG_NEG_LOG2E (-1.4426950408889634f)
-__device__ __forceinline__ float rdg_log2_gauss(float A2, float B, float C2, float dx, float dy, float& t, float& v) {
-    t = A2 * dx;
-    v = C2 * dy;
-    const float u = fmaf(v, dy, t * dx);
-    return fmaf(0.5f, u, (B * dx) * dy);
+struct RdgConicS { float hA, beta, gam; };
+__device__ __forceinline__ RdgConicS rdg_stage_conic(float a, float b, float c) {
+    const float A2 = RDG_NEG_LOG2E * a, B = RDG_NEG_LOG2E * b, C2 = RDG_NEG_LOG2E * c;
+    RdgConicS s;
+    s.hA = 0.5f * A2;
+    s.beta = (A2 < 0.0f) ? B / A2 : 0.0f;
+    s.gam = 0.5f * (C2 - s.beta * B);
+    return s;
+}
+__device__ __forceinline__ float rdg_log2_gauss(float hA, float beta, float gam, float dx, float dy) {
+    const float w = fmaf(beta, dy, dx);
+    return fmaf(hA * w, w, (gam * dy) * dy);
 }
 
 // wave votes straight from the ballot (hip's __any/__all go through an int compare per lane)
@@ -93,8 +103,9 @@ __device__ __forceinline__ unsigned long long rdg_uniform_u64(unsigned long long
     return ((unsigned long long)hi << 32) | lo;
 }
 
+template <bool NORMAL>
 __global__ void __launch_bounds__(256)
-rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, const float* __restrict__ bg,
+rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
                       const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RdgRec* __restrict__ rec, long long capacity, const int32_t* __restrict__ num_rendered,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
@@ -141,10 +152,11 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
             const uint32_t id = point_list[range.x + k];
             const RdgRec* p = rec + id;
             const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
-            sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
-            *(float2*)&sQ1[tid] = make_float2(RDG_NEG_LOG2E * q1.x, q1.y);
+            const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
+            sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
+            *(float2*)&sQ1[tid] = make_float2(cs.gam, q1.y);
             sQ2[tid] = make_float4(q2.x, q2.y, q2.z, q1.z);
-            if (render_normal) sQ3[tid] = p->q3;
+            if (NORMAL) sQ3[tid] = p->q3;
             qbits = rdg_quadrant_bits(q0, q1, X0, Y0);
             over_cap = q1.y > RDG_ALPHA_CAP;
         }
@@ -170,18 +182,18 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
             while (mask) {
                 const int jb = __builtin_ctzll(mask);
                 const int j = s * 64 + jb;
-                mask &= mask - 1;
-                // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar
-                // for every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
+                const unsigned long long bit = 1ull << jb;
+                mask ^= bit;
+                // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the
+                // scalar for every array: a VALU instruction with a scalar source issues at half the rate)
                 int aj = j * 16;
                 asm volatile("" : "+v"(aj));
                 const float4 q0 = *(const float4*)((const char*)sQ0 + aj);
                 const float2 q1 = *(const float2*)((const char*)sQ1 + aj);
                 const float dx = q0.x - pixx, dy = q0.y - pixy;
-                float t_, v_;
-                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
+                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
                 float alpha = q1.y * __builtin_amdgcn_exp2f(power);
-                if ((cap >> jb) & 1ull) {
+                if (cap & bit) {
                     asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
                     alpha = fminf(RDG_ALPHA_CAP, alpha);
                 }
@@ -189,11 +201,11 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                 // materialised through a 0/1 vector)
                 const unsigned long long cand = __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= amin);
                 if (!cand) continue;
-                seen |= 1ull << jb;
-                // A lane that does not blend the splat runs the same instructions with alpha_eff = 0: T (1 - 0) = T, zero
-                // weight.  T >= RDG_T_STOP is an invariant of every lane (the update that would break it is the one that is
-                // not applied), so "T (1 - alpha_eff) < RDG_T_STOP" alone says "this pixel stops here"; the stopping lanes
-                // are repaired in the (rare) branch below.
+                seen |= bit;
+                // A lane that does not blend the splat runs the same instructions with alpha_eff = 0: T (1 - 0) = T,
+                // zero weight.  T >= RDG_T_STOP is an invariant of every lane (the update that would break it is the one
+                // that is not applied), so "T (1 - alpha_eff) < RDG_T_STOP" alone says "this pixel stops here"; the
+                // stopping lanes are repaired in the (rare) branch below.
                 float aeff;
                 asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(aeff) : "v"(alpha), "s"(cand));
                 float test_T = T * (1.0f - aeff);
@@ -211,13 +223,14 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, int render_normal, cons
                     if (rdg_all(amin > 1.0f)) { mask = 0ull; }
                 }
                 T = test_T;
-                // last_contributor = upd ? idx : last_contributor as ONE vector instruction (a move under the lane mask;
-                // the select would need the scalar index copied into a VGPR first).  The walk runs with all lanes enabled.
+                // last_contributor = upd ? idx : last_contributor as ONE vector instruction (a move under the lane
+                // mask; the select would need the scalar index copied into a VGPR first).  The walk runs with all
+                // lanes enabled.
                 asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1"
                              : "+v"(last_contributor) : "s"(upd), "s"(idx));
                 C0 += wgt * q2.x; C1 += wgt * q2.y; C2 += wgt * q2.z;
                 Dp += wgt * q2.w;
-                if (render_normal) {
+                if (NORMAL) {
                     const float4 q3 = *(const float4*)((const char*)sQ3 + aj);
                     N0 += wgt * q3.x; N1 += wgt * q3.y; N2 += wgt * q3.z;
                 }
@@ -253,10 +266,13 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const int nblk = ((n_tiles + 7) / 8) * 8;
     // zeroed by the binning stage (rdg_launch_bin), which always runs before this launch
     unsigned long long* hitbits = (unsigned long long*)((char*)bin_ws + B.hit);
-    hipLaunchKernelGGL(rdg_render_fwd_kernel, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, d.render_normal,
-                       bg, (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),
-                       (long long)capacity, num_rendered, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),
-                       out_color, out_depth, out_normal, out_alpha, hitbits);
+#define RDG_FWD_LAUNCH(NORMAL)                                                                                      \
+    hipLaunchKernelGGL(rdg_render_fwd_kernel<NORMAL>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,       \
+                       (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),           \
+                       (long long)capacity, num_rendered, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),    \
+                       out_color, out_depth, out_normal, out_alpha, hitbits)
+    if (d.render_normal) RDG_FWD_LAUNCH(true); else RDG_FWD_LAUNCH(false);
+#undef RDG_FWD_LAUNCH
     return rdg_check_hip(hipGetLastError(), "render_fwd launch");
 }
 
@@ -270,8 +286,8 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
 // partials of component c (foff = where that component sits inside a quad pair).
 // `scale` = this lane's constant factor for component (lane & 15), see the derivative block of the kernel.
 template <bool HAS_DEPTH>
-__device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], const uint32_t* ids, int n, int lane,
-                                               float scale, int foff, float* __restrict__ grow) {
+__device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], int n, int lane, float scale, int foff,
+                                               float* __restrict__ grow) {
     // LDS operations of one wave execute in program order; the fences only pin the compiler's ordering
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -283,7 +299,11 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], co
             const float* r = &ring[e][0][0] + foff;
             constexpr int G = 2 * RDG_RING_Q;   // floats per pixel row (quad pair)
             const float v = (((r[0] + r[G]) + (r[2 * G] + r[3 * G])) + ((r[4 * G] + r[5 * G]) + (r[6 * G] + r[7 * G]))) * scale;
-            if (v != 0.0f) atomicAdd(grow + (size_t)ids[e] * RDG_GROW + c, v);
+#ifdef RDG_ABL_NOATOMIC   // ablation build (scripts/render_ablation.sh): results are wrong, only the timing is read
+            if (v == 123.456f) atomicAdd(grow + (size_t)__float_as_uint(ring[e][1][4]) * RDG_GROW + c, v);
+#else
+            if (v != 0.0f) atomicAdd(grow + (size_t)__float_as_uint(ring[e][1][4]) * RDG_GROW + c, v);
+#endif
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -308,7 +328,6 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     if (tile >= n_tiles) return;
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
     __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
-    __shared__ uint32_t sRingId[4][RDG_RING];
     __shared__ unsigned long long sMask[4][4];
     __shared__ unsigned long long sCap[4];   // per staging wave: splats whose opacity exceeds the alpha cap
     __shared__ int sMax[4];
@@ -333,9 +352,11 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         if (HAS_DEPTH) dLd = g_depth[pid];
         if (g_alpha) dLa = g_alpha[pid];
     }
+    // What lies BEHIND the last splat of a pixel, in units of "colour . dL/dpixel": the background, and the alpha
+    // output (alpha_out = 1 - T_final) as a colour of -dL/dalpha_out.  Starting the behind-value recurrence from it
+    // makes dL/dalpha_k = T_k (s_k - behind_k) exact with no separate T_final term.
     const float bgdot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
-    const float tail = dLa - bgdot;  // d(out)/dT_final chain: alpha_out = 1 - T_final, colour += T_final*bg
-    const float Ttail = T_final * tail;   // per-pixel constant of the dL/dalpha recurrence
+    float behind = bgdot - dLa;
 
     // wave / block maxima of last_contributor: splats at list positions >= max are skipped wholesale
     int wmax = last_contributor;
@@ -347,7 +368,6 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     const int kmax = max(max(m0, m1), max(m2, m3));
     const int rounds = (kmax + RDG_BATCH - 1) / RDG_BATCH;
 
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
     int ring_n = 0;   // wave-uniform fill level of this wave's ring
     const int fc = lane & 15;
     // components 0, 1 are the raw first moments sum(G dL/dG dx), sum(G dL/dG dy): the per-Gaussian backward turns them
@@ -376,8 +396,9 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     const uint32_t id = point_list[range.x + k];
                     const RdgRec* p = rec + id;
                     const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
-                    sQ0[tid] = make_float4(q0.x, q0.y, RDG_NEG_LOG2E * q0.z, RDG_NEG_LOG2E * q0.w);
-                    sQ1[tid] = make_float4(RDG_NEG_LOG2E * q1.x, q1.y, q1.z, 0.0f);
+                    const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
+                    sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
+                    sQ1[tid] = make_float4(cs.gam, q1.y, q1.z, 0.0f);
                     sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(id));
                     over_cap = q1.y > RDG_ALPHA_CAP;
                 }
@@ -402,7 +423,8 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             while (mask) {
                 const int jb = __builtin_ctzll(mask);
                 const int j = s * 64 + jb;
-                mask &= mask - 1;
+                const unsigned long long bit = 1ull << jb;
+                mask ^= bit;
                 const int k = kbase - j;  // list position of this splat
                 // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar
                 // for every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
@@ -411,11 +433,10 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 const float4 q0 = *(const float4*)((const char*)sQ0 + aj);
                 const float4 q1 = *(const float4*)((const char*)sQ1 + aj);
                 const float dx = q0.x - pixx, dy = q0.y - pixy;
-                float t_, v_;
-                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy, t_, v_);
+                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
                 const float G = __builtin_amdgcn_exp2f(power);
                 float alpha = q1.y * G;
-                if ((cap >> jb) & 1ull) {
+                if (cap & bit) {
                     asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
                     alpha = fminf(RDG_ALPHA_CAP, alpha);
                 }
@@ -423,24 +444,25 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 if (!rdg_any(hit)) continue;
                 const float4 q2 = *(const float4*)((const char*)sQ2 + aj);
                 // Branch-free per-pixel derivatives.  A lane that does not blend this splat runs the same instructions
-                // with alpha_eff = 0, which leaves every piece of its state unchanged (T/(1-0) = T, B += 0*(c - B)) and
-                // zeroes its contributions, so no per-variable selects are needed.  B* is the colour accumulated
-                // BEHIND the current splat (back-to-front recurrence B <- alpha c + (1 - alpha) B), i.e. upstream's
-                // accum_rec evaluated eagerly instead of through last_alpha / last_color.
-                const float aeff = hit ? alpha : 0.0f;
+                // with alpha_eff = 0, which leaves every piece of its state unchanged (T / (1 - 0) = T, behind += 0) and
+                // zeroes its contributions, so no per-variable selects are needed.  The colour accumulated BEHIND the
+                // current splat (back-to-front recurrence B <- alpha c + (1 - alpha) B, upstream's accum_rec evaluated
+                // eagerly) only ever enters through its product with the pixel's dL/dpixel, a per-pixel constant: so the
+                // recurrence runs on that ONE scalar, behind = B . dL/dpixel, with s = c . dL/dpixel per splat.
+                const float Gm = hit ? G : 0.0f;                      // the ONE select of the visit
+                float aeff = q1.y * Gm;                               // = alpha on the lanes that blend, 0 elsewhere
+                if (cap & bit) {
+                    asm volatile("; opacity above the cap" ::: "memory");
+                    aeff = fminf(RDG_ALPHA_CAP, aeff);
+                }
                 const float inv1ma = __builtin_amdgcn_rcpf(1.0f - aeff);
                 T = T * inv1ma;
                 const float dch = aeff * T;
-                const float e0 = q2.x - acc0, e1 = q2.y - acc1, e2 = q2.z - acc2;
-                float dL_dalpha = e0 * dLp0 + e1 * dLp1 + e2 * dLp2;
-                acc0 += aeff * e0; acc1 += aeff * e1; acc2 += aeff * e2;
-                if (HAS_DEPTH) {
-                    const float ed = q1.z - accd;
-                    dL_dalpha += ed * dLd;
-                    accd += aeff * ed;
-                }
-                dL_dalpha = fmaf(dL_dalpha, T, Ttail * inv1ma);
-                dL_dalpha = hit ? dL_dalpha : 0.0f;
+                float s_ = q2.x * dLp0 + q2.y * dLp1 + q2.z * dLp2;
+                if (HAS_DEPTH) s_ += q1.z * dLd;
+                const float e_ = s_ - behind;
+                behind = fmaf(aeff, e_, behind);
+                const float dL_dalpha = e_ * T;
                 // What leaves the lane: the weight t0 = G dL/dalpha (= dL/dopacity; G dL/dG = opacity * t0, the opacity
                 // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 dx and
                 // t2 = t0 dx^2, and the colour terms.  The y-moments are NOT formed per pixel: the eight lanes of a
@@ -448,7 +470,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 // are formed from the row totals (two multiplies per visit instead of three, and six values to reduce
                 // instead of nine).  The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per
                 // flushed row total (rdg_ring_flush).
-                const float t0 = G * dL_dalpha;
+                const float t0 = Gm * dL_dalpha;
                 const float t1 = t0 * dx;
                 const float t2 = t1 * dx;
                 const float c0 = dch * dLp0, c1 = dch * dLp1, c2 = dch * dLp2, cd = HAS_DEPTH ? dch * dLd : 0.0f;
@@ -507,14 +529,20 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     // One lane per quad parks the quad's totals in this wave's private ring with PLAIN LDS stores (LDS
                     // float atomics into a table shared by the 4 waves cost a third of the kernel); the 8 pixel-row
                     // partials are added when the ring is flushed.
+#ifdef RDG_ABL_NOPARK
+                    if (lane == 63 && m2 == 123.456f) {
+#else
                     if ((lane & 3) == 0) {
+#endif
                         float* gr = &sRing[wv][ring_n][lane >> 2][0];
                         gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = m1; gr[4] = m2;
                         if (HAS_DEPTH) gr[5] = r3;
-                        if (lane == 0) sRingId[wv][ring_n] = __float_as_uint(q2.w);
+                        // the Gaussian's row index rides in a slot no component uses (quad B has no dy^2 moment); LDS
+                        // stores of a wave land in program order, so this one overrides m2 of lane 4
+                        if (lane == 4) gr[4] = q2.w;
                     }
                     if (++ring_n == RDG_RING) {
-                        rdg_ring_flush<HAS_DEPTH>(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, flush_off, grow);
+                        rdg_ring_flush<HAS_DEPTH>(sRing[wv], ring_n, lane, flush_scale, flush_off, grow);
                         ring_n = 0;
                     }
                 }
@@ -522,7 +550,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         }
         __syncthreads();   // every wave is done with this round's staged records
     }
-    rdg_ring_flush<HAS_DEPTH>(sRing[wv], sRingId[wv], ring_n, lane, flush_scale, flush_off, grow);
+    rdg_ring_flush<HAS_DEPTH>(sRing[wv], ring_n, lane, flush_scale, flush_off, grow);
 }
 
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,

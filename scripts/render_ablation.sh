@@ -1,0 +1,12 @@
+#!/bin/bash
+# Ablation builds of the compositing backward on the GPU box: rebuilds rdg_render.o with one piece removed and prints the
+# stage timers of the bench.  Results of these builds are WRONG by construction; only the timing is read.
+cd "$(dirname "$0")/.."
+for v in "" "-DRDG_ABL_NOATOMIC" "-DRDG_ABL_NOPARK" "-DRDG_ABL_NOATOMIC -DRDG_ABL_NOPARK" $EXTRA_VARIANTS; do
+  rm -f rodygs_amd/csrc/rdg_render.o
+  make -C rodygs_amd/csrc EXTRA="$v" > /dev/null 2>&1 || { echo "build failed: $v"; continue; }
+  python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('variant [$v]', round(d['value'],1), {k:round(x,4) for k,x in d['stage_ms'].items() if 'render' in k})"
+done
+rm -f rodygs_amd/csrc/rdg_render.o; make -C rodygs_amd/csrc > /dev/null 2>&1
