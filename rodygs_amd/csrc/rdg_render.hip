@@ -38,8 +38,8 @@ __device__ __forceinline__ int rdg_tile_of_block(int bid, int n_tiles) {
 // centres (not the axis-aligned box of the ellipse, which lets diagonal splats through): the minimum of the convex Q
 // over a box is 0 if the centre is inside, otherwise it sits on one of the four edges, where it is a clamped 1-D
 // parabola.  r2 carries a margin (0.02 in the log + 1e-3 relative) that dwarfs the rounding of this evaluation, so no
-// blending pixel is ever skipped; the result is identical to visiting every splat.  Anything unusual (indefinite
-// conic, NaN) keeps the splat for every quadrant.
+// blending pixel is ever skipped; the result is identical to visiting every splat.  A conic that is not positive definite (NaN
+// input) drops the splat.
 __device__ __forceinline__ float rdg_edge_min(float a, float b2, float c, float inv_c, float ue, float v0, float v1) {
     // min over v in [v0, v1] of a ue^2 + 2 b ue v + c v^2   (b2 = 2 b)
     const float t = b2 * ue;
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const flo
     const float t255 = 255.0f * o;
     if (t255 < 0.99f) return 0u;  // alpha can never reach 1/255 (margin below)
     const float det = a * c - b * b;
-    if (!(det > 0.0f) || !(a > 0.0f) || !(c > 0.0f)) return 0xFu;
+    if (!(det > 0.0f) || !(a > 0.0f) || !(c > 0.0f)) return 0u;   // not a positive-definite conic (NaN input): never blended
     const float r2 = 2.0f * (__logf(t255) + 0.02f) * 1.001f;
     const float inv_a = 1.0f / a, inv_c = 1.0f / c, b2 = 2.0f * b;
     uint32_t bits = 0u;
@@ -103,6 +103,89 @@ __device__ __forceinline__ unsigned long long rdg_uniform_u64(unsigned long long
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// The forward's walk over one 64-slot word of staged splats.  The compositing kernels turned out to be bound by the
+// SCALAR unit (one per CU, shared by the four SIMDs: 8 extra scalar instructions per visit cost 31 % in an ablation
+// build, 8 extra vector ones 6 %), so the walk is written to spend as few scalar instructions per visit as possible:
+//   * s_bitset0 / s_bitset1 on the walk mask and the visit record instead of shift + xor / or,
+//   * "power <= 0 and alpha >= threshold" as ONE unsigned compare: the sign bit of power is copied onto the bits of
+//     alpha (both terms of the completed square are <= 0, so a blending pair has it set; alpha >= 0), and the lane's
+//     threshold carries the same bit -- 0x80000000 | bits(1/255), or 0xffffffff once the pixel has stopped / lies
+//     outside the image.  No mask combination on the scalar side,
+//   * the alpha cap is only ever tested in words that hold a splat whose opacity exceeds it (CAPPED).
+#define RDG_THR_LIVE (0x80000000u | 0x3b808081u)   // sign | bits(1.0f / 255.0f)
+#define RDG_THR_DONE 0xffffffffu
+template <bool NORMAL, bool CAPPED>
+__device__ __forceinline__ void rdg_fwd_walk(unsigned long long mask, const unsigned long long cap, const int sbase,
+                                             const uint32_t wbase, const char* sQ0, const char* sQ1, const char* sQ2,
+                                             const char* sQ3, const float pixx, const float pixy,
+                                             unsigned long long& seen, uint32_t& thrU, float& T,
+                                             uint32_t& last_contributor, float& C0, float& C1, float& C2, float& Dp,
+                                             float& N0, float& N1, float& N2) {
+    while (mask) {
+        const int jb = __builtin_ctzll(mask);
+        asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(jb));
+        // byte offset of the slot, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar for
+        // every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
+        int aj = (jb << 4) + sbase;
+        asm volatile("" : "+v"(aj));
+#ifdef RDG_ABL_FXSALU   // ablation build: 8 extra scalar instructions per visit
+        asm volatile("s_add_u32 s90, s90, 1\n\ts_add_u32 s91, s91, 1\n\ts_add_u32 s90, s90, 1\n\ts_add_u32 s91, s91, 1\n\t"
+                     "s_add_u32 s90, s90, 1\n\ts_add_u32 s91, s91, 1\n\ts_add_u32 s90, s90, 1\n\ts_add_u32 s91, s91, 1" ::: "s90", "s91", "scc");
+#endif
+#ifdef RDG_ABL_FXVALU   // ablation build: 8 extra (fast-class) vector instructions per visit
+        { float xa = T, xb = C0;
+          asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %0\n\tv_mov_b32 %0, %1\n\tv_mov_b32 %1, %0\n\t"
+                       "v_mov_b32 %0, %1\n\tv_mov_b32 %1, %0\n\tv_mov_b32 %0, %1\n\tv_mov_b32 %1, %0" : "+v"(xa), "+v"(xb)); }
+#endif
+        const float4 q0 = *(const float4*)(sQ0 + aj);
+        const float2 q1 = *(const float2*)(sQ1 + aj);
+        const float dx = q0.x - pixx, dy = q0.y - pixy;
+        const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
+        float alpha = q1.y * __builtin_amdgcn_exp2f(power);
+        if (CAPPED && ((cap >> jb) & 1ull)) {
+            asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
+            alpha = fminf(RDG_ALPHA_CAP, alpha);
+        }
+        const uint32_t key = (__float_as_uint(power) & 0x80000000u) | __float_as_uint(alpha);
+        // lanes that may blend this splat
+        const unsigned long long cand = __builtin_amdgcn_ballot_w64(key >= thrU);
+        if (!cand) continue;
+        asm("s_bitset1_b64 %0, %1" : "+s"(seen) : "s"(jb));
+        // A lane that does not blend the splat runs the same instructions with alpha_eff = 0: T (1 - 0) = T, zero
+        // weight.  T >= RDG_T_STOP is an invariant of every lane (the update that would break it is the one that is
+        // not applied), so "T (1 - alpha_eff) < RDG_T_STOP" alone says "this pixel stops here"; the stopping lanes
+        // are repaired in the (rare) branch below.
+        float aeff;
+        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(aeff) : "v"(alpha), "s"(cand));
+        float test_T = T * (1.0f - aeff);
+        float wgt = aeff * T;
+        const float4 q2 = *(const float4*)(sQ2 + aj);
+        const uint32_t idx = wbase + (uint32_t)jb;
+        unsigned long long upd = cand;   // lanes that blend this splat
+        const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < RDG_T_STOP);
+        if (stopm) {
+            const bool stop = test_T < RDG_T_STOP;
+            upd &= ~stopm;
+            wgt = stop ? 0.0f : wgt;
+            test_T = stop ? T : test_T;
+            thrU = stop ? RDG_THR_DONE : thrU;
+            if (rdg_all(thrU == RDG_THR_DONE)) { mask = 0ull; }
+        }
+        T = test_T;
+        // last_contributor = upd ? idx : last_contributor as ONE vector instruction (a move under the lane mask; the
+        // select would need the scalar index copied into a VGPR first).  The walk runs with all lanes enabled.
+        asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1"
+                     : "+v"(last_contributor) : "s"(upd), "s"(idx));
+        C0 += wgt * q2.x; C1 += wgt * q2.y; C2 += wgt * q2.z;
+        Dp += wgt * q2.w;
+        if (NORMAL) {
+            const float4 q3 = *(const float4*)(sQ3 + aj);
+            N0 += wgt * q3.x; N1 += wgt * q3.y; N2 += wgt * q3.z;
+        }
+    }
+}
+
+
 template <bool NORMAL>
 __global__ void __launch_bounds__(256)
 rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
@@ -119,6 +202,10 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH], sQ3[RDG_BATCH];
     __shared__ unsigned long long sMask[4][4];  // [consumer quadrant][staging wave]
     __shared__ unsigned long long sCap[4];      // per staging wave: splats whose opacity exceeds the alpha cap
+#ifdef RDG_ABL_FPAD   // ablation build: LDS padding that lowers the occupancy
+    __shared__ float sPad[RDG_ABL_FPAD];
+    if (W < 0) sPad[threadIdx.x] = 1.0f;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int tx = tile % gx, ty = tile / gx;
@@ -137,14 +224,12 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     // start at (range.x / 64 + tile), which cannot overlap the next tile's; zeroed by the launcher
     unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
 
-    // "this pixel has stopped" is folded into its alpha threshold (+inf once stopped / outside the image): the hot
-    // test is two compares, and no loop-carried lane mask has to be re-canonicalised every iteration
-    float amin = inside ? RDG_ALPHA_MIN : __builtin_inff();
+    uint32_t thrU = inside ? RDG_THR_LIVE : RDG_THR_DONE;   // see rdg_fwd_walk
     float T = 1.0f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
     uint32_t last_contributor = 0;
     for (int r = 0; r < rounds; ++r) {
-        if (__syncthreads_count(amin > 1.0f) == 256) break;
+        if (__syncthreads_count(thrU == RDG_THR_DONE) == 256) break;
         const int k = r * RDG_BATCH + tid;
         uint32_t qbits = 0;
         bool over_cap = false;
@@ -172,69 +257,21 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             if (lane == 0) sCap[wv] = m;
         }
         __syncthreads();
-        const uint32_t base_idx = (uint32_t)(r * RDG_BATCH);
 #pragma unroll 1
         for (int s = 0; s < 4; ++s) {
-            if (rdg_all(amin > 1.0f)) break;   // once per 64 staged splats; inside the walk only after a pixel stops
-            unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
+            if (rdg_all(thrU == RDG_THR_DONE)) break;   // once per 64 staged splats; inside the walk only after a pixel stops
+            const unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
             const unsigned long long cap = rdg_uniform_u64(sCap[s]);
             unsigned long long seen = 0ull;    // splats of this 64-slot word that some pixel of the quadrant may blend
-            while (mask) {
-                const int jb = __builtin_ctzll(mask);
-                const int j = s * 64 + jb;
-                const unsigned long long bit = 1ull << jb;
-                mask ^= bit;
-                // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the
-                // scalar for every array: a VALU instruction with a scalar source issues at half the rate)
-                int aj = j * 16;
-                asm volatile("" : "+v"(aj));
-                const float4 q0 = *(const float4*)((const char*)sQ0 + aj);
-                const float2 q1 = *(const float2*)((const char*)sQ1 + aj);
-                const float dx = q0.x - pixx, dy = q0.y - pixy;
-                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
-                float alpha = q1.y * __builtin_amdgcn_exp2f(power);
-                if (cap & bit) {
-                    asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
-                    alpha = fminf(RDG_ALPHA_CAP, alpha);
-                }
-                // lanes that may blend this splat, as a scalar mask (a ballot of the combined predicate would be
-                // materialised through a 0/1 vector)
-                const unsigned long long cand = __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= amin);
-                if (!cand) continue;
-                seen |= bit;
-                // A lane that does not blend the splat runs the same instructions with alpha_eff = 0: T (1 - 0) = T,
-                // zero weight.  T >= RDG_T_STOP is an invariant of every lane (the update that would break it is the one
-                // that is not applied), so "T (1 - alpha_eff) < RDG_T_STOP" alone says "this pixel stops here"; the
-                // stopping lanes are repaired in the (rare) branch below.
-                float aeff;
-                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(aeff) : "v"(alpha), "s"(cand));
-                float test_T = T * (1.0f - aeff);
-                float wgt = aeff * T;
-                const float4 q2 = *(const float4*)((const char*)sQ2 + aj);
-                const uint32_t idx = base_idx + (uint32_t)j + 1u;
-                unsigned long long upd = cand;   // lanes that blend this splat
-                const unsigned long long stopm = __builtin_amdgcn_ballot_w64(test_T < RDG_T_STOP);
-                if (stopm) {
-                    const bool stop = test_T < RDG_T_STOP;
-                    upd &= ~stopm;
-                    wgt = stop ? 0.0f : wgt;
-                    test_T = stop ? T : test_T;
-                    amin = stop ? __builtin_inff() : amin;
-                    if (rdg_all(amin > 1.0f)) { mask = 0ull; }
-                }
-                T = test_T;
-                // last_contributor = upd ? idx : last_contributor as ONE vector instruction (a move under the lane
-                // mask; the select would need the scalar index copied into a VGPR first).  The walk runs with all
-                // lanes enabled.
-                asm volatile("s_mov_b64 exec, %1\n\tv_mov_b32 %0, %2\n\ts_mov_b64 exec, -1"
-                             : "+v"(last_contributor) : "s"(upd), "s"(idx));
-                C0 += wgt * q2.x; C1 += wgt * q2.y; C2 += wgt * q2.z;
-                Dp += wgt * q2.w;
-                if (NORMAL) {
-                    const float4 q3 = *(const float4*)((const char*)sQ3 + aj);
-                    N0 += wgt * q3.x; N1 += wgt * q3.y; N2 += wgt * q3.z;
-                }
-            }
+            const uint32_t wbase = (uint32_t)(r * RDG_BATCH + s * 64 + 1);
+            if (cap)
+                rdg_fwd_walk<NORMAL, true>(mask, cap, s * 1024, wbase, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
+                                           (const char*)sQ3, pixx, pixy, seen, thrU, T, last_contributor, C0, C1, C2, Dp,
+                                           N0, N1, N2);
+            else
+                rdg_fwd_walk<NORMAL, false>(mask, cap, s * 1024, wbase, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
+                                            (const char*)sQ3, pixx, pixy, seen, thrU, T, last_contributor, C0, C1, C2, Dp,
+                                            N0, N1, N2);
             if (lane == 0 && seen) hit[(size_t)(r * 4 + s) * 4 + wv] = seen;
         }
     }
@@ -276,7 +313,11 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
     return rdg_check_hip(hipGetLastError(), "render_fwd launch");
 }
 
-#define RDG_RING 8
+// 4 entries = one flush instruction per component row, and 6 KB of ring per workgroup: 8 workgroups per CU instead of 6
+// (the kernel is latency-bound: 0.457 -> 0.422 ms; 16 entries: 0.553 ms)
+#ifndef RDG_RING
+#define RDG_RING 4
+#endif
 // A ring entry holds, for each of the wave's 16 quads (quad = lane >> 2; two quads = one 8-pixel row of the quadrant),
 // six floats: see the reduction in the kernel.  Stride 6 keeps the parking stores 8-byte aligned and the 16 writer
 // lanes on 16 different banks.
@@ -314,6 +355,162 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], in
 // ---------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------
+// The backward's walk over one 64-slot word of staged splats (the scalar-instruction budget of rdg_fwd_walk applies).
+// jthr: per lane, the slot bit index above which the list position lies below the pixel's last contributor.
+template <bool HAS_DEPTH, bool CAPPED>
+__device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsigned long long cap, const int sbase,
+                                             const char* sQ0, const char* sQ1, const char* sQ2, const float pixx,
+                                             const float pixy, const int jthr, const float dLp0, const float dLp1,
+                                             const float dLp2, const float dLd, const int lane,
+                                             float (*ring)[16][RDG_RING_Q], const float flush_scale, const int flush_off,
+                                             float* __restrict__ grow, float& T, float& behind, int& ring_n) {
+    while (mask) {
+        const int jb = __builtin_ctzll(mask);
+        asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(jb));
+        // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar
+        // for every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
+        int aj = (jb << 4) + sbase;
+        asm volatile("" : "+v"(aj));
+        const float4 q0 = *(const float4*)(sQ0 + aj);
+        const float4 q1 = *(const float4*)(sQ1 + aj);
+        const float dx = q0.x - pixx, dy = q0.y - pixy;
+        const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
+        const float G = __builtin_amdgcn_exp2f(power);
+        float alpha = q1.y * G;
+        const bool capped = CAPPED && ((cap >> jb) & 1ull);
+        if (capped) {
+            asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
+            alpha = fminf(RDG_ALPHA_CAP, alpha);
+        }
+        // "power <= 0 and alpha >= 1/255" as one unsigned compare (see rdg_fwd_walk); "list position below the pixel's
+        // last contributor" as a compare of the slot's bit index with a per-lane bound formed once per word
+        const uint32_t key = (__float_as_uint(power) & 0x80000000u) | __float_as_uint(alpha);
+        const bool hit = (jb > jthr) && key >= RDG_THR_LIVE;
+        if (!rdg_any(hit)) continue;
+#ifdef RDG_ABL_PREONLY   // ablation build: the walk + the blend test only
+        if (G != 123.456f) continue;
+#endif
+        const float4 q2 = *(const float4*)(sQ2 + aj);
+        // Branch-free per-pixel derivatives.  A lane that does not blend this splat runs the same instructions
+        // with alpha_eff = 0, which leaves every piece of its state unchanged (T / (1 - 0) = T, behind += 0) and
+        // zeroes its contributions, so no per-variable selects are needed.  The colour accumulated BEHIND the
+        // current splat (back-to-front recurrence B <- alpha c + (1 - alpha) B, upstream's accum_rec evaluated
+        // eagerly) only ever enters through its product with the pixel's dL/dpixel, a per-pixel constant: so the
+        // recurrence runs on that ONE scalar, behind = B . dL/dpixel, with s = c . dL/dpixel per splat.
+        const float Gm = hit ? G : 0.0f;                      // the ONE select of the visit
+        float aeff = q1.y * Gm;                               // = alpha on the lanes that blend, 0 elsewhere
+        if (capped) {
+            asm volatile("; opacity above the cap" ::: "memory");
+            aeff = fminf(RDG_ALPHA_CAP, aeff);
+        }
+        const float inv1ma = __builtin_amdgcn_rcpf(1.0f - aeff);
+        T = T * inv1ma;
+        const float dch = aeff * T;
+        float s_ = q2.x * dLp0 + q2.y * dLp1 + q2.z * dLp2;
+        if (HAS_DEPTH) s_ += q1.z * dLd;
+        const float e_ = s_ - behind;
+        behind = fmaf(aeff, e_, behind);
+        const float dL_dalpha = e_ * T;
+        // What leaves the lane: the weight t0 = G dL/dalpha (= dL/dopacity; G dL/dG = opacity * t0, the opacity
+        // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 dx and
+        // t2 = t0 dx^2, and the colour terms.  The y-moments are NOT formed per pixel: the eight lanes of a
+        // pixel row share dy, so sum(t0 dy) = dy sum(t0), sum(t0 dx dy) = dy sum(t1), sum(t0 dy^2) = dy^2 sum(t0)
+        // are formed from the row totals (two multiplies per visit instead of three, and six values to reduce
+        // instead of nine).  The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per
+        // flushed row total (rdg_ring_flush).
+        const float t0 = Gm * dL_dalpha;
+        const float t1 = t0 * dx;
+        const float t2 = t1 * dx;
+        const float c0 = dch * dLp0, c1 = dch * dLp1, c2 = dch * dLp2, cd = HAS_DEPTH ? dch * dLd : 0.0f;
+        // Transposed reduction over the 8 lanes of a pixel row: DPP write masks work on quads (bank_mask), so the
+        // step across the row's two quads comes first and folds two values into one register (quad A = lanes
+        // 0-3 of the row keeps the pair sums of the first value, quad B of the second: one DPP add per bank
+        // mask into the same register, which the compiler cannot express), then two plain quad butterflies.
+        // 12 DPP adds (15 with depth) instead of 20 (21) for nine row totals over 16 lanes.  DPP needs two wait
+        // states after the VALU write of the register it reads: the order below keeps at least two instructions
+        // between every producer and its DPP consumer; s_nop 1 covers the inputs.
+        // Result, in every lane of a quad:   quad A: r0 = sum t0, r1 = sum t2, r2 = sum c1
+        //                                    quad B: r0 = sum t1, r1 = sum c0, r2 = sum c2     (r3 = sum cd)
+        float r0, r1, r2, r3 = 0.0f;
+#ifdef RDG_ABL_NODPP
+        r0 = t0 + t1; r1 = t2 + c0; r2 = c1 + c2; r3 = cd;
+        if (true) {
+        } else if (HAS_DEPTH) {
+#else
+        if (HAS_DEPTH) {
+#endif
+            asm volatile(
+                "s_nop 1\n\t"
+                "v_add_f32_dpp %[r0], %[t0], %[t0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %[r0], %[t1], %[t1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %[r1], %[t2], %[t2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %[r1], %[c0], %[c0] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %[r2], %[c1], %[c1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %[r2], %[c2], %[c2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %[r3], %[cd], %[cd] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+                : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [cd] "v"(cd));
+        } else {
+            asm volatile(
+                "s_nop 1\n\t"
+                "v_add_f32_dpp %[r0], %[t0], %[t0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %[r0], %[t1], %[t1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %[r1], %[t2], %[t2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %[r1], %[c0], %[c0] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %[r2], %[c1], %[c1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                "v_add_f32_dpp %[r2], %[c2], %[c2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2)
+                : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2));
+        }
+        // y-moments of the row from its totals (quad A: dy sum t0, dy^2 sum t0; quad B: dy sum t1)
+        const float m1 = r0 * dy;
+        const float m2 = m1 * dy;
+        {
+            // One lane per quad parks the quad's totals in this wave's private ring with PLAIN LDS stores (LDS
+            // float atomics into a table shared by the 4 waves cost a third of the kernel); the 8 pixel-row
+            // partials are added when the ring is flushed.
+#if defined(RDG_PARK_ALL)
+            {   // tuning build: every lane of a quad stores the quad's (identical) totals to the same address
+                float* gr = &ring[ring_n][lane >> 2][0];
+                gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = m1; gr[4] = ((lane >> 2) == 1) ? q2.w : m2;
+                if (HAS_DEPTH) gr[5] = r3;
+            }
+#else
+#ifdef RDG_ABL_NOPARK
+            if (lane == 63 && m2 == 123.456f) {
+#else
+            if ((lane & 3) == 0) {
+#endif
+                float* gr = &ring[ring_n][lane >> 2][0];
+                gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = m1; gr[4] = m2;
+                if (HAS_DEPTH) gr[5] = r3;
+                // the Gaussian's row index rides in a slot no component uses (quad B has no dy^2 moment); LDS
+                // stores of a wave land in program order, so this one overrides m2 of lane 4
+                if (lane == 4) gr[4] = q2.w;
+            }
+#endif
+            if (++ring_n == RDG_RING) {
+                rdg_ring_flush<HAS_DEPTH>(ring, ring_n, lane, flush_scale, flush_off, grow);
+                ring_n = 0;
+            }
+        }
+    }
+}
+
 // HAS_DEPTH = false: no upstream gradient for the depth image (photometric-only losses) -- the depth channel drops out
 // of the per-pair arithmetic and of the reduction.
 template <bool HAS_DEPTH>
@@ -420,133 +617,19 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         for (int s = 0; s < 4; ++s) {
             unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
             const unsigned long long cap = rdg_uniform_u64(sCap[s]);
-            while (mask) {
-                const int jb = __builtin_ctzll(mask);
-                const int j = s * 64 + jb;
-                const unsigned long long bit = 1ull << jb;
-                mask ^= bit;
-                const int k = kbase - j;  // list position of this splat
-                // byte offset of slot j, pinned in one VGPR (the compiler otherwise re-materialises it from the scalar
-                // for every array: a VALU instruction with a scalar source issues at half the rate of a plain one)
-                int aj = j * 16;
-                asm volatile("" : "+v"(aj));
-                const float4 q0 = *(const float4*)((const char*)sQ0 + aj);
-                const float4 q1 = *(const float4*)((const char*)sQ1 + aj);
-                const float dx = q0.x - pixx, dy = q0.y - pixy;
-                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
-                const float G = __builtin_amdgcn_exp2f(power);
-                float alpha = q1.y * G;
-                if (cap & bit) {
-                    asm volatile("; opacity above the cap" ::: "memory");   // keeps this a scalar branch (not min + select)
-                    alpha = fminf(RDG_ALPHA_CAP, alpha);
-                }
-                const bool hit = (k < last_contributor) && power <= 0.0f && alpha >= RDG_ALPHA_MIN;
-                if (!rdg_any(hit)) continue;
-                const float4 q2 = *(const float4*)((const char*)sQ2 + aj);
-                // Branch-free per-pixel derivatives.  A lane that does not blend this splat runs the same instructions
-                // with alpha_eff = 0, which leaves every piece of its state unchanged (T / (1 - 0) = T, behind += 0) and
-                // zeroes its contributions, so no per-variable selects are needed.  The colour accumulated BEHIND the
-                // current splat (back-to-front recurrence B <- alpha c + (1 - alpha) B, upstream's accum_rec evaluated
-                // eagerly) only ever enters through its product with the pixel's dL/dpixel, a per-pixel constant: so the
-                // recurrence runs on that ONE scalar, behind = B . dL/dpixel, with s = c . dL/dpixel per splat.
-                const float Gm = hit ? G : 0.0f;                      // the ONE select of the visit
-                float aeff = q1.y * Gm;                               // = alpha on the lanes that blend, 0 elsewhere
-                if (cap & bit) {
-                    asm volatile("; opacity above the cap" ::: "memory");
-                    aeff = fminf(RDG_ALPHA_CAP, aeff);
-                }
-                const float inv1ma = __builtin_amdgcn_rcpf(1.0f - aeff);
-                T = T * inv1ma;
-                const float dch = aeff * T;
-                float s_ = q2.x * dLp0 + q2.y * dLp1 + q2.z * dLp2;
-                if (HAS_DEPTH) s_ += q1.z * dLd;
-                const float e_ = s_ - behind;
-                behind = fmaf(aeff, e_, behind);
-                const float dL_dalpha = e_ * T;
-                // What leaves the lane: the weight t0 = G dL/dalpha (= dL/dopacity; G dL/dG = opacity * t0, the opacity
-                // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 dx and
-                // t2 = t0 dx^2, and the colour terms.  The y-moments are NOT formed per pixel: the eight lanes of a
-                // pixel row share dy, so sum(t0 dy) = dy sum(t0), sum(t0 dx dy) = dy sum(t1), sum(t0 dy^2) = dy^2 sum(t0)
-                // are formed from the row totals (two multiplies per visit instead of three, and six values to reduce
-                // instead of nine).  The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per
-                // flushed row total (rdg_ring_flush).
-                const float t0 = Gm * dL_dalpha;
-                const float t1 = t0 * dx;
-                const float t2 = t1 * dx;
-                const float c0 = dch * dLp0, c1 = dch * dLp1, c2 = dch * dLp2, cd = HAS_DEPTH ? dch * dLd : 0.0f;
-                // Transposed reduction over the 8 lanes of a pixel row: DPP write masks work on quads (bank_mask), so the
-                // step across the row's two quads comes first and folds two values into one register (quad A = lanes
-                // 0-3 of the row keeps the pair sums of the first value, quad B of the second: one DPP add per bank
-                // mask into the same register, which the compiler cannot express), then two plain quad butterflies.
-                // 12 DPP adds (15 with depth) instead of 20 (21) for nine row totals over 16 lanes.  DPP needs two wait
-                // states after the VALU write of the register it reads: the order below keeps at least two instructions
-                // between every producer and its DPP consumer; s_nop 1 covers the inputs.
-                // Result, in every lane of a quad:   quad A: r0 = sum t0, r1 = sum t2, r2 = sum c1
-                //                                    quad B: r0 = sum t1, r1 = sum c0, r2 = sum c2     (r3 = sum cd)
-                float r0, r1, r2, r3 = 0.0f;
-                if (HAS_DEPTH) {
-                    asm volatile(
-                        "s_nop 1\n\t"
-                        "v_add_f32_dpp %[r0], %[t0], %[t0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                        "v_add_f32_dpp %[r0], %[t1], %[t1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                        "v_add_f32_dpp %[r1], %[t2], %[t2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                        "v_add_f32_dpp %[r1], %[c0], %[c0] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                        "v_add_f32_dpp %[r2], %[c1], %[c1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                        "v_add_f32_dpp %[r2], %[c2], %[c2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                        "v_add_f32_dpp %[r3], %[cd], %[cd] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r3], %[r3], %[r3] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
-                        : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [cd] "v"(cd));
-                } else {
-                    asm volatile(
-                        "s_nop 1\n\t"
-                        "v_add_f32_dpp %[r0], %[t0], %[t0] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                        "v_add_f32_dpp %[r0], %[t1], %[t1] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                        "v_add_f32_dpp %[r1], %[t2], %[t2] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                        "v_add_f32_dpp %[r1], %[c0], %[c0] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                        "v_add_f32_dpp %[r2], %[c1], %[c1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-                        "v_add_f32_dpp %[r2], %[c2], %[c2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r0], %[r0], %[r0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r1], %[r1], %[r1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                        "v_add_f32_dpp %[r2], %[r2], %[r2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2)
-                        : [t0] "v"(t0), [t1] "v"(t1), [t2] "v"(t2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2));
-                }
-                // y-moments of the row from its totals (quad A: dy sum t0, dy^2 sum t0; quad B: dy sum t1)
-                const float m1 = r0 * dy;
-                const float m2 = m1 * dy;
-                {
-                    // One lane per quad parks the quad's totals in this wave's private ring with PLAIN LDS stores (LDS
-                    // float atomics into a table shared by the 4 waves cost a third of the kernel); the 8 pixel-row
-                    // partials are added when the ring is flushed.
-#ifdef RDG_ABL_NOPARK
-                    if (lane == 63 && m2 == 123.456f) {
-#else
-                    if ((lane & 3) == 0) {
+#ifdef RDG_ABL_STAGEONLY   // ablation build: staging and barriers only
+            if (T != 123.456f) mask = 0ull;
 #endif
-                        float* gr = &sRing[wv][ring_n][lane >> 2][0];
-                        gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = m1; gr[4] = m2;
-                        if (HAS_DEPTH) gr[5] = r3;
-                        // the Gaussian's row index rides in a slot no component uses (quad B has no dy^2 moment); LDS
-                        // stores of a wave land in program order, so this one overrides m2 of lane 4
-                        if (lane == 4) gr[4] = q2.w;
-                    }
-                    if (++ring_n == RDG_RING) {
-                        rdg_ring_flush<HAS_DEPTH>(sRing[wv], ring_n, lane, flush_scale, flush_off, grow);
-                        ring_n = 0;
-                    }
-                }
-            }
+            // list position of slot bit jb of this word: kbase - 64 s - jb; below last_contributor <=> jb > jthr
+            const int jthr = kbase - s * 64 - last_contributor;
+            if (cap)
+                rdg_bwd_walk<HAS_DEPTH, true>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2, pixx,
+                                              pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale, flush_off,
+                                              grow, T, behind, ring_n);
+            else
+                rdg_bwd_walk<HAS_DEPTH, false>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2, pixx,
+                                               pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale, flush_off,
+                                               grow, T, behind, ring_n);
         }
         __syncthreads();   // every wave is done with this round's staged records
     }

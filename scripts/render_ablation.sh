@@ -1,8 +1,10 @@
 #!/bin/bash
-# Ablation builds of the compositing backward on the GPU box: rebuilds rdg_render.o with one piece removed and prints the
-# stage timers of the bench.  Results of these builds are WRONG by construction; only the timing is read.
+# Ablation / tuning builds of the compositing kernels on the GPU box: rebuilds rdg_render.o with the given macro sets
+# (one argument = one variant) and prints the bench's stage timers.  Results of RDG_ABL_* builds are WRONG by
+# construction; only the timing is read.   usage: scripts/render_ablation.sh ["-DA" "-DB -DC" ...]
 cd "$(dirname "$0")/.."
-for v in "" "-DRDG_ABL_NOATOMIC" "-DRDG_ABL_NOPARK" "-DRDG_ABL_NOATOMIC -DRDG_ABL_NOPARK" $EXTRA_VARIANTS; do
+if [ $# -eq 0 ]; then set -- "-DRDG_ABL_NOATOMIC" "-DRDG_ABL_NOATOMIC -DRDG_ABL_NOPARK" "-DRDG_ABL_NODPP" "-DRDG_ABL_PREONLY"; fi
+for v in "" "$@"; do
   rm -f rodygs_amd/csrc/rdg_render.o
   make -C rodygs_amd/csrc EXTRA="$v" > /dev/null 2>&1 || { echo "build failed: $v"; continue; }
   python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python -c "
