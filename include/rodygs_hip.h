@@ -182,6 +182,13 @@ int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews
                                  const float* means3D, const float* shs, const float* opacities, const float* scales,
                                  const float* rotations, const float* viewmatrices, const float* projmatrix,
                                  void* geom_ws, int32_t* radii, void* stream);
+/* The same launch restricted to rows [row0, row0 + s_host->P) of the slice (row0 a multiple of 256; every pointer is
+ * that of row 0): lets the owner stage run in row chunks so that the record exchange of a chunk (all-to-all #1 of the
+ * sharded step) overlaps the projection of the next.                                        */
+int rdg_preprocess_forward_views_rows(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                      int32_t row0, const float* means3D, const float* shs, const float* opacities,
+                                      const float* scales, const float* rotations, const float* viewmatrices,
+                                      const float* projmatrix, void* geom_ws, int32_t* radii, void* stream);
 int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
                                   const float* means3D, const float* shs, const float* opacities, const float* scales,
                                   const float* rotations, const float* viewmatrices, const float* projmatrix,

@@ -58,6 +58,8 @@ _SIGS = {
     "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 2 +
                                      [C.c_double, C.c_double, C.c_float, C.c_int32, _vp]),
     "rdg_preprocess_forward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 10),
+    "rdg_preprocess_forward_views_rows": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32, C.c_int32]
+                                          + [_vp] * 10),
     "rdg_preprocess_backward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 18),
     "rdg_geom_export": (C.c_int, [C.c_int32] + [_vp] * 8),
     "rdg_image_export": (C.c_int, [C.c_int32, C.c_int32] + [_vp] * 4),

@@ -287,20 +287,30 @@ static int rdg_views_args(const RdgRasterSettings* s_host, int32_t nviews, int32
     return 0;
 }
 
-int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
-                                 const float* means3D, const float* shs, const float* opacities, const float* scales,
-                                 const float* rotations, const float* viewmatrices, const float* projmatrix,
-                                 void* geom_ws, int32_t* radii, void* stream) {
+int rdg_preprocess_forward_views_rows(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                      int32_t row0, const float* means3D, const float* shs, const float* opacities,
+                                      const float* scales, const float* rotations, const float* viewmatrices,
+                                      const float* projmatrix, void* geom_ws, int32_t* radii, void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
     if (rdg_views_args(s_host, nviews, stride_rows, shs, scales, rotations)) return -1;
+    if (row0 < 0 || row0 % RDG_PRE_BLOCK || (int64_t)row0 + s_host->P > stride_rows)
+        return rdg_set_error("views: row0 must be a multiple of %d with row0 + P <= stride_rows", RDG_PRE_BLOCK);
     hipStream_t st = (hipStream_t)stream;
     rdg_stage_begin(RDG_STAGE_PREPROCESS, st);
-    int rc = rdg_launch_preprocess_fwd_views(d, nviews, stride_rows, means3D, shs, opacities, scales, rotations,
+    int rc = rdg_launch_preprocess_fwd_views(d, nviews, stride_rows, row0, means3D, shs, opacities, scales, rotations,
                                              viewmatrices, projmatrix, geom_ws, radii, st);
     if (rc) return rc;
     rdg_stage_end(RDG_STAGE_PREPROCESS, st);
     return 0;
+}
+
+int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
+                                 const float* means3D, const float* shs, const float* opacities, const float* scales,
+                                 const float* rotations, const float* viewmatrices, const float* projmatrix,
+                                 void* geom_ws, int32_t* radii, void* stream) {
+    return rdg_preprocess_forward_views_rows(s_host, nviews, stride_rows, 0, means3D, shs, opacities, scales, rotations,
+                                             viewmatrices, projmatrix, geom_ws, radii, stream);
 }
 
 int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,

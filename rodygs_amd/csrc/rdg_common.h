@@ -228,9 +228,10 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
                               float* dcolors, float* dopac, float* dscales, float* drots, float* dcov3D,
                               float* dview, hipStream_t s, const RdgShAdam* sh_adam = nullptr);
 
-int rdg_launch_preprocess_fwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
-                                    const float* shs, const float* opac, const float* scales, const float* rots,
-                                    const float* views, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s);
+int rdg_launch_preprocess_fwd_views(const RdgDev& d, int32_t nviews, int32_t stride, int32_t row0,
+                                    const float* means3D, const float* shs, const float* opac, const float* scales,
+                                    const float* rots, const float* views, const float* proj, void* geom_ws,
+                                    int32_t* radii, hipStream_t s);
 int rdg_launch_preprocess_bwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
                                     const float* shs, const float* opac, const float* scales, const float* rots,
                                     const float* views, const float* proj, const int32_t* radii, const void* geom_ws,

@@ -35,16 +35,19 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                           const float* __restrict__ cov3Dp, RdgRec* __restrict__ rec_b,
                           uint32_t* __restrict__ tiles_touched_b, uint8_t* __restrict__ clampedm_b,
                           uint32_t* __restrict__ block_sums_b, int32_t* __restrict__ radii_b, int nviews_arg,
-                          int vstride_arg) {
+                          int vstride_arg, int blk0_arg) {
     const int nviews = MULTI ? nviews_arg : 1, vstride = MULTI ? vstride_arg : 0;   // MULTI = false: the single-camera kernel
+    // row-range launches of the multi-camera kernel (chunked owner stage, pipelined with the exchange): workgroup
+    // blockIdx.x works on rows [(blk0 + blockIdx.x) * RDG_PRE_BLOCK, ...) and d.P is the END row of the range
+    const int bid = (MULTI ? blk0_arg : 0) + (int)blockIdx.x;
     // nviews > 1 (sharded frame-DP owner stage): the same Gaussians under the cameras of a whole step.  Time-dependent
     // inputs (means3D, rotations) and all outputs are stacked per camera with a row stride of vstride (multiple of
     // 256); SH rows, scales and opacities are shared -- the SH rows are staged into LDS once for all cameras.
-    const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    const int i = bid * RDG_PRE_BLOCK + threadIdx.x;
     // SH rows of the wave's 64 Gaussians: staged through LDS with wave-contiguous loads (rdg_rows_to_lds)
     __shared__ float sSH[RDG_PRE_BLOCK / 64][64 * 49];
     const int sh_row = d.M * 3, sh_stride = sh_row | 1;
-    const long long wave_first = (long long)blockIdx.x * RDG_PRE_BLOCK + (threadIdx.x >> 6) * 64;
+    const long long wave_first = (long long)bid * RDG_PRE_BLOCK + (threadIdx.x >> 6) * 64;
     if (shs && wave_first < d.P) {
         rdg_rows_to_lds(shs, wave_first, d.P, sh_row, sh_stride, sSH[threadIdx.x >> 6], threadIdx.x & 63);
         rdg_wave_lds_sync();
@@ -219,12 +222,12 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
         clampedm[i] = cl;
         radii[i] = radius_out;
     }
-    // block sum of tiles_touched -> block_sums[blockIdx.x]
+    // block sum of tiles_touched -> block_sums[bid]
     uint32_t inc = rdg_wave_scan_incl(my_tiles);
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) block_sums[bid] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (nviews > 1) __syncthreads();       // wsum is reused by the next camera
     }
 }
@@ -314,7 +317,7 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
     if (d.P > 0) {
         hipLaunchKernelGGL(rdg_preprocess_fwd_kernel<false>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
                            shs, colors, opac, scales, rots, cov3D, (RdgRec*)(g + L.rec),
-                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0);
+                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0, 0);
     }
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
                        num_rendered, zero_buf, (int)zero_words);
@@ -323,16 +326,21 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
 
 // All cameras of a step in one launch (sharded frame-DP owner stage): camera v owns rows [v*stride, v*stride + d.P) of
 // a workspace laid out for nviews*stride rows, so that the records of all cameras form ONE contiguous send buffer.
-int rdg_launch_preprocess_fwd_views(const RdgDev& d, int32_t nviews, int32_t stride, const float* means3D,
-                                    const float* shs, const float* opac, const float* scales, const float* rots,
-                                    const float* views, const float* proj, void* geom_ws, int32_t* radii, hipStream_t s) {
+// row0 / d.P: the launch covers rows [row0, row0 + d.P) of the slice (row0 a multiple of RDG_PRE_BLOCK); all pointers
+// are those of row 0.
+int rdg_launch_preprocess_fwd_views(const RdgDev& d_in, int32_t nviews, int32_t stride, int32_t row0,
+                                    const float* means3D, const float* shs, const float* opac, const float* scales,
+                                    const float* rots, const float* views, const float* proj, void* geom_ws,
+                                    int32_t* radii, hipStream_t s) {
     const RdgGeomLayout L = rdg_geom_layout(nviews * stride);
     char* g = (char*)geom_ws;
-    const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
-    if (d.P > 0)
+    const int nblk = (d_in.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    RdgDev d = d_in;
+    d.P = row0 + d_in.P;
+    if (d_in.P > 0)
         hipLaunchKernelGGL(rdg_preprocess_fwd_kernel<true>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, views, proj, means3D,
                            shs, (const float*)nullptr, opac, scales, rots, (const float*)nullptr,
                            (RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped),
-                           (uint32_t*)(g + L.block_sums), radii, nviews, stride);
+                           (uint32_t*)(g + L.block_sums), radii, nviews, stride, row0 / RDG_PRE_BLOCK);
     return rdg_check_hip(hipGetLastError(), "preprocess_fwd views launch");
 }

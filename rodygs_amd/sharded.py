@@ -25,6 +25,7 @@ parity tests, ``HostStagedExchange`` lets real processes share one GPU over gloo
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -45,6 +46,21 @@ class DistExchange:
     def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
         dist.all_to_all_single(recv, send)
 
+    def all_to_all_rows(self, recv: torch.Tensor, send: torch.Tensor, stride: int, r0: int, r1: int) -> None:
+        """Rows [r0, r1) of every shard of the equal-split all-to-all (shard = ``stride`` rows of 64 B): the row range of
+        my slice under camera v goes to rank v, into the same rows of my shard there.  One grouped send / receive."""
+        world, me = dist.get_world_size(), dist.get_rank()
+        sv, rv = send.view(world, stride, -1), recv.view(world, stride, -1)
+        ops = []
+        for p in range(world):
+            if p != me:                 # grouped point-to-point (RCCL fuses the batch into one launch; works on gloo too)
+                ops.append(dist.P2POp(dist.isend, sv[p, r0:r1], p))
+                ops.append(dist.P2POp(dist.irecv, rv[p, r0:r1], p))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        rv[me, r0:r1].copy_(sv[me, r0:r1])
+        for q in reqs:
+            q.wait()
+
     def all_reduce(self, t: torch.Tensor) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
@@ -64,6 +80,13 @@ class HostStagedExchange(DistExchange):
         r = torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(r, send.cpu())
         recv.copy_(r)
+
+    def all_to_all_rows(self, recv, send, stride, r0, r1):
+        world = dist.get_world_size()
+        sv, rv = send.view(world, stride, -1), recv.view(world, stride, -1)
+        r = torch.empty(world, r1 - r0, sv.shape[2], dtype=recv.dtype)
+        dist.all_to_all_single(r, sv[:, r0:r1].contiguous().cpu())
+        rv[:, r0:r1].copy_(r)
 
     def all_reduce(self, t):
         c = t.cpu()
@@ -163,6 +186,9 @@ class ShardedDynamicScene:
             if float(allc.max() - allc.min()) != 0.0:
                 raise RuntimeError("ShardedDynamicScene: the replicated MLP / pose parameters differ between ranks "
                                    f"(checksums {allc.tolist()}); build the replica with the same seed on every rank")
+        # all-to-all #1 in this many row chunks, each overlapped with the projection of the next (1 = one exchange after
+        # the whole owner stage)
+        self.a2a_chunks = max(1, int(os.environ.get("RDG_A2A_CHUNKS", "1")))
         self.stats = None                # DensifyStats of my slice once track_densification() is called
         self.counts = [min(per, max(ds.P - r * per, 0)) for r in range(world)]      # slice sizes of all ranks
         self._time_ind_full = None
@@ -212,6 +238,7 @@ class ShardedDynamicScene:
         self._capacity = 0
         rs = GaussianRasterizationSettings(self.H, self.W, self.tanfovx, self.tanfovy, self.bg, 1.0, self.proj_t,
                                            self.sh_degree, False, False, True, True)
+        self._rs, self._cs_rows = rs, {}                # settings of a row range of the owner stage, by row count
         self.cs_own = _c_settings(rs, n, self.K)        # per-Gaussian stages: my n Gaussians (per camera)
         self.cs_cam = _c_settings(rs, R, self.K)        # compositing stages: every row of the gathered records
         self.key = (R, self.H, self.W)
@@ -228,8 +255,20 @@ class ShardedDynamicScene:
             self._rows_cache[key] = r
         return r
 
-    def phase_owner_forward(self, step: int, perm: Sequence[int]) -> None:
-        """Deformation + activations + projection of MY Gaussians for the cameras of every rank -> ``rec_own``."""
+    def chunk_ranges(self, chunks: int):
+        """Row ranges [r0, r1) (multiples of 256, the same on every rank) that cut a shard of ``stride`` rows into at most
+        ``chunks`` pieces."""
+        blocks = self.stride // 256
+        per = -(-blocks // max(1, min(chunks, blocks)))
+        return [(b * 256, min(b + per, blocks) * 256) for b in range(0, blocks, per)]
+
+    def phase_owner_forward(self, step: int, perm: Sequence[int], chunks: int = 1, exchange: bool = False) -> None:
+        """Deformation + activations + projection of MY Gaussians for the cameras of every rank -> ``rec_own``.
+        ``chunks`` > 1: the slice is processed in row ranges (same arithmetic, same bits); with ``exchange`` the records of
+        a range go on the wire (all-to-all #1, on a side stream) while the next range is projected -- on return
+        ``rec_cam`` is complete on the current stream."""
+        if chunks > 1 or exchange:
+            return self._owner_forward_chunked(step, perm, chunks, exchange)
         L, Wn, T, n, dev = _lib.lib(), self.world, self.T, self.n, self.device
         self.frames = [frame_for(step, r, Wn, perm) for r in range(Wn)]
         self._frames_c = (C.c_int32 * Wn)(*self.frames)
@@ -258,6 +297,52 @@ class ShardedDynamicScene:
                                                       _lib.ptr(self.ro), _lib.ptr(self.views), _lib.ptr(self.proj_t),
                                                       _lib.ptr(self.geom_own), _lib.ptr(self.radii_own), st),
                        "rdg_preprocess_forward_views")
+
+    def _owner_forward_chunked(self, step: int, perm: Sequence[int], chunks: int, exchange: bool) -> None:
+        L, Wn, T, n, dev = _lib.lib(), self.world, self.T, self.n, self.device
+        self.frames = [frame_for(step, r, Wn, perm) for r in range(Wn)]
+        self._frames_c = (C.c_int32 * Wn)(*self.frames)
+        fp, sp = self.fp, self.sp
+        with torch.cuda.device(dev):
+            main = torch.cuda.current_stream()
+            st = _lib.stream_ptr()
+            allb = self.net.motion_basis(self._emb_rows(self.frames))                   # [T+W,16,7]
+            self._allb = allb
+            self._bases_all = torch.cat([allb[:T].unsqueeze(0).expand(Wn, -1, -1, -1), allb[T:].unsqueeze(1)], dim=1)
+            b = self._bases_all.detach()
+            _lib.check(L.rdg_pose_views_forward(T, Wn, self._frames_c, _lib.ptr(sp["cam_q"]), _lib.ptr(sp["cam_t"]),
+                                                _lib.ptr(self.views), st), "rdg_pose_views_forward")
+            if exchange and getattr(self, "_comm_stream", None) is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            for r0, r1 in self.chunk_ranges(chunks):
+                m = min(r1, n) - r0                     # my rows in this range (the rest of the range is zero padding)
+                if m > 0:
+                    _lib.check(L.rdg_dyn_getter_views_forward(m, T, Wn, self.stride, _lib.ptr(fp["motion_coeff"][r0:]),
+                                                              _lib.ptr(self.time_ind[r0:]), _lib.ptr(b),
+                                                              float(self.spatial_lr_scale), _lib.ptr(fp["xyz"][r0:]),
+                                                              _lib.ptr(fp["scaling"][r0:]), _lib.ptr(fp["rotation"][r0:]),
+                                                              _lib.ptr(fp["opacity"][r0:]), _lib.ptr(self.m3[0, r0:]),
+                                                              _lib.ptr(self.sc[r0:]), _lib.ptr(self.ro[0, r0:]),
+                                                              _lib.ptr(self.op[r0:]), st), "rdg_dyn_getter_views_forward")
+                    cs = self._cs_rows.get(m)
+                    if cs is None:
+                        cs = self._cs_rows[m] = _c_settings(self._rs, m, self.K)
+                    _lib.check(L.rdg_preprocess_forward_views_rows(C.byref(cs), Wn, self.stride, r0, _lib.ptr(self.m3),
+                                                                   _lib.ptr(fp["features"]), _lib.ptr(self.op),
+                                                                   _lib.ptr(self.sc), _lib.ptr(self.ro),
+                                                                   _lib.ptr(self.views), _lib.ptr(self.proj_t),
+                                                                   _lib.ptr(self.geom_own), _lib.ptr(self.radii_own), st),
+                               "rdg_preprocess_forward_views_rows")
+                if exchange:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    with torch.cuda.stream(self._comm_stream):
+                        self._comm_stream.wait_event(ready)
+                        self.ex.all_to_all_rows(self.rec_cam, self.rec_own, self.stride, r0, r1)
+            if exchange:
+                done = torch.cuda.Event()
+                done.record(self._comm_stream)
+                main.wait_event(done)
 
     def _composite_forward(self) -> None:
         L, dev = _lib.lib(), self.device
@@ -506,8 +591,11 @@ class ShardedDynamicScene:
 
     # ---- one step over the process group ---------------------------------------------------------------------------
     def train_step(self, step: int, perm: Sequence[int]) -> torch.Tensor:
-        self.phase_owner_forward(step, perm)
-        self.ex.all_to_all(self.rec_cam, self.rec_own)
+        if self.a2a_chunks > 1:         # records of a row range on the wire while the next range is projected
+            self.phase_owner_forward(step, perm, chunks=self.a2a_chunks, exchange=True)
+        else:
+            self.phase_owner_forward(step, perm)
+            self.ex.all_to_all(self.rec_cam, self.rec_own)
         loss = self.phase_camera()
         self.ex.all_to_all(self.row_own, self.row_cam)
         self.phase_owner_backward()

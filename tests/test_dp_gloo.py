@@ -222,3 +222,32 @@ def test_sharded_exchange_reproduces_replicated_gradients():
             assert float(ref.abs().max()) > 0
             assert torch.allclose(gr, ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max())), (r, k)
         assert torch.allclose(res[r]["dview"], torch.stack(want_view), rtol=1e-4, atol=1e-5)
+
+
+def _rows_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rodygs_amd.sharded import DistExchange
+    ex = DistExchange()
+    stride, cols = 12, 16
+    send = (torch.arange(world * stride * cols, dtype=torch.float32) + 1000.0 * rank).view(world, stride, cols)
+    whole = torch.empty_like(send)
+    ex.all_to_all(whole.view(-1), send.view(-1).contiguous())
+    pieces = torch.zeros_like(send)
+    for r0, r1 in ((0, 5), (5, 6), (6, 12)):
+        ex.all_to_all_rows(pieces.view(-1), send.view(-1), stride, r0, r1)
+    torch.save({"whole": whole, "pieces": pieces}, os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_range_exchange_equals_the_whole_all_to_all():
+    """all-to-all #1 of the sharded step cut into row ranges (DistExchange.all_to_all_rows, grouped point-to-point) fills
+    the receive buffer exactly as the one equal-split all_to_all_single does (world 2 and 3, gloo)."""
+    for world in (2, 3):
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(_rows_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+            for r in range(world):
+                g = torch.load(os.path.join(d, f"r{r}.pt"))
+                assert torch.equal(g["whole"], g["pieces"])

@@ -1524,6 +1524,8 @@ def _two_process_worker(rank, world, port, outdir):
         ds.make_ground_truth(Or.synthetic_scene(1500, 256, 192, 3, seed=72), range(6))
         ss = ShardedDynamicScene.from_replica(ds, rank, world, exchange=HostStagedExchange())
         ss.seed_rng(500 + rank)
+        if full:
+            ss.a2a_chunks = 3           # the owner stage in row chunks, each chunk's records exchanged on the side stream
         losses = [float(ss.train_step(s_, list(range(6)))) for s_ in range(4, 7)]      # step 5: rigidity (full)
         sd = ss.export_state_dict(iteration=7)
         out[full] = {"losses": losses, "params": {k: v.cpu() for k, v in ss.gather_params().items()},
@@ -1578,6 +1580,31 @@ def test_sharded_step_in_two_real_processes():
     i0, i1 = got[0]["densify"], got[1]["densify"]
     assert i0[2] == i1[2] and i0[3] == i1[3] and i0[3] == [i0[1], i1[1]] and i0[0]["P"] == i0[1] + i1[1]
     assert np.isfinite(i0[4]) and np.isfinite(i1[4])
+
+
+def test_owner_stage_in_row_chunks_is_bit_identical():
+    """The chunked owner stage (rdg_preprocess_forward_views_rows + the getter on row ranges), which the pipelined
+    all-to-all #1 runs, writes exactly the records, radii and tile counts of the one-launch owner stage -- ragged last
+    shard, three virtual ranks, chunk counts that do and do not divide the shard."""
+    from rodygs_amd.sharded import ShardedDynamicScene
+    from rodygs_amd.trainstep import DynamicScene
+    sc = O.synthetic_scene(5003, 256, 192, 3, seed=91)
+    ds = DynamicScene(sc, num_frames=6, device=DEV)
+    ds.make_ground_truth(O.synthetic_scene(1200, 256, 192, 3, seed=92), range(6))
+    shards = [ShardedDynamicScene.from_replica(ds, r, 3, exchange=object()) for r in range(3)]
+    for sh in shards:
+        assert sh.chunk_ranges(1) == [(0, sh.stride)] and sh.chunk_ranges(64)[-1][1] == sh.stride
+        sh.phase_owner_forward(7, list(range(6)))
+        torch.cuda.synchronize()
+        want = (sh.geom_own.clone(), sh.radii_own.clone(), sh.m3.clone(), sh.ro.clone(), sh.sc.clone(), sh.op.clone())
+        for chunks in (2, 3, 5):
+            for t in (sh.geom_own, sh.radii_own, sh.m3, sh.ro, sh.sc, sh.op):
+                t.zero_()
+            sh.phase_owner_forward(7, list(range(6)), chunks=chunks)
+            torch.cuda.synchronize()
+            got = (sh.geom_own, sh.radii_own, sh.m3, sh.ro, sh.sc, sh.op)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), (sh.rank, chunks)
 
 
 def _two_process_allreduce_worker(rank, world, port, outdir):
