@@ -51,7 +51,18 @@ typedef float float2v __attribute__((ext_vector_type(2)));
     X(35, "v_mul_legacy / v_mul_f32 neg","v_mul_f32_e64 %0, -%0, %2",                          a) \
     X(36, "v_bfe_u32",                   "v_bfe_u32 %0, %0, 3, 5",                             a) \
     X(37, "v_fma_f32 sgpr src",          "v_fma_f32 %0, %0, %4, %3",                           a) \
-    X(38, "v_sub_f32 sgpr src",          "v_sub_f32 %0, %4, %0",                               a)
+    X(38, "v_sub_f32 sgpr src",          "v_sub_f32 %0, %4, %0",                               a) \
+    X(39, "v_min_f64",                   "v_min_f64 %1, %1, %5",                               p) \
+    X(40, "v_max_f64",                   "v_max_f64 %1, %1, %5",                               p) \
+    X(41, "v_cmp_lt_u64 vcc",            "v_cmp_lt_u64 vcc, %1, %5",                           p) \
+    X(42, "v_and_or_b32 sgpr",           "v_and_or_b32 %0, %0, %4, %2",                        a) \
+    X(43, "v_mov_b32 sgpr src",          "v_mov_b32 %0, %4",                                   a) \
+    X(44, "v_cmp_ge_u32 e64 sgpr dst",   "v_cmp_ge_u32_e64 s[22:23], %0, %2",                  a) \
+    X(45, "v_fma_f32 inline const",      "v_fma_f32 %0, %0, 0.5, %3",                          a) \
+    X(46, "v_add_f64",                   "v_add_f64 %1, %1, %5",                               p) \
+    X(47, "v_pk_min... v_min3_f32",      "v_min3_f32 %0, %0, %2, %3",                          a) \
+    X(48, "v_mul_f32 + v_exp pairs",     "v_mul_f32 %0, %0, %2\n\tv_exp_f32 %0, %0",            a) \
+    X(49, "v_permlane32_swap",           "v_permlane32_swap_b32 %0, %0",                       a)
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) probe(float* out, float seed, float sc) {
