@@ -54,6 +54,15 @@ static RdgWin rdg_make_window() {
 // reads per input (instead of 11 each), a thread of the vertical pass RB vertically adjacent pixels from RB + 10 rows.
 #define RB 4
 
+// The window weights arrive as kernel arguments (SGPRs); a VALU instruction with a scalar source issues at half the
+// rate of one with vector sources on gfx950 (profiles/r02_valu_issue_cost.txt), and the filters are nothing but such
+// multiply-adds: keep the eleven weights in VGPRs.
+#define RDG_LOSS_WEIGHTS(w, win)                                      \
+    float w[11];                                                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < 11; ++k_) { w[k_] = (win).w[k_]; asm volatile("" : "+v"(w[k_])); }
+
+#define RDG_LOSS_HITEMS ((LWY * (LTX / RB) + 255) / 256)   // horizontal-pass work items per thread (2)
+
 __global__ void __launch_bounds__(256)
 rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
                     float* __restrict__ maps, float* __restrict__ sums) {
@@ -63,6 +72,7 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
     const int tid = threadIdx.x;
     int ox, oy, c; size_t bid;
     if (!rdg_loss_tile((Wd + LTX - 1) / LTX, (H + LTY - 1) / LTY, C, ox, oy, c, bid)) return;
+    RDG_LOSS_WEIGHTS(w, win)
     const size_t hw = (size_t)H * Wd;
     const float* X = img + c * hw;
     const float* Y = gt + c * hw;
@@ -99,8 +109,8 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
             float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
 #pragma unroll
             for (int k = 0; k < 11; ++k) {
-                const float w = win.w[k], xv = xs[o + k], yv = ys[o + k];
-                const float wx = w * xv, wy = w * yv;
+                const float xv = xs[o + k], yv = ys[o + k];
+                const float wx = w[k] * xv, wy = w[k] * yv;
                 h0 += wx; h1 += wy; h2 += wx * xv; h3 += wy * yv; h4 += wx * yv;
             }
             sh[0][r][c0 + o] = h0; sh[1][r][c0 + o] = h1; sh[2][r][c0 + o] = h2; sh[3][r][c0 + o] = h3;
@@ -123,8 +133,7 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
         for (int o = 0; o < RB; ++o) {
             const int k = rr - o;
             if (k >= 0 && k < 11) {
-                const float w = win.w[k];
-                mu1[o] += w * a0; mu2[o] += w * a1; e11[o] += w * a2; e22[o] += w * a3; e12[o] += w * a4;
+                mu1[o] += w[k] * a0; mu2[o] += w[k] * a1; e11[o] += w[k] * a2; e22[o] += w[k] * a3; e12[o] += w[k] * a4;
             }
         }
     }
@@ -185,11 +194,14 @@ __global__ void __launch_bounds__(256)
 rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
                     const float* __restrict__ maps, const float* __restrict__ grad_loss, float inv_n, float lambda,
                     float* __restrict__ d_img) {
-    __shared__ float sa[3][LWY][LWX + 1];
-    __shared__ float sh[3][LWY][LTX];
+    // one LDS buffer: the halo tiles of the three maps, then (registers in between) their horizontally filtered rows
+    __shared__ float smem[3 * LWY * (LWX + 1)];
+    float (*sa)[LWY][LWX + 1] = (float (*)[LWY][LWX + 1])smem;
+    float (*sh)[LWY][LTX] = (float (*)[LWY][LTX])smem;
     const int tid = threadIdx.x;
     int ox, oy, c; size_t bid;
     if (!rdg_loss_tile((Wd + LTX - 1) / LTX, (H + LTY - 1) / LTY, C, ox, oy, c, bid)) return;
+    RDG_LOSS_WEIGHTS(w, win)
     const size_t hw = (size_t)H * Wd;
     const size_t stride = (size_t)C * hw;
     {
@@ -213,20 +225,32 @@ rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
         }
     }
     __syncthreads();
-    for (int item = tid; item < LWY * (LTX / RB); item += 256) {
-        const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
-        float v0[RB + 10], v1[RB + 10], v2[RB + 10];
+    float hreg[RDG_LOSS_HITEMS][RB][3];
 #pragma unroll
-        for (int k = 0; k < RB + 10; ++k) { v0[k] = sa[0][r][c0 + k]; v1[k] = sa[1][r][c0 + k]; v2[k] = sa[2][r][c0 + k]; }
+    for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
+        const int item = tid + 256 * hi;
+        if (item < LWY * (LTX / RB)) {
+            const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+            float v0[RB + 10], v1[RB + 10], v2[RB + 10];
 #pragma unroll
-        for (int o = 0; o < RB; ++o) {
-            float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+            for (int k = 0; k < RB + 10; ++k) { v0[k] = sa[0][r][c0 + k]; v1[k] = sa[1][r][c0 + k]; v2[k] = sa[2][r][c0 + k]; }
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float w = win.w[k];
-                h0 += w * v0[o + k]; h1 += w * v1[o + k]; h2 += w * v2[o + k];
+            for (int o = 0; o < RB; ++o) {
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) { h0 += w[k] * v0[o + k]; h1 += w[k] * v1[o + k]; h2 += w[k] * v2[o + k]; }
+                hreg[hi][o][0] = h0; hreg[hi][o][1] = h1; hreg[hi][o][2] = h2;
             }
-            sh[0][r][c0 + o] = h0; sh[1][r][c0 + o] = h1; sh[2][r][c0 + o] = h2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
+        const int item = tid + 256 * hi;
+        if (item < LWY * (LTX / RB)) {
+            const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+#pragma unroll
+            for (int o = 0; o < RB; ++o) { sh[0][r][c0 + o] = hreg[hi][o][0]; sh[1][r][c0 + o] = hreg[hi][o][1]; sh[2][r][c0 + o] = hreg[hi][o][2]; }
         }
     }
     __syncthreads();
@@ -241,7 +265,7 @@ rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
 #pragma unroll
         for (int o = 0; o < RB; ++o) {
             const int k = rr - o;
-            if (k >= 0 && k < 11) { const float w = win.w[k]; u0[o] += w * a0; u1[o] += w * a1; u2[o] += w * a2; }
+            if (k >= 0 && k < 11) { u0[o] += w[k] * a0; u1[o] += w[k] * a1; u2[o] += w[k] * a2; }
         }
     }
     const float go = grad_loss ? grad_loss[0] : 1.0f;
