@@ -245,6 +245,44 @@ def test_culled_and_degenerate_inputs():
     assert torch.allclose(out[0][:, 0, 0].cpu(), torch.tensor([0.5, 0.25, 0.125])) and out[4].numel() == 0
 
 
+def test_non_finite_gaussians_do_not_poison_the_frame():
+    """A Gaussian whose scale / rotation / position is NaN or inf (a diverged optimiser row) must not turn the image or
+    the other Gaussians' gradients into NaN: its conic is not positive definite, so no pixel blends it (the compositing
+    kernels drop such a splat when they stage it; the per-Gaussian stage culls most of them before that)."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    sc = O.synthetic_scene(3000, 160, 128, 3, seed=21)
+    bad = torch.arange(0, 3000, 250)
+    good = torch.ones(3000, dtype=torch.bool); good[bad] = False
+
+    def render(scene):
+        ins = {k: scene[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+        rs = HS.make_settings(scene, 3, bg=torch.tensor([0.1, 0.2, 0.3]))
+        m2 = torch.zeros(3000, 3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                     scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+        (out[0].sum() + 0.1 * out[1].sum()).backward()
+        torch.cuda.synchronize()
+        return out, ins
+
+    ref = {k: v.clone() if torch.is_tensor(v) else v for k, v in sc.items()}
+    ref["opacities"][bad] = 0.0                       # the same frame without those Gaussians
+    out_ref, ins_ref = render(ref)
+    poisoned = {k: v.clone() if torch.is_tensor(v) else v for k, v in sc.items()}
+    poisoned["scales"][bad[0::4]] = float("nan")
+    poisoned["scales"][bad[1::4], 1] = float("inf")
+    poisoned["rotations"][bad[2::4]] = float("nan")
+    poisoned["means3D"][bad[3::4], 0] = float("nan")
+    out, ins = render(poisoned)
+    for i in range(4):
+        assert bool(torch.isfinite(out[i]).all()), i
+        rel_ok(out[i], out_ref[i].detach(), tol=1e-5, what=f"output {i}")
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        g = ins[k].grad[good.to(DEV)]
+        assert bool(torch.isfinite(g).all()), k
+        rel_ok(g, ins_ref[k].grad[good.to(DEV)], tol=1e-4, what="d_" + k)
+
+
 def test_capacity_overflow_retries_and_retain_graph():
     """A too-small binning capacity must be detected on the device and retried, and backward must be repeatable
     (loss.backward(retain_graph=True) at /root/reference/src/trainer/rodygs.py:310)."""
