@@ -6,21 +6,35 @@
 // coalesced 64-B gather per thread; inside the loop every lane reads the same LDS address (broadcast).
 //
 // Wave-level occupancy masks (the wave64 replacement for per-thread rejection): while staging, the thread that
-// holds splat j tests the axis-aligned box of the splat's "alpha >= 1/255" ellipse against each of the four
-// quadrants; a ballot per quadrant turns the 256 verdicts into four 64-bit masks per wave in LDS.  A wave then
-// walks only the set bits of its own masks with scalar bit ops (s_ff1 / s_andn2) -- on the bench scene 60 % of the
-// (wave, splat) pairs are never touched.  The test is conservative (power margin 0.01 + inflated box), so the
-// result is identical to visiting every splat; order inside the list is preserved.
+// holds splat j tests the splat's "alpha >= 1/255" ellipse against the rectangle of pixel centres of each of the four
+// quadrants (exact up to a safety margin: rdg_quadrant_bits); a ballot per quadrant turns the 256 verdicts into four
+// 64-bit masks per wave in LDS.  A wave then walks only the set bits of its own masks with scalar bit ops
+// (s_ff1 / s_bitset0) -- on the bench scene 60 % of the (wave, splat) pairs are never touched.  The result is
+// identical to visiting every splat; order inside the list is preserved.
 //
-// Backward: per (wave, splat) the 10 partial derivatives are reduced with a TRANSPOSED DPP reduction (the value
-// index is folded into the lane index: 14 DPP adds instead of 60) down to one total per 16-lane row; the row totals
-// are parked with plain LDS stores in a ring PRIVATE to the wave (no LDS atomics -- ds_add_f32 into a table shared
-// by the 4 waves was a third of the kernel), and every 16 splats the wave flushes its ring with 64-B-row global
-// float atomics: 16 consecutive lanes cover the 16 floats of a Gaussian's accumulator row, 4 Gaussians per
-// instruction, which is the access shape the global float-atomic unit runs at full rate for (MI355X_MICROARCH.md
-// "Global float atomics").  Atomics are therefore per (wave, splat) that a pixel actually blended.
+// What the kernels are bound by (profiles/r02_valu_issue_cost.txt, scripts/render_ablation.sh):
+// plain f32 mul / add / fma with VGPR sources issue at twice the rate of everything else (compares, selects, DPP,
+// anything with a scalar source, packed f32), the walk is limited by the CU's one scalar unit, and both kernels lose
+// about 10 % per lost wave of occupancy.  So: few "slow" instructions per visit, few scalar instructions per visit,
+// 8 workgroups per CU.
 //
-// The kernels are VALU/transcendental bound, not HBM bound.
+// Forward, per visit: exponent as a completed square (5 instructions), alpha = opacity * exp2 (the 0.99 cap is a scalar
+// branch on a per-splat bit), blend test as ONE unsigned compare (rdg_fwd_walk), alpha_eff form of the update with the
+// rare "pixel stops here" case repaired in a branch, n_contrib as one move under the lane mask.
+//
+// Backward, per visit: one select (on G); the colour behind the splat enters only through its product with the pixel's
+// dL/dpixel, so the back-to-front recurrence runs on that one scalar, started from the background term; SIX values per
+// pixel leave the lane (weight t0 = G dL/dalpha, t0 dx, t0 dx^2, three colour terms) and are reduced over the 8 lanes
+// of a pixel row with a TRANSPOSED quad-masked DPP reduction (12 v_add_f32_dpp); the y-moments are formed from the row
+// totals (the 8 lanes share dy).  One lane per quad parks the totals with plain LDS stores in a ring PRIVATE to the
+// wave (no LDS atomics -- ds_add_f32 into a table shared by the 4 waves was a third of the kernel); every 4 splats the
+// wave flushes its ring with 64-B-row global float atomics: 16 consecutive lanes cover the 16 floats of a Gaussian's
+// accumulator row, 4 Gaussians per instruction, which is the access shape the global float-atomic unit runs at full
+// rate for (MI355X_MICROARCH.md "Global float atomics"), the eight pixel-row partials being summed by the flush.
+// Atomics are therefore per (wave, splat) that a pixel actually blended.
+//
+// RDG_ABL_* / RDG_PARK_ALL / RDG_RING: switches of the ablation and tuning builds (scripts/render_ablation.sh); a
+// product build defines none of them.
 #include "rdg_common.h"
 
 #define RDG_BATCH 256
