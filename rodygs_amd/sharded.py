@@ -112,6 +112,14 @@ def shard_rows(P: int, world: int):
     return per, (per + 255) // 256 * 256
 
 
+def chunk_ranges(stride: int, chunks: int):
+    """Row ranges [r0, r1) (multiples of 256, the same on every rank) that cut a shard of ``stride`` rows into at most
+    ``chunks`` pieces (the pipelined all-to-all #1)."""
+    blocks = stride // 256
+    per = -(-blocks // max(1, min(chunks, blocks)))
+    return [(b * 256, min(b + per, blocks) * 256) for b in range(0, blocks, per)]
+
+
 class ShardedDynamicScene:
     """One rank's slice of a ``trainstep.DynamicScene`` (same parameters, same step arithmetic, gradients summed over
     the cameras of all ranks before Adam) -- build it with ``from_replica``."""
@@ -256,11 +264,7 @@ class ShardedDynamicScene:
         return r
 
     def chunk_ranges(self, chunks: int):
-        """Row ranges [r0, r1) (multiples of 256, the same on every rank) that cut a shard of ``stride`` rows into at most
-        ``chunks`` pieces."""
-        blocks = self.stride // 256
-        per = -(-blocks // max(1, min(chunks, blocks)))
-        return [(b * 256, min(b + per, blocks) * 256) for b in range(0, blocks, per)]
+        return chunk_ranges(self.stride, chunks)
 
     def phase_owner_forward(self, step: int, perm: Sequence[int], chunks: int = 1, exchange: bool = False) -> None:
         """Deformation + activations + projection of MY Gaussians for the cameras of every rank -> ``rec_own``.

@@ -251,3 +251,16 @@ def test_row_range_exchange_equals_the_whole_all_to_all():
             for r in range(world):
                 g = torch.load(os.path.join(d, f"r{r}.pt"))
                 assert torch.equal(g["whole"], g["pieces"])
+
+
+def test_chunk_ranges_cover_the_shard_in_aligned_pieces():
+    """The row ranges of the pipelined all-to-all #1: multiples of 256, disjoint, in order, covering [0, stride), at most
+    the requested number of pieces -- the same on every rank because they depend on the stride alone."""
+    from rodygs_amd.sharded import chunk_ranges, shard_rows
+    for P, world in ((1_000_000, 8), (6001, 2), (5003, 3), (37, 8), (4_000_000, 8)):
+        _, stride = shard_rows(P, world)
+        for chunks in (1, 2, 3, 4, 7, 64, 10_000):
+            r = chunk_ranges(stride, chunks)
+            assert r[0][0] == 0 and r[-1][1] == stride and len(r) <= max(1, min(chunks, stride // 256))
+            assert all(a % 256 == 0 and b % 256 == 0 and a < b for a, b in r)
+            assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))
