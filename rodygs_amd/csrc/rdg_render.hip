@@ -63,7 +63,7 @@ __device__ __forceinline__ float rdg_edge_min(float a, float b2, float c, float 
 __device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const float4 q1, float X0, float Y0) {
     const float a = q0.z, b = q0.w, c = q1.x, o = q1.y;
     const float t255 = 255.0f * o;
-    if (t255 < 0.99f) return 0u;  // alpha can never reach 1/255 (margin below)
+    if (!(t255 >= 0.99f)) return 0u;  // alpha can never reach 1/255 (margin below); written so that a NaN opacity is dropped too
     const float det = a * c - b * b;
     if (!(det > 0.0f) || !(a > 0.0f) || !(c > 0.0f)) return 0u;   // not a positive-definite conic (NaN input): never blended
     const float r2 = 2.0f * (__logf(t255) + 0.02f) * 1.001f;

@@ -273,6 +273,8 @@ def test_non_finite_gaussians_do_not_poison_the_frame():
     poisoned["scales"][bad[1::4], 1] = float("inf")
     poisoned["rotations"][bad[2::4]] = float("nan")
     poisoned["means3D"][bad[3::4], 0] = float("nan")
+    poisoned["opacities"][bad[0]] = float("nan")
+    poisoned["opacities"][bad[5]] = -0.7
     out, ins = render(poisoned)
     for i in range(4):
         assert bool(torch.isfinite(out[i]).all()), i
