@@ -285,6 +285,37 @@ def test_non_finite_gaussians_do_not_poison_the_frame():
         rel_ok(g, ins_ref[k].grad[good.to(DEV)], tol=1e-4, what="d_" + k)
 
 
+def test_render_without_the_normal_channels_is_the_same_frame():
+    """`rasterizer.RENDER_NORMAL = False` (the compositing forward without its normal accumulators: another kernel
+    instantiation) gives bit-identical colour / depth / alpha / radii and gradients, and a zero normal image."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer, rasterizer
+    sc = O.synthetic_scene(4000, 200, 152, 3, seed=33)
+
+    def render():
+        ins = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+        rs = HS.make_settings(sc, 3, bg=torch.tensor([0.3, 0.1, 0.2]))
+        m2 = torch.zeros(4000, 3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(rs)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                     scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+        w = torch.linspace(0.5, 1.5, 200, device=DEV)
+        ((out[0] * w).sum() + 0.1 * (out[1] * w).sum() + (out[3] * w).sum()).backward()
+        torch.cuda.synchronize()
+        return out, ins
+
+    with_n, ins_n = render()
+    try:
+        rasterizer.RENDER_NORMAL = False
+        without, ins_w = render()
+    finally:
+        rasterizer.RENDER_NORMAL = True
+    for i in (0, 1, 3, 4):
+        assert torch.equal(with_n[i], without[i]), i
+    assert float(without[2].detach().abs().max()) == 0.0 and float(with_n[2].detach().abs().max()) > 0.0
+    for k in ("means3D", "opacities", "scales", "rotations", "viewmatrix"):
+        rel_ok(ins_w[k].grad, ins_n[k].grad, tol=1e-5, what="d_" + k)     # float atomics: not bitwise
+
+
 def test_capacity_overflow_retries_and_retain_graph():
     """A too-small binning capacity must be detected on the device and retried, and backward must be repeatable
     (loss.backward(retain_graph=True) at /root/reference/src/trainer/rodygs.py:310)."""
