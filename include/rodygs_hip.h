@@ -145,6 +145,17 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
                            const void* binning_ws, int64_t capacity, const void* image_ws,
                            const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
                            void* grad_ws, void* stream);
+/* Deterministic form of rdg_composite_backward (SURVEY.md section 5b "deterministic mode: no float atomics -> bit-
+ * reproducible"; the reference's un-vendored rasterizer accumulates with float atomics, whose order changes from run to
+ * run): every wave STORES its per-(tile, splat) totals to its own quarter of a 256-B row per list position in det_ws
+ * (rdg_det_bytes(n_instances) bytes, n_instances >= the frame's num_rendered; zeroed by this call), then one pass adds
+ * them up per Gaussian in the order of its tile rectangle.  Same gradient rows as rdg_composite_backward up to the
+ * rounding of a different summation order; two calls on the same inputs give the same bits.                          */
+size_t rdg_det_bytes(int64_t n_instances);
+int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
+                               const void* binning_ws, int64_t capacity, const void* image_ws,
+                               const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
+                               void* grad_ws, void* det_ws, int64_t n_instances, void* stream);
 /* gradient rows (grad_ws) -> input gradients; geom_ws / radii are those of THIS rank's rdg_preprocess_forward      */
 int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
                             const float* colors_precomp, const float* opacities, const float* scales,

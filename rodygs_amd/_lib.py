@@ -54,6 +54,9 @@ _SIGS = {
     "rdg_geom_from_records": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 4),
     "rdg_composite_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, _vp, C.c_int64] + [_vp] * 7),
     "rdg_composite_backward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6),
+    "rdg_det_bytes": (C.c_size_t, [C.c_int64]),
+    "rdg_composite_backward_det": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6 +
+                                   [C.c_int64, _vp]),
     "rdg_preprocess_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 22),
     "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 2 +
                                      [C.c_double, C.c_double, C.c_float, C.c_int32, _vp]),

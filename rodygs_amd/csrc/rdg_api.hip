@@ -201,6 +201,31 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
     return rc;
 }
 
+size_t rdg_det_bytes(int64_t n_instances) {
+    return rdg_align_up((size_t)(n_instances > 0 ? n_instances : 1) * 4 * RDG_GROW * 4, 256);
+}
+
+int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
+                               const void* binning_ws, int64_t capacity, const void* image_ws,
+                               const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
+                               void* grad_ws, void* det_ws, int64_t n_instances, void* stream) {
+    RdgDev d;
+    if (rdg_make_dev(s_host, &d)) return -1;
+    if (!det_ws || !grad_ws) return rdg_set_error("rdg_composite_backward_det: NULL workspace");
+    if (n_instances < 0 || n_instances > capacity)
+        return rdg_set_error("rdg_composite_backward_det: n_instances must be in [num_rendered, capacity]");
+    hipStream_t st = (hipStream_t)stream;
+    rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
+    // rows of positions no wave visits stay zero; the gradient rows themselves are written (not accumulated) by the
+    // reduction, every one of them
+    hipError_t e = hipMemsetAsync(det_ws, 0, rdg_det_bytes(n_instances), st);
+    if (e != hipSuccess) return rdg_check_hip(e, "det row memset");
+    int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
+                                   grad_out_alpha, (float*)grad_ws, st, (float*)det_ws);
+    rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
+    return rc;
+}
+
 int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
                             const float* colors_precomp, const float* opacities, const float* scales,
                             const float* rotations, const float* cov3D_precomp, const float* viewmatrix,

@@ -325,11 +325,31 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
 // ---------------------------------------------------------------------------------------------------------
 typedef float rdg_f32x4 __attribute__((ext_vector_type(4)));
 #define RDG_DEF_G 8  // groups of 4 Gaussians gathered per loop iteration
+#define RDG_DEF_ACC_BLOCKS 2048   // workgroups (of 4 waves) of the dB accumulation with a table
+#define RDG_DEF_PART_MAX_TU 1024  // the partial-slot form covers tables of up to this many birth times
+// slots of the deterministic partial sums: (waves + birth indices) rows of 112 floats, kept behind the sorted copy
+#define RDG_DEF_PART_BYTES ((size_t)(RDG_DEF_ACC_BLOCKS * 4 + RDG_DEF_PART_MAX_TU) * 16 * RDG_DEF_K * 4)
+__host__ __device__ __forceinline__ int rdg_deform_rows_per_wave(int P, int nwaves) {
+    const int per = (P + nwaves - 1) / nwaves;
+    return (per + 4 * RDG_DEF_G - 1) / (4 * RDG_DEF_G) * (4 * RDG_DEF_G);
+}
+static inline size_t rdg_deform_gs_bytes(int32_t P) { return rdg_align_up((size_t)(P > 0 ? P : 1) * 32 + 256, 256); }
 
+// part != nullptr (deterministic form, only with a table): the wave STORES its total for birth index u to the slot
+// (wave + u) of `part` -- along the birth-sorted sequence either the wave or the birth index advances from one
+// (wave, u) pair to the next, so the sum is a unique slot number -- and rdg_deform_part_finalize_kernel adds the slots
+// of a birth index in wave order.  No float atomics: the same bits on every run.
 __device__ __forceinline__ void rdg_deform_flush(rdg_f32x4 acc, int u, int lane, bool has_table,
-                                                 float* __restrict__ d_basis_t, float* __restrict__ d_table) {
+                                                 float* __restrict__ d_basis_t, float* __restrict__ d_table,
+                                                 float* __restrict__ part = nullptr, int wave = 0) {
     const int k = lane & 15;
     if (u < 0 || k >= RDG_DEF_K) return;
+    if (part) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            part[(size_t)(wave + u) * (16 * RDG_DEF_K) + ((lane >> 4) * 4 + r) * RDG_DEF_K + k] = acc[r];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = (lane >> 4) * 4 + r;
@@ -348,12 +368,11 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
                                const int* __restrict__ order, const float* __restrict__ g_xyz,
                                const float* __restrict__ g_rot, float scale, int has_table,
                                float* __restrict__ d_basis_t, float* __restrict__ d_table,
-                               const float* __restrict__ gs) {
+                               const float* __restrict__ gs, float* __restrict__ part) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * (blockDim.x >> 6);
-    int per = (P + nwaves - 1) / nwaves;
-    per = (per + 4 * RDG_DEF_G - 1) / (4 * RDG_DEF_G) * (4 * RDG_DEF_G);
+    const int per = rdg_deform_rows_per_wave(P, nwaves);
     const int beg = min(P, wave * per), end = min(P, beg + per);
     const int slot = lane >> 4, j = lane & 15;
     rdg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -408,7 +427,7 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
                     const int us = __builtin_amdgcn_readlane(u, sl * 16);
                     if (us < 0) continue;
                     if (us != cur_u) {
-                        rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table);
+                        rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table, part, wave);
                         acc = rdg_f32x4{0.f, 0.f, 0.f, 0.f};
                         cur_u = us;
                     }
@@ -417,7 +436,35 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
             }
         }
     }
-    rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table);
+    rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table, part, wave);
+}
+
+// dB_table[u] = -(sum over the waves whose row range meets birth index u, in wave order, of their partial totals).
+// Where the birth-sorted sequence switches to index u is found by binary search on the sequence itself (the sorted
+// compact copy carries the index in its 8th float; without the copy: time_ind[order[.]]).
+__global__ void __launch_bounds__(128)
+rdg_deform_part_finalize_kernel(int P, int per, const float* __restrict__ gs, const long long* __restrict__ time_ind,
+                                const int* __restrict__ order, const float* __restrict__ part,
+                                float* __restrict__ d_table) {
+    const int u = blockIdx.x, e = threadIdx.x;
+    if (e >= 16 * RDG_DEF_K) return;
+    int bound[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {           // first sorted position whose birth index is >= u + q
+        int lo = 0, hi = P;
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            const int um = gs ? __float_as_int(gs[(size_t)mid * 8 + 7]) : (int)time_ind[order[mid]];
+            if (um < u + q) lo = mid + 1; else hi = mid;
+        }
+        bound[q] = lo;
+    }
+    float acc = 0.0f;
+    if (bound[1] > bound[0]) {
+        const int w0 = bound[0] / per, w1 = (bound[1] - 1) / per;
+        for (int w = w0; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
+    }
+    d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -acc;
 }
 
 
@@ -801,7 +848,7 @@ int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, con
     return rdg_check_hip(hipGetLastError(), "deform_fwd launch");
 }
 
-size_t rdg_deform_sorted_ws_bytes(int32_t P) { return (size_t)(P > 0 ? P : 1) * 32 + 256; }
+size_t rdg_deform_sorted_ws_bytes(int32_t P) { return rdg_deform_gs_bytes(P) + RDG_DEF_PART_BYTES; }
 size_t rdg_deform_sorted_views_ws_bytes(int32_t P, int32_t nviews) {
     return (size_t)(P > 0 ? P : 1) * 32 * (size_t)(nviews > 0 ? nviews : 1) + 256;
 }
@@ -852,9 +899,18 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
         }
         if (mfma) {
             // without a table every wave flushes into the same 112 floats: keep the wave count low there
-            hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? 2048 : 64), dim3(256), 0, st, P, coeff,
-                               (const long long*)time_ind, (const int*)order, g_xyz, g_rot, spatial_scale,
-                               table ? 1 : 0, d_basis_t, d_table, use_gs ? (const float*)sorted_ws : (const float*)nullptr);
+            // with a table and a workspace: per-(wave, birth index) partial totals + a fixed-order sum (no float atomics)
+            float* part = (table && d_table && sorted_ws && Tu <= RDG_DEF_PART_MAX_TU)
+                              ? (float*)((char*)sorted_ws + rdg_deform_gs_bytes(P)) : nullptr;
+            hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? RDG_DEF_ACC_BLOCKS : 64), dim3(256), 0, st, P,
+                               coeff, (const long long*)time_ind, (const int*)order, g_xyz, g_rot, spatial_scale,
+                               table ? 1 : 0, d_basis_t, d_table, use_gs ? (const float*)sorted_ws : (const float*)nullptr,
+                               part);
+            if (part)
+                hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P,
+                                   rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4),
+                                   use_gs ? (const float*)sorted_ws : (const float*)nullptr, (const long long*)time_ind,
+                                   (const int*)order, (const float*)part, d_table);
             if (table)
                 hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3((row + 127) / 128), dim3(128), 0, st, Tu, row, d_table,
                                    d_basis_t);
@@ -911,9 +967,13 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
                            (const int*)inv_order, (float4*)sorted_ws, d_bases, (Tu + 1) * 112);
-        hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(2048), dim3(256), 0, st, P, coeff,
+        float* part = (float*)((char*)sorted_ws + rdg_deform_gs_bytes(P));
+        hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(RDG_DEF_ACC_BLOCKS), dim3(256), 0, st, P, coeff,
                            (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,
-                           spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws);
+                           spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws, part);
+        hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P,
+                           rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const float*)sorted_ws,
+                           (const long long*)time_ind, (const int*)order, (const float*)part, d_table);
         hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3(1), dim3(128), 0, st, Tu, 112, d_table, d_basis_t);
     }
     rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);

@@ -340,7 +340,10 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
 // which is the access shape the global float-atomic unit runs at full rate for.  Lane c sums the eight pixel-row
 // partials of component c (foff = where that component sits inside a quad pair).
 // `scale` = this lane's constant factor for component (lane & 15), see the derivative block of the kernel.
-template <bool HAS_DEPTH>
+// DET (deterministic mode, rdg_composite_backward_det): the ring entry names the LIST POSITION of the instance instead of
+// the Gaussian, and the wave's totals are STORED to its own 64-B quarter of that position's row in a D-long scratch
+// buffer (grow = scratch + 16 * wave) -- no atomics; rdg_det_reduce_kernel then adds them up per Gaussian in a fixed order.
+template <bool HAS_DEPTH, bool DET>
 __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], int n, int lane, float scale, int foff,
                                                float* __restrict__ grow) {
     // LDS operations of one wave execute in program order; the fences only pin the compiler's ordering
@@ -357,7 +360,8 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], in
 #ifdef RDG_ABL_NOATOMIC   // ablation build (scripts/render_ablation.sh): results are wrong, only the timing is read
             if (v == 123.456f) atomicAdd(grow + (size_t)__float_as_uint(ring[e][1][4]) * RDG_GROW + c, v);
 #else
-            if (v != 0.0f) atomicAdd(grow + (size_t)__float_as_uint(ring[e][1][4]) * RDG_GROW + c, v);
+            if (DET) grow[(size_t)__float_as_uint(ring[e][1][4]) * (4 * RDG_GROW) + c] = v;
+            else if (v != 0.0f) atomicAdd(grow + (size_t)__float_as_uint(ring[e][1][4]) * RDG_GROW + c, v);
 #endif
         }
     }
@@ -371,7 +375,7 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], in
 // ---------------------------------------------------------------------------------------------------------
 // The backward's walk over one 64-slot word of staged splats (the scalar-instruction budget of rdg_fwd_walk applies).
 // jthr: per lane, the slot bit index above which the list position lies below the pixel's last contributor.
-template <bool HAS_DEPTH, bool CAPPED>
+template <bool HAS_DEPTH, bool CAPPED, bool DET>
 __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsigned long long cap, const int sbase,
                                              const char* sQ0, const char* sQ1, const char* sQ2, const float pixx,
                                              const float pixy, const int jthr, const float dLp0, const float dLp1,
@@ -518,7 +522,7 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
             }
 #endif
             if (++ring_n == RDG_RING) {
-                rdg_ring_flush<HAS_DEPTH>(ring, ring_n, lane, flush_scale, flush_off, grow);
+                rdg_ring_flush<HAS_DEPTH, DET>(ring, ring_n, lane, flush_scale, flush_off, grow);
                 ring_n = 0;
             }
         }
@@ -527,7 +531,7 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
 
 // HAS_DEPTH = false: no upstream gradient for the depth image (photometric-only losses) -- the depth channel drops out
 // of the per-pair arithmetic and of the reduction.
-template <bool HAS_DEPTH>
+template <bool HAS_DEPTH, bool DET>
 __global__ void __launch_bounds__(256)
 rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
                       const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -580,6 +584,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     const int rounds = (kmax + RDG_BATCH - 1) / RDG_BATCH;
 
     int ring_n = 0;   // wave-uniform fill level of this wave's ring
+    float* __restrict__ const gdst = DET ? grow + wv * RDG_GROW : grow;   // DET: this wave's quarter of an instance row
     const int fc = lane & 15;
     // components 0, 1 are the raw first moments sum(G dL/dG dx), sum(G dL/dG dy): the per-Gaussian backward turns them
     // into dL/dmean2D with the conic it has anyway (two multiplies and two fused multiply-adds per pair less here)
@@ -610,7 +615,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
                     sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
                     sQ1[tid] = make_float4(cs.gam, q1.y, q1.z, 0.0f);
-                    sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(id));
+                    sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(DET ? range.x + (uint32_t)k : id));
                     over_cap = q1.y > RDG_ALPHA_CAP;
                 }
             }
@@ -637,22 +642,66 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             // list position of slot bit jb of this word: kbase - 64 s - jb; below last_contributor <=> jb > jthr
             const int jthr = kbase - s * 64 - last_contributor;
             if (cap)
-                rdg_bwd_walk<HAS_DEPTH, true>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2, pixx,
-                                              pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale, flush_off,
-                                              grow, T, behind, ring_n);
+                rdg_bwd_walk<HAS_DEPTH, true, DET>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
+                                                   pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale,
+                                                   flush_off, gdst, T, behind, ring_n);
             else
-                rdg_bwd_walk<HAS_DEPTH, false>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2, pixx,
-                                               pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale, flush_off,
-                                               grow, T, behind, ring_n);
+                rdg_bwd_walk<HAS_DEPTH, false, DET>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
+                                                    pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale,
+                                                    flush_off, gdst, T, behind, ring_n);
         }
         __syncthreads();   // every wave is done with this round's staged records
     }
-    rdg_ring_flush<HAS_DEPTH>(sRing[wv], ring_n, lane, flush_scale, flush_off, grow);
+    rdg_ring_flush<HAS_DEPTH, DET>(sRing[wv], ring_n, lane, flush_scale, flush_off, gdst);
 }
 
+// Deterministic mode, second half: one 16-lane group per Gaussian, lane c = component c of the 64-B gradient row.  The
+// group walks the Gaussian's tile rectangle in row-major order (the order its instances were emitted in), finds the
+// instance's position in the tile's sorted list by binary search on the composite (depth bits, index) -- the order of
+// every tile list in both binning modes (rdg_binning.hip) -- and adds the four per-wave partial rows of that position in
+// a fixed order.  Every float addition of the accumulation therefore happens in an order fixed by the geometry alone.
+__global__ void __launch_bounds__(256)
+rdg_det_reduce_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
+                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const float* __restrict__ det, float* __restrict__ grow) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int g = (int)(t >> 4), c = (int)(t & 15);
+    if (g >= P) return;
+    float acc = 0.0f;
+    if (tiles_touched[g] > 0) {
+        const float4 q0 = rec[g].q0, q1 = rec[g].q1;
+        const int radius = __float_as_int(q1.w);
+        const unsigned long long want = ((unsigned long long)__float_as_uint(q1.z) << 32) | (unsigned long long)(uint32_t)g;
+        // the rectangle rule of the binning stage (rdg_rect_dup, rdg_binning.hip), restated on the record
+        const float r = (float)radius;
+        const int x0 = min(gx, max(0, (int)((q0.x - r) / (float)RDG_TILE)));
+        const int y0 = min(gy, max(0, (int)((q0.y - r) / (float)RDG_TILE)));
+        const int x1 = min(gx, max(0, (int)((((q0.x + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+        const int y1 = min(gy, max(0, (int)((((q0.y + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+        for (int ty = y0; ty < y1; ++ty)
+            for (int tx = x0; tx < x1; ++tx) {
+                const uint2 rg = ranges[ty * gx + tx];
+                uint32_t lo = rg.x, hi = rg.y;      // first position whose composite is >= want
+                while (lo < hi) {
+                    const uint32_t mid = lo + ((hi - lo) >> 1);
+                    const uint32_t id = point_list[mid];
+                    const unsigned long long have =
+                        ((unsigned long long)__float_as_uint(rec[id].q1.z) << 32) | (unsigned long long)id;
+                    if (have < want) lo = mid + 1; else hi = mid;
+                }
+                if (lo < rg.y && point_list[lo] == (uint32_t)g) {
+                    const float* row = det + (size_t)lo * (4 * RDG_GROW) + c;
+                    acc += (row[0] + row[RDG_GROW]) + (row[2 * RDG_GROW] + row[3 * RDG_GROW]);
+                }
+            }
+    }
+    grow[(size_t)g * RDG_GROW + c] = acc;
+}
+
+// det != nullptr: deterministic mode -- `det` holds 4 * RDG_GROW floats per list position (zeroed by the caller)
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
                           int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
-                          const float* g_alpha, float* grow, hipStream_t s) {
+                          const float* g_alpha, float* grow, hipStream_t s, float* det) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const RdgBinLayout B = rdg_bin_layout(capacity);
     const RdgImageLayout I = rdg_image_layout(d.H, d.W);
@@ -662,12 +711,21 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const uint32_t* plist = (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a));
     const char* im = (const char*)image_ws;
     const int nblk = ((n_tiles + 7) / 8) * 8;
-#define RDG_BWD_LAUNCH(DEPTH)                                                                                      \
-    hipLaunchKernelGGL(rdg_render_bwd_kernel<DEPTH>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,    \
+#define RDG_BWD_LAUNCH(DEPTH, DET, DST)                                                                            \
+    hipLaunchKernelGGL((rdg_render_bwd_kernel<DEPTH, DET>), dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg, \
                        (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),        \
                        (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
-                       g_alpha, grow, (const unsigned long long*)(b + B.hit))
-    if (g_depth) RDG_BWD_LAUNCH(true); else RDG_BWD_LAUNCH(false);
+                       g_alpha, DST, (const unsigned long long*)(b + B.hit))
+    if (det) {
+        if (g_depth) RDG_BWD_LAUNCH(true, true, det); else RDG_BWD_LAUNCH(false, true, det);
+        if (d.P > 0)
+            hipLaunchKernelGGL(rdg_det_reduce_kernel, dim3((unsigned)(((long long)d.P * 16 + 255) / 256)), dim3(256), 0, s,
+                               d.P, d.gx, d.gy, (const RdgRec*)((const char*)geom_ws + G.rec),
+                               (const uint32_t*)((const char*)geom_ws + G.tiles_touched), (const uint2*)(im + I.ranges),
+                               plist, (const float*)det, grow);
+    } else {
+        if (g_depth) RDG_BWD_LAUNCH(true, false, grow); else RDG_BWD_LAUNCH(false, false, grow);
+    }
 #undef RDG_BWD_LAUNCH
     return rdg_check_hip(hipGetLastError(), "render_bwd launch");
 }

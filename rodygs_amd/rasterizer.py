@@ -16,6 +16,7 @@ device memory and the stream.  There is no CPU or eager fallback: CPU tensors ra
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -34,6 +35,11 @@ _BIN_HINT = {}                # (P, H, W) -> 1 while the largest tile list of th
 BIN_RADIX_ABOVE = 32768
 BIN_BUCKET_BELOW = 16384
 
+
+# Deterministic backward (RDG_DETERMINISTIC=1 or set at run time): the compositing backward stores
+# per-(wave, list position) partial rows and reduces them per Gaussian in a fixed order instead of accumulating with float
+# atomics (rdg_composite_backward_det) -- two runs give the same bits; ~2x the backward time and 256 B per instance.
+DETERMINISTIC = os.environ.get("RDG_DETERMINISTIC", "0") == "1"
 
 DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
 _PENDING = []                     # (event, pinned int32[1], key, capacity) of forwards not yet checked
@@ -125,6 +131,23 @@ def _f32c(t: Optional[torch.Tensor], name: str, dev) -> Optional[torch.Tensor]:
 
 def _empty(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if (t is None or t.numel() == 0) else t
+
+
+def _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws):
+    """The compositing half of backward: float-atomic accumulation, or the deterministic two-pass form."""
+    if not DETERMINISTIC:
+        _lib.check(L.rdg_composite_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
+                                            ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
+                                            _lib.ptr(g_alpha), _lib.ptr(gws), _lib.stream_ptr()),
+                   "rdg_composite_backward")
+        return
+    # D is known on the host except in deferred-overflow mode, where the capacity bounds it
+    n_inst = ctx.num_rendered if 0 <= ctx.num_rendered <= ctx.capacity else ctx.capacity
+    det = torch.empty(L.rdg_det_bytes(n_inst), dtype=torch.uint8, device=gws.device)
+    _lib.check(L.rdg_composite_backward_det(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
+                                            ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
+                                            _lib.ptr(g_alpha), _lib.ptr(gws), _lib.ptr(det), n_inst,
+                                            _lib.stream_ptr()), "rdg_composite_backward_det")
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -287,10 +310,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if prm.data_ptr() != shs.data_ptr() or prm.numel() != shs.numel():
                     raise RuntimeError("grad_sinks['shs_adam']['param'] must be the storage passed to the rasterizer as shs")
                 step = fused["step"]() if callable(fused["step"]) else int(fused["step"])
-                _lib.check(L.rdg_composite_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
-                                                    ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
-                                                    _lib.ptr(g_alpha), _lib.ptr(gws), _lib.stream_ptr()),
-                           "rdg_composite_backward")
+                _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws)
                 _lib.check(L.rdg_preprocess_backward_adam(
                     C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(vm),
                     _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(gws), _lib.ptr(d_m3), _lib.ptr(d_m2),
@@ -299,14 +319,24 @@ class _RasterizeGaussians(torch.autograd.Function):
                     float(fused["lr_tail"]), float(fused["betas"][0]), float(fused["betas"][1]), float(fused["eps"]),
                     step, _lib.stream_ptr()), "rdg_preprocess_backward_adam")
                 return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None
-            rc = L.rdg_rasterize_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col),
-                                          _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm),
-                                          _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning),
-                                          ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
-                                          _lib.ptr(g_alpha), _lib.ptr(gws), _lib.ptr(d_m3), _lib.ptr(d_m2),
-                                          _lib.ptr(d_sh), _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_sc),
-                                          _lib.ptr(d_ro), _lib.ptr(d_cov), _lib.ptr(d_vm), _lib.stream_ptr())
-            _lib.check(rc, "rdg_rasterize_backward")
+            if DETERMINISTIC:
+                _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws)
+                rc = L.rdg_preprocess_backward(C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col), _lib.ptr(op),
+                                               _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm), _lib.ptr(pm),
+                                               _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(gws), _lib.ptr(d_m3),
+                                               _lib.ptr(d_m2), _lib.ptr(d_sh), _lib.ptr(d_col), _lib.ptr(d_op),
+                                               _lib.ptr(d_sc), _lib.ptr(d_ro), _lib.ptr(d_cov), _lib.ptr(d_vm),
+                                               _lib.stream_ptr())
+                _lib.check(rc, "rdg_preprocess_backward")
+            else:
+                rc = L.rdg_rasterize_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col),
+                                              _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm),
+                                              _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning),
+                                              ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
+                                              _lib.ptr(g_alpha), _lib.ptr(gws), _lib.ptr(d_m3), _lib.ptr(d_m2),
+                                              _lib.ptr(d_sh), _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_sc),
+                                              _lib.ptr(d_ro), _lib.ptr(d_cov), _lib.ptr(d_vm), _lib.stream_ptr())
+                _lib.check(rc, "rdg_rasterize_backward")
         if sink_sh is not None:
             d_sh = None
             ready = ctx.grad_sinks.get("on_shs_ready")
