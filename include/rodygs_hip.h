@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RDG_ABI_VERSION 2
+#define RDG_ABI_VERSION 3
 #define RDG_MAX_VIEWS 16   /* cameras per step in the *_views entry points */
 
 /* Mirror of GaussianRasterizationSettings (renderer.py:50-63) + sizes. Host struct, passed by pointer. */
@@ -247,12 +247,17 @@ int rdg_deform_forward(int32_t P, int32_t B, int32_t Tu, const float* coeff, con
  * (v_mfma_f32_16x16x4_f32, one per 4 Gaussians); NULL selects the order-free LDS-atomic form.
  * inv_order (int32 [P], inv_order[order[i]] = i) + sorted_ws (rdg_deform_sorted_ws_bytes(P), 16-B aligned):
  * optional; with them the gradient rows are re-laid once in birth-sorted order so that the dB reduction
- * streams them instead of gathering 12/16/8-byte pieces (either may be NULL).                              */
+ * streams them instead of gathering 12/16/8-byte pieces (either may be NULL).
+ * With a table and the workspace the reduction uses NO float atomics (bit-reproducible): every wave stores its total
+ * per birth index and a last stage adds them in wave order.  seg_start (int32 [Tu+1], optional, cached with `order`):
+ * seg_start[u] = first position of birth index u in the sorted sequence, seg_start[Tu] = P; NULL = the library finds
+ * the boundaries by binary search (slower: ~25 us at P = 1 M).                                               */
 size_t rdg_deform_sorted_ws_bytes(int32_t P);
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
                         const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table,
-                        const int32_t* order, const int32_t* inv_order, void* sorted_ws, void* stream);
+                        const int32_t* order, const int32_t* inv_order, const int32_t* seg_start, void* sorted_ws,
+                        void* stream);
 
 /* ---- time-deformation MLP on the matrix cores (csrc/rdg_mlp.hip) --------------------------------------------
  * MLPBasisNetwork.batch_inference / the basis part of forward (/root/reference/src/model/rodygs_dynamic.py:296-327):
@@ -278,7 +283,7 @@ int rdg_mlp_backward(int32_t NR, int32_t D0, int32_t H, int32_t NB, int32_t OUT,
  * bases [Tu+1,16,7]: the Tu birth-time rows of the motion table followed by B(t).  rdg_dyn_getter_supported(B, Tu)
  * tells whether the table fits the kernel (else use rdg_deform_* + rdg_activate_*).  Backward overwrites the five
  * parameter gradients and d_bases [Tu+1,16,7]; g_* may be NULL (no upstream gradient); order / inv_order /
- * sorted_ws as for rdg_deform_backward (all required here).                                                      */
+ * sorted_ws as for rdg_deform_backward (all required here), seg_start optional.                                  */
 int rdg_dyn_getter_supported(int32_t B, int32_t Tu);
 int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
                            float spatial_scale, const float* xyz, const float* scaling, const float* rotation,
@@ -287,8 +292,8 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
                             float spatial_scale, const float* scaling, const float* rotation, const float* opacity,
                             const float* g_means3D, const float* g_scales, const float* g_rots, const float* g_opac,
                             float* d_xyz, float* d_scaling, float* d_rotation, float* d_opacity, float* d_coeff,
-                            float* d_bases, const int32_t* order, const int32_t* inv_order, void* sorted_ws,
-                            void* stream);
+                            float* d_bases, const int32_t* order, const int32_t* inv_order, const int32_t* seg_start,
+                            void* sorted_ws, void* stream);
 
 /* The fused getter for the nviews (<= RDG_MAX_VIEWS) camera times of one step over the same P Gaussians (sharded
  * frame-DP): bases_all [nviews,Tu+1,16,7] (table rows identical in every view); means3D / rots are stacked per view

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RDG_LIB_PATH: load another build of the same ABI (A/B runs of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("RDG_LIB_PATH") or os.path.join(_HERE, "csrc", "librodygs_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _lock = threading.Lock()
@@ -69,10 +69,10 @@ _SIGS = {
     "rdg_bin_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 8),
     "rdg_sort_pairs": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int32, _vp, _vp]),
     "rdg_deform_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp]),
-    "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 9),
+    "rdg_deform_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, C.c_float] + [_vp] * 10),
     "rdg_dyn_getter_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "rdg_dyn_getter_forward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 9),
-    "rdg_dyn_getter_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 17),
+    "rdg_dyn_getter_backward": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_float] + [_vp] * 18),
     "rdg_dyn_getter_views_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "rdg_deform_sorted_views_ws_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "rdg_dyn_getter_views_forward": (C.c_int, [C.c_int32] * 4 + [_vp, _vp, _vp, C.c_float] + [_vp] * 9),

@@ -251,11 +251,11 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
                           const float* __restrict__ g_scales, const float* __restrict__ g_rots,
                           const float* __restrict__ g_opac, float* __restrict__ d_xyz, float* __restrict__ d_scaling,
                           float* __restrict__ d_rotation, float* __restrict__ d_opacity, float* __restrict__ d_coeff,
-                          const int* __restrict__ inv_order, float4* __restrict__ gs, float* __restrict__ zero_out,
+                          const int* __restrict__ inv_order, float4* __restrict__ gs, uint32_t* __restrict__ zero_out,
                           int n_zero) {
     extern __shared__ __attribute__((aligned(16))) float smem_dg[];
-    // the (Tu + 1) x 112 accumulator the NEXT kernel adds into is cleared here (one memset launch less)
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero; k += gridDim.x * blockDim.x) zero_out[k] = 0.0f;
+    // the finished-workgroup counter of the dB reduction's last stage is cleared here (one memset launch less)
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero; k += gridDim.x * blockDim.x) zero_out[k] = 0u;
     rdg_diff16_to_lds(smem_dg, Tu, bases);
     __syncthreads();
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
@@ -328,7 +328,7 @@ typedef float rdg_f32x4 __attribute__((ext_vector_type(4)));
 #define RDG_DEF_ACC_BLOCKS 2048   // workgroups (of 4 waves) of the dB accumulation with a table
 #define RDG_DEF_PART_MAX_TU 1024  // the partial-slot form covers tables of up to this many birth times
 // slots of the deterministic partial sums: (waves + birth indices) rows of 112 floats, kept behind the sorted copy
-#define RDG_DEF_PART_BYTES ((size_t)(RDG_DEF_ACC_BLOCKS * 4 + RDG_DEF_PART_MAX_TU) * 16 * RDG_DEF_K * 4)
+#define RDG_DEF_PART_BYTES (256 + (size_t)(RDG_DEF_ACC_BLOCKS * 4 + RDG_DEF_PART_MAX_TU) * 16 * RDG_DEF_K * 4)   // counter, slots
 __host__ __device__ __forceinline__ int rdg_deform_rows_per_wave(int P, int nwaves) {
     const int per = (P + nwaves - 1) / nwaves;
     return (per + 4 * RDG_DEF_G - 1) / (4 * RDG_DEF_G) * (4 * RDG_DEF_G);
@@ -439,34 +439,72 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
     rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table, part, wave);
 }
 
-// dB_table[u] = -(sum over the waves whose row range meets birth index u, in wave order, of their partial totals).
-// Where the birth-sorted sequence switches to index u is found by binary search on the sequence itself (the sorted
-// compact copy carries the index in its 8th float; without the copy: time_ind[order[.]]).
-__global__ void __launch_bounds__(128)
-rdg_deform_part_finalize_kernel(int P, int per, const float* __restrict__ gs, const long long* __restrict__ time_ind,
-                                const int* __restrict__ order, const float* __restrict__ part,
-                                float* __restrict__ d_table) {
-    const int u = blockIdx.x, e = threadIdx.x;
-    if (e >= 16 * RDG_DEF_K) return;
-    int bound[2];
+// sum over u of d_table[u][c] in a fixed order (eight interleaved partial sums, then a tree)
+__device__ __forceinline__ float rdg_dbt_sum(const float* __restrict__ d_table, int Tu, int row, int c) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int u = 0;
+    for (; u + 7 < Tu; u += 8) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {           // first sorted position whose birth index is >= u + q
-        int lo = 0, hi = P;
-        while (lo < hi) {
-            const int mid = lo + ((hi - lo) >> 1);
-            const int um = gs ? __float_as_int(gs[(size_t)mid * 8 + 7]) : (int)time_ind[order[mid]];
-            if (um < u + q) lo = mid + 1; else hi = mid;
-        }
-        bound[q] = lo;
+        for (int q = 0; q < 8; ++q) a[q] += d_table[(size_t)(u + q) * row + c];
     }
-    float acc = 0.0f;
-    if (bound[1] > bound[0]) {
-        const int w0 = bound[0] / per, w1 = (bound[1] - 1) / per;
-        for (int w = w0; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
-    }
-    d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -acc;
+    for (; u < Tu; ++u) a[0] += d_table[(size_t)u * row + c];
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
+// dB_table[u] = -(sum over the waves whose row range meets birth index u, in wave order, of their partial totals);
+// the workgroup that finishes last then forms dB(t) = -sum_u dB_table[u] (one launch less; `counter` must be zero on
+// entry and is left zero).  Where the birth-sorted sequence switches to index u: seg_start[u] (int32 [Tu + 1], the
+// host caches it with the permutation) or, without it, a binary search on the sequence itself (the sorted compact copy
+// carries the index in its 8th float; without the copy: time_ind[order[.]]) -- 20 dependent loads, 25 us at P = 1 M.
+__global__ void __launch_bounds__(128)
+rdg_deform_part_finalize_kernel(int P, int Tu, int per, const int* __restrict__ seg_start,
+                                const float* __restrict__ gs, const long long* __restrict__ time_ind,
+                                const int* __restrict__ order, const float* __restrict__ part,
+                                float* __restrict__ d_table, float* __restrict__ d_basis_t,
+                                uint32_t* __restrict__ counter) {
+    const int u = blockIdx.x, e = threadIdx.x;
+    __shared__ uint32_t sOld;
+    if (e < 16 * RDG_DEF_K) {
+        int bound[2];
+        if (seg_start) {
+            bound[0] = seg_start[u]; bound[1] = seg_start[u + 1];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {           // first sorted position whose birth index is >= u + q
+                int lo = 0, hi = P;
+                while (lo < hi) {
+                    const int mid = lo + ((hi - lo) >> 1);
+                    const int um = gs ? __float_as_int(gs[(size_t)mid * 8 + 7]) : (int)time_ind[order[mid]];
+                    if (um < u + q) lo = mid + 1; else hi = mid;
+                }
+                bound[q] = lo;
+            }
+        }
+        float acc = 0.0f;
+        if (bound[1] > bound[0]) {
+            const int w0 = bound[0] / per, w1 = (bound[1] - 1) / per;
+            for (int w = w0; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
+        }
+        d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -acc;
+    }
+    // publish this row (agent-scope release), count the finished workgroups; the last one acquires and reduces over u
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (e == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        sOld = atomicAdd(counter, 1u);
+    }
+    __syncthreads();
+    if (sOld != (uint32_t)(Tu - 1)) return;
+    if (e == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *counter = 0u;
+    }
+    __syncthreads();
+    if (e < 16 * RDG_DEF_K) d_basis_t[e] = -rdg_dbt_sum(d_table, Tu, 16 * RDG_DEF_K, e);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Multi-view dynamic getter (Gaussian-sharded frame-DP, rodygs_amd/sharded.py): the same Gaussians deformed to the
@@ -735,14 +773,7 @@ __global__ void rdg_deform_dbt_views_kernel(int Tu, float* __restrict__ d_bases_
 __global__ void rdg_deform_dbt_kernel(int Tu, int row, const float* __restrict__ d_table, float* __restrict__ d_basis_t) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= row) return;
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int u = 0;
-    for (; u + 7 < Tu; u += 8) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] += d_table[(size_t)(u + q) * row + c];
-    }
-    for (; u < Tu; ++u) a[0] += d_table[(size_t)u * row + c];
-    d_basis_t[c] = -(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
+    d_basis_t[c] = -rdg_dbt_sum(d_table, Tu, row, c);
 }
 
 // Fused Adam over a flat f32 segment.  row_len > 1 gives the segment a row structure whose first head_len floats
@@ -856,7 +887,7 @@ size_t rdg_deform_sorted_views_ws_bytes(int32_t P, int32_t nviews) {
 int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, const int64_t* time_ind,
                         const float* basis_t, const float* table, float spatial_scale, const float* g_xyz,
                         const float* g_rot, float* d_coeff, float* d_basis_t, float* d_table, const int32_t* order,
-                        const int32_t* inv_order, void* sorted_ws, void* stream) {
+                        const int32_t* inv_order, const int32_t* seg_start, void* sorted_ws, void* stream) {
     if (B <= 0 || B > RDG_DEF_MAXB * 4) return rdg_set_error("deform: bad basis count %d", B);
     hipStream_t st = (hipStream_t)stream;
     const int row = B * RDG_DEF_K;
@@ -900,18 +931,23 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
         if (mfma) {
             // without a table every wave flushes into the same 112 floats: keep the wave count low there
             // with a table and a workspace: per-(wave, birth index) partial totals + a fixed-order sum (no float atomics)
-            float* part = (table && d_table && sorted_ws && Tu <= RDG_DEF_PART_MAX_TU)
-                              ? (float*)((char*)sorted_ws + rdg_deform_gs_bytes(P)) : nullptr;
+            uint32_t* counter = (table && d_table && sorted_ws && Tu >= 1 && Tu <= RDG_DEF_PART_MAX_TU)
+                                    ? (uint32_t*)((char*)sorted_ws + rdg_deform_gs_bytes(P)) : nullptr;
+            float* part = counter ? (float*)((char*)counter + 256) : nullptr;
+            if (counter) {
+                hipError_t ec = hipMemsetAsync(counter, 0, 4, st);
+                if (ec != hipSuccess) return rdg_check_hip(ec, "deform_bwd counter memset");
+            }
             hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? RDG_DEF_ACC_BLOCKS : 64), dim3(256), 0, st, P,
                                coeff, (const long long*)time_ind, (const int*)order, g_xyz, g_rot, spatial_scale,
                                table ? 1 : 0, d_basis_t, d_table, use_gs ? (const float*)sorted_ws : (const float*)nullptr,
                                part);
             if (part)
-                hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P,
-                                   rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4),
+                hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P, Tu,
+                                   rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const int*)seg_start,
                                    use_gs ? (const float*)sorted_ws : (const float*)nullptr, (const long long*)time_ind,
-                                   (const int*)order, (const float*)part, d_table);
-            if (table)
+                                   (const int*)order, (const float*)part, d_table, d_basis_t, counter);
+            else if (table)
                 hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3((row + 127) / 128), dim3(128), 0, st, Tu, row, d_table,
                                    d_basis_t);
         }
@@ -944,8 +980,8 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
                             float spatial_scale, const float* scaling, const float* rotation, const float* opacity,
                             const float* g_means3D, const float* g_scales, const float* g_rots, const float* g_opac,
                             float* d_xyz, float* d_scaling, float* d_rotation, float* d_opacity, float* d_coeff,
-                            float* d_bases, const int32_t* order, const int32_t* inv_order, void* sorted_ws,
-                            void* stream) {
+                            float* d_bases, const int32_t* order, const int32_t* inv_order, const int32_t* seg_start,
+                            void* sorted_ws, void* stream) {
     if (!rdg_dyn_getter_supported(16, Tu)) return rdg_set_error("dyn_getter: unsupported table size Tu = %d", Tu);
     if (!order || !inv_order || !sorted_ws || (((uintptr_t)sorted_ws) & 15))
         return rdg_set_error("dyn_getter_backward needs order, inv_order and a 16-B aligned sorted workspace");
@@ -963,18 +999,19 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
     if (P > 0) {
         int nb = (P + 1023) / 1024;
         if (nb > rdg_getter_grid_cap()) nb = rdg_getter_grid_cap();
+        uint32_t* counter = (uint32_t*)((char*)sorted_ws + rdg_deform_gs_bytes(P));
         hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
-                           (const int*)inv_order, (float4*)sorted_ws, d_bases, (Tu + 1) * 112);
-        float* part = (float*)((char*)sorted_ws + rdg_deform_gs_bytes(P));
+                           (const int*)inv_order, (float4*)sorted_ws, counter, 1);
+        float* part = (float*)((char*)counter + 256);
         hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(RDG_DEF_ACC_BLOCKS), dim3(256), 0, st, P, coeff,
                            (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,
                            spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws, part);
-        hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P,
-                           rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const float*)sorted_ws,
-                           (const long long*)time_ind, (const int*)order, (const float*)part, d_table);
-        hipLaunchKernelGGL(rdg_deform_dbt_kernel, dim3(1), dim3(128), 0, st, Tu, 112, d_table, d_basis_t);
+        hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P, Tu,
+                           rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const int*)seg_start,
+                           (const float*)sorted_ws, (const long long*)time_ind, (const int*)order, (const float*)part,
+                           d_table, d_basis_t, counter);
     }
     rdg_stage_end(RDG_STAGE_DEFORM_BWD, st);
     return rdg_check_hip(hipGetLastError(), "dyn_getter_bwd launch");

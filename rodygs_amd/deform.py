@@ -230,12 +230,13 @@ class MLPBasisNetwork(nn.Module):
 _ORDER_CACHE = {}
 
 
-def _birth_order(time_ind: torch.Tensor):
-    """(order, inverse): int32 permutation sorting the Gaussians by birth index and its inverse; cached until
+def _birth_order(time_ind: torch.Tensor, n_births: int = 0):
+    """(order, inverse, seg_start): int32 permutation sorting the Gaussians by birth index, its inverse, and (for
+    n_births > 0) where each birth index starts in the sorted sequence (int32 [n_births + 1]); cached until
     time_ind changes (it only does at densification), so the sort is not part of the step.  The key is the tensor's
     address / version / length: code that REPLACES a birth-index tensor (densification does) calls
     ``invalidate_birth_order_cache()`` so that a new tensor reusing a freed address cannot inherit a stale permutation."""
-    key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device))
+    key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device), int(n_births))
     o = _ORDER_CACHE.get(key)
     if o is None:
         if len(_ORDER_CACHE) > 8:
@@ -243,7 +244,12 @@ def _birth_order(time_ind: torch.Tensor):
         order = torch.argsort(time_ind, stable=True)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
-        o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous())
+        seg = None
+        if n_births > 0:
+            seg = torch.searchsorted(time_ind[order].contiguous(),
+                                     torch.arange(n_births + 1, device=order.device, dtype=time_ind.dtype))
+            seg = seg.to(torch.int32).contiguous()
+        o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous(), seg)
         _ORDER_CACHE[key] = o
     return o
 
@@ -314,14 +320,14 @@ class _DeformFn(torch.autograd.Function):
             d_tb = None if tb is None else torch.empty_like(tb)
         with torch.cuda.device(dev):
             if tb is not None:
-                order, inv = _birth_order(ti)
+                order, inv, seg = _birth_order(ti, Tu)
                 sws = torch.empty(L.rdg_deform_sorted_ws_bytes(P), dtype=torch.uint8, device=dev)
             else:
-                order, inv, sws = _identity_order(P, dev), None, None
+                order, inv, seg, sws = _identity_order(P, dev), None, None, None
             _lib.check(L.rdg_deform_backward(P, B, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bt), _lib.ptr(tb),
                                              ctx.scale, _lib.ptr(g_xyz), _lib.ptr(g_rot), _lib.ptr(d_c),
                                              _lib.ptr(d_bt), _lib.ptr(d_tb), _lib.ptr(order), _lib.ptr(inv),
-                                             _lib.ptr(sws), _lib.stream_ptr()),
+                                             _lib.ptr(seg), _lib.ptr(sws), _lib.stream_ptr()),
                        "rdg_deform_backward")
         if sink_c is not None:
             d_c = None
@@ -394,14 +400,15 @@ class _DynamicGetter(torch.autograd.Function):
             out[k] = t if t is not None else torch.empty(*shp, **f32)
         d_bases = torch.empty_like(bs)
         with torch.cuda.device(dev):
-            order, inv = _birth_order(ti)
+            order, inv, seg = _birth_order(ti, Tu)
             sws = torch.empty(L.rdg_deform_sorted_ws_bytes(P), dtype=torch.uint8, device=dev)
             _lib.check(L.rdg_dyn_getter_backward(P, Tu, _lib.ptr(c), _lib.ptr(ti), _lib.ptr(bs), ctx.scale, _lib.ptr(sc),
                                                  _lib.ptr(ro), _lib.ptr(op), _lib.ptr(g_m), _lib.ptr(g_s), _lib.ptr(g_r),
                                                  _lib.ptr(g_o), _lib.ptr(out["xyz"]), _lib.ptr(out["scaling"]),
                                                  _lib.ptr(out["rotation"]), _lib.ptr(out["opacity"]),
                                                  _lib.ptr(out["coeff"]), _lib.ptr(d_bases), _lib.ptr(order), _lib.ptr(inv),
-                                                 _lib.ptr(sws), _lib.stream_ptr()), "rdg_dyn_getter_backward")
+                                                 _lib.ptr(seg), _lib.ptr(sws), _lib.stream_ptr()),
+                       "rdg_dyn_getter_backward")
         ret = [None if k in sinks and sinks[k] is not None else out[k] for k in ("xyz", "scaling", "rotation", "opacity")]
         d_c = None if sinks.get("coeff") is not None else out["coeff"]
         return ret[0], ret[1], ret[2], ret[3], d_c, None, d_bases, None, None

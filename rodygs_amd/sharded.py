@@ -471,7 +471,7 @@ class ShardedDynamicScene:
                 self.stats.max_radii2D = torch.maximum(self.stats.max_radii2D, rad)
             b = self._bases_all.detach()
             if n:
-                order, inv = _birth_order(self.time_ind)
+                order, inv, _ = _birth_order(self.time_ind)
                 # all cameras in one pass: the five parameter gradients come out summed over the cameras, straight
                 # into the flat gradient bucket
                 _lib.check(L.rdg_dyn_getter_views_backward(

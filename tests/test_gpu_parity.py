@@ -1189,6 +1189,42 @@ def test_train_loop_with_densification():
     assert float(ds.fp["xyz"].grad.abs().sum()) > 0 and ds.m2.grad.shape[0] == info["P"]
 
 
+def test_deterministic_train_step_is_bit_reproducible():
+    """RDG_DETERMINISTIC end to end: the photometric train step bench.py times (MLP -> deformation -> rasterizer -> loss
+    -> backward -> Adam, SH Adam inside backward, one densification) run twice from the same state ends with the SAME
+    BITS in every parameter and both Adam moments -- no float atomic is left on that path (compositing backward: per-
+    instance partial rows + ordered reduction; dB reduction: per-(wave, birth index) slots + ordered sum)."""
+    import rodygs_amd.rasterizer as R
+    from rodygs_amd.trainstep import DynamicScene
+    sc = O.synthetic_scene(20000, 320, 240, 3, seed=5)
+    tgt = O.synthetic_scene(5000, 320, 240, 3, seed=6)
+
+    def run(det):
+        old = R.DETERMINISTIC
+        R.DETERMINISTIC = det
+        try:
+            torch.manual_seed(1234)                       # split samples of the densification
+            ds = DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True)
+            ds.make_ground_truth(tgt, range(8))
+            ds.track_densification()
+            for s_ in range(20):
+                ds.train_step(s_, perm=list(range(8)))
+            ds.densify(max_grad=2e-5, min_opacity=0.05, percent_dense=0.002)
+            for s_ in range(20, 40):
+                ds.train_step(s_, perm=list(range(8)))
+            torch.cuda.synchronize()
+        finally:
+            R.DETERMINISTIC = old
+        return [t.clone() for t in (ds.fp.flat, ds.fp.exp_avg, ds.fp.exp_avg_sq, ds.sp.flat, ds.sp.exp_avg,
+                                    ds.sp.exp_avg_sq)]
+
+    a, b = run(True), run(True)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape and torch.equal(x, y), f"deterministic train step: buffer {i} differs between two runs"
+    c = run(False)     # the atomic path takes the same decisions at the densification (rounding noise only up to there)
+    assert bool(torch.isfinite(c[0]).all())
+
+
 def test_full_loss_train_step_runs_and_reduces_loss():
     """Config-5 loss set in the loop: photometric + Pearson depth (global + local) + motion regularisers + rigidity on
     the HIP K-NN every 5th step; gradients of several losses accumulate into the same flat segments."""
@@ -1442,7 +1478,7 @@ def test_multi_view_getter_matches_single_view_getter(NV):
     d = {k: torch.zeros_like(t) for k, t in (("xyz", xyz), ("scaling", scaling), ("rotation", rotation),
                                              ("opacity", opacity), ("coeff", coeff))}
     d_bases = torch.zeros_like(bases_all)
-    order, inv = _birth_order(ti)
+    order, inv, _ = _birth_order(ti)
     sws = torch.empty(L.rdg_deform_sorted_views_ws_bytes(P, NV), dtype=torch.uint8, device=DEV)
     _lib.check(L.rdg_dyn_getter_views_backward(P, Tu, NV, stride, coeff.data_ptr(), ti.data_ptr(), bases_all.data_ptr(),
                                                5.0, scaling.data_ptr(), rotation.data_ptr(), opacity.data_ptr(),
