@@ -2299,24 +2299,49 @@ def test_bench_runs_both_dp_formulations_the_way_the_driver_launches_it():
 
 def test_psnr_delta_through_the_real_train_step():
     """BASELINE metric "PSNR delta vs ref" (north_star: within 0.05 dB), at 20 k dynamic Gaussians, 320x240, 500
-    optimiser steps with one densification: the train step bench.py times (fused kernels, fused Adam, SH Adam inside
-    backward -- and the same with the separate Adam launch; two runs of each) against a CPU loop driven by the oracle
-    rasterizer + torch.optim.Adam, same initial state, frames, ground truth, split samples and densification masks
-    (scripts/psnr_delta.py).  PSNR per /root/reference/src/utils/eval_utils.py:36-39.  Two runs of the SAME HIP program
-    differ by a few hundredths of a dB at the end (float atomics + Adam), so the end-of-training gate is on the mean of
-    the HIP runs, widened by their own spread; the early gate (before the trajectories separate) is per run."""
+    optimiser steps with one densification (scripts/psnr_delta.py; PSNR per /root/reference/src/utils/eval_utils.py:36-39).
+    Free-running trainings separate chaotically (Adam, eps 1e-15: two runs of one float-atomic binary end 0.1-0.2 dB
+    apart), so the statement is split into what can be decided:
+      * systematic part -- teacher-forced: at every state of the ORACLE's training the HIP gradient is evaluated too and
+        the next states the two gradients lead to are scored; the accumulated difference is deterministic and must be
+        within 0.05 dB (measured: ~1e-5 dB);
+      * the train step bench.py times, free-running in DETERMINISTIC mode (one reproducible trajectory): within 0.01 dB
+        of the oracle at step 100 and 0.03 dB at the densification, SH-Adam-in-backward == separate launch bit for bit;
+      * chaotic part -- 4 float-atomic runs: same early gates per run; at the end the oracle (one more draw of the same
+        process) within 0.05 dB + 2 standard errors of their mean."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "psnr_delta", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "psnr_delta.py"))
     M = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(M)
-    res = M.run(points=20000, width=320, height=240, steps=500, frames=8)
+    res = M.run(points=20000, width=320, height=240, steps=500, frames=8, atomic_runs=4)
     sm = res["summary"]
-    for k in sm["hip_runs"] + ["oracle"]:
+    for k in sm["hip_runs"] + ["det_fused", "det_unfused", "oracle"]:
         assert res[k]["psnr_end_db"] > res[k]["psnr_start_db"] + 5.0, (k, res[k])     # it really trained
         assert res[k]["densify"]["cloned"] + res[k]["densify"]["split"] > 0, (k, res[k])
         assert res[k]["P_end"] == res["oracle"]["P_end"]
+    tf = res["teacher_forced"]
+    assert tf["steps"] == 500 and abs(tf["drift_db"]) <= 0.05, tf
+    assert tf["abs_sum_db"] <= 0.05, tf                  # even with every per-step difference taken with one sign
+    assert sm["det_fused_equals_unfused"], sm
     for k, d in res["delta_db_at_step"]["100"].items():
         assert abs(d) <= 0.01, (k, d, res["delta_db_at_step"])
-    assert abs(sm["mean_delta_db"]) <= 0.05 + 2.0 * sm["hip_std_end_db"], sm
-    assert sm["hip_std_end_db"] < 0.15, sm
+    for k, d in res["delta_db_at_step"]["250"].items():
+        # the float-atomic runs have begun to separate by then (measured up to 0.06 dB); the deterministic one has not
+        assert abs(d) <= (0.03 if k.startswith("det_") else 0.1), (k, d, res["delta_db_at_step"])
+    assert abs(sm["mean_delta_db"]) <= 0.05 + 2.0 * sm["mean_delta_se_db"], sm
+    assert sm["hip_std_end_db"] < 0.2, sm
+
+
+def test_teacher_forced_psnr_drift_detects_a_one_percent_gradient_error():
+    """Power of the teacher-forced gate: scaling ONE HIP gradient (dL/dopacity) by 1.01 must show up as a drift orders of
+    magnitude above the unbiased kernels' (same 60 steps)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "psnr_delta", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "psnr_delta.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    clean = M.teacher_forced(points=5000, width=160, height=120, steps=60, frames=4)
+    biased = M.teacher_forced(points=5000, width=160, height=120, steps=60, frames=4, bias=0.01)
+    assert abs(clean["drift_db"]) < 1e-4, clean
+    assert abs(biased["drift_db"]) > 50 * max(abs(clean["drift_db"]), 1e-7), (clean["drift_db"], biased["drift_db"])
