@@ -33,13 +33,38 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP32_VALU_PEAK_TFLOPS = 157.3  # same guide: FP32 vector peak
-PMC_FILE = "r02_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
+SQ_FILE = "r03_pmc_sq_counters.json"     # rocprofv3 --pmc SQ_* pass of this bench command (scripts/pmc_summary.py)
+N_SIMD = 1024                            # 256 CUs x 4 SIMDs
+# measured issue cost of a wave64 VALU instruction with every SIMD saturated (scripts/valu_probe.hip,
+# profiles/r02_valu_issue_cost.txt), in cycles per instruction and SIMD
+VALU_ISSUE_CLASSES = {"f32 mul/add/fma/mov with VGPR sources": 2.3, "every other VALU instruction": 4.2,
+                      "transcendental": 8.4}
+PMC_FILE = "r03_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
 
 
-def workload_label(P, W, H, frames, full_losses, world):
+def kernel_source_hash(files=("rdg_render.hip", "rdg_common.h")):
+    """sha256 over the sources of the dominant kernel: stamps a PMC file (scripts/pmc_hbm_traffic.py) and decides whether
+    the traffic figure in it still belongs to the kernel that runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "rodygs_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def metric_label(P, W, H):
+    """The metric string from the arguments: BASELINE.json's wording at its own shape, the actual shape otherwise."""
+    pts = f"{P // 1000000}M" if P % 1000000 == 0 else (f"{P // 1000}k" if P % 1000 == 0 else str(P))
+    res = {(1920, 1080): "1080p", (3840, 2160): "4K"}.get((W, H), f"{W}x{H}")
+    return f"train-step fps at {pts} dynamic Gaussians / {res} (fwd+bwd+Adam, one camera per GPU per step)"
+
+
+def workload_label(P, W, H, frames, full_losses, world, variant="uniform"):
     """Name the workload from the arguments (BASELINE.json configs by shape), never from a hard-coded string."""
     base = f"{P} dynamic Gaussians + deformation MLP, {W}x{H}, SH3, {frames}-frame synthetic video"
+    if variant != "uniform":
+        return base + f" (scene variant '{variant}': not a BASELINE config)"
     if (P, W, H) == (1000000, 1920, 1080) and not full_losses:
         return base + (" (BASELINE configs[2])" if world == 1 else f" (BASELINE configs[3] shape on {world} GPUs)")
     if (P, W, H) == (4000000, 3840, 2160) and full_losses:
@@ -242,10 +267,11 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
             out["D"] = int(rasterizer._CAPACITY_HINT.get(ss.key, 0))
             out["V"] = ss.visible_count()
         else:
-            out["D"] = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
+            # D, V and S of ONE frame: this forward reads its instance count back (deferred mode is off again)
             with torch.no_grad():
                 o, _ = ds.render(perm[0])
                 out["V"] = int((o[4] > 0).sum().item())
+            out["D"] = int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
         with torch.no_grad():
             _, n_contrib = rasterizer.last_compositing_state()
             out["S"] = int(n_contrib.sum(dtype=torch.int64).item())
@@ -266,6 +292,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--gt-frames", type=int, default=16, help="distinct frames with ground truth resident in HBM")
+    ap.add_argument("--scene", choices=["uniform", "sheets", "dense"], default="uniform",
+                    help="rodygs_amd.synthetic variant: 'uniform' = the SURVEY 8d generator (the headline workload); "
+                         "'sheets' = opaque depth sheets (early termination); 'dense' = 3x the projected sigma (D ~ 9x)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads of the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=60.0,
@@ -306,11 +335,12 @@ def main():
 
     from rodygs_amd.synthetic import synthetic_scene
     from rodygs_amd import _lib
+    from rodygs_amd import rasterizer as rasterizer_mod
     _lib.lib()
 
     P, W, H = args.points, args.width, args.height
-    scene = synthetic_scene(P, W, H, 3, seed=777)
-    target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234)
+    scene = synthetic_scene(P, W, H, 3, seed=777, variant=args.scene)
+    target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234, variant=args.scene)
     if force_shard:
         modes = ["shard"]
     elif world == 1:
@@ -332,14 +362,22 @@ def main():
         alg_bytes = D * 44 + H * W * 40 + V * 40
         # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs, gfx950 correction applied); only valid for the workload it was taken on
-        traffic = None
+        # and for the kernel source it was taken with (kernel_source_hash): a stale file gives null, not a wrong number
+        traffic, traffic_note = None, "no PMC file for this workload"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
             wl = pmc["workload"]
-            if (wl["points"], wl["width"], wl["height"]) == (P, W, H):
+            if (wl["points"], wl["width"], wl["height"], wl.get("scene", "uniform")) != (P, W, H, args.scene):
+                traffic_note = f"profiles/{PMC_FILE} was taken on another workload"
+            elif pmc.get("kernel_source_hash") != kernel_source_hash():
+                traffic_note = (f"profiles/{PMC_FILE} was taken with kernel sources {pmc.get('kernel_source_hash')}, "
+                                f"the build has {kernel_source_hash()}: re-run scripts/refresh_profiles.sh")
+            else:
                 traffic = pmc["kernels"]["rdg_render_bwd_kernel"]["hbm_bytes_corrected"]
-        except Exception:
-            traffic = None
+                traffic_note = (f"profiles/{PMC_FILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                f"kernel sources {pmc['kernel_source_hash']}")
+        except Exception as e:
+            traffic, traffic_note = None, f"profiles/{PMC_FILE} unreadable: {e}"
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # whole-step and per-stage algorithmic bytes for the algorithm that actually ran
         # (stage_bytes), and the FP32-VALU fraction of the two compositing kernels
@@ -355,9 +393,35 @@ def main():
                               "hbm_frac": (b / (sms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if sms[k] > 0 else None}
                           for k, b in sb.items()}
         b_step = sum(sb.values())
-        valu = {k: {"flops": S * f, "tflops": S * f / (per_stage[k] * 1e-3) / 1e12,
-                    "frac_of_fp32_vector_peak": S * f / (per_stage[k] * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS}
-                for k, f in (("render_fwd", 22), ("render_bwd", 60)) if per_stage[k] > 0}
+        # VALU-issue roofline of the two compositing kernels (they are issue-bound, not HBM-bound): wave instructions
+        # per launch from the SQ counters (committed PMC pass, valid only for the kernel sources it was taken with) over
+        # the kernel's SIMD-cycles = cycles per VALU instruction and SIMD, to be read against the measured issue classes
+        valu = {"issue_classes_cycles_per_inst": VALU_ISSUE_CLASSES, "source": None}
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", SQ_FILE)))
+            meta = sq.get("_meta", {})
+            wl = meta.get("workload") or {}
+            if meta.get("kernel_source_hash") != kernel_source_hash():
+                valu["source"] = f"profiles/{SQ_FILE} is stale (kernel sources changed): no VALU-issue figure"
+            elif (wl.get("points"), wl.get("width"), wl.get("height"), wl.get("scene", "uniform")) != (P, W, H, args.scene):
+                valu["source"] = f"profiles/{SQ_FILE} was taken on another workload"
+            else:
+                valu["source"] = f"profiles/{SQ_FILE} (rocprofv3 --pmc SQ_INSTS_VALU ... pass of this command)"
+                for stage, prefix in (("render_fwd", "void rdg_render_fwd_kernel"), ("render_bwd", "void rdg_render_bwd_kernel")):
+                    row = next((v for k_, v in sq.items() if k_.startswith(prefix)), None)
+                    if row is None or per_stage[stage] <= 0:
+                        continue
+                    # GRBM_GUI_ACTIVE counts per XCD (8 of them): the kernel's duration in shader-clock cycles
+                    cycles = row["GRBM_GUI_ACTIVE"] / 8.0
+                    cpi = cycles * N_SIMD / row["SQ_INSTS_VALU"]
+                    valu[stage] = {"valu_wave_insts_per_launch": row["SQ_INSTS_VALU"],
+                                   "salu_wave_insts_per_launch": row["SQ_INSTS_SALU"],
+                                   "kernel_cycles": cycles, "cycles_per_valu_inst_per_simd": cpi,
+                                   # every slot filled with the cheapest class would be 2.3: the fraction of the
+                                   # issue-rate ceiling this kernel's instruction stream reaches
+                                   "frac_of_issue_ceiling": VALU_ISSUE_CLASSES["f32 mul/add/fma/mov with VGPR sources"] / cpi}
+        except Exception as e:
+            valu["source"] = f"profiles/{SQ_FILE} unreadable: {e}"
         if world == 1:
             parallelism = "single GPU (frame-dp1)"
         elif sharded:
@@ -366,13 +430,18 @@ def main():
             parallelism = (f"frame-dp{world}, replicated cloud + RCCL all-reduce of Gaussian / pose gradients "
                            f"(BASELINE north_star formulation)")
         res = {
-            "metric": "train-step fps at 1M dynamic Gaussians / 1080p (fwd+bwd+Adam, one camera per GPU per step)",
+            "metric": metric_label(P, W, H),
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_label(P, W, H, args.frames, args.full_losses, world), "points": P,
-                       "width": W, "height": H,
+            "config": {"workload": workload_label(P, W, H, args.frames, args.full_losses, world, args.scene), "points": P,
+                       "width": W, "height": H, "scene": args.scene,
                        "frames": args.frames,
+                       # switches that shape the number: no read-back of the instance count inside the timed steps
+                       # (capacity from the warm-up; an overflow renders that frame empty and raises afterwards), and
+                       # whether every rank shares one device (functional check of the N > 1 flow, not a measurement)
+                       "deferred_overflow_check": True, "one_device": bool(os.environ.get("RDG_ONE_DEVICE")),
+                       "deterministic_backward": bool(rasterizer_mod.DETERMINISTIC),
                        "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",
                        # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH
@@ -388,12 +457,15 @@ def main():
                               "frac_of_6.3TBps_achievable": b_step * fps / world / 1e9 / 6300.0,
                               "pixel_splat_pairs_S": S},
             "stage_roofline": stage_roofline,
-            "render_valu": valu,
+            "render_valu_issue": valu,
             "roofline": {"bound": "hbm", "kernel": "rdg_render_bwd_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": dom_ms,
-                         "note": "compositing kernels are VALU/exp/LDS-bound (SURVEY.md §8d); the HBM fraction is "
-                                 "reported because north_star asks for it"},
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_ms": dom_ms,
+                         "note": "the compositing kernels are VALU-issue bound (render_valu_issue); the HBM fraction is "
+                                 "reported because north_star asks for it",
+                         "second_roofline": {"bound": "valu_issue", **(valu.get("render_bwd") or {}),
+                                             "source": valu["source"]}},
         }
         if world > 1:
             # every formulation that was timed (each EXACTLY --steps steps between barriers, max over ranks)

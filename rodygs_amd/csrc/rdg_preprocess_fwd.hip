@@ -276,7 +276,12 @@ rdg_geom_from_records_kernel(int P, int gx, int gy, const RdgRec* __restrict__ r
     if (i < P) {
         const float4 q0 = rec[i].q0;
         const int radius = __float_as_int(rec[i].q1.w);
-        if (radius > 0) {
+        // The per-tile sort compares (depth bits << 32 | id) composites as IEEE doubles (v_min_f64 / v_max_f64,
+        // rdg_binning.hip rdg_cx): valid only for depth bits of a positive finite float.  This stage's own records
+        // satisfy it by the near cull (vz > RDG_NEAR_CULL, which a NaN fails); records that arrived from another rank
+        // are checked here -- anything else is dropped (tiles_touched = 0), never sorted.
+        const uint32_t dbits = __float_as_uint(rec[i].q1.z);
+        if (radius > 0 && dbits > 0u && dbits < 0x7f800000u) {
             int x0, y0, x1, y1;
             rdg_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
             my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));

@@ -100,7 +100,8 @@ def rebuild_flat_params(fp: FlatParams, src: torch.Tensor, keep_moments: torch.T
 
 def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad: float,
                       min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01, N: int = 2,
-                      z: Optional[torch.Tensor] = None, decisions: Optional[Dict[str, torch.Tensor]] = None) -> DensifyResult:
+                      z: Optional[torch.Tensor] = None, decisions: Optional[Dict[str, torch.Tensor]] = None,
+                      spatial_order: bool = False) -> DensifyResult:
     """``fp`` holds at least xyz [P,3], scaling [P,3] (log), rotation [P,4] (raw), opacity [P,1] (logit); every other
     segment (SH features, motion coefficients, ...) is carried along row-wise.  ``per_point``: further [P,...]
     tensors that follow the Gaussians (gaussian_to_time, gaussian_to_time_ind).  ``z``: optional standard-normal
@@ -108,7 +109,9 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
     masks of an earlier call ({"clone": [P], "split": [P], "prune": [rows after clone + split]}, as returned in
     ``DensifyResult.decisions``) instead of thresholding this run's statistics -- for experiments that must hold the set
     of Gaussians fixed across runs (scripts/psnr_delta.py: a borderline Gaussian crossing the gradient threshold in one
-    run and not in the other changes P and, from there, the whole trajectory)."""
+    run and not in the other changes P and, from there, the whole trajectory).  ``spatial_order``: re-sort the surviving
+    rows along the Z curve of their new positions (rodygs_amd/layout.py) -- clones and split children are appended at the
+    end, so without it the memory coherence the kernels profit from decays with every densification."""
     if not fp.flat.is_cuda:
         raise RuntimeError("rodygs_amd.densify_and_prune: buffers must be on the GPU (no CPU fallback exists)")
     if fp.shapes["scaling"][1:] != (3,):
@@ -164,6 +167,11 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
                                                          _lib.ptr(fp["rotation"].detach()), _lib.ptr(zz), _lib.ptr(xo),
                                                          _lib.ptr(so_), _lib.stream_ptr()), "rdg_split_children")
         new_pp = {k: v[src] for k, v in per_point.items()}
+        if spatial_order:
+            from .layout import morton_order
+            perm = morton_order(out["xyz"].detach())
+            out = rebuild_flat_params(out, perm, torch.ones_like(perm, dtype=torch.bool))
+            new_pp = {k: v[perm] for k, v in new_pp.items()}
         from .deform import invalidate_birth_order_cache
         invalidate_birth_order_cache()       # the per-point tensors (birth indices) are new objects from here on
         n_new = int(src.numel())

@@ -201,9 +201,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             normal = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
-            # written by the per-Gaussian stage's scan whenever there is at least one Gaussian
-            # [0] = D (instances), [1] = largest tile list, both written by the forward
-            nren = torch.zeros(2, dtype=torch.int32, device=dev)
+            # [0] = D (instances), [1] = largest tile list: both written by the forward on every path (the block-sum scan
+            # writes [0] even for an empty cloud, the tile scan / tile max kernels write [1] also on capacity overflow),
+            # so no fill launch
+            nren = torch.empty(2, dtype=torch.int32, device=dev)
             key = (P, H, W)
             cs.num_rendered_stats = 1
             cs.bin_mode = int(_BIN_HINT.get(key, 0))

@@ -114,8 +114,11 @@ def shard_rows(P: int, world: int):
 
 def chunk_ranges(stride: int, chunks: int):
     """Row ranges [r0, r1) (multiples of 256, the same on every rank) that cut a shard of ``stride`` rows into at most
-    ``chunks`` pieces (the pipelined all-to-all #1)."""
+    ``chunks`` pieces (the pipelined all-to-all #1).  An empty shard (P = 0: stride 0) is ONE empty range, so that the
+    sequence of collectives stays the same on every rank."""
     blocks = stride // 256
+    if blocks == 0:
+        return [(0, 0)]
     per = -(-blocks // max(1, min(chunks, blocks)))
     return [(b * 256, min(b + per, blocks) * 256) for b in range(0, blocks, per)]
 

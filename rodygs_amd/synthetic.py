@@ -37,19 +37,33 @@ def _camera(W, H, fovx_deg):
 
 
 def synthetic_scene(P: int, W: int, H: int, sh_degree_max: int = 3, seed: int = 777, fovx_deg: float = 50.0,
-                    device="cpu"):
-    """Seeded synthetic cloud + camera of SURVEY.md §8d (uniform in the frustum slab z in [2,20])."""
+                    device="cpu", variant: str = "uniform"):
+    """Seeded synthetic cloud + camera of SURVEY.md §8d (uniform in the frustum slab z in [2,20]).
+
+    ``variant`` (same draws, same camera; not the headline workload -- two regimes the survey's generator never enters):
+      * "sheets": surface-like -- the Gaussians lie on eight fronto-parallel sheets (z = 4, 6, ... 18, +-1 %) with
+        opacities 0.6-0.99 and twice the projected sigma, so a pixel saturates (T < 1e-4) within the first sheets and the
+        compositing stops early: most of every tile list is never walked;
+      * "dense": three times the projected sigma (D ~ 9x: >= 15 M tile instances at 1 M Gaussians / 1080p) with the
+        survey's opacities -- a heavily densified scene."""
+    if variant not in ("uniform", "sheets", "dense"):
+        raise ValueError(f"unknown scene variant {variant!r}")
     g = torch.Generator().manual_seed(seed)
     fovx, fovy, focal, tanx, tany = _camera(W, H, fovx_deg)
     z = 2.0 + 18.0 * torch.rand(P, generator=g)
+    if variant == "sheets":
+        z = (4.0 + 2.0 * torch.floor((z - 2.0) / 18.0 * 8.0).clamp(0, 7)) * (1.0 + 0.01 * (2 * torch.rand(P, generator=g) - 1))
     x = (2 * torch.rand(P, generator=g) - 1) * 1.1 * z * tanx
     y = (2 * torch.rand(P, generator=g) - 1) * 1.1 * z * tany
     xyz = torch.stack([x, y, z], dim=1)
     sigma_px = min(max(2.0 * (1e6 / P) ** (1.0 / 3.0) * (W / 1920.0), 0.7), 8.0)
+    sigma_px *= {"uniform": 1.0, "sheets": 2.0, "dense": 3.0}[variant]
     scales = (sigma_px * z / focal).unsqueeze(1) * torch.exp(0.5 * torch.randn(P, 3, generator=g))
     q = torch.randn(P, 4, generator=g)
     q = q / q.norm(dim=1, keepdim=True)
     opac = torch.sigmoid(2.0 * torch.randn(P, 1, generator=g))
+    if variant == "sheets":
+        opac = 0.6 + 0.39 * torch.rand(P, 1, generator=g)
     K = (sh_degree_max + 1) ** 2
     shs = torch.zeros(P, K, 3)
     shs[:, 0] = (torch.rand(P, 3, generator=g) - 0.5) / SH_C0

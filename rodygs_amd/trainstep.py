@@ -309,7 +309,7 @@ class DynamicScene:
         allreduce_stats_(self.stats)
         res = densify_and_prune(self.fp, self.stats, {"time_ind": self.time_ind}, max_grad, min_opacity,
                                 extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense,
-                                z=z, decisions=decisions)
+                                z=z, decisions=decisions, spatial_order=self.spatial_order)
         self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
         self.P = self.fp.shapes["xyz"][0]
         self.m2 = torch.zeros(self.P, 3, device=self.device, requires_grad=True)

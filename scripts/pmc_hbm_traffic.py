@@ -1,6 +1,11 @@
 """Build profiles/*_pmc_hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, separate runs as
-MI355X_MICROARCH.md prescribes).  usage: python scripts/pmc_hbm_traffic.py <fetch_dir> <write_dir> <out.json> P W H"""
-import collections, csv, glob, json, re, sys
+MI355X_MICROARCH.md prescribes).  usage: python scripts/pmc_hbm_traffic.py <fetch_dir> <write_dir> <out.json> P W H [scene]
+The file is stamped with bench.kernel_source_hash(): bench.py reports the traffic figure only while the dominant
+kernel's sources are the ones the counters were taken with."""
+import collections, csv, glob, json, os, re, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 
 
 def short(name):
@@ -22,7 +27,9 @@ def load(d, counter):
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes) --output-format csv -- python "
                   "bench.py --steps 4 --warmup 2 --no-cpu-baseline",
-       "workload": {"points": int(sys.argv[4]), "width": int(sys.argv[5]), "height": int(sys.argv[6])},
+       "workload": {"points": int(sys.argv[4]), "width": int(sys.argv[5]), "height": int(sys.argv[6]),
+                    "scene": sys.argv[7] if len(sys.argv) > 7 else "uniform"},
+       "kernel_source_hash": kernel_source_hash(),
        "units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are KB counters; hbm_bytes_corrected = 2*FETCH_SIZE*1024 + "
                 "WRITE_SIZE*1024 (gfx950: FETCH_SIZE reports half of wide reads, MI355X_MICROARCH.md HBM section; float "
                 "atomics are counted in WRITE_SIZE)",

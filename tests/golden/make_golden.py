@@ -29,6 +29,14 @@ What is pinned: the pieces of the hot path that exist as import
   G11 optimizer : get_expon_lr_func (src/utils/general_utils.py:40-73) and reset_opacity + replace_tensor_to_optimizer
                    (src/trainer/rodygs_static.py:151-160, src/trainer/utils.py:15-32) on a real torch.optim.Adam state,
                    plus the Adam step that follows (``... make_golden.py optimizer``)
+  G12 checkpoint: a checkpoint dictionary written by rodygs_amd.checkpoint.export_state_dict goes through the file format
+                   and is read back BY THE REFERENCE: DynRoDyGS.create_from_state_dict (src/model/rodygs_dynamic.py:
+                   106-120, rodygs_static.py:172-182; ``.cuda()`` neutralised), sync_gaussian_to_time_ind,
+                   get_total_motion_table, get_gaussian_deformation and the activated getters; its optimizer state is
+                   loaded into the optimizer the reference's own ThreeDGSTrainer.optim_setup + DynTrainer.
+                   append_motion_optim build (src/trainer/rodygs_static.py:106-141, rodygs_dynamic.py:93-116), one Adam
+                   step is taken, and DynTrainer.state_dict (rodygs_dynamic.py:217-222) writes the checkpoint the
+                   import direction is tested on (``... make_golden.py checkpoint``)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -341,14 +349,133 @@ def optimizer_golden():
                next_m=st2["exp_avg"].numpy().copy(), next_v=st2["exp_avg_sq"].numpy().copy())
     np.savez_compressed(os.path.join(OUT, "optimizer_golden.npz"), **out)
 
+CKPT_P, CKPT_K, CKPT_T = 257, 16, 7
+CKPT_SCALE = 4.2
+# the shipped training configuration (/root/reference/configs/train/train_kubric_mrig.yaml, dynamic model)
+CKPT_LR = dict(position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+               position_lr_max_steps=30000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.001, rotation_lr=0.001)
+CKPT_DEFORM = dict(deform_lr_init=0.0016, deform_lr_final=0.00016, deform_lr_delay_mult=0.01, deform_lr_max_steps=30000,
+                   motion_coeff_lr=0.00016)
+
+
+def checkpoint_inputs(seed=1212):
+    """The build's side of G12 (shared with tests/test_abi_and_host.py, which imports this function -- it touches no
+    reference code): flat buckets with random values, moments and a step count, the MLP in its small bucket."""
+    from rodygs_amd.deform import MLPBasisNetwork as Net
+    from rodygs_amd.dp import FlatParams
+    from rodygs_amd.trainstep import bind_module_to_flat
+    P, K, T = CKPT_P, CKPT_K, CKPT_T
+    g = torch.Generator().manual_seed(seed)
+    spec = {"xyz": ((P, 3), CKPT_LR["position_lr_init"] * CKPT_SCALE), "features": ((P, K, 3), CKPT_LR["feature_lr"]),
+            "scaling": ((P, 3), CKPT_LR["scaling_lr"]), "rotation": ((P, 4), CKPT_LR["rotation_lr"]),
+            "opacity": ((P, 1), CKPT_LR["opacity_lr"]), "motion_coeff": ((P, 1, 16), CKPT_DEFORM["motion_coeff_lr"])}
+    fp = FlatParams(spec, "cpu")
+    with torch.no_grad():
+        fp.flat.copy_(0.5 * torch.randn(fp.numel, generator=g))
+        fp.exp_avg.copy_(1e-3 * torch.randn(fp.numel, generator=g))
+        fp.exp_avg_sq.copy_(1e-6 * torch.rand(fp.numel, generator=g))
+    fp.step_count = 5
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed + 1)
+        net = Net(128, 16, 26, False)
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.copy_(torch.randn_like(p_) * (0.3 if p_.dim() > 1 else 0.1))
+    sp = bind_module_to_flat(net, CKPT_DEFORM["deform_lr_init"], "cpu")
+    with torch.no_grad():
+        sp.exp_avg.copy_(1e-3 * torch.randn(sp.numel, generator=g))
+        sp.exp_avg_sq.copy_(1e-6 * torch.rand(sp.numel, generator=g))
+    sp.step_count = 5
+    times = torch.arange(T, dtype=torch.float32) / T
+    g2t = times[torch.randint(0, T, (P,), generator=g)]
+    cams = (torch.randn(T, 4, generator=g), torch.randn(T, 3, generator=g))
+    return fp, net, sp, g2t, cams, g
+
+
+def checkpoint_golden():
+    import tempfile
+    from src.model.rodygs_dynamic import DynRoDyGS
+    from src.trainer.rodygs_dynamic import DynTrainer
+    from rodygs_amd import checkpoint as CK
+    fp, net, sp, g2t, cams, g = checkpoint_inputs()
+    sd = CK.export_state_dict(fp, 5, 3, CKPT_SCALE, net, g2t, cams, feature_lr_rest=CKPT_LR["feature_lr"] / 20.0,
+                              deform_state=sp, deform_lr=CKPT_DEFORM["deform_lr_init"])
+    with tempfile.TemporaryDirectory() as td:
+        CK.save_checkpoint(os.path.join(td, "dynamic_last.ckpt"), sd)
+        loaded = torch.load(os.path.join(td, "dynamic_last.ckpt"), weights_only=False)     # as evaluator/eval.py:58
+    assert isinstance(loaded, tuple) and loaded[1] == 5
+    loaded = loaded[0]
+    # ---- the reference's loader, with its hard-coded .cuda() calls neutralised for the duration ----
+    t_cuda, m_cuda = torch.Tensor.cuda, torch.nn.Module.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        model = DynRoDyGS(3, 128, 26, False, 16, inverse_motion=True)
+        model.create_from_state_dict(loaded, CKPT_SCALE)
+        out = dict(time_ind=model.gaussian_to_time_ind.numpy().astype(np.int64),
+                   real_times=model.real_times.numpy(), unique_keys=np.array(model.unique_times, dtype=np.int64),
+                   table=model.get_total_motion_table().detach().numpy().copy())
+        for i, t in enumerate((0.0, 0.37)):
+            tr, ro = model.get_gaussian_deformation(torch.tensor(t))
+            out[f"deform_xyz_{i}"] = tr.detach().numpy().copy()
+            out[f"deform_rot_{i}"] = ro.detach().numpy().copy()
+        # .copy(): get_xyz IS the parameter -- the array would alias storage the optimizer step below updates in place
+        out.update(get_xyz=model.get_xyz.detach().numpy().copy(), get_features=model.get_features.detach().numpy().copy(),
+                   get_opacity=model.get_opacity.detach().numpy().copy(),
+                   get_scaling=model.get_scaling.detach().numpy().copy(),
+                   get_rotation=model.get_rotation.detach().numpy().copy())
+        # ---- the reference's optimizer: its own group construction, our state loaded into it, one step ----
+        tr_ = object.__new__(DynTrainer)
+        tr_.model, tr_.spatial_lr_scale, tr_.is_optimizable_cam = model, CKPT_SCALE, False
+        tr_.optim_setup(**CKPT_LR)
+        tr_.append_motion_optim(**CKPT_DEFORM)
+        names = [g_["name"] for g_ in tr_.optimizer.param_groups]
+        assert names == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "deform_network", "motion_coeff"], names
+        assert [len(g_["params"]) for g_ in tr_.optimizer.param_groups] == [1, 1, 1, 1, 1, 1, 70, 1]
+        tr_.optimizer.load_state_dict(loaded["optim"]["optimizer"])
+        out["group_lr"] = np.array([g_["lr"] for g_ in tr_.optimizer.param_groups], dtype=np.float64)
+        flat_params = [q for g_ in tr_.optimizer.param_groups for q in g_["params"]]
+        grads = []
+        for q in flat_params:
+            q.grad = 1e-2 * torch.randn(q.shape, generator=g)
+            grads.append(q.grad.numpy().copy())
+        tr_.optimizer.step()
+        tr_.max_radii2D = torch.arange(CKPT_P, dtype=torch.float32)
+        tr_.xyz_gradient_accum = torch.full((CKPT_P, 1), 0.25)
+        tr_.denom = torch.full((CKPT_P, 1), 2.0)
+        ref_sd = tr_.state_dict(6)                         # DynTrainer.state_dict (rodygs_dynamic.py:217-222)
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = t_cuda, m_cuda
+    assert set(ref_sd) == {"iteration", "active_sh_degree", "model", "optim", "spatial_lr_scale"}
+    for i, a in enumerate(grads):
+        out[f"grad_{i}"] = a
+    # the reference-written checkpoint, as plain arrays (import direction): model tensors, MLP state_dict, optimizer state
+    for k, v in ref_sd["model"].items():
+        if k == "_deform_network":
+            for kk, vv in v.items():
+                out["ref_mlp." + kk] = vv.detach().numpy().copy()
+        else:
+            out["ref_model." + k] = v.detach().numpy().copy()
+    ro = ref_sd["optim"]["optimizer"]
+    out["ref_group_sizes"] = np.array([len(g_["params"]) for g_ in ro["param_groups"]], dtype=np.int64)
+    out["ref_group_lr"] = np.array([g_["lr"] for g_ in ro["param_groups"]], dtype=np.float64)
+    for i, st in ro["state"].items():
+        out[f"ref_state_{i}.step"] = np.float64(float(st["step"]))
+        out[f"ref_state_{i}.exp_avg"] = st["exp_avg"].numpy().copy()
+        out[f"ref_state_{i}.exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+    out["ref_n_state"] = np.int64(len(ro["state"]))
+    out["ref_iteration"] = np.int64(ref_sd["iteration"])
+    out["ref_active_sh_degree"] = np.int64(ref_sd["active_sh_degree"])
+    np.savez_compressed(os.path.join(OUT, "checkpoint_golden.npz"), **out)
+
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose", "optimizer"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose", "optimizer", "checkpoint"):
         sys.dont_write_bytecode = True
         _stub_modules()
         sys.path.insert(0, REF)
         {"rigidity": rigidity_golden, "depth": depth_loss_golden, "motion": motion_reg_golden,
-         "pose": eval_pose_golden, "optimizer": optimizer_golden}[sys.argv[1]]()
+         "pose": eval_pose_golden, "optimizer": optimizer_golden, "checkpoint": checkpoint_golden}[sys.argv[1]]()
         print(sys.argv[1], "golden written to", OUT)
     else:
         main()

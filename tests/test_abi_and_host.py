@@ -159,14 +159,20 @@ def test_checkpoint_wire_format_round_trip_and_torch_adam_compat(tmp_path):
         assert torch.equal(fp[k], fp2[k]), k
         assert torch.equal(fp.exp_avg[o:o + n], fp2.exp_avg[o2:o2 + n2]), k
         assert torch.equal(fp.exp_avg_sq[o:o + n], fp2.exp_avg_sq[o2:o2 + n2]), k
-    # a torch Adam with the reference's single-tensor groups accepts the exported optimizer state
+    # a torch Adam with the reference's groups (six single-tensor groups, the MLP's 70 tensors as "deform_network", then
+    # the motion coefficients: rodygs_static.py:106-141, rodygs_dynamic.py:93-116) accepts the exported optimizer state
     m = back["model"]
     order = [("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
-             ("scaling", "_scaling"), ("rotation", "_rotation"), ("motion_coeff", "_motion_coeff")]
+             ("scaling", "_scaling"), ("rotation", "_rotation")]
     params = [torch.nn.Parameter(m[key].clone()) for _, key in order]
-    opt = torch.optim.Adam([{"params": [p], "lr": 1e-3, "name": nm} for p, (nm, _) in zip(params, order)], eps=1e-15)
+    mlp = [torch.nn.Parameter(m["_deform_network"][n].clone()) for n in CK.reference_mlp_param_names(16)]
+    coeff = torch.nn.Parameter(m["_motion_coeff"].clone())
+    groups = [{"params": [p], "lr": 1e-3, "name": nm} for p, (nm, _) in zip(params, order)]
+    groups += [{"params": mlp, "lr": 1e-3, "name": "deform_network"}, {"params": [coeff], "lr": 1e-3, "name": "motion_coeff"}]
+    opt = torch.optim.Adam(groups, eps=1e-15)
     opt.load_state_dict(back["optim"]["optimizer"])
-    assert [g_["name"] for g_ in opt.param_groups] == [nm for nm, _ in order]
+    assert [g_["name"] for g_ in opt.param_groups] == [nm for nm, _ in order] + ["deform_network", "motion_coeff"]
+    assert len(opt.param_groups[6]["params"]) == 70 and opt.state[coeff]["exp_avg"].shape == (P, 1, B)
     assert abs(opt.param_groups[2]["lr"] - 2.5e-3 / 20) < 1e-12
     assert torch.equal(opt.state[params[1]]["exp_avg"], back["optim"]["optimizer"]["state"][1]["exp_avg"])
     # PSNR: 10 log10(1 / MSE) on clipped images
@@ -174,6 +180,129 @@ def test_checkpoint_wire_format_round_trip_and_torch_adam_compat(tmp_path):
     b = a + 0.1
     assert abs(float(CK.psnr(a, b)) - 20.0) < 1e-4
     assert abs(float(CK.psnr(a, a + 2.0)) - float(10 * torch.log10(torch.tensor(1 / 0.25)))) < 1e-5   # clipped to 1
+
+
+def _golden_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    return M
+
+
+def _reference_layout_optimizer(model_dict):
+    """torch.optim.Adam over the tensors of a checkpoint's "model" entry with the reference's eight groups."""
+    import torch
+    from rodygs_amd import checkpoint as CK
+    single = [("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+              ("scaling", "_scaling"), ("rotation", "_rotation")]
+    params = {nm: torch.nn.Parameter(model_dict[key].clone()) for nm, key in single}
+    mlp_names = CK.reference_mlp_param_names(16)
+    mlp = [torch.nn.Parameter(model_dict["_deform_network"][n].clone()) for n in mlp_names]
+    params["motion_coeff"] = torch.nn.Parameter(model_dict["_motion_coeff"].clone())
+    groups = [{"params": [params[nm]], "lr": 0.0, "name": nm} for nm, _ in single]
+    groups += [{"params": mlp, "lr": 0.0, "name": "deform_network"},
+               {"params": [params["motion_coeff"]], "lr": 0.0, "name": "motion_coeff"}]
+    return torch.optim.Adam(groups, lr=0.0, eps=1e-15), params, dict(zip(mlp_names, mlp))
+
+
+def test_exported_checkpoint_as_the_reference_loader_reads_it_golden():
+    """G12 (tests/golden/make_golden.py checkpoint): the dictionary rodygs_amd.checkpoint.export_state_dict writes was
+    saved, loaded and handed to the REFERENCE's DynRoDyGS.create_from_state_dict / sync_gaussian_to_time_ind /
+    get_total_motion_table / get_gaussian_deformation / getters, and its optimizer state to the optimizer the
+    reference's trainer builds (eight groups, deform_network before motion_coeff), which then took one Adam step and
+    wrote its own checkpoint.  Here: (a) what the reference computed from the dictionary equals what the build computes
+    from its flat buckets; (b) a torch Adam in the reference's layout, loaded with the exported state and given the same
+    gradients, lands on the reference's post-step parameters and moments; (c) the reference-written checkpoint imports
+    back into the flat buckets (Gaussians and MLP, values and both moments)."""
+    import numpy as np
+    import torch
+    from oracle import deform_oracle as DO
+    from rodygs_amd import checkpoint as CK
+    from rodygs_amd.deform import MLPBasisNetwork
+    from rodygs_amd.trainstep import bind_module_to_flat
+    M = _golden_module()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "checkpoint_golden.npz"))
+    fp, net, sp, g2t, cams, _ = M.checkpoint_inputs()
+    sd = CK.export_state_dict(fp, 5, 3, M.CKPT_SCALE, net, g2t, cams, feature_lr_rest=M.CKPT_LR["feature_lr"] / 20.0,
+                              deform_state=sp, deform_lr=M.CKPT_DEFORM["deform_lr_init"])
+    T = lambda k: torch.from_numpy(g[k])   # noqa: E731
+    # ---- (a) the model the reference built from the dictionary ----
+    keys = torch.trunc(g2t * 1000).to(torch.int64)
+    uniq = torch.unique(keys)
+    assert uniq.tolist() == g["unique_keys"].tolist()
+    time_ind = torch.searchsorted(uniq, keys)
+    assert torch.equal(time_ind, T("time_ind"))
+    real_times = torch.sort(torch.unique(g2t)).values
+    assert torch.equal(real_times, T("real_times"))
+    with torch.no_grad():
+        table = net.batch_inference(net.batch_embedding(real_times))
+        assert float((table - T("table")).abs().max()) <= 2e-6 * float(T("table").abs().max())
+        c = fp["motion_coeff"]
+        for i, t in enumerate((0.0, 0.37)):
+            basis = net.motion_basis(net.t_embedder(torch.tensor(t)).reshape(1, -1)).squeeze(0)
+            dxyz, drot = DO.gaussian_deformation(c, time_ind, basis, table, M.CKPT_SCALE)
+            # the random MLP weights make the deltas O(100): relative bar
+            sx, sr = float(T(f"deform_xyz_{i}").abs().max()), float(T(f"deform_rot_{i}").abs().max())
+            assert float((dxyz - T(f"deform_xyz_{i}")).abs().max()) <= 2e-6 * sx, i
+            assert float((drot - T(f"deform_rot_{i}")).abs().max()) <= 2e-6 * sr, i
+        assert torch.equal(fp["xyz"], T("get_xyz")) and torch.equal(fp["features"], T("get_features"))
+        assert torch.allclose(torch.sigmoid(fp["opacity"]), T("get_opacity"), atol=1e-7)
+        assert torch.allclose(torch.exp(fp["scaling"]), T("get_scaling"), rtol=1e-6)
+        assert torch.allclose(torch.nn.functional.normalize(fp["rotation"]), T("get_rotation"), atol=1e-6)
+    assert np.allclose(g["group_lr"], [M.CKPT_LR["position_lr_init"] * M.CKPT_SCALE, M.CKPT_LR["feature_lr"],
+                                       M.CKPT_LR["feature_lr"] / 20.0, M.CKPT_LR["opacity_lr"], M.CKPT_LR["scaling_lr"],
+                                       M.CKPT_LR["rotation_lr"], M.CKPT_DEFORM["deform_lr_init"],
+                                       M.CKPT_DEFORM["motion_coeff_lr"]], rtol=1e-12)
+    # ---- (b) the reference's optimizer step from the exported state ----
+    opt, params, mlp = _reference_layout_optimizer(sd["model"])
+    opt.load_state_dict(sd["optim"]["optimizer"])
+    assert [g_["name"] for g_ in opt.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation",
+                                                        "deform_network", "motion_coeff"]
+    flat = [q for g_ in opt.param_groups for q in g_["params"]]
+    assert len(flat) == 77 and g["ref_group_sizes"].tolist() == [1, 1, 1, 1, 1, 1, 70, 1]
+    for i, q in enumerate(flat):
+        q.grad = T(f"grad_{i}")
+    opt.step()
+    ref_model = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                 "scaling": "_scaling", "rotation": "_rotation", "motion_coeff": "_motion_coeff"}
+    for nm, key in ref_model.items():
+        assert torch.allclose(params[nm].detach(), T("ref_model." + key), rtol=0, atol=1e-7), nm
+    for n, q in mlp.items():
+        assert torch.allclose(q.detach(), T("ref_mlp." + n), rtol=0, atol=1e-7), n
+    for i, q in enumerate(flat):
+        assert float(opt.state[q]["step"]) == float(g[f"ref_state_{i}.step"]) == 6.0
+        assert torch.allclose(opt.state[q]["exp_avg"], T(f"ref_state_{i}.exp_avg"), rtol=0, atol=1e-9), i
+        assert torch.allclose(opt.state[q]["exp_avg_sq"], T(f"ref_state_{i}.exp_avg_sq"), rtol=1e-6, atol=1e-12), i
+    # ---- (c) the checkpoint the reference wrote, imported into the flat buckets ----
+    names = ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "deform_network", "motion_coeff"]
+    sizes = g["ref_group_sizes"].tolist()
+    groups, k = [], 0
+    for nm, n_, lr in zip(names, sizes, g["ref_group_lr"].tolist()):
+        groups.append({"name": nm, "lr": lr, "params": list(range(k, k + n_))})
+        k += n_
+    state = {i: {"step": torch.tensor(float(g[f"ref_state_{i}.step"])), "exp_avg": T(f"ref_state_{i}.exp_avg"),
+                 "exp_avg_sq": T(f"ref_state_{i}.exp_avg_sq")} for i in range(int(g["ref_n_state"]))}
+    ref_sd = {"iteration": int(g["ref_iteration"]), "active_sh_degree": int(g["ref_active_sh_degree"]),
+              "model": {k_[len("ref_model."):]: T(k_) for k_ in g.files if k_.startswith("ref_model.")},
+              "optim": {"optimizer": {"state": state, "param_groups": groups}}, "spatial_lr_scale": M.CKPT_SCALE}
+    ref_sd["model"]["_deform_network"] = {k_[len("ref_mlp."):]: T(k_) for k_ in g.files if k_.startswith("ref_mlp.")}
+    assert set(ref_sd["model"]) == set(sd["model"])
+    fp2 = CK.flat_params_from_state_dict(ref_sd, dict(fp.lr), "cpu")
+    assert fp2.step_count == 6
+    feats = torch.cat([params["f_dc"].detach(), params["f_rest"].detach()], dim=1)
+    assert torch.allclose(fp2["features"], feats, atol=1e-7) and torch.allclose(fp2["xyz"], params["xyz"].detach(), atol=1e-7)
+    o, n = fp2.offsets["motion_coeff"]
+    assert torch.allclose(fp2.exp_avg[o:o + n].view(-1), opt.state[params["motion_coeff"]]["exp_avg"].reshape(-1), atol=1e-9)
+    net2 = MLPBasisNetwork(128, 16, 26, False)
+    net2.load_state_dict(ref_sd["model"]["_deform_network"])
+    sp2 = bind_module_to_flat(net2, 0.0016, "cpu")
+    assert CK.restore_deform_state(ref_sd, sp2) and sp2.step_count == 6
+    for n, q in mlp.items():
+        assert torch.allclose(CK._mlp_segment(sp2.flat, sp2, n), q.detach(), atol=1e-7), n
+        assert torch.allclose(CK._mlp_segment(sp2.exp_avg, sp2, n), opt.state[q]["exp_avg"], atol=1e-9), n
+        assert torch.allclose(CK._mlp_segment(sp2.exp_avg_sq, sp2, n), opt.state[q]["exp_avg_sq"], rtol=1e-6, atol=1e-12), n
 
 
 def test_eval_pose_helpers_against_reference_golden():

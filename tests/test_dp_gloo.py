@@ -264,3 +264,6 @@ def test_chunk_ranges_cover_the_shard_in_aligned_pieces():
             assert r[0][0] == 0 and r[-1][1] == stride and len(r) <= max(1, min(chunks, stride // 256))
             assert all(a % 256 == 0 and b % 256 == 0 and a < b for a, b in r)
             assert all(r[i][1] == r[i + 1][0] for i in range(len(r) - 1))
+    # an empty cloud: one empty range on every rank (the collective sequence must not depend on the data)
+    for chunks in (1, 3, 64):
+        assert chunk_ranges(shard_rows(0, 8)[1], chunks) == [(0, 0)]

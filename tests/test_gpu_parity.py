@@ -1907,6 +1907,67 @@ def test_test_time_pose_optimisation_recovers_camera():
     assert p1 > p0 + 8.0 and e1 < 0.25 * e0, (p0, p1, e0, e1)
 
 
+def test_pose_optimisation_trajectory_matches_the_oracle():
+    """The evaluator's test-time pose optimisation (/root/reference/src/evaluator/eval.py:342-420: Adam(lr, eps 1e-15) on a
+    LearnableCamera's quaternion + translation, l2 loss on the rendered image, Gaussians frozen) run step for step
+    through the HIP rasterizer and through the oracle from the same start: 60 steps, the loss curve and the pose
+    parameters after every step must coincide (the only gradient in play is dL/dviewmatrix)."""
+    import math
+    from rodygs_amd.pose_optimizer import LearnablePose, l2_loss
+    from rodygs_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    W, H, steps, lr = 128, 96, 60, 2e-3
+    sc = O.synthetic_scene(2500, W, H, 3, seed=83)
+    dev = torch.device(DEV)
+    gs = {k: sc[k].to(dev) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    rs = GaussianRasterizationSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3, device=dev), 1.0,
+                                       sc["projmatrix"].to(dev), 3, False, False, True, True)
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 3)
+
+    def render_hip(vm):
+        return GaussianRasterizer(rs)(means3D=gs["means3D"], means2D=torch.zeros_like(gs["means3D"]), shs=gs["shs"],
+                                      opacities=gs["opacities"], scales=gs["scales"], rotations=gs["rotations"],
+                                      viewmatrix=vm)[0]
+
+    def render_oracle(vm):
+        return O.rasterize(sc["means3D"], torch.zeros(sc["means3D"].shape[0], 3), sc["opacities"], vm, st, shs=sc["shs"],
+                           scales=sc["scales"], rotations=sc["rotations"])[0]
+
+    def c2w(angle, shift):
+        c, s_ = math.cos(angle), math.sin(angle)
+        m = torch.eye(4)
+        m[:3, :3] = torch.tensor([[c, 0.0, s_], [0.0, 1.0, 0.0], [-s_, 0.0, c]])
+        m[:3, 3] = torch.tensor(shift)
+        return m
+
+    target = torch.inverse(c2w(0.031, [0.21, 0.03, -0.02]))
+    start = torch.inverse(c2w(0.02, [0.15, 0.0, 0.0]))
+    with torch.no_grad():
+        rgb = render_oracle(target.t().contiguous())
+
+    def optimise(render, device, view_of):
+        cam = LearnablePose(start[:3, :3].clone(), start[:3, 3].clone()).to(device)
+        opt = torch.optim.Adam(cam.parameters(), lr=lr, eps=1e-15)
+        gt = rgb.to(device)
+        losses, traj = [], []
+        for _ in range(steps):
+            loss = l2_loss(render(view_of(cam)), gt)
+            loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(loss))
+            traj.append(torch.cat([cam.R_c2w_quat.detach().cpu(), cam.T_c2w.detach().cpu()]))
+        return torch.tensor(losses, dtype=torch.float64), torch.stack(traj).double()
+
+    lh, th = optimise(render_hip, dev, lambda cam: cam.viewmatrix())                       # HIP pose op + rasterizer
+    lo, to = optimise(render_oracle, "cpu", lambda cam: cam.world_view_transform.t().contiguous())
+    assert float(lo[-1]) < 0.2 * float(lo[0])                                              # the optimisation did its job
+    moved = float((to[-1] - to[0]).abs().max())
+    assert moved > 10 * lr
+    assert float(((lh - lo).abs() / lo).max()) <= 2e-3, ((lh - lo).abs() / lo).max()
+    assert float((th - to).abs().max()) <= 2e-2 * moved, (float((th - to).abs().max()), moved)
+    assert float((th[:10] - to[:10]).abs().max()) <= 1e-5                                  # early steps: bit-level agreement
+
+
 def test_sh_adam_in_backward_equals_separate_optimiser_step():
     """rdg_preprocess_backward_adam (the SH features stepped inside the per-Gaussian backward kernel, dL/dshs never
     written) against rdg_preprocess_backward + rdg_adam_step_multi on the gradient it writes, from the SAME gradient rows:
@@ -2043,6 +2104,55 @@ def test_reset_opacity_matches_reference_golden():
     rel_ok(fp["opacity"], g["next_logit"], tol=1e-5, what="logits after the next Adam step")
     rel_ok(fp.exp_avg[o:o + cnt].view(n, 1), g["next_m"], tol=1e-6, what="exp_avg")
     rel_ok(fp.exp_avg_sq[o:o + cnt].view(n, 1), g["next_v"], tol=1e-6, what="exp_avg_sq")
+
+
+def test_fused_adam_reproduces_the_reference_optimizer_step_from_a_checkpoint():
+    """G12 on the GPU: the checkpoint of tests/golden/checkpoint_golden.npz (read by the REFERENCE loader, its optimizer
+    built by the reference's trainer code, one torch Adam step taken there) -- the same state imported into the flat
+    buckets, the same gradients, ONE fused HIP launch over both buckets (Gaussians + MLP) must land on the parameters
+    the reference wrote into its own checkpoint."""
+    import importlib.util
+    from rodygs_amd import checkpoint as CK
+    from rodygs_amd.deform import MLPBasisNetwork
+    from rodygs_amd.trainstep import bind_module_to_flat, fused_adam_
+    spec = importlib.util.spec_from_file_location(
+        "make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "checkpoint_golden.npz"))
+    fp0, net0, sp0, g2t, cams, _ = M.checkpoint_inputs()
+    sd = CK.export_state_dict(fp0, 5, 3, M.CKPT_SCALE, net0, g2t, cams, feature_lr_rest=M.CKPT_LR["feature_lr"] / 20.0,
+                              deform_state=sp0, deform_lr=M.CKPT_DEFORM["deform_lr_init"])
+    fp = CK.flat_params_from_state_dict(sd, dict(fp0.lr), DEV)
+    net = MLPBasisNetwork(128, 16, 26, False)
+    net.load_state_dict(sd["model"]["_deform_network"])
+    sp = bind_module_to_flat(net.to(DEV), M.CKPT_DEFORM["deform_lr_init"], DEV)
+    assert CK.restore_deform_state(sd, sp) and sp.step_count == fp.step_count == 5
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)   # noqa: E731
+    # gradients in the reference's parameter order: xyz, f_dc, f_rest, opacity, scaling, rotation, 70 MLP tensors, coeff
+    with torch.no_grad():
+        fp["xyz"].grad.copy_(T("grad_0"))
+        fp["features"].grad.copy_(torch.cat([T("grad_1"), T("grad_2")], dim=1))
+        fp["opacity"].grad.copy_(T("grad_3"))
+        fp["scaling"].grad.copy_(T("grad_4"))
+        fp["rotation"].grad.copy_(T("grad_5"))
+        for j, n in enumerate(CK.reference_mlp_param_names(16)):
+            CK._mlp_segment(sp.flat_grad, sp, n).copy_(T(f"grad_{6 + j}"))
+        fp["motion_coeff"].grad.copy_(T("grad_76"))
+    K = fp.shapes["features"][1]
+    fused_adam_(fp, row_lr={"features": (K * 3, 3, M.CKPT_LR["feature_lr"] / 20.0)}, extra=(sp,))
+    torch.cuda.synchronize()
+    want = {"xyz": T("ref_model._xyz"), "features": torch.cat([T("ref_model._features_dc"), T("ref_model._features_rest")], 1),
+            "opacity": T("ref_model._opacity"), "scaling": T("ref_model._scaling"), "rotation": T("ref_model._rotation"),
+            "motion_coeff": T("ref_model._motion_coeff")}
+    for k, w in want.items():
+        assert float((fp[k].detach() - w).abs().max()) <= 2e-6 * max(1.0, float(w.abs().max())), k
+    for n in CK.reference_mlp_param_names(16):
+        w = T("ref_mlp." + n)
+        assert float((CK._mlp_segment(sp.flat, sp, n) - w).abs().max()) <= 2e-6 * max(1.0, float(w.abs().max())), n
+    o, n_ = fp.offsets["xyz"]
+    assert torch.allclose(fp.exp_avg[o:o + n_].view(-1), T("ref_state_0.exp_avg").reshape(-1), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(fp.exp_avg_sq[o:o + n_].view(-1), T("ref_state_0.exp_avg_sq").reshape(-1), rtol=1e-5, atol=1e-12)
 
 
 def test_adam_lr_override_is_per_segment_and_per_step():
