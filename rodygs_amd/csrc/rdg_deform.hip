@@ -377,6 +377,13 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
     const int slot = lane >> 4, j = lane & 15;
     rdg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int cur_u = -1;
+    // The partial-slot form is only right for a sequence that really is sorted by birth index (`order` comes from a host
+    // cache): every wave checks its own stretch -- and the row before it -- and raises a flag the last stage turns into
+    // NaN gradients.  A stale permutation must fail loudly, not train on garbage.
+    int prev_u = -1;
+    if (part && beg > 0 && beg < end)
+        prev_u = gs ? __float_as_int(gs[(size_t)(beg - 1) * 8 + 7]) : (int)time_ind[order[beg - 1]];
+    bool unsorted = false;
     const int jx = min(j, 2), jr = min(max(j - 3, 0), 3);
     const float wx = j < 3 ? scale : 0.0f, wr = (j >= 3 && j < RDG_DEF_K) ? 1.0f : 0.0f;
     for (int base = beg; base < end; base += 4 * RDG_DEF_G) {
@@ -427,6 +434,7 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
                     const int us = __builtin_amdgcn_readlane(u, sl * 16);
                     if (us < 0) continue;
                     if (us != cur_u) {
+                        unsorted |= us < max(cur_u, prev_u);
                         rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table, part, wave);
                         acc = rdg_f32x4{0.f, 0.f, 0.f, 0.f};
                         cur_u = us;
@@ -437,6 +445,8 @@ rdg_deform_bwd_acc_mfma_kernel(int P, const float* __restrict__ coeff, const lon
         }
     }
     rdg_deform_flush(acc, cur_u, lane, has_table != 0, d_basis_t, d_table, part, wave);
+    // the flag sits in the word after the finished-workgroup counter, 256 B before the slots
+    if (part && unsorted && lane == 0) atomicOr(reinterpret_cast<unsigned int*>(part) - 63, 1u);
 }
 
 // sum over u of d_table[u][c] in a fixed order (eight interleaved partial sums, then a tree)
@@ -485,6 +495,7 @@ rdg_deform_part_finalize_kernel(int P, int Tu, int per, const int* __restrict__ 
             const int w0 = bound[0] / per, w1 = (bound[1] - 1) / per;
             for (int w = w0; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
         }
+        if (counter[1] != 0u) acc = __int_as_float(0x7fc00000);   // `order` was not sorted by birth index: poison, loudly
         d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -acc;
     }
     // publish this row (agent-scope release), count the finished workgroups; the last one acquires and reduces over u
@@ -935,7 +946,7 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
                                     ? (uint32_t*)((char*)sorted_ws + rdg_deform_gs_bytes(P)) : nullptr;
             float* part = counter ? (float*)((char*)counter + 256) : nullptr;
             if (counter) {
-                hipError_t ec = hipMemsetAsync(counter, 0, 4, st);
+                hipError_t ec = hipMemsetAsync(counter, 0, 8, st);
                 if (ec != hipSuccess) return rdg_check_hip(ec, "deform_bwd counter memset");
             }
             hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? RDG_DEF_ACC_BLOCKS : 64), dim3(256), 0, st, P,
@@ -1003,7 +1014,7 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
         hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
-                           (const int*)inv_order, (float4*)sorted_ws, counter, 1);
+                           (const int*)inv_order, (float4*)sorted_ws, counter, 2);
         float* part = (float*)((char*)counter + 256);
         hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(RDG_DEF_ACC_BLOCKS), dim3(256), 0, st, P, coeff,
                            (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,

@@ -234,8 +234,10 @@ def _birth_order(time_ind: torch.Tensor, n_births: int = 0):
     """(order, inverse, seg_start): int32 permutation sorting the Gaussians by birth index, its inverse, and (for
     n_births > 0) where each birth index starts in the sorted sequence (int32 [n_births + 1]); cached until
     time_ind changes (it only does at densification), so the sort is not part of the step.  The key is the tensor's
-    address / version / length: code that REPLACES a birth-index tensor (densification does) calls
-    ``invalidate_birth_order_cache()`` so that a new tensor reusing a freed address cannot inherit a stale permutation."""
+    address / version / length, and the entry keeps the tensor alive: a live tensor's address cannot be handed to another
+    one, so a key never matches a different birth-index array (the dB reduction REQUIRES a truly sorted sequence: its
+    kernel checks that and poisons the gradient with NaN otherwise).  Code that replaces a birth-index tensor
+    (densification does) calls ``invalidate_birth_order_cache()`` to drop the old entries."""
     key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device), int(n_births))
     o = _ORDER_CACHE.get(key)
     if o is None:
@@ -249,9 +251,9 @@ def _birth_order(time_ind: torch.Tensor, n_births: int = 0):
             seg = torch.searchsorted(time_ind[order].contiguous(),
                                      torch.arange(n_births + 1, device=order.device, dtype=time_ind.dtype))
             seg = seg.to(torch.int32).contiguous()
-        o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous(), seg)
+        o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous(), seg, time_ind)
         _ORDER_CACHE[key] = o
-    return o
+    return o[:3]
 
 
 def invalidate_birth_order_cache() -> None:

@@ -819,6 +819,33 @@ def test_fused_dynamic_getter_equals_deformation_plus_activations(use_sinks):
     rel_ok(b["bases"].grad, a["bases"].grad, tol=2e-5, what="fused getter d_bases")
 
 
+def test_unsorted_birth_order_poisons_the_basis_gradient():
+    """The dB reduction stores one partial total per (wave, birth index) and adds them in a fixed order -- right only for
+    a sequence that really is sorted by birth index.  A wrong permutation (a stale host cache) must not produce a
+    plausible-looking gradient: the kernel notices and the basis gradient comes back NaN."""
+    from rodygs_amd import deform as DF
+    g = torch.Generator().manual_seed(3)
+    P, Tu = 6000, 9
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(DEV)   # noqa: E731
+    leaves = [t.requires_grad_(True) for t in (rnd(P, 3), 0.3 * rnd(P, 3), rnd(P, 4), rnd(P, 1), 0.2 * rnd(P, 16))]
+    ti = torch.randint(0, Tu, (P,), generator=g).to(DEV)
+    bases = (0.1 * rnd(Tu + 1, 16, 7)).requires_grad_(True)
+    out = DF.dynamic_gaussians(*leaves, ti, bases, 2.0)
+    order, inv, seg = DF._birth_order(ti, Tu)
+    key = next(k for k, v in DF._ORDER_CACHE.items() if v[0] is order)
+    bad = torch.roll(order, 1234)                     # still a permutation, no longer sorted by birth index
+    bad_inv = torch.empty_like(bad)
+    bad_inv[bad.long()] = torch.arange(P, device=DEV, dtype=torch.int32)
+    try:
+        DF._ORDER_CACHE[key] = (bad, bad_inv, seg, ti)
+        torch.autograd.backward([out[0], out[2]], [rnd(P, 3), rnd(P, 4)])
+        torch.cuda.synchronize()
+    finally:
+        DF.invalidate_birth_order_cache()
+    assert bool(torch.isnan(bases.grad).all())
+    assert bool(torch.isfinite(leaves[4].grad).all())            # dL/dcoeff does not go through the reduction
+
+
 def test_deformation_field_matches_reference_golden_on_gpu():
     """End to end against the imported-reference golden (MLP in torch on the GPU + HIP per-Gaussian op)."""
     from rodygs_amd.deform import MLPBasisNetwork, gaussian_deformation
