@@ -211,6 +211,8 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         train_step = lambda st_: ss.train_step(st_, perm)                       # noqa: E731
     else:
         train_step = lambda st_: ds.train_step(st_, rank, world, perm)          # noqa: E731
+    graphed = None
+    use_graph = bool(args.graph and world == 1 and not sharded and not args.full_losses)
 
     def sync():
         if world > 1:
@@ -226,9 +228,18 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     # inside the forward (no host wait in the step).  Capacity is 1.25x the last D; an overflow would render that
     # frame empty and raise RasterizerCapacityOverflow at the next forward / at the final poll below.
     rasterizer.DEFERRED_OVERFLOW_CHECK = True
+    if use_graph:
+        # capture after the warm-up (capacity and binning hints are known); the timed region replays the graph
+        from rodygs_amd.trainstep import GraphedStep
+        rasterizer.DEFERRED_OVERFLOW_CHECK = False
+        graphed = GraphedStep(ds, perm, warmup=2, first_step=step)
+        step = graphed.next_step
+        train_step_eager = train_step
+        train_step = lambda st_: graphed.step()                                  # noqa: E731
     # Inside the timed region only the dominant kernel is bracketed by hipEvents (every timed stage costs ~10 us of
-    # stream gap); the per-stage table is taken from a few extra steps afterwards.
-    _lib.timing_enable(True, stages=["render_bwd"])
+    # stream gap); the per-stage table is taken from a few extra steps afterwards.  (A replayed graph cannot bracket one
+    # of its kernels: the dominant kernel's time is then taken from the eager steps after the timed region.)
+    _lib.timing_enable(not use_graph, stages=["render_bwd"])
     _lib.timing_reset()
     # the interpreter's cyclic collector runs a full (generation-2) pass once the start-up garbage has piled up -- a
     # 40 ms host stall that would land somewhere in a 20-step window: collect now, and keep the survivors out of later
@@ -243,6 +254,11 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         step += 1
     sync()
     dt = time.perf_counter() - t0
+    if graphed is not None:
+        graphed.check()                      # raises if a replayed frame outgrew the captured capacity
+        step = graphed.next_step
+        graphed.close()
+        train_step = train_step_eager
     rasterizer.poll_overflow(block=True)
     dom = _lib.stage_times()["render_bwd"]
     _lib.timing_enable(True)
@@ -253,7 +269,8 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     sync()
     rasterizer.poll_overflow(block=True)
     stages = _lib.stage_times()
-    stages["render_bwd"] = dom
+    if graphed is None:
+        stages["render_bwd"] = dom
     _lib.timing_enable(False)
     rasterizer.DEFERRED_OVERFLOW_CHECK = False
     if world > 1:
@@ -261,6 +278,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     out = {"mode": mode, "sharded": sharded, "dt": dt, "loss": float(loss.item()), "spatial_order": spatial_order,
+           "graph": graphed is not None,
            "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
         if sharded:
@@ -295,6 +313,10 @@ def main():
     ap.add_argument("--scene", choices=["uniform", "sheets", "dense"], default="uniform",
                     help="rodygs_amd.synthetic variant: 'uniform' = the SURVEY 8d generator (the headline workload); "
                          "'sheets' = opaque depth sheets (early termination); 'dense' = 3x the projected sigma (D ~ 9x)")
+    ap.add_argument("--graph", action="store_true", default=os.environ.get("RDG_GRAPH", "0") == "1",
+                    help="N = 1, photometric: replay the step as ONE captured hipGraph (trainstep.GraphedStep) instead of "
+                         "launching its ~50 kernels from Python -- what makes the step kernel-bound at the size of the "
+                         "reference's real clouds (~100 k points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads of the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=60.0,
@@ -353,6 +375,7 @@ def main():
         best = min(runs, key=lambda r: r["dt"])
         sharded, dt, per_stage = best["sharded"], best["dt"], best["per_stage"]
         D, V, S, spatial_order = best["D"], best["V"], best["S"], best["spatial_order"]
+        graph_replay = best["graph"]
         fps = args.steps * world / dt
         # dominant kernel: render backward.  Algorithmic bytes per launch (DESIGN.md §5 / SURVEY.md §8d):
         #   D*44 (sorted id + 40-B splat features) + H*W*40 (5 upstream-gradient channels, final_T, n_contrib, +pad
@@ -441,6 +464,9 @@ def main():
                        # (capacity from the warm-up; an overflow renders that frame empty and raises afterwards), and
                        # whether every rank shares one device (functional check of the N > 1 flow, not a measurement)
                        "deferred_overflow_check": True, "one_device": bool(os.environ.get("RDG_ONE_DEVICE")),
+                       # True: the timed steps are replays of ONE captured hipGraph (trainstep.GraphedStep); the
+                       # dominant kernel's avg_ms then comes from eager steps after the timed region
+                       "graph_replay": graph_replay,
                        "deterministic_backward": bool(rasterizer_mod.DETERMINISTIC),
                        "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",

@@ -463,6 +463,33 @@ int rdg_pose_views_forward(int32_t T, int32_t nviews, const int32_t* frames_host
 int rdg_pose_views_backward(int32_t T, int32_t nviews, const int32_t* frames_host, const float* cam_q,
                             const float* cam_t, const float* g_views, float* d_q, float* d_t, void* stream);
 
+/* ---- per-step scalars in device memory (hipGraph replay of a train step, rodygs_amd/trainstep.py GraphedStep) --------
+ * A captured graph bakes every by-value kernel argument.  The three values of a train step that change from step to step
+ * -- Adam's two bias corrections and the index of the rendered frame -- can instead be read from this 16-byte device
+ * struct, which the host refreshes (one small H2D copy) before each replay.  The *_dev entry points below are the
+ * by-pointer forms of rdg_pose_view_forward / _backward, rdg_adam_step_multi and rdg_preprocess_backward_adam; same
+ * arithmetic, same bits (the host computes the corrections exactly as the by-value forms do).                       */
+typedef struct RdgStepScalars {
+    float inv_bias_correction1;    /* (float)(1 / (1 - beta1^step))    */
+    float sqrt_bias_correction2;   /* (float)sqrt(1 - beta2^step)      */
+    int32_t frame;                 /* row of the camera tables to render */
+    int32_t reserved;
+} RdgStepScalars;
+int rdg_pose_view_forward_dev(int32_t T, const RdgStepScalars* dev, const float* cam_q, const float* cam_t,
+                              float* out_view16, void* stream);
+int rdg_pose_view_backward_dev(int32_t T, const RdgStepScalars* dev, const float* cam_q, const float* cam_t,
+                               const float* g_view16, float* d_q, float* d_t, void* stream);
+int rdg_adam_step_multi_dev(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps,
+                            const RdgStepScalars* dev, void* stream);
+int rdg_preprocess_backward_adam_dev(const RdgRasterSettings* s_host, const float* means3D, float* shs,
+                                     const float* opacities, const float* scales, const float* rotations,
+                                     const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+                                     const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
+                                     float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                                     float* dL_dviewmatrix, float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len,
+                                     float lr_head, float lr_tail, double beta1, double beta2, float eps,
+                                     const RdgStepScalars* dev, void* stream);
+
 /* ---- measurement hooks -----------------------------------------------------------------------------------
  * When enabled, every stage is bracketed by hipEvents recorded on the launch stream.  rdg_stage_time_ms()
  * synchronises on the recorded events and returns accumulated milliseconds + launch count since the last

@@ -33,6 +33,11 @@ class RdgAdamSeg(C.Structure):
                 ("head_len", C.c_int32)]
 
 
+class RdgStepScalars(C.Structure):
+    _fields_ = [("inv_bias_correction1", C.c_float), ("sqrt_bias_correction2", C.c_float), ("frame", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 STAGES = {
     "preprocess": 0, "scan_dup": 1, "sort": 2, "ranges": 3, "render_fwd": 4, "render_bwd": 5,
     "preprocess_bwd": 6, "deform_fwd": 7, "deform_bwd": 8, "adam": 9, "loss_fwd": 10, "loss_bwd": 11, "mlp_fwd": 12, "mlp_bwd": 13,
@@ -60,6 +65,11 @@ _SIGS = {
     "rdg_preprocess_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 22),
     "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 2 +
                                      [C.c_double, C.c_double, C.c_float, C.c_int32, _vp]),
+    "rdg_preprocess_backward_adam_dev": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 2 +
+                                         [C.c_double, C.c_double, C.c_float, _vp, _vp]),
+    "rdg_pose_view_forward_dev": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "rdg_pose_view_backward_dev": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdg_adam_step_multi_dev": (C.c_int, [C.c_int32, C.POINTER(RdgAdamSeg), C.c_double, C.c_double, C.c_float, _vp, _vp]),
     "rdg_preprocess_forward_views": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32] + [_vp] * 10),
     "rdg_preprocess_forward_views_rows": (C.c_int, [C.POINTER(RdgRasterSettings), C.c_int32, C.c_int32, C.c_int32]
                                           + [_vp] * 10),

@@ -248,31 +248,36 @@ int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3
     return rc;
 }
 
-int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* means3D, float* shs,
-                                 const float* opacities, const float* scales, const float* rotations,
-                                 const float* viewmatrix, const float* projmatrix, const int32_t* radii,
-                                 const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
-                                 float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dviewmatrix,
-                                 float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len, float lr_head, float lr_tail,
-                                 double beta1, double beta2, float eps, int32_t step, void* stream) {
+static int rdg_pre_bwd_adam(const RdgRasterSettings* s_host, const float* means3D, float* shs, const float* opacities,
+                            const float* scales, const float* rotations, const float* viewmatrix,
+                            const float* projmatrix, const int32_t* radii, const void* geom_ws, void* grad_ws,
+                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dopacities, float* dL_dscales,
+                            float* dL_drotations, float* dL_dviewmatrix, float* sh_exp_avg, float* sh_exp_avg_sq,
+                            int32_t head_len, float lr_head, float lr_tail, double beta1, double beta2, float eps,
+                            int32_t step, const RdgStepScalars* dev, void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
     if (!shs || !scales || !rotations || !sh_exp_avg || !sh_exp_avg_sq)
         return rdg_set_error("rdg_preprocess_backward_adam: shs, scales, rotations and both moment buffers are required");
     if (rdg_check_inputs(s_host, shs, nullptr, scales, rotations, nullptr)) return -1;
-    if (step < 1) return rdg_set_error("adam: step must be >= 1");
+    if (!dev && step < 1) return rdg_set_error("adam: step must be >= 1");
     hipStream_t st = (hipStream_t)stream;
     const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
     float* posebuf = (float*)((char*)grad_ws + grow_bytes);
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     RdgShAdam ad;
     ad.m = sh_exp_avg; ad.v = sh_exp_avg_sq;
-    // the same scalars rdg_adam_step_multi hands its kernel (float(lr) * float(1 / bc1)), so that the fused update and
-    // the separate launch produce the same bits
-    const float inv_bc1 = (float)(1.0 / bc1);
-    ad.step_head = lr_head * inv_bc1; ad.step_tail = lr_tail * inv_bc1;
+    ad.dev = dev; ad.lr_head = lr_head; ad.lr_tail = lr_tail;
+    ad.step_head = ad.step_tail = ad.bc2_sqrt = 0.0f;
+    if (!dev) {
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        // the same scalars rdg_adam_step_multi hands its kernel (float(lr) * float(1 / bc1)), so that the fused update and
+        // the separate launch produce the same bits
+        const float inv_bc1 = (float)(1.0 / bc1);
+        ad.step_head = lr_head * inv_bc1; ad.step_tail = lr_tail * inv_bc1;
+        ad.bc2_sqrt = (float)sqrt(bc2);
+    }
     ad.b1 = (float)beta1; ad.b2 = (float)beta2; ad.omb1 = (float)(1.0 - beta1); ad.omb2 = (float)(1.0 - beta2);
-    ad.eps = eps; ad.bc2_sqrt = (float)sqrt(bc2);
+    ad.eps = eps;
     ad.head_len = head_len;
     rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
     int rc = rdg_launch_preprocess_bwd(d, means3D, shs, nullptr, opacities, scales, rotations, nullptr, viewmatrix,
@@ -281,6 +286,32 @@ int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* m
                                        dL_dviewmatrix, st, &ad);
     rdg_stage_end(RDG_STAGE_PREPROCESS_BWD, st);
     return rc;
+}
+
+int rdg_preprocess_backward_adam(const RdgRasterSettings* s_host, const float* means3D, float* shs,
+                                 const float* opacities, const float* scales, const float* rotations,
+                                 const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+                                 const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
+                                 float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dviewmatrix,
+                                 float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len, float lr_head, float lr_tail,
+                                 double beta1, double beta2, float eps, int32_t step, void* stream) {
+    return rdg_pre_bwd_adam(s_host, means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, radii, geom_ws,
+                            grad_ws, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations, dL_dviewmatrix,
+                            sh_exp_avg, sh_exp_avg_sq, head_len, lr_head, lr_tail, beta1, beta2, eps, step, nullptr, stream);
+}
+
+int rdg_preprocess_backward_adam_dev(const RdgRasterSettings* s_host, const float* means3D, float* shs,
+                                     const float* opacities, const float* scales, const float* rotations,
+                                     const float* viewmatrix, const float* projmatrix, const int32_t* radii,
+                                     const void* geom_ws, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
+                                     float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                                     float* dL_dviewmatrix, float* sh_exp_avg, float* sh_exp_avg_sq, int32_t head_len,
+                                     float lr_head, float lr_tail, double beta1, double beta2, float eps,
+                                     const RdgStepScalars* dev, void* stream) {
+    if (!dev) return rdg_set_error("rdg_preprocess_backward_adam_dev: NULL step scalars");
+    return rdg_pre_bwd_adam(s_host, means3D, shs, opacities, scales, rotations, viewmatrix, projmatrix, radii, geom_ws,
+                            grad_ws, dL_dmeans3D, dL_dmeans2D, dL_dopacities, dL_dscales, dL_drotations, dL_dviewmatrix,
+                            sh_exp_avg, sh_exp_avg_sq, head_len, lr_head, lr_tail, beta1, beta2, eps, 0, dev, stream);
 }
 
 int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, const float* means3D, const float* shs,

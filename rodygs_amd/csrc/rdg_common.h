@@ -201,7 +201,23 @@ struct RdgShAdam {
     float* m; float* v;
     float step_head, step_tail, b1, b2, omb1, omb2, eps, bc2_sqrt;   // omb = 1 - beta, rounded from double
     int head_len;
+    // graph replay: the bias corrections come from device memory (rdg_sh_adam_resolve), lr_* are the raw rates
+    const RdgStepScalars* dev;
+    float lr_head, lr_tail;
 };
+
+#ifdef __HIPCC__
+// by-pointer form of the per-step scalars: the same products the host forms for the by-value form
+__device__ __forceinline__ RdgShAdam rdg_sh_adam_resolve(RdgShAdam ad) {
+    if (ad.dev) {
+        const float inv = ad.dev->inv_bias_correction1;
+        ad.step_head = ad.lr_head * inv;
+        ad.step_tail = ad.lr_tail * inv;
+        ad.bc2_sqrt = ad.dev->sqrt_bias_correction2;
+    }
+    return ad;
+}
+#endif
 
 // ---- kernel launchers (one per .hip file) ----------------------------------------------------------------
 int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,

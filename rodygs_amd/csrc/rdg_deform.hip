@@ -493,7 +493,16 @@ rdg_deform_part_finalize_kernel(int P, int Tu, int per, const int* __restrict__ 
         float acc = 0.0f;
         if (bound[1] > bound[0]) {
             const int w0 = bound[0] / per, w1 = (bound[1] - 1) / per;
-            for (int w = w0; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
+            // eight independent loads in flight, added in wave order (the order is what makes the sum reproducible)
+            int w = w0;
+            for (; w + 7 <= w1; w += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(w + q + u) * (16 * RDG_DEF_K) + e];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += v[q];
+            }
+            for (; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
         }
         if (counter[1] != 0u) acc = __int_as_float(0x7fc00000);   // `order` was not sorted by birth index: poison, loudly
         d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -acc;
@@ -859,7 +868,8 @@ struct RdgAdamSegs { RdgAdamSeg s[RDG_ADAM_MAX_SEGS]; };
 template <int VAR>
 __global__ void __launch_bounds__(256)
 rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float omb1, float omb2, float eps,
-                      float bc2_sqrt) {
+                      float bc2_sqrt, const RdgStepScalars* __restrict__ dev) {
+    if (dev) { inv_bc1 = dev->inv_bias_correction1; bc2_sqrt = dev->sqrt_bias_correction2; }   // graph replay
     const RdgAdamSeg sg = segs.s[blockIdx.y];
     rdg_adam_segment<VAR>(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, sg.lr_head * inv_bc1, sg.lr_tail * inv_bc1,
                      sg.row_len, sg.head_len, b1, b2, omb1, omb2, eps, bc2_sqrt);
@@ -1131,11 +1141,11 @@ int rdg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
     return rdg_adam_launch(n, param, grad, exp_avg, exp_avg_sq, 1, 1, lr, lr, beta1, beta2, eps, step, stream);
 }
 
-int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps, int32_t step,
-                        void* stream) {
+static int rdg_adam_multi_launch(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps,
+                                 int32_t step, const RdgStepScalars* dev, void* stream) {
     if (nseg <= 0) return 0;
     if (nseg > RDG_ADAM_MAX_SEGS) return rdg_set_error("adam: at most %d segments per launch", RDG_ADAM_MAX_SEGS);
-    if (step < 1) return rdg_set_error("adam: step must be >= 1");
+    if (!dev && step < 1) return rdg_set_error("adam: step must be >= 1");
     hipStream_t st = (hipStream_t)stream;
     RdgAdamSegs segs;
     long long nmax = 0;
@@ -1144,8 +1154,8 @@ int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1,
         if (segs.s[i].row_len < 1) segs.s[i].row_len = 1;
         if (segs.s[i].n > nmax) nmax = segs.s[i].n;
     }
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const double bc1 = dev ? 1.0 : 1.0 - pow(beta1, (double)step);
+    const double bc2 = dev ? 1.0 : 1.0 - pow(beta2, (double)step);
     // measured at 75 M parameters (scripts/adam_probe.py): streaming (nontemporal) loads/stores + 16 k workgroups per
     // segment 367 us = 5.7 TB/s; cached accesses + 2 k workgroups 416 us.  RDG_ADAM_VAR=0 / RDG_ADAM_BLOCKS override.
     static int var = -1, cap = 16384;
@@ -1160,13 +1170,24 @@ int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1,
     if (var & 1)
         hipLaunchKernelGGL(rdg_adam_multi_kernel<1>, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs,
                            (float)(1.0 / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
-                           (float)sqrt(bc2));
+                           (float)sqrt(bc2), dev);
     else
         hipLaunchKernelGGL(rdg_adam_multi_kernel<0>, dim3((unsigned)blocks, nseg), dim3(256), 0, st, segs,
                            (float)(1.0 / bc1), (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps,
-                           (float)sqrt(bc2));
+                           (float)sqrt(bc2), dev);
     rdg_stage_end(RDG_STAGE_ADAM, st);
     return rdg_check_hip(hipGetLastError(), "adam multi launch");
+}
+
+int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps, int32_t step,
+                        void* stream) {
+    return rdg_adam_multi_launch(nseg, segs_host, beta1, beta2, eps, step, nullptr, stream);
+}
+
+int rdg_adam_step_multi_dev(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps,
+                            const RdgStepScalars* dev, void* stream) {
+    if (!dev) return rdg_set_error("rdg_adam_step_multi_dev: NULL step scalars");
+    return rdg_adam_multi_launch(nseg, segs_host, beta1, beta2, eps, 0, dev, stream);
 }
 
 int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int32_t row_len,

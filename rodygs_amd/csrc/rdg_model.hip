@@ -113,9 +113,12 @@ __device__ void rdg_pose_view_row(int frame, const float* __restrict__ cam_q, co
     view[15] = 1.0f;
 }
 
-__global__ void rdg_pose_view_fwd_kernel(int frame, const float* __restrict__ cam_q, const float* __restrict__ cam_t,
+// dev != nullptr: the frame index comes from device memory (graph replay), clamped to the table
+__global__ void rdg_pose_view_fwd_kernel(int T, int frame, const RdgStepScalars* __restrict__ dev,
+                                         const float* __restrict__ cam_q, const float* __restrict__ cam_t,
                                          float* __restrict__ view) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (dev) frame = min(max(dev->frame, 0), T - 1);
     rdg_pose_view_row(frame, cam_q, cam_t, view);
 }
 
@@ -164,9 +167,11 @@ __device__ void rdg_pose_view_bwd_row(int frame, const float* __restrict__ cam_q
     d_q[4 * frame + 3] = o3 + (s * gk + dotM * ds_scale * k);
 }
 
-__global__ void rdg_pose_view_bwd_kernel(int T, int frame, const float* __restrict__ cam_q,
+__global__ void rdg_pose_view_bwd_kernel(int T, int frame, const RdgStepScalars* __restrict__ dev,
+                                         const float* __restrict__ cam_q,
                                          const float* __restrict__ cam_t, const float* __restrict__ g_view,
                                          float* __restrict__ d_q, float* __restrict__ d_t) {
+    if (dev) frame = min(max(dev->frame, 0), T - 1);
     // zero the other frames' rows, then thread 0 writes the rendered frame's row
     for (int k = threadIdx.x; k < T * 4; k += blockDim.x) if (k / 4 != frame) d_q[k] = 0.0f;
     for (int k = threadIdx.x; k < T * 3; k += blockDim.x) if (k / 3 != frame) d_t[k] = 0.0f;
@@ -225,14 +230,31 @@ int rdg_activate_backward(int32_t P, int32_t K, const float* scaling, const floa
 int rdg_pose_view_forward(int32_t T, int32_t frame, const float* cam_q, const float* cam_t, float* out_view16,
                           void* stream) {
     if (frame < 0 || frame >= T) return rdg_set_error("pose: frame %d out of range [0,%d)", frame, T);
-    hipLaunchKernelGGL(rdg_pose_view_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, frame, cam_q, cam_t, out_view16);
+    hipLaunchKernelGGL(rdg_pose_view_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, T, frame,
+                       (const RdgStepScalars*)nullptr, cam_q, cam_t, out_view16);
+    return rdg_check_hip(hipGetLastError(), "pose_view_fwd launch");
+}
+
+int rdg_pose_view_forward_dev(int32_t T, const RdgStepScalars* dev, const float* cam_q, const float* cam_t,
+                              float* out_view16, void* stream) {
+    if (!dev || T < 1) return rdg_set_error("pose_view_forward_dev: NULL step scalars / empty table");
+    hipLaunchKernelGGL(rdg_pose_view_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, T, 0, dev, cam_q, cam_t,
+                       out_view16);
     return rdg_check_hip(hipGetLastError(), "pose_view_fwd launch");
 }
 
 int rdg_pose_view_backward(int32_t T, int32_t frame, const float* cam_q, const float* cam_t, const float* g_view16,
                            float* d_q, float* d_t, void* stream) {
     if (frame < 0 || frame >= T) return rdg_set_error("pose: frame %d out of range [0,%d)", frame, T);
-    hipLaunchKernelGGL(rdg_pose_view_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, frame, cam_q, cam_t,
+    hipLaunchKernelGGL(rdg_pose_view_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, frame,
+                       (const RdgStepScalars*)nullptr, cam_q, cam_t, g_view16, d_q, d_t);
+    return rdg_check_hip(hipGetLastError(), "pose_view_bwd launch");
+}
+
+int rdg_pose_view_backward_dev(int32_t T, const RdgStepScalars* dev, const float* cam_q, const float* cam_t,
+                               const float* g_view16, float* d_q, float* d_t, void* stream) {
+    if (!dev || T < 1) return rdg_set_error("pose_view_backward_dev: NULL step scalars / empty table");
+    hipLaunchKernelGGL(rdg_pose_view_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, 0, dev, cam_q, cam_t,
                        g_view16, d_q, d_t);
     return rdg_check_hip(hipGetLastError(), "pose_view_bwd launch");
 }

@@ -358,7 +358,8 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
         rdg_wave_lds_sync();
         const float* tile = MULTI ? sGR[threadIdx.x >> 6] : sSH[threadIdx.x >> 6];
         if (!MULTI && sh_adam.m)       // optimizer in backward: the SH parameters are updated from the LDS tile
-            rdg_lds_adam_rows(const_cast<float*>(shs), sh_adam, wave_first, d.P, sh_row, sh_stride, tile, threadIdx.x & 63);
+            rdg_lds_adam_rows(const_cast<float*>(shs), rdg_sh_adam_resolve(sh_adam), wave_first, d.P, sh_row, sh_stride, tile,
+                              threadIdx.x & 63);
         else
             rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, tile, threadIdx.x & 63);
     }

@@ -168,9 +168,10 @@ def gs_properties(static: Dict[str, torch.Tensor], dynamic: Dict[str, torch.Tens
 
 class _PoseView(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cam_q, cam_t, frame, grad_sinks=None):
+    def forward(ctx, cam_q, cam_t, frame, grad_sinks=None, step_scalars=None):
         L = _lib.lib()
         ctx.grad_sinks = grad_sinks
+        ctx.step_scalars = step_scalars
         if not cam_q.is_cuda:
             raise RuntimeError("rodygs_amd.pose_view_matrix: tensors must be on the GPU (no CPU fallback exists)")
         q = cam_q.detach().to(torch.float32).contiguous()
@@ -178,8 +179,12 @@ class _PoseView(torch.autograd.Function):
         T = q.shape[0]
         view = torch.empty(4, 4, dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
-            _lib.check(L.rdg_pose_view_forward(T, int(frame), _lib.ptr(q), _lib.ptr(t), _lib.ptr(view),
-                                               _lib.stream_ptr()), "rdg_pose_view_forward")
+            if step_scalars is not None:      # graph replay: the frame index is read from device memory
+                _lib.check(L.rdg_pose_view_forward_dev(T, _lib.ptr(step_scalars), _lib.ptr(q), _lib.ptr(t),
+                                                       _lib.ptr(view), _lib.stream_ptr()), "rdg_pose_view_forward_dev")
+            else:
+                _lib.check(L.rdg_pose_view_forward(T, int(frame), _lib.ptr(q), _lib.ptr(t), _lib.ptr(view),
+                                                   _lib.stream_ptr()), "rdg_pose_view_forward")
         ctx.save_for_backward(q, t)
         ctx.frame = int(frame)
         return view
@@ -201,14 +206,22 @@ class _PoseView(torch.autograd.Function):
             d_q = torch.empty_like(q)
             d_t = torch.empty_like(t)
         with torch.cuda.device(q.device):
-            _lib.check(L.rdg_pose_view_backward(T, ctx.frame, _lib.ptr(q), _lib.ptr(t), _lib.ptr(g), _lib.ptr(d_q),
-                                                _lib.ptr(d_t), _lib.stream_ptr()), "rdg_pose_view_backward")
+            if ctx.step_scalars is not None:
+                _lib.check(L.rdg_pose_view_backward_dev(T, _lib.ptr(ctx.step_scalars), _lib.ptr(q), _lib.ptr(t),
+                                                        _lib.ptr(g), _lib.ptr(d_q), _lib.ptr(d_t), _lib.stream_ptr()),
+                           "rdg_pose_view_backward_dev")
+            else:
+                _lib.check(L.rdg_pose_view_backward(T, ctx.frame, _lib.ptr(q), _lib.ptr(t), _lib.ptr(g), _lib.ptr(d_q),
+                                                    _lib.ptr(d_t), _lib.stream_ptr()), "rdg_pose_view_backward")
         if sinks is not None:
-            return None, None, None, None
-        return d_q, d_t, None, None
+            return None, None, None, None, None
+        return d_q, d_t, None, None, None
 
 
-def pose_view_matrix(cam_q: torch.Tensor, cam_t: torch.Tensor, frame: int, grad_sinks=None) -> torch.Tensor:
+def pose_view_matrix(cam_q: torch.Tensor, cam_t: torch.Tensor, frame: int, grad_sinks=None,
+                     step_scalars=None) -> torch.Tensor:
     """W2C^T (glm storage, what the rasterizer takes as ``viewmatrix``) of frame ``frame`` from the learnable
-    camera-to-world quaternions cam_q[T,4] (r,i,j,k) and translations cam_t[T,3]."""
-    return _PoseView.apply(cam_q, cam_t, frame, grad_sinks)
+    camera-to-world quaternions cam_q[T,4] (r,i,j,k) and translations cam_t[T,3].  ``step_scalars``: a device
+    ``RdgStepScalars`` (16-byte tensor) whose ``frame`` field replaces the argument -- the form a captured hipGraph can
+    replay for a different frame (rodygs_amd.trainstep.GraphedStep)."""
+    return _PoseView.apply(cam_q, cam_t, frame, grad_sinks, step_scalars)

@@ -41,6 +41,12 @@ BIN_BUCKET_BELOW = 16384
 # atomics (rdg_composite_backward_det) -- two runs give the same bits; ~2x the backward time and 256 B per instance.
 DETERMINISTIC = os.environ.get("RDG_DETERMINISTIC", "0") == "1"
 
+# hipGraph capture (rodygs_amd.trainstep.GraphedStep sets it around capture): the forward touches nothing on the host --
+# capacity and binning mode come from the hints of the warm-up steps, the instance count stays on the device
+# (last_num_rendered()) and is checked by the owner of the graph between replays.
+GRAPH_CAPTURE = False
+_LAST_NREN = [None]               # (nren int32[2] device tensor, key, capacity) of the most recent forward
+
 DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
 _PENDING = []                     # (event, pinned int32[1], key, capacity) of forwards not yet checked
 _PINNED_FREE = []
@@ -210,7 +216,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             cs.bin_mode = int(_BIN_HINT.get(key, 0))
             cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
             stream = _lib.stream_ptr()
-            deferred = DEFERRED_OVERFLOW_CHECK and key in _CAPACITY_HINT
+            if GRAPH_CAPTURE and key not in _CAPACITY_HINT:
+                raise RuntimeError("rasterizer.GRAPH_CAPTURE needs a warm-up forward of this (P, H, W) first")
+            deferred = DEFERRED_OVERFLOW_CHECK and key in _CAPACITY_HINT and not GRAPH_CAPTURE
             if deferred:
                 poll_overflow(block=False)
             while True:
@@ -221,6 +229,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                                              _lib.ptr(color), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha),
                                              _lib.ptr(radii), _lib.ptr(nren), stream)
                 _lib.check(rc, "rdg_rasterize_forward")
+                _LAST_NREN[0] = (nren, key, cap)
+                if GRAPH_CAPTURE:
+                    n = -1
+                    break
                 if deferred:
                     # opt-in: no host wait at all.  D goes to pinned memory asynchronously and is checked by
                     # poll_overflow() at the next forward / on demand; on overflow the device has rendered an
@@ -310,8 +322,19 @@ class _RasterizeGaussians(torch.autograd.Function):
                 prm = fused["param"]
                 if prm.data_ptr() != shs.data_ptr() or prm.numel() != shs.numel():
                     raise RuntimeError("grad_sinks['shs_adam']['param'] must be the storage passed to the rasterizer as shs")
-                step = fused["step"]() if callable(fused["step"]) else int(fused["step"])
                 _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws)
+                if fused.get("step_scalars") is not None:
+                    # graph replay: the bias corrections are read from device memory (RdgStepScalars)
+                    _lib.check(L.rdg_preprocess_backward_adam_dev(
+                        C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro),
+                        _lib.ptr(vm), _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(gws), _lib.ptr(d_m3),
+                        _lib.ptr(d_m2), _lib.ptr(d_op), _lib.ptr(d_sc), _lib.ptr(d_ro), _lib.ptr(d_vm),
+                        _lib.ptr(fused["exp_avg"]), _lib.ptr(fused["exp_avg_sq"]), int(fused["head_len"]),
+                        float(fused["lr_head"]), float(fused["lr_tail"]), float(fused["betas"][0]),
+                        float(fused["betas"][1]), float(fused["eps"]), _lib.ptr(fused["step_scalars"]),
+                        _lib.stream_ptr()), "rdg_preprocess_backward_adam_dev")
+                    return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None
+                step = fused["step"]() if callable(fused["step"]) else int(fused["step"])
                 _lib.check(L.rdg_preprocess_backward_adam(
                     C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(vm),
                     _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(gws), _lib.ptr(d_m3), _lib.ptr(d_m2),
@@ -347,6 +370,15 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 
 _LAST_IMAGE_WS = [None]
+
+
+def last_num_rendered():
+    """(nren, key, capacity): the device tensor [D, largest tile list] the most recent forward wrote, the (P, H, W) key
+    of its hints and the capacity it ran with.  The owner of a captured graph reads it between replays: D > capacity
+    means that frame was rendered empty and the graph must be re-captured with the raised hint."""
+    if _LAST_NREN[0] is None:
+        raise RuntimeError("no rasterizer forward has run yet")
+    return _LAST_NREN[0]
 
 
 def last_compositing_state():

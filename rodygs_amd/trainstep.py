@@ -61,7 +61,7 @@ def expon_lr(step: int, lr_init: float, lr_final: float, lr_delay_steps: int = 0
 
 
 def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1e-15, row_lr=None, extra=(),
-                names=None, advance: bool = True, lr_override=None) -> None:
+                names=None, advance: bool = True, lr_override=None, step_scalars=None) -> None:
     """ONE fused HIP launch for all parameter groups of the flat buffers (rdg_adam_step_multi).
     lr_override: {segment name: lr} for THIS step only (the reference re-sets the xyz group's lr every iteration,
     rodygs_static.py:143-149); segments not named keep ``fp.lr``.
@@ -69,7 +69,9 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
     extra: further FlatParams stepped by the same launch (e.g. the MLP + camera-pose bucket); neighbouring
     segments of one buffer with the same learning rate are merged (their alignment padding has zero gradients).
     names: restrict ``fp`` to these segments (one piece of an overlapped gradient exchange); ``advance`` = this call
-    opens a new optimiser step (the step counter moves once per step, however many pieces it is applied in)."""
+    opens a new optimiser step (the step counter moves once per step, however many pieces it is applied in).
+    step_scalars: a device ``RdgStepScalars`` tensor -- the bias corrections are read from it instead of being computed
+    from the step counter (the form a captured hipGraph can replay, see GraphedStep)."""
     L = _lib.lib()
     if advance:
         fp.step_count += 1
@@ -103,6 +105,10 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
         segs[i].lr_tail = lr_tail * lr_scale
         segs[i].row_len = row_len
         segs[i].head_len = head_len
+    if step_scalars is not None:
+        _lib.check(L.rdg_adam_step_multi_dev(len(entries), segs, betas[0], betas[1], eps, _lib.ptr(step_scalars),
+                                             _lib.stream_ptr()), "rdg_adam_step_multi_dev")
+        return
     _lib.check(L.rdg_adam_step_multi(len(entries), segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
                "rdg_adam_step_multi")
 
@@ -229,6 +235,7 @@ class DynamicScene:
         # optimizer-in-backward for the SH features (see render()); train_step switches it on for the single-GPU
         # photometric step only -- gradient exchange, densification statistics and extra losses need the plain path
         self.fuse_sh_adam = False
+        self._graph_inputs = None    # GraphedStep: (time-embedding rows, ground truth, RdgStepScalars) at fixed addresses
         self._grad_one = None
         self._plain_full = False     # full_losses on a step without rigidity: the photometric step's fused kernels
         if full_losses:
@@ -250,7 +257,8 @@ class DynamicScene:
         """DynRoDyGS.get_gaussian_deformation + activations for the frame's time."""
         fp, net = self.fp, self.net
         # ONE pass of the MLP over the T birth-time rows + the frame's own time (row T)
-        allb = net.motion_basis(self.emb_rows[frame])                     # [T+1,16,7]: table rows, then B(t)
+        gi = self._graph_inputs
+        allb = net.motion_basis(self.emb_rows[frame] if gi is None else gi[0])   # [T+1,16,7]: table rows, then B(t)
         self._last_allb = allb
         if (not self.full_losses or self._plain_full) and dynamic_getter_supported(allb.shape[1], allb.shape[0] - 1):
             # deformation + activations in ONE kernel each way; all five parameter gradients go straight to the bucket
@@ -273,7 +281,9 @@ class DynamicScene:
 
     def render(self, frame: int):
         xyz, opacity, scaling, rot, feats = self.gaussians_at(frame)
-        vm = pose_view_matrix(self.cam_q, self.cam_t, frame, grad_sinks=self.pose_sinks)
+        gi = self._graph_inputs
+        vm = pose_view_matrix(self.cam_q, self.cam_t, frame, grad_sinks=self.pose_sinks,
+                              step_scalars=None if gi is None else gi[2])
         m2 = self.m2
         m2.grad = None
         sinks = {"shs": self.fp["features"].grad,
@@ -287,7 +297,8 @@ class DynamicScene:
             sinks = {"shs_adam": {"param": self.fp["features"], "exp_avg": self.fp.exp_avg[o:o + n],
                                   "exp_avg_sq": self.fp.exp_avg_sq[o:o + n], "head_len": head,
                                   "lr_head": self.fp.lr["features"], "lr_tail": lr_tail, "betas": (0.9, 0.999),
-                                  "eps": 1e-15, "step": lambda: self.fp.step_count + 1}}
+                                  "eps": 1e-15, "step": lambda: self.fp.step_count + 1,
+                                  "step_scalars": None if gi is None else gi[2]}}
         out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
                                                   rotations=rot, viewmatrix=vm, grad_sinks=sinks)
         self._last_radii = out[4]
@@ -419,7 +430,8 @@ class DynamicScene:
                 out, _ = self.render(frame)
             finally:
                 self.fuse_sh_adam = False
-            loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
+            gi = self._graph_inputs
+            loss = fused_photometric_loss(out[0], self.gt[frame] if gi is None else gi[1], 0.2)
         # the seed gradient is a resident 1.0 (autograd would otherwise launch a fill kernel for ones_like(loss))
         if self._grad_one is None or self._grad_one.device != loss.device:
             self._grad_one = torch.ones((), dtype=torch.float32, device=loss.device)
@@ -441,7 +453,107 @@ class DynamicScene:
                 first = False
         elif (not self.full_losses or after is not None) and fuse:
             # the SH features were stepped inside backward; everything else in the usual single launch
-            fused_adam_(self.fp, names=[k for k in self.fp.names if k != "features"], extra=(self.sp,))
+            fused_adam_(self.fp, names=[k for k in self.fp.names if k != "features"], extra=(self.sp,),
+                        step_scalars=None if self._graph_inputs is None else self._graph_inputs[2])
         else:
-            fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,))
+            fused_adam_(self.fp, row_lr=self.row_lr, extra=(self.sp,),
+                        step_scalars=None if self._graph_inputs is None else self._graph_inputs[2])
         return loss.detach()
+
+
+class GraphedStep:
+    """hipGraph replay of ``DynamicScene.train_step`` (single GPU, photometric loss): ONE graph launch per step instead of
+    ~50 kernel launches, ~30 allocations and ten autograd nodes driven from Python.  At the size of the reference's real
+    clouds (<= 120 k points per cloud, /root/reference/configs/train/train_kubric_mrig.yaml:42,102) the eager step is
+    host-bound; the graph runs at the speed of its kernels.
+
+    What changes from step to step lives in device memory at fixed addresses, refreshed before each replay: the frame's
+    time-embedding rows and ground-truth image (two device copies), and a 16-byte ``RdgStepScalars`` (Adam's two bias
+    corrections, computed on the host exactly as the eager path does, and the frame index for the camera-pose kernels)
+    -- one small H2D copy out of a ring of pinned slots.  Same kernels, same arithmetic, same bits as the eager step.
+    The instance count of a frame stays on the device; ``check()`` reads it (one sync) and raises
+    ``RasterizerCapacityOverflow`` if a frame outgrew the capacity the graph was captured with (re-build the GraphedStep
+    then; also after a densification, which changes every buffer)."""
+
+    RING = 256
+
+    def __init__(self, ds: "DynamicScene", perm, warmup: int = 2, first_step: int = 0):
+        from . import rasterizer
+        if ds.full_losses or ds.stats is not None:
+            raise NotImplementedError("GraphedStep covers the photometric step without densification statistics")
+        self.ds, self.perm = ds, list(perm)
+        dev = ds.device
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)                    # RdgStepScalars
+        self.ring = torch.zeros(self.RING, 4, dtype=torch.float32).pin_memory()
+        self.ring_i32 = self.ring.view(torch.int32)
+        self.emb_in = torch.empty_like(ds.emb_rows[0])
+        self.gt_in = torch.empty_like(ds.gt[self.perm[0]])
+        self._slot, self._fence = 0, []
+        ds._graph_inputs = (self.emb_in, self.gt_in, self.scal)
+        step = first_step
+        for _ in range(max(1, warmup)):          # eager, on the same staged inputs: hints, caches, lazy initialisation
+            self._stage(step)
+            ds.train_step(step, 0, 1, self.perm)
+            step += 1
+        self.next_step = step
+        torch.cuda.synchronize(dev)
+        counts = (ds.fp.step_count, ds.sp.step_count)
+        self.graph = torch.cuda.CUDAGraph()
+        rasterizer.GRAPH_CAPTURE = True
+        try:
+            self._stage(step)
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(self.graph):
+                self.loss = ds.train_step(step, 0, 1, self.perm)       # recorded, not executed
+        finally:
+            rasterizer.GRAPH_CAPTURE = False
+        ds.fp.step_count, ds.sp.step_count = counts                    # capture advanced the host counters only
+        self._nren, self._key, self._cap = rasterizer.last_num_rendered()
+
+    def _stage(self, step: int) -> int:
+        ds = self.ds
+        frame = frame_for(step, 0, 1, self.perm)
+        k = ds.fp.step_count + 1
+        i = self._slot
+        self._slot = (i + 1) % self.RING
+        if i % (self.RING // 2) == 0:
+            # the half of the ring about to be rewritten was copied from more than RING / 2 steps ago: wait for the
+            # event recorded half a ring ago (after those copies in stream order), then leave one for the next half
+            if self._fence:
+                self._fence.pop(0).synchronize()
+            ev = torch.cuda.Event()
+            ev.record()
+            self._fence.append(ev)
+        # float(1 / bc1) and float(sqrt(bc2)) from doubles: what rdg_adam_step_multi computes on the host
+        self.ring[i, 0] = 1.0 / (1.0 - 0.9 ** k)
+        self.ring[i, 1] = math.sqrt(1.0 - 0.999 ** k)
+        self.ring_i32[i, 2] = frame
+        self.scal.copy_(self.ring[i], non_blocking=True)
+        self.emb_in.copy_(ds.emb_rows[frame])
+        self.gt_in.copy_(ds.gt[frame])
+        return frame
+
+    def step(self) -> torch.Tensor:
+        """Stage the step's inputs, replay the graph; returns the (device) loss of the step."""
+        ds = self.ds
+        self._stage(self.next_step)
+        self.graph.replay()
+        self.next_step += 1
+        ds.fp.step_count += 1
+        ds.sp.step_count = ds.fp.step_count
+        return self.loss
+
+    def check(self) -> int:
+        """Instance count of the last replayed frame (synchronises); raises if it exceeded the captured capacity."""
+        from . import rasterizer
+        n, largest = (int(v) for v in self._nren.tolist())
+        rasterizer._CAPACITY_HINT[self._key] = max(n, int(rasterizer._CAPACITY_HINT.get(self._key, 0) * 0.9))
+        if n > self._cap:
+            rasterizer._CAPACITY_HINT[self._key] = n
+            raise rasterizer.RasterizerCapacityOverflow(
+                f"a replayed frame needed {n} instances, the graph was captured with {self._cap}: that frame was "
+                f"rendered empty; re-build the GraphedStep (the capacity hint is now {n})")
+        return n
+
+    def close(self) -> None:
+        self.ds._graph_inputs = None

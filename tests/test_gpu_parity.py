@@ -1252,6 +1252,42 @@ def test_deterministic_train_step_is_bit_reproducible():
     assert bool(torch.isfinite(c[0]).all())
 
 
+def test_graph_replay_of_the_train_step_is_bit_identical_to_the_eager_step():
+    """trainstep.GraphedStep: the photometric train step captured ONCE as a hipGraph and replayed with the per-step
+    values (frame's embedding rows, ground truth, Adam bias corrections, frame index) refreshed in device memory --
+    against the same steps launched kernel by kernel from Python.  Deterministic backward on both sides, so every
+    parameter, both Adam moments (Gaussians, MLP, camera poses) and the losses must agree BIT FOR BIT."""
+    import rodygs_amd.rasterizer as R
+    from rodygs_amd.trainstep import DynamicScene, GraphedStep
+    sc = O.synthetic_scene(20000, 320, 240, 3, seed=5)
+    tgt = O.synthetic_scene(5000, 320, 240, 3, seed=6)
+    old = R.DETERMINISTIC
+    R.DETERMINISTIC = True
+    try:
+        def fresh():
+            ds = DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True)
+            ds.make_ground_truth(tgt, range(8))
+            return ds
+        perm, n = [0, 3, 5, 6, 1], 23
+        a = fresh()
+        la = [a.train_step(s_, perm=perm) for s_ in range(n)]
+        b = fresh()
+        gs = GraphedStep(b, perm, warmup=2)                 # two eager steps, then steps 2 .. n-1 as replays
+        lb = [gs.step().clone() for _ in range(n - 2)]
+        assert gs.check() > 0 and gs.next_step == n and b.fp.step_count == a.fp.step_count == n
+        gs.close()
+        torch.cuda.synchronize()
+    finally:
+        R.DETERMINISTIC = old
+    for x, y in zip(la[2:], lb):
+        assert torch.equal(x, y)
+    for name in ("flat", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(a.fp, name), getattr(b.fp, name)), "Gaussian bucket " + name
+        assert torch.equal(getattr(a.sp, name), getattr(b.sp, name)), "MLP + pose bucket " + name
+    # and the scene keeps training eagerly after the graph is dropped
+    assert torch.isfinite(b.train_step(n, perm=perm))
+
+
 def test_full_loss_train_step_runs_and_reduces_loss():
     """Config-5 loss set in the loop: photometric + Pearson depth (global + local) + motion regularisers + rigidity on
     the HIP K-NN every 5th step; gradients of several losses accumulate into the same flat segments."""
