@@ -112,6 +112,34 @@ static inline RdgHeavyLayout rdg_heavy_layout(int64_t capacity) {
     return L;
 }
 
+// ---- split path of the compositing stage (rdg_render.hip): tiles with more than RDG_SPLIT_MIN instances are cut into
+// segments of RDG_SPLIT_SEG list positions, one workgroup each.  Sized by the capacity alone: a split tile has more
+// than RDG_SPLIT_MIN instances, so there are < cap / RDG_SPLIT_MIN of them and < cap / RDG_SPLIT_SEG + that many segments.
+#define RDG_SPLIT_MIN 4096
+#define RDG_SPLIT_SEG 2048     // multiple of the staging batch (256) and of the visit-record word (64)
+#define RDG_SEG_F 12           // floats per (segment, pixel): see rdg_render.hip
+struct RdgSplitLayout {
+    size_t header;    // uint32[64]: [0] = segments (work items), [1] = split tiles
+    size_t work;      // uint4[max_seg]: (tile, segment, segments of the tile, first segment slot)
+    size_t tiles;     // uint4[max_tiles]: (tile, segments, first segment slot, -)
+    size_t seg_pix;   // float[max_seg][RDG_SEG_F][256]
+    size_t total;
+    uint32_t max_seg, max_tiles;
+};
+static inline RdgSplitLayout rdg_split_layout(int64_t capacity) {
+    RdgSplitLayout L;
+    const size_t cap = (size_t)(capacity > 0 ? capacity : 1);
+    L.max_tiles = (uint32_t)(cap / RDG_SPLIT_MIN + 1);
+    L.max_seg = (uint32_t)(cap / RDG_SPLIT_SEG + 1) + L.max_tiles;
+    size_t o = 0;
+    L.header = o;   o = rdg_align_up(o + 256, 256);
+    L.work = o;     o = rdg_align_up(o + (size_t)L.max_seg * 16, 256);
+    L.tiles = o;    o = rdg_align_up(o + (size_t)L.max_tiles * 16, 256);
+    L.seg_pix = o;  o = rdg_align_up(o + (size_t)L.max_seg * RDG_SEG_F * RDG_TILE_PIX * 4, 256);
+    L.total = o;
+    return L;
+}
+
 // ---- binning workspace layout ----------------------------------------------------------------------------
 struct RdgBinLayout {
     size_t keys_a, keys_b;  // uint64[cap]
@@ -120,6 +148,7 @@ struct RdgBinLayout {
     size_t heavy;           // RdgHeavyLayout: work list of the multi-workgroup sort of tiles > RDG_TSORT_LDS instances
     size_t hit;             // uint64[cap/64 + n_tiles + 2][4]: per 64 list slots of a tile, per quadrant, "the forward
                             // had a pixel that could blend this splat" (lets the backward skip the other visits)
+    size_t split;           // RdgSplitLayout: work lists and per-segment pixel records of the split compositing path
     size_t total;
 };
 static inline RdgBinLayout rdg_bin_layout(int64_t capacity, int32_t n_tiles = 0) {
@@ -133,6 +162,8 @@ static inline RdgBinLayout rdg_bin_layout(int64_t capacity, int32_t n_tiles = 0)
     L.sort_tmp = o; o = rdg_align_up(o + rdg_sort_layout(capacity).total, 256);
     L.heavy = o;   o = rdg_align_up(o + rdg_heavy_layout(capacity).total, 256);
     L.hit = o;     o = rdg_align_up(o + (cap / 64 + (size_t)(n_tiles > 0 ? n_tiles : 262144) + 2) * 32, 256);
+    // LAST: its offset depends on n_tiles (callers that only need the earlier offsets pass 0), its size does not
+    L.split = o;   o = rdg_align_up(o + rdg_split_layout(capacity).total, 256);
     L.total = o;
     return L;
 }
@@ -185,6 +216,7 @@ struct RdgDev {
     float tanx, tany, fx, fy, smod;
     int32_t prefiltered, cov_grad, sh_grad, render_normal;
     int32_t bin_mode, nren_stats;
+    int32_t split_lists;       // RdgRasterSettings.split_lists: run the split compositing path for lists > RDG_SPLIT_MIN
     int32_t tile_cnt_zeroed;   // internal: the per-tile counters were cleared by the per-Gaussian stage's scan kernel
 };
 
@@ -234,6 +266,9 @@ int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32
 int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, void* bin_ws,
                           int64_t capacity, void* image_ws, const int32_t* num_rendered, float* out_color,
                           float* out_depth, float* out_normal, float* out_alpha, hipStream_t s);
+// device-side work lists of the split compositing path, from the tile ranges (rdg_render.hip)
+int rdg_launch_split_build(const RdgDev& d, void* bin_ws, int64_t capacity, const void* image_ws,
+                           const int32_t* num_rendered, hipStream_t s);
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
                           int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
                           const float* g_alpha, float* grow, hipStream_t s, float* det = nullptr);

@@ -200,54 +200,25 @@ __device__ __forceinline__ void rdg_fwd_walk(unsigned long long mask, const unsi
 }
 
 
+// The compositing loop of one workgroup over list positions [k_begin, k_end) of its tile (k_begin a multiple of 64).
+// The whole-tile kernel calls it with (0, list length); the kernels of the split path (lists too long for one
+// workgroup, below) with one segment and the transmittance the pixels arrive with.
 template <bool NORMAL>
-__global__ void __launch_bounds__(256)
-rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
-                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const RdgRec* __restrict__ rec, long long capacity, const int32_t* __restrict__ num_rendered,
-                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-                      float* __restrict__ out_depth, float* __restrict__ out_normal, float* __restrict__ out_alpha,
-                      unsigned long long* __restrict__ hitbits) {
-    // on capacity overflow the binning stage has emptied every tile range: this kernel then renders the background
-    const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
-    if (tile >= n_tiles) return;
-    // sQ1 = (conic c, opacity, -, -): only its first half is read; same 16-B stride as the others so that one address
-    // register serves all four arrays.  sQ2 = (r, g, b, depth).
-    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH], sQ3[RDG_BATCH];
-    __shared__ unsigned long long sMask[4][4];  // [consumer quadrant][staging wave]
-    __shared__ unsigned long long sCap[4];      // per staging wave: splats whose opacity exceeds the alpha cap
-#ifdef RDG_ABL_FPAD   // ablation build: LDS padding that lowers the occupancy
-    __shared__ float sPad[RDG_ABL_FPAD];
-    if (W < 0) sPad[threadIdx.x] = 1.0f;
-#endif
+__device__ __forceinline__ void
+rdg_fwd_composite(const int k_begin, const int k_end, const uint2 range, const float X0, const float Y0, const float pixx,
+                  const float pixy, const uint32_t* __restrict__ point_list, const RdgRec* __restrict__ rec,
+                  unsigned long long* __restrict__ hit, float4* sQ0, float4* sQ1, float4* sQ2, float4* sQ3,
+                  unsigned long long (*sMask)[4], unsigned long long* sCap, uint32_t& thrU, float& T, float& C0, float& C1,
+                  float& C2, float& Dp, float& N0, float& N1, float& N2, uint32_t& last_contributor) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int tx = tile % gx, ty = tile / gx;
-    const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
-    const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    float pixx = (float)pxi, pixy = (float)pyi;
-    // opaque to the compiler: it otherwise re-converts the integer coordinate inside the visit loop (one VALU
-    // instruction per visit to save one register)
-    asm volatile("" : "+v"(pixx), "+v"(pixy));
-    const float X0 = (float)(tx * RDG_TILE), Y0 = (float)(ty * RDG_TILE);
-    const uint2 range = ranges[tile];
-    const int todo_total = (int)(range.y - range.x);
-    const int rounds = (todo_total + RDG_BATCH - 1) / RDG_BATCH;
-    // visit record for the backward: word w of this tile covers list slots [64 w, 64 w + 63]; the words of a tile
-    // start at (range.x / 64 + tile), which cannot overlap the next tile's; zeroed by the launcher
-    unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
-
-    uint32_t thrU = inside ? RDG_THR_LIVE : RDG_THR_DONE;   // see rdg_fwd_walk
-    float T = 1.0f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
-    uint32_t last_contributor = 0;
+    const int rounds = (k_end - k_begin + RDG_BATCH - 1) / RDG_BATCH;
     for (int r = 0; r < rounds; ++r) {
         if (__syncthreads_count(thrU == RDG_THR_DONE) == 256) break;
-        const int k = r * RDG_BATCH + tid;
+        const int k = k_begin + r * RDG_BATCH + tid;
         uint32_t qbits = 0;
         bool over_cap = false;
-        if (k < todo_total) {
+        if (k < k_end) {
             const uint32_t id = point_list[range.x + k];
             const RdgRec* p = rec + id;
             const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
@@ -277,7 +248,7 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             const unsigned long long mask = rdg_uniform_u64(sMask[wv][s]);
             const unsigned long long cap = rdg_uniform_u64(sCap[s]);
             unsigned long long seen = 0ull;    // splats of this 64-slot word that some pixel of the quadrant may blend
-            const uint32_t wbase = (uint32_t)(r * RDG_BATCH + s * 64 + 1);
+            const uint32_t wbase = (uint32_t)(k_begin + r * RDG_BATCH + s * 64 + 1);
             if (cap)
                 rdg_fwd_walk<NORMAL, true>(mask, cap, s * 1024, wbase, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
                                            (const char*)sQ3, pixx, pixy, seen, thrU, T, last_contributor, C0, C1, C2, Dp,
@@ -286,9 +257,57 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                 rdg_fwd_walk<NORMAL, false>(mask, cap, s * 1024, wbase, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
                                             (const char*)sQ3, pixx, pixy, seen, thrU, T, last_contributor, C0, C1, C2, Dp,
                                             N0, N1, N2);
-            if (lane == 0 && seen) hit[(size_t)(r * 4 + s) * 4 + wv] = seen;
+            if (lane == 0 && seen) hit[(size_t)((k_begin >> 6) + r * 4 + s) * 4 + wv] = seen;
         }
     }
+}
+
+// split_min: tiles whose list is longer than this are composited by the split path (rdg_render_seg_* below), launched
+// only when the previous frame of this shape had such a list; INT_MAX = this kernel composites every tile itself.
+template <bool NORMAL>
+__global__ void __launch_bounds__(256)
+rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
+                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const RdgRec* __restrict__ rec, long long capacity, const int32_t* __restrict__ num_rendered,
+                      float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+                      float* __restrict__ out_depth, float* __restrict__ out_normal, float* __restrict__ out_alpha,
+                      unsigned long long* __restrict__ hitbits, int split_min) {
+    // on capacity overflow the binning stage has emptied every tile range: this kernel then renders the background
+    const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;
+    // sQ1 = (conic c, opacity, -, -): only its first half is read; same 16-B stride as the others so that one address
+    // register serves all four arrays.  sQ2 = (r, g, b, depth).
+    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH], sQ3[RDG_BATCH];
+    __shared__ unsigned long long sMask[4][4];  // [consumer quadrant][staging wave]
+    __shared__ unsigned long long sCap[4];      // per staging wave: splats whose opacity exceeds the alpha cap
+#ifdef RDG_ABL_FPAD   // ablation build: LDS padding that lowers the occupancy
+    __shared__ float sPad[RDG_ABL_FPAD];
+    if (W < 0) sPad[threadIdx.x] = 1.0f;
+#endif
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int tx = tile % gx, ty = tile / gx;
+    const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
+    const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
+    const bool inside = pxi < W && pyi < H;
+    float pixx = (float)pxi, pixy = (float)pyi;
+    // opaque to the compiler: it otherwise re-converts the integer coordinate inside the visit loop (one VALU
+    // instruction per visit to save one register)
+    asm volatile("" : "+v"(pixx), "+v"(pixy));
+    const float X0 = (float)(tx * RDG_TILE), Y0 = (float)(ty * RDG_TILE);
+    const uint2 range = ranges[tile];
+    const int todo_total = (int)(range.y - range.x);
+    if (todo_total > split_min) return;          // composited by the split path
+    // visit record for the backward: word w of this tile covers list slots [64 w, 64 w + 63]; the words of a tile
+    // start at (range.x / 64 + tile), which cannot overlap the next tile's; zeroed by the launcher
+    unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
+
+    uint32_t thrU = inside ? RDG_THR_LIVE : RDG_THR_DONE;   // see rdg_fwd_walk
+    float T = 1.0f;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+    uint32_t last_contributor = 0;
+    rdg_fwd_composite<NORMAL>(0, todo_total, range, X0, Y0, pixx, pixy, point_list, rec, hit, sQ0, sQ1, sQ2, sQ3, sMask,
+                              sCap, thrU, T, C0, C1, C2, Dp, N0, N1, N2, last_contributor);
     if (inside) {
         const size_t hw = (size_t)H * W;
         const size_t pid = (size_t)pyi * W + pxi;
@@ -303,27 +322,266 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Split path: tile lists too long for one workgroup.  Front-to-back compositing is associative over list segments --
+// a segment is a map (T, C) -> (T t_s, C + T c_s) -- so a list of n > RDG_SPLIT_MIN instances is cut into segments of
+// RDG_SPLIT_SEG and composited by as many workgroups (a 200 k-instance tile walked by ONE workgroup took 15 ms):
+//   pass 1  every segment's own transmittance product per pixel, t_s (alpha tests only, no early stop);
+//   pass 2  every segment again, now knowing the transmittance it starts from, T_in = prod_{s' < s} t_s' -- the exact
+//           walk of the whole-tile kernel from there (same blend / skip / stop decisions: the unstopped product is
+//           monotone, so "the pixel stopped in an earlier segment" is exactly T_in < 1e-4), partial sums already
+//           weighted by the global transmittance, the segment's last contributor and the transmittance it ends with;
+//   pass 3  one workgroup per split tile adds the partial sums in list order and writes the pixels.
+// Against the one-workgroup walk only the association of the transmittance product differs (last bits).
+// The work lists are built on the device by the binning stage (rdg_split_build); the three launches happen only when
+// the previous frame of this shape had a list above the threshold (RdgRasterSettings.split_lists, a host hint that
+// decides speed, never the result: without it the whole-tile kernel walks every list itself).
+// ---------------------------------------------------------------------------------------------------------
+// per (segment, pixel) record, planar: RDG_SEG_F floats x 256 pixels
+#define RDG_SEG_TS 0       // pass 1: transmittance product of the segment alone
+#define RDG_SEG_TOUT 1     // pass 2: transmittance after the segment (of the pixel's true, possibly stopped, walk)
+#define RDG_SEG_C 2        // 2..4 colour, 5 depth, 6..8 normal: partial sums weighted by the global transmittance
+#define RDG_SEG_LAST 9     // last contributor inside this segment (list position + 1, uint bits), 0 = none
+#define RDG_SEG_LIVE 10    // 1.0 if the pixel entered this segment alive (T_in >= 1e-4 and inside the image)
+
+__device__ __forceinline__ float* rdg_seg_row(float* seg_pix, uint32_t seg, int field) {
+    return seg_pix + ((size_t)seg * RDG_SEG_F + field) * RDG_TILE_PIX;
+}
+
+__global__ void __launch_bounds__(256)
+rdg_render_seg_T_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                        const RdgRec* __restrict__ rec, const uint32_t* __restrict__ sp_header,
+                        const uint4* __restrict__ sp_work, float* __restrict__ seg_pix) {
+    __shared__ float4 sQ0[RDG_BATCH];
+    __shared__ float2 sQ1[RDG_BATCH];
+    const int tid = threadIdx.x;
+    const uint32_t n_work = sp_header[0];
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint4 w = sp_work[wi];                     // (tile, segment, segments of the tile, first segment slot)
+        const int tile = (int)w.x;
+        const int tx = tile % gx, ty = tile / gx;
+        const int wv = tid >> 6, lane = tid & 63;
+        const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
+        const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
+        const float pixx = (float)pxi, pixy = (float)pyi;
+        const uint2 range = ranges[tile];
+        const int k_begin = (int)w.y * RDG_SPLIT_SEG, k_end = min(k_begin + RDG_SPLIT_SEG, (int)(range.y - range.x));
+        float T = 1.0f;
+        for (int k0 = k_begin; k0 < k_end; k0 += RDG_BATCH) {
+            __syncthreads();
+            const int k = k0 + tid;
+            if (k < k_end) {
+                const RdgRec* p = rec + point_list[range.x + k];
+                const float4 q0 = p->q0, q1 = p->q1;
+                const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
+                sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
+                sQ1[tid] = make_float2(cs.gam, q1.y);
+            }
+            __syncthreads();
+            const int n = min(RDG_BATCH, k_end - k0);
+            for (int j = 0; j < n; ++j) {
+                // the staged values, the expression and the test of rdg_fwd_walk: identical blend decisions
+                const float4 q0 = sQ0[j];
+                const float2 q1 = sQ1[j];
+                const float dx = q0.x - pixx, dy = q0.y - pixy;
+                const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
+                float alpha = q1.y * __builtin_amdgcn_exp2f(power);
+                if (q1.y > RDG_ALPHA_CAP) alpha = fminf(RDG_ALPHA_CAP, alpha);
+                const uint32_t key = (__float_as_uint(power) & 0x80000000u) | __float_as_uint(alpha);
+                if (key >= RDG_THR_LIVE) T = T * (1.0f - alpha);
+            }
+        }
+        rdg_seg_row(seg_pix, w.w + w.y, RDG_SEG_TS)[tid] = T;
+    }
+}
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(256)
+rdg_render_seg_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const RdgRec* __restrict__ rec, const uint32_t* __restrict__ sp_header,
+                      const uint4* __restrict__ sp_work, float* __restrict__ seg_pix,
+                      unsigned long long* __restrict__ hitbits) {
+    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH], sQ3[RDG_BATCH];
+    __shared__ unsigned long long sMask[4][4];
+    __shared__ unsigned long long sCap[4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t n_work = sp_header[0];
+    for (uint32_t wi = blockIdx.x; wi < n_work; wi += gridDim.x) {
+        const uint4 w = sp_work[wi];
+        const int tile = (int)w.x;
+        const int tx = tile % gx, ty = tile / gx;
+        const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
+        const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        float pixx = (float)pxi, pixy = (float)pyi;
+        asm volatile("" : "+v"(pixx), "+v"(pixy));
+        const float X0 = (float)(tx * RDG_TILE), Y0 = (float)(ty * RDG_TILE);
+        const uint2 range = ranges[tile];
+        const int k_begin = (int)w.y * RDG_SPLIT_SEG, k_end = min(k_begin + RDG_SPLIT_SEG, (int)(range.y - range.x));
+        unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
+        // the transmittance this segment starts from: the product of the earlier segments' own products, in list order
+        float T = 1.0f;
+        for (uint32_t s = 0; s < w.y; ++s) T *= rdg_seg_row(seg_pix, w.w + s, RDG_SEG_TS)[tid];
+        const bool live = inside && !(T < RDG_T_STOP);
+        uint32_t thrU = live ? RDG_THR_LIVE : RDG_THR_DONE;
+        float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+        uint32_t last_contributor = 0;
+        __syncthreads();          // the staging arrays of the previous work item are free
+        rdg_fwd_composite<NORMAL>(k_begin, k_end, range, X0, Y0, pixx, pixy, point_list, rec, hit, sQ0, sQ1, sQ2, sQ3,
+                                  sMask, sCap, thrU, T, C0, C1, C2, Dp, N0, N1, N2, last_contributor);
+        const uint32_t seg = w.w + w.y;
+        rdg_seg_row(seg_pix, seg, RDG_SEG_TOUT)[tid] = T;
+        rdg_seg_row(seg_pix, seg, RDG_SEG_C + 0)[tid] = C0;
+        rdg_seg_row(seg_pix, seg, RDG_SEG_C + 1)[tid] = C1;
+        rdg_seg_row(seg_pix, seg, RDG_SEG_C + 2)[tid] = C2;
+        rdg_seg_row(seg_pix, seg, RDG_SEG_C + 3)[tid] = Dp;
+        if (NORMAL) {
+            rdg_seg_row(seg_pix, seg, RDG_SEG_C + 4)[tid] = N0;
+            rdg_seg_row(seg_pix, seg, RDG_SEG_C + 5)[tid] = N1;
+            rdg_seg_row(seg_pix, seg, RDG_SEG_C + 6)[tid] = N2;
+        }
+        rdg_seg_row(seg_pix, seg, RDG_SEG_LAST)[tid] = __uint_as_float(last_contributor);
+        rdg_seg_row(seg_pix, seg, RDG_SEG_LIVE)[tid] = live ? 1.0f : 0.0f;
+    }
+}
+
+template <bool NORMAL>
+__global__ void __launch_bounds__(256)
+rdg_render_seg_combine_kernel(int W, int H, int gx, const float* __restrict__ bg, const uint32_t* __restrict__ sp_header,
+                              const uint4* __restrict__ sp_tiles, const float* __restrict__ seg_pix,
+                              float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                              float* __restrict__ out_color, float* __restrict__ out_depth,
+                              float* __restrict__ out_normal, float* __restrict__ out_alpha) {
+    const int tid = threadIdx.x;
+    const uint32_t n_tiles_split = sp_header[1];
+    for (uint32_t ti = blockIdx.x; ti < n_tiles_split; ti += gridDim.x) {
+        const uint4 t = sp_tiles[ti];                    // (tile, segments, first segment slot, -)
+        const int tile = (int)t.x;
+        const int tx = tile % gx, ty = tile / gx;
+        const int wv = tid >> 6, lane = tid & 63;
+        const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
+        const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
+        if (!(pxi < W && pyi < H)) continue;
+        float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f;
+        uint32_t last = 0;
+        for (uint32_t s = 0; s < t.y; ++s) {
+            const float* base = seg_pix + (size_t)(t.z + s) * RDG_SEG_F * RDG_TILE_PIX + tid;
+            if (base[RDG_SEG_LIVE * RDG_TILE_PIX] == 0.0f) continue;     // the pixel had stopped before this segment
+            T = base[RDG_SEG_TOUT * RDG_TILE_PIX];
+            C0 += base[(RDG_SEG_C + 0) * RDG_TILE_PIX]; C1 += base[(RDG_SEG_C + 1) * RDG_TILE_PIX];
+            C2 += base[(RDG_SEG_C + 2) * RDG_TILE_PIX]; Dp += base[(RDG_SEG_C + 3) * RDG_TILE_PIX];
+            if (NORMAL) {
+                N0 += base[(RDG_SEG_C + 4) * RDG_TILE_PIX]; N1 += base[(RDG_SEG_C + 5) * RDG_TILE_PIX];
+                N2 += base[(RDG_SEG_C + 6) * RDG_TILE_PIX];
+            }
+            last = max(last, __float_as_uint(base[RDG_SEG_LAST * RDG_TILE_PIX]));
+        }
+        const size_t hw = (size_t)H * W;
+        const size_t pid = (size_t)pyi * W + pxi;
+        final_T[pid] = T;
+        n_contrib[pid] = last;
+        out_color[pid] = C0 + T * bg[0];
+        out_color[hw + pid] = C1 + T * bg[1];
+        out_color[2 * hw + pid] = C2 + T * bg[2];
+        out_depth[pid] = Dp;
+        out_alpha[pid] = 1.0f - T;
+        out_normal[pid] = N0; out_normal[hw + pid] = N1; out_normal[2 * hw + pid] = N2;
+    }
+}
+
+// Work lists of the split path from the tile ranges: one workgroup, every tile looked at once.  Segment slots of a tile
+// are consecutive (first slot = running total), so a pixel's per-segment records can be walked in list order.
+__global__ void __launch_bounds__(1024)
+rdg_split_build_kernel(int n_tiles, const uint2* __restrict__ ranges, long long capacity,
+                       const int32_t* __restrict__ num_rendered, uint32_t* __restrict__ sp_header,
+                       uint4* __restrict__ sp_work, uint4* __restrict__ sp_tiles, uint32_t max_seg, uint32_t max_tiles) {
+    __shared__ uint32_t sSeg, sTiles;
+    if (threadIdx.x == 0) { sSeg = 0u; sTiles = 0u; }
+    __syncthreads();
+    if ((long long)num_rendered[0] <= capacity)
+        for (int i = threadIdx.x; i < n_tiles; i += 1024) {
+            const uint2 r = ranges[i];
+            const uint32_t n = r.y - r.x;
+            if (n > (uint32_t)RDG_SPLIT_MIN) {
+                const uint32_t nseg = (n + RDG_SPLIT_SEG - 1) / RDG_SPLIT_SEG;
+                const uint32_t base = atomicAdd(&sSeg, nseg), ti = atomicAdd(&sTiles, 1u);
+                if (base + nseg <= max_seg && ti < max_tiles) {      // always true (rdg_split_layout)
+                    sp_tiles[ti] = make_uint4((uint32_t)i, nseg, base, 0u);
+                    for (uint32_t c = 0; c < nseg; ++c) sp_work[base + c] = make_uint4((uint32_t)i, c, nseg, base);
+                }
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) { sp_header[0] = min(sSeg, max_seg); sp_header[1] = min(sTiles, max_tiles); }
+}
+
+int rdg_launch_split_build(const RdgDev& d, void* bin_ws, int64_t capacity, const void* image_ws,
+                           const int32_t* num_rendered, hipStream_t s) {
+    const int n_tiles = d.gx * d.gy;
+    const RdgBinLayout B = rdg_bin_layout(capacity, n_tiles);
+    const RdgSplitLayout SL = rdg_split_layout(capacity);
+    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
+    char* sp = (char*)bin_ws + B.split;
+    hipLaunchKernelGGL(rdg_split_build_kernel, dim3(1), dim3(1024), 0, s, n_tiles,
+                       (const uint2*)((const char*)image_ws + I.ranges), (long long)capacity, num_rendered,
+                       (uint32_t*)(sp + SL.header), (uint4*)(sp + SL.work), (uint4*)(sp + SL.tiles), SL.max_seg,
+                       SL.max_tiles);
+    return rdg_check_hip(hipGetLastError(), "split_build launch");
+}
+
 int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, void* bin_ws,
                           int64_t capacity, void* image_ws, const int32_t* num_rendered, float* out_color,
                           float* out_depth, float* out_normal, float* out_alpha, hipStream_t s) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
-    const RdgBinLayout B = rdg_bin_layout(capacity);
-    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
     const int n_tiles = d.gx * d.gy;
+    const RdgBinLayout B = rdg_bin_layout(capacity, n_tiles);
+    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
     const int npass = (rdg_key_bits(n_tiles) + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
     const char* b = (const char*)bin_ws;
     const uint32_t* plist = (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a));
     char* im = (char*)image_ws;
     const int nblk = ((n_tiles + 7) / 8) * 8;
+    const RdgRec* rec = (const RdgRec*)((const char*)geom_ws + G.rec);
+    const uint2* ranges = (const uint2*)(im + I.ranges);
+    float* final_T = (float*)(im + I.final_T);
+    uint32_t* n_contrib = (uint32_t*)(im + I.n_contrib);
     // zeroed by the binning stage (rdg_launch_bin), which always runs before this launch
     unsigned long long* hitbits = (unsigned long long*)((char*)bin_ws + B.hit);
+    const int split_min = d.split_lists ? RDG_SPLIT_MIN : 0x7fffffff;
 #define RDG_FWD_LAUNCH(NORMAL)                                                                                      \
     hipLaunchKernelGGL(rdg_render_fwd_kernel<NORMAL>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,       \
-                       (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),           \
-                       (long long)capacity, num_rendered, (float*)(im + I.final_T), (uint32_t*)(im + I.n_contrib),    \
-                       out_color, out_depth, out_normal, out_alpha, hitbits)
+                       ranges, plist, rec, (long long)capacity, num_rendered, final_T, n_contrib,                    \
+                       out_color, out_depth, out_normal, out_alpha, hitbits, split_min)
     if (d.render_normal) RDG_FWD_LAUNCH(true); else RDG_FWD_LAUNCH(false);
 #undef RDG_FWD_LAUNCH
+    if (d.split_lists) {
+        // long lists: work lists from the ranges, then per-segment transmittance, per-segment composite, ordered combine
+        int rc = rdg_launch_split_build(d, bin_ws, capacity, image_ws, num_rendered, s);
+        if (rc) return rc;
+        const RdgSplitLayout SL = rdg_split_layout(capacity);
+        char* sp = (char*)bin_ws + B.split;
+        const uint32_t* sp_header = (const uint32_t*)(sp + SL.header);
+        const uint4* sp_work = (const uint4*)(sp + SL.work);
+        const uint4* sp_tiles = (const uint4*)(sp + SL.tiles);
+        float* seg_pix = (float*)(sp + SL.seg_pix);
+        const unsigned gseg = SL.max_seg < 2048u ? SL.max_seg : 2048u, gtile = SL.max_tiles < 1024u ? SL.max_tiles : 1024u;
+        hipLaunchKernelGGL(rdg_render_seg_T_kernel, dim3(gseg), dim3(256), 0, s, d.W, d.H, d.gx, ranges, plist, rec,
+                           sp_header, sp_work, seg_pix);
+        if (d.render_normal) {
+            hipLaunchKernelGGL(rdg_render_seg_kernel<true>, dim3(gseg), dim3(256), 0, s, d.W, d.H, d.gx, ranges, plist, rec,
+                               sp_header, sp_work, seg_pix, hitbits);
+            hipLaunchKernelGGL(rdg_render_seg_combine_kernel<true>, dim3(gtile), dim3(256), 0, s, d.W, d.H, d.gx, bg,
+                               sp_header, sp_tiles, (const float*)seg_pix, final_T, n_contrib, out_color, out_depth,
+                               out_normal, out_alpha);
+        } else {
+            hipLaunchKernelGGL(rdg_render_seg_kernel<false>, dim3(gseg), dim3(256), 0, s, d.W, d.H, d.gx, ranges, plist, rec,
+                               sp_header, sp_work, seg_pix, hitbits);
+            hipLaunchKernelGGL(rdg_render_seg_combine_kernel<false>, dim3(gtile), dim3(256), 0, s, d.W, d.H, d.gx, bg,
+                               sp_header, sp_tiles, (const float*)seg_pix, final_T, n_contrib, out_color, out_depth,
+                               out_normal, out_alpha);
+        }
+    }
     return rdg_check_hip(hipGetLastError(), "render_fwd launch");
 }
 
@@ -529,76 +787,29 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
     }
 }
 
-// HAS_DEPTH = false: no upstream gradient for the depth image (photometric-only losses) -- the depth channel drops out
-// of the per-pair arithmetic and of the reduction.
+// The back-to-front walk of one workgroup over list positions [k_lo, k_top) of its tile (k_lo a multiple of 64): the
+// whole-tile kernel calls it with (0, largest last contributor of the tile), the split path with one segment.
+// m0..m3: per quadrant, the largest last contributor of its pixels.  T / behind: the pixel's transmittance after, and the
+// (normalised) colour-gradient product behind, list position k_top - 1.
 template <bool HAS_DEPTH, bool DET>
-__global__ void __launch_bounds__(256)
-rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
-                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const RdgRec* __restrict__ rec, const float* __restrict__ final_T,
-                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ g_color,
-                      const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
-                      float* __restrict__ grow, const unsigned long long* __restrict__ hitbits) {
-    const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
-    if (tile >= n_tiles) return;
-    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
-    __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
-    __shared__ unsigned long long sMask[4][4];
-    __shared__ unsigned long long sCap[4];   // per staging wave: splats whose opacity exceeds the alpha cap
-    __shared__ int sMax[4];
+__device__ __forceinline__ void
+rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int m0, const int m1, const int m2, const int m3,
+                  const int last_contributor, const float pixx, const float pixy, const float dLp0, const float dLp1,
+                  const float dLp2, const float dLd, const uint32_t* __restrict__ point_list,
+                  const RdgRec* __restrict__ rec, const unsigned long long* __restrict__ hit, float4* sQ0, float4* sQ1,
+                  float4* sQ2, unsigned long long (*sMask)[4], unsigned long long* sCap, float (*ring)[16][RDG_RING_Q],
+                  const float flush_scale, const int flush_off, float* __restrict__ gdst, float& T, float& behind,
+                  int& ring_n) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int tx = tile % gx, ty = tile / gx;
-    const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
-    const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
-    const bool inside = pxi < W && pyi < H;
-    const float pixx = (float)pxi, pixy = (float)pyi;
-    const uint2 range = ranges[tile];
-    const size_t hw = (size_t)H * W;
-    const size_t pid = (size_t)pyi * W + pxi;
-
-    const unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
-    const float T_final = inside ? final_T[pid] : 0.0f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pid] : 0;
-    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
-    if (inside) {
-        if (g_color) { dLp0 = g_color[pid]; dLp1 = g_color[hw + pid]; dLp2 = g_color[2 * hw + pid]; }
-        if (HAS_DEPTH) dLd = g_depth[pid];
-        if (g_alpha) dLa = g_alpha[pid];
-    }
-    // What lies BEHIND the last splat of a pixel, in units of "colour . dL/dpixel": the background, and the alpha
-    // output (alpha_out = 1 - T_final) as a colour of -dL/dalpha_out.  Starting the behind-value recurrence from it
-    // makes dL/dalpha_k = T_k (s_k - behind_k) exact with no separate T_final term.
-    const float bgdot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
-    float behind = bgdot - dLa;
-
-    // wave / block maxima of last_contributor: splats at list positions >= max are skipped wholesale
-    int wmax = last_contributor;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
-    if (lane == 0) sMax[wv] = wmax;
-    __syncthreads();
-    const int m0 = sMax[0], m1 = sMax[1], m2 = sMax[2], m3 = sMax[3];
-    const int kmax = max(max(m0, m1), max(m2, m3));
-    const int rounds = (kmax + RDG_BATCH - 1) / RDG_BATCH;
-
-    int ring_n = 0;   // wave-uniform fill level of this wave's ring
-    float* __restrict__ const gdst = DET ? grow + wv * RDG_GROW : grow;   // DET: this wave's quarter of an instance row
-    const int fc = lane & 15;
-    // components 0, 1 are the raw first moments sum(G dL/dG dx), sum(G dL/dG dy): the per-Gaussian backward turns them
-    // into dL/dmean2D with the conic it has anyway (two multiplies and two fused multiply-adds per pair less here)
-    const float flush_scale = (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : 1.0f;
-    // where component fc sits in a pixel row's two quads (A = slots 0..5, B = slots 6..11): see the reduction below
-    const int flush_off = (int)((0x5827049136ull >> (4 * fc)) & 15ull);
-
+    const int rounds = (k_top - k_lo + RDG_BATCH - 1) / RDG_BATCH;
     for (int r = 0; r < rounds; ++r) {
-        const int kbase = kmax - 1 - r * RDG_BATCH;  // list position of slot 0 of this batch
+        const int kbase = k_top - 1 - r * RDG_BATCH;  // list position of slot 0 of this batch
         uint32_t qbits = 0;
         bool over_cap = false;
         {
             const int k = kbase - tid;
-            if (k >= 0) {
+            if (k >= k_lo) {
                 // a quadrant whose pixels all stopped before this list position never needs the splat ...
                 qbits = (uint32_t)(k < m0) | ((uint32_t)(k < m1) << 1) | ((uint32_t)(k < m2) << 2) |
                         ((uint32_t)(k < m3) << 3);
@@ -643,16 +854,112 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
             const int jthr = kbase - s * 64 - last_contributor;
             if (cap)
                 rdg_bwd_walk<HAS_DEPTH, true, DET>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
-                                                   pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale,
+                                                   pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, ring, flush_scale,
                                                    flush_off, gdst, T, behind, ring_n);
             else
                 rdg_bwd_walk<HAS_DEPTH, false, DET>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
-                                                    pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, sRing[wv], flush_scale,
+                                                    pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, ring, flush_scale,
                                                     flush_off, gdst, T, behind, ring_n);
         }
         __syncthreads();   // every wave is done with this round's staged records
     }
-    rdg_ring_flush<HAS_DEPTH, DET>(sRing[wv], ring_n, lane, flush_scale, flush_off, gdst);
+}
+
+// HAS_DEPTH = false: no upstream gradient for the depth image (photometric-only losses) -- the depth channel drops out
+// of the per-pair arithmetic and of the reduction.
+// SEG: the split path (see the forward): one work item = one segment of a long list; the pixel's transmittance after
+// the segment is the one the forward stored, and what lies behind it is rebuilt from the later segments' partial sums.
+template <bool HAS_DEPTH, bool DET, bool SEG>
+__global__ void __launch_bounds__(256)
+rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
+                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const RdgRec* __restrict__ rec, const float* __restrict__ final_T,
+                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ g_color,
+                      const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
+                      float* __restrict__ grow, const unsigned long long* __restrict__ hitbits, int split_min,
+                      const uint32_t* __restrict__ sp_header, const uint4* __restrict__ sp_work,
+                      const float* __restrict__ seg_pix) {
+    __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
+    __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
+    __shared__ unsigned long long sMask[4][4];
+    __shared__ unsigned long long sCap[4];   // per staging wave: splats whose opacity exceeds the alpha cap
+    __shared__ int sMax[4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const size_t hw = (size_t)H * W;
+    const int fc = lane & 15;
+    // components 0, 1 are the raw first moments sum(G dL/dG dx), sum(G dL/dG dy): the per-Gaussian backward turns them
+    // into dL/dmean2D with the conic it has anyway (two multiplies and two fused multiply-adds per pair less here)
+    const float flush_scale = (fc == 2 || fc == 4) ? -0.5f : fc == 3 ? -1.0f : 1.0f;
+    // where component fc sits in a pixel row's two quads (A = slots 0..5, B = slots 6..11): see the reduction below
+    const int flush_off = (int)((0x5827049136ull >> (4 * fc)) & 15ull);
+    float* __restrict__ const gdst = DET ? grow + wv * RDG_GROW : grow;   // DET: this wave's quarter of an instance row
+    const uint32_t n_items = SEG ? sp_header[0] : 1u;
+    for (uint32_t wi = SEG ? blockIdx.x : 0u; wi < n_items; wi += SEG ? gridDim.x : 1u) {
+        uint4 item = make_uint4(0u, 0u, 0u, 0u);
+        int tile;
+        if (SEG) { item = sp_work[wi]; tile = (int)item.x; }
+        else { tile = rdg_tile_of_block(blockIdx.x, n_tiles); if (tile >= n_tiles) return; }
+        const int tx = tile % gx, ty = tile / gx;
+        const int pxi = tx * RDG_TILE + (wv & 1) * 8 + (lane & 7);
+        const int pyi = ty * RDG_TILE + (wv >> 1) * 8 + (lane >> 3);
+        const bool inside = pxi < W && pyi < H;
+        const float pixx = (float)pxi, pixy = (float)pyi;
+        const uint2 range = ranges[tile];
+        if (!SEG && (int)(range.y - range.x) > split_min) return;      // walked by the split path
+        const size_t pid = (size_t)pyi * W + pxi;
+        const unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
+        const float T_final = inside ? final_T[pid] : 0.0f;
+        const int last_contributor = inside ? (int)n_contrib[pid] : 0;
+        float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
+        if (inside) {
+            if (g_color) { dLp0 = g_color[pid]; dLp1 = g_color[hw + pid]; dLp2 = g_color[2 * hw + pid]; }
+            if (HAS_DEPTH) dLd = g_depth[pid];
+            if (g_alpha) dLa = g_alpha[pid];
+        }
+        // What lies BEHIND the last splat of a pixel, in units of "colour . dL/dpixel": the background, and the alpha
+        // output (alpha_out = 1 - T_final) as a colour of -dL/dalpha_out.  Starting the behind-value recurrence from it
+        // makes dL/dalpha_k = T_k (s_k - behind_k) exact with no separate T_final term.
+        const float bgdot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
+        float T = T_final;
+        float behind = bgdot - dLa;
+        int k_lo = 0, k_hi = 0x7fffffff;
+        if (SEG) {
+            k_lo = (int)item.y * RDG_SPLIT_SEG;
+            k_hi = min(k_lo + RDG_SPLIT_SEG, (int)(range.y - range.x));
+            // The pixel takes part in this segment only if its last contributor lies beyond the segment's first slot.
+            // Then: transmittance after the segment = what the forward stored; behind it = the later segments' partial
+            // sums (already weighted by the global transmittance) + the background term, brought to this point's scale.
+            if (last_contributor > k_lo) {
+                float far = T_final * (bgdot - dLa);
+                for (uint32_t s2 = item.y + 1; s2 < item.z; ++s2) {
+                    const float* b2 = seg_pix + (size_t)(item.w + s2) * RDG_SEG_F * RDG_TILE_PIX + tid;
+                    far += b2[(RDG_SEG_C + 0) * RDG_TILE_PIX] * dLp0 + b2[(RDG_SEG_C + 1) * RDG_TILE_PIX] * dLp1 +
+                           b2[(RDG_SEG_C + 2) * RDG_TILE_PIX] * dLp2;
+                    if (HAS_DEPTH) far += b2[(RDG_SEG_C + 3) * RDG_TILE_PIX] * dLd;
+                }
+                T = seg_pix[((size_t)(item.w + item.y) * RDG_SEG_F + RDG_SEG_TOUT) * RDG_TILE_PIX + tid];
+                behind = far / T;
+            } else {
+                T = 1.0f; behind = 0.0f;      // never blends here: finite values keep the branch-free arithmetic clean
+            }
+        }
+        // wave / block maxima of last_contributor: splats at list positions >= max are skipped wholesale
+        int wmax = last_contributor;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+        __syncthreads();                       // SEG: the previous work item is done with sMax
+        if (lane == 0) sMax[wv] = wmax;
+        __syncthreads();
+        const int m0 = sMax[0], m1 = sMax[1], m2 = sMax[2], m3 = sMax[3];
+        const int kmax = max(max(m0, m1), max(m2, m3));
+        const int k_top = min(kmax, k_hi);
+        int ring_n = 0;   // wave-uniform fill level of this wave's ring
+        rdg_bwd_composite<HAS_DEPTH, DET>(k_lo, k_top, range, m0, m1, m2, m3, last_contributor, pixx, pixy, dLp0, dLp1, dLp2,
+                                          dLd, point_list, rec, hit, sQ0, sQ1, sQ2, sMask, sCap, sRing[wv], flush_scale,
+                                          flush_off, gdst, T, behind, ring_n);
+        rdg_ring_flush<HAS_DEPTH, DET>(sRing[wv], ring_n, lane, flush_scale, flush_off, gdst);
+    }
 }
 
 // Deterministic mode, second half: one 16-lane group per Gaussian, lane c = component c of the 64-B gradient row.  The
@@ -703,28 +1010,39 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
                           int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
                           const float* g_alpha, float* grow, hipStream_t s, float* det) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
-    const RdgBinLayout B = rdg_bin_layout(capacity);
-    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
     const int n_tiles = d.gx * d.gy;
+    const RdgBinLayout B = rdg_bin_layout(capacity, n_tiles);
+    const RdgImageLayout I = rdg_image_layout(d.H, d.W);
     const int npass = (rdg_key_bits(n_tiles) + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
     const char* b = (const char*)bin_ws;
     const uint32_t* plist = (const uint32_t*)(b + ((npass & 1) ? B.vals_b : B.vals_a));
     const char* im = (const char*)image_ws;
     const int nblk = ((n_tiles + 7) / 8) * 8;
-#define RDG_BWD_LAUNCH(DEPTH, DET, DST)                                                                            \
-    hipLaunchKernelGGL((rdg_render_bwd_kernel<DEPTH, DET>), dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg, \
+    const RdgSplitLayout SL = rdg_split_layout(capacity);
+    const char* sp = b + B.split;
+    const int split_min = d.split_lists ? RDG_SPLIT_MIN : 0x7fffffff;
+    const unsigned gseg = SL.max_seg < 2048u ? SL.max_seg : 2048u;
+#define RDG_BWD_LAUNCH(DEPTH, DET, SEG, GRID, DST)                                                                 \
+    hipLaunchKernelGGL((rdg_render_bwd_kernel<DEPTH, DET, SEG>), dim3(GRID), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg, \
                        (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),        \
                        (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
-                       g_alpha, DST, (const unsigned long long*)(b + B.hit))
+                       g_alpha, DST, (const unsigned long long*)(b + B.hit), split_min,                            \
+                       (const uint32_t*)(sp + SL.header), (const uint4*)(sp + SL.work), (const float*)(sp + SL.seg_pix))
     if (det) {
-        if (g_depth) RDG_BWD_LAUNCH(true, true, det); else RDG_BWD_LAUNCH(false, true, det);
+        if (g_depth) RDG_BWD_LAUNCH(true, true, false, nblk, det); else RDG_BWD_LAUNCH(false, true, false, nblk, det);
+        if (d.split_lists) {
+            if (g_depth) RDG_BWD_LAUNCH(true, true, true, gseg, det); else RDG_BWD_LAUNCH(false, true, true, gseg, det);
+        }
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_det_reduce_kernel, dim3((unsigned)(((long long)d.P * 16 + 255) / 256)), dim3(256), 0, s,
                                d.P, d.gx, d.gy, (const RdgRec*)((const char*)geom_ws + G.rec),
                                (const uint32_t*)((const char*)geom_ws + G.tiles_touched), (const uint2*)(im + I.ranges),
                                plist, (const float*)det, grow);
     } else {
-        if (g_depth) RDG_BWD_LAUNCH(true, false, grow); else RDG_BWD_LAUNCH(false, false, grow);
+        if (g_depth) RDG_BWD_LAUNCH(true, false, false, nblk, grow); else RDG_BWD_LAUNCH(false, false, false, nblk, grow);
+        if (d.split_lists) {
+            if (g_depth) RDG_BWD_LAUNCH(true, false, true, gseg, grow); else RDG_BWD_LAUNCH(false, false, true, gseg, grow);
+        }
     }
 #undef RDG_BWD_LAUNCH
     return rdg_check_hip(hipGetLastError(), "render_bwd launch");

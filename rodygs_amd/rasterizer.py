@@ -34,6 +34,13 @@ _BIN_HINT = {}                # (P, H, W) -> 1 while the largest tile list of th
 # largest tile list (it arrives with num_rendered: no extra read-back), with hysteresis.
 BIN_RADIX_ABOVE = 32768
 BIN_BUCKET_BELOW = 16384
+# Compositing of long tile lists: one workgroup walks a tile's list front to back, which is serial in the list length (a
+# 200 k-instance tile: 15 ms).  Lists above 4096 instances can be cut into segments composited by a workgroup each
+# (csrc/rdg_render.hip "split path"; the backward follows the forward's choice) -- three extra launches in the forward and
+# one in the backward, so, like the binning algorithm, the choice is made per frame from the previous frame's largest list.
+_SPLIT_HINT = {}              # (P, H, W) -> 1 while the largest tile list of the last frame calls for the split path
+SPLIT_ABOVE = 4096            # = RDG_SPLIT_MIN of the library: shorter lists are never split
+SPLIT_BELOW = 3072
 
 
 # Deterministic backward (RDG_DETERMINISTIC=1 or set at run time): the compositing backward stores
@@ -67,6 +74,10 @@ def _note_largest_tile(key, largest: int) -> None:
         _BIN_HINT[key] = 1
     elif largest < BIN_BUCKET_BELOW:
         _BIN_HINT.pop(key, None)
+    if largest > SPLIT_ABOVE:
+        _SPLIT_HINT[key] = 1
+    elif largest < SPLIT_BELOW:
+        _SPLIT_HINT.pop(key, None)
 
 
 def poll_overflow(block: bool = False) -> None:
@@ -120,6 +131,7 @@ def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int) -> _lib.RdgRa
     s.render_normal = int(bool(RENDER_NORMAL))
     s.bin_mode = 0
     s.num_rendered_stats = 0
+    s.split_lists = 0
     return s
 
 
@@ -214,6 +226,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             key = (P, H, W)
             cs.num_rendered_stats = 1
             cs.bin_mode = int(_BIN_HINT.get(key, 0))
+            # deterministic mode: the choice must not depend on what the previous frame looked like (the split path
+            # associates the transmittance product differently: same result to the last bits only)
+            cs.split_lists = 1 if DETERMINISTIC else int(_SPLIT_HINT.get(key, 0))
             cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
             stream = _lib.stream_ptr()
             if GRAPH_CAPTURE and key not in _CAPACITY_HINT:

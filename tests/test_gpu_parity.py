@@ -571,6 +571,50 @@ def test_skewed_scene_long_tile_lists(heavy):
     assert int(res[5][5]["n_contrib"].max()) > 8192      # compositing really walked the long list
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_split_compositing_of_long_tile_lists(deterministic):
+    """Lists above 4096 instances composited by several workgroups (per-segment partial composites + ordered combine,
+    RdgRasterSettings.split_lists) against the oracle AND against the one-workgroup walk of the same frame: a 70 k-
+    instance tile (35 segments), tiles at 4.2-7.9 k (3-4 segments, ragged last segment), shorter ones untouched, depth
+    ties, coloured background.  Images, final_T and every gradient to 1e-4 / oracle and 2e-5 / unsplit; n_contrib exact
+    up to the discontinuity allowance; pixels that stop early inside a segment (the opaque variant) included."""
+    import hip_stages as HS
+    import rodygs_amd.rasterizer as R
+    from rodygs_amd import GaussianRasterizer
+    W, H = 320, 240
+    bg = (0.1, 0.2, 0.3)
+    for opaque in (False, True):
+        sc = O.skewed_scene(W, H, [(5, 6, 70000), (14, 3, 7900), (9, 11, 4200), (2, 2, 2500), (17, 12, 1300)],
+                            background=3000, sh_degree_max=3, seed=79, equal_depth_every=5,
+                            opacity=(0.02, 0.5) if opaque else (0.006, 0.03))
+        sc["viewmatrix"] = orbit_view(1.0, -0.7, (0.04, -0.02, 0.08))
+        P = sc["means3D"].shape[0]
+        key = (P, H, W)
+        old_det = R.DETERMINISTIC
+        R.DETERMINISTIC = deterministic
+        try:
+            R._SPLIT_HINT.pop(key, None)
+            R.SPLIT_ABOVE, keep = 10 ** 9, R.SPLIT_ABOVE          # the hint can never set: one workgroup per tile
+            try:
+                unsplit = _hip_grads(sc, 3, bg, deterministic)
+            finally:
+                R.SPLIT_ABOVE = keep
+            R._SPLIT_HINT[key] = 1
+            res = run_pair(sc, 3, bg, seed=11)                    # HIP (split path) + oracle, same loss weights
+            assert R._SPLIT_HINT.get(key) == 1                    # the frame's largest list keeps the hint set
+            split = {k: res[0][k].grad for k in NAMES}
+            split["means2D"] = res[1].grad
+        finally:
+            R.DETERMINISTIC = old_det
+            R._SPLIT_HINT.pop(key, None)
+        check_pair(res, NAMES)
+        if not opaque:  # thousands of splats deep, and pixels that saturate only in a LATER segment of the long list
+            nc, fT = res[5][5]["n_contrib"], res[5][5]["final_T"]
+            assert int(nc.max()) > 8192 and int(((fT < 2e-4) & (nc > 2048)).sum()) > 0
+        for k in split:
+            rel_ok(split[k], unsplit[k], tol=2e-5, outliers=OUTLIER_FRAC, what=f"split vs one-workgroup d_{k} (opaque={opaque})")
+
+
 # ---- full-size properties (BASELINE config 3 shape: 1 M Gaussians, 1080p) --------------------------------------
 
 def test_full_size_properties_1m_1080p():
