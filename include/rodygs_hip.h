@@ -65,11 +65,12 @@ typedef struct RdgRasterSettings {
                               * (a tile holding 200 k instances).  Callers pick it from num_rendered[1] of the previous frame. */
     int32_t num_rendered_stats; /* 1: num_rendered points to int32[2] and the binning stage also writes
                               * [1] = largest number of instances in one tile                                    */
-    int32_t split_lists;     /* 1: tile lists longer than 4096 instances are composited (forward AND the backward that
-                              * follows: keep the struct) by several workgroups each -- per-segment partial composites, an
-                              * ordered combine; three extra launches, so callers set it from num_rendered[1] of the
-                              * previous frame.  0: one workgroup walks every list.  A speed hint: the result is the same
-                              * up to the association of the transmittance product (last bits).                       */
+    int32_t list_hints;      /* what the previous frame of this shape says about tile-list lengths (num_rendered[1]); speed
+                              * hints, never the result:
+                              *   bit 0: lists longer than 4096 instances are composited (forward AND the backward that
+                              *          follows: keep the struct) by several workgroups each -- per-segment partial
+                              *          composites + an ordered combine (three extra launches); 0: one workgroup walks
+                              *          every list.  Same result up to the association of the transmittance product.  */
 } RdgRasterSettings;
 
 /* stage ids for rdg_stage_time_ms() */

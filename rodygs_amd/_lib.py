@@ -23,7 +23,7 @@ class RdgRasterSettings(C.Structure):
         ("image_width", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
         ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("enable_cov_grad", C.c_int32), ("enable_sh_grad", C.c_int32), ("render_normal", C.c_int32),
-        ("bin_mode", C.c_int32), ("num_rendered_stats", C.c_int32), ("split_lists", C.c_int32),
+        ("bin_mode", C.c_int32), ("num_rendered_stats", C.c_int32), ("list_hints", C.c_int32),
     ]
 
 

@@ -76,7 +76,7 @@ static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     d->smod = s->scale_modifier;
     d->prefiltered = s->prefiltered; d->cov_grad = s->enable_cov_grad; d->sh_grad = s->enable_sh_grad;
     d->render_normal = s->render_normal;
-    d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats; d->split_lists = s->split_lists;
+    d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats; d->list_hints = s->list_hints;
     d->tile_cnt_zeroed = 0;
     return 0;
 }

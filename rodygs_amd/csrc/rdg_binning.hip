@@ -488,9 +488,14 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
                 hv_desc[h] = d;
                 for (uint32_t c = 0; c < nch; ++c) hv_work[wb + c] = make_uint2(h, c);
             }
-        } else if (v > RDG_TSORT_SMALL) {
+        } else if (v > RDG_TSORT_MID) {
             const uint32_t wb = atomicAdd(&sWork, 1u);
-            if (wb < max_work) hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0u);
+            if (wb < max_work) hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0xffffffffu);
+        } else if (v > RDG_TSORT_SMALL) {
+            const uint32_t nch = (v + RDG_TSORT_SMALL - 1) / RDG_TSORT_SMALL;
+            const uint32_t wb = atomicAdd(&sWork, nch);
+            if (wb + nch <= max_work)
+                for (uint32_t c = 0; c < nch; ++c) hv_work[wb + c] = make_uint2(0x80000000u | (uint32_t)i, c);
         }
         run += v;
       }
@@ -690,8 +695,9 @@ __device__ __forceinline__ void rdg_lane_merges_reg(uint64_t (&v)[E]) {
     }
 }
 
-template <int E>
-__device__ __forceinline__ void rdg_tile_sort_lanes(const uint64_t* __restrict__ g, uint32_t n, uint32_t first,
+// INPLACE: the sorted composites go back where they came from (a chunk of a longer list: rdg_tile_merge_chunks follows)
+template <int E, bool INPLACE = false>
+__device__ __forceinline__ void rdg_tile_sort_lanes(uint64_t* __restrict__ g, uint32_t n, uint32_t first,
                                                     uint32_t tile, uint64_t* a, uint32_t lane,
                                                     uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out) {
     uint64_t v[E];
@@ -703,31 +709,52 @@ __device__ __forceinline__ void rdg_tile_sort_lanes(const uint64_t* __restrict__
     for (int e = 0; e < E; ++e) {
         const uint32_t i = lane * E + e;
         if (i < n) {
+            if (INPLACE) { g[i] = v[e]; continue; }
             vals_out[first + i] = (uint32_t)v[e];
             if (keys_full_out) keys_full_out[first + i] = ((uint64_t)tile << 32) | (v[e] >> 32);
         }
     }
 }
 
+template <bool INPLACE>
+__device__ __forceinline__ void rdg_tile_sort_lanes_n(uint64_t* __restrict__ g, uint32_t n, uint32_t first, uint32_t tile,
+                                                      uint64_t* a, uint32_t lane, uint32_t* __restrict__ vals_out,
+                                                      uint64_t* __restrict__ keys_full_out) {
+    if (n <= 64) rdg_tile_sort_lanes<1, INPLACE>(g, n, first, tile, a, lane, vals_out, keys_full_out);
+    else if (n <= 128) rdg_tile_sort_lanes<2, INPLACE>(g, n, first, tile, a, lane, vals_out, keys_full_out);
+    else if (n <= 256) rdg_tile_sort_lanes<4, INPLACE>(g, n, first, tile, a, lane, vals_out, keys_full_out);
+    else if (n <= 512) rdg_tile_sort_lanes<8, INPLACE>(g, n, first, tile, a, lane, vals_out, keys_full_out);
+    else rdg_tile_sort_lanes<16, INPLACE>(g, n, first, tile, a, lane, vals_out, keys_full_out);
+}
+
+// Besides its own tile every wave takes its share of the chunk items of the work list: 1024-instance chunks of lists of
+// RDG_TSORT_SMALL + 1 .. RDG_TSORT_MID instances, sorted in place (rdg_tile_sort_large_kernel merges them).  The list is
+// empty on an ordinary frame: one load per wave.
 __global__ void __launch_bounds__(256)
-rdg_tile_sort_lanes_kernel(int n_tiles, const uint2* __restrict__ ranges, const uint64_t* __restrict__ comp,
+rdg_tile_sort_lanes_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64_t* __restrict__ comp,
                            uint32_t* __restrict__ vals_out, uint64_t* __restrict__ keys_full_out, long long capacity,
-                           const int32_t* __restrict__ num_rendered) {
+                           const int32_t* __restrict__ num_rendered, const uint32_t* __restrict__ hv_header,
+                           const uint2* __restrict__ hv_work) {
     if ((long long)(*num_rendered) > capacity) return;
     __shared__ uint64_t sA[4][RDG_TSORT_SMALL];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + (int)wv;
-    if (tile >= n_tiles) return;
-    const uint2 rg = ranges[tile];
-    const uint32_t n = rg.y - rg.x;
-    if (n == 0 || n > RDG_TSORT_SMALL) return;
-    const uint64_t* g = comp + rg.x;
     uint64_t* a = sA[wv];
-    if (n <= 64) rdg_tile_sort_lanes<1>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
-    else if (n <= 128) rdg_tile_sort_lanes<2>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
-    else if (n <= 256) rdg_tile_sort_lanes<4>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
-    else if (n <= 512) rdg_tile_sort_lanes<8>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
-    else rdg_tile_sort_lanes<16>(g, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+    const int tile = blockIdx.x * 4 + (int)wv;
+    if (tile < n_tiles) {
+        const uint2 rg = ranges[tile];
+        const uint32_t n = rg.y - rg.x;
+        if (n != 0 && n <= RDG_TSORT_SMALL)
+            rdg_tile_sort_lanes_n<false>(comp + rg.x, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
+    }
+    const uint32_t n_work = hv_header[0];
+    for (uint32_t wi = blockIdx.x * 4 + wv; wi < n_work; wi += gridDim.x * 4) {
+        const uint2 item = hv_work[wi];
+        if (!(item.x & 0x80000000u) || item.y == 0xffffffffu) continue;
+        const uint2 rg = ranges[item.x & 0x7fffffffu];
+        const uint32_t lo = item.y * RDG_TSORT_SMALL;
+        const uint32_t nc = min((uint32_t)RDG_TSORT_SMALL, rg.y - rg.x - lo);
+        rdg_tile_sort_lanes_n<true>(comp + rg.x + lo, nc, 0u, 0u, a, lane, nullptr, nullptr);
+    }
 }
 
 // ---- heavy tiles: chunk sort + merge tree over several workgroups --------------------------------------------
@@ -878,6 +905,49 @@ __device__ void rdg_heavy_item(const RdgHeavyDesc d, uint32_t chunk, uint64_t* _
     }
 }
 
+// A list of RDG_TSORT_SMALL + 1 .. RDG_TSORT_MID instances whose 1024-instance chunks are sorted (by
+// rdg_tile_sort_lanes_kernel, the launch before): one workgroup merges them in LDS -- run length 1024, 2048 -- ping-pong
+// between the two halves of sK; every thread produces n / 256 consecutive outputs of a level from a merge-path split.
+// (The workgroup-wide bitonic network this replaces pads to a power of two and moves every element through LDS in each of
+// its 66-78 stages: a scene with 2 000 instances per tile spent 1.2 ms there, three quarters of its binning time.)
+__device__ __forceinline__ void rdg_tile_merge_chunks(const uint64_t* __restrict__ g, uint32_t n, uint32_t first,
+                                                      uint32_t tile, uint64_t* sK, uint32_t tid,
+                                                      uint32_t* __restrict__ vals_out,
+                                                      uint64_t* __restrict__ keys_full_out) {
+    uint64_t* src = sK;
+    uint64_t* dst = sK + RDG_TSORT_MID;
+    for (uint32_t i = tid; i < n; i += 256) src[i] = g[i];
+    __syncthreads();
+    const uint32_t per = (n + 255) / 256;
+    for (uint32_t len = RDG_TSORT_SMALL; len < n; len <<= 1) {
+        const uint32_t d0 = min(tid * per, n), d1 = min(d0 + per, n);
+        if (d0 < d1) {
+            // the pair of runs output d0 falls into; a thread's outputs may run over into the next pair
+            uint32_t base = d0 / (2 * len) * (2 * len);
+            uint32_t nA = min(len, n - base), nB = min(len, n - base - nA);
+            uint32_t i = rdg_merge_path(src + base, nA, src + base + nA, nB, d0 - base), j = d0 - base - i;
+            for (uint32_t d = d0; d < d1; ++d) {
+                if (d - base == nA + nB) {        // next pair
+                    base += 2 * len;
+                    nA = min(len, n - base); nB = min(len, n - base - nA);
+                    i = 0; j = 0;
+                }
+                const uint64_t x = i < nA ? src[base + i] : ~0ull, y = j < nB ? src[base + nA + j] : ~0ull;
+                const bool ta = x < y;
+                dst[d] = ta ? x : y;
+                i += ta ? 1u : 0u; j += ta ? 0u : 1u;
+            }
+        }
+        __syncthreads();
+        uint64_t* t = src; src = dst; dst = t;
+    }
+    for (uint32_t i = tid; i < n; i += 256) {
+        const uint64_t k = src[i];
+        vals_out[first + i] = (uint32_t)k;
+        if (keys_full_out) keys_full_out[first + i] = ((uint64_t)tile << 32) | (k >> 32);
+    }
+}
+
 // Lists of more than RDG_TSORT_SMALL instances: a fixed grid of workgroups walks the device-side work list the scan
 // kernel wrote (tiles of up to RDG_TSORT_LDS instances: one LDS sort each; heavier tiles: one item per chunk, see
 // above).  On an ordinary frame the list is empty and the launch costs one load per workgroup.
@@ -900,6 +970,11 @@ rdg_tile_sort_large_kernel(const uint2* __restrict__ ranges, uint64_t* __restric
             const uint32_t tile = item.x & 0x7fffffffu;
             const uint2 rg = ranges[tile];
             const uint32_t n = rg.y - rg.x;
+            if (item.y != 0xffffffffu) {
+                // chunk item of a mid list: the workgroup that holds chunk 0 merges the tile's sorted chunks
+                if (item.y == 0u) rdg_tile_merge_chunks(comp + rg.x, n, rg.x, tile, sK, tid, vals_out, keys_full_out);
+                continue;
+            }
             uint32_t N2 = 2;
             while (N2 < n) N2 <<= 1;
             const uint64_t* g = comp + rg.x;
@@ -1002,7 +1077,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         rdg_stage_begin(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
         hipLaunchKernelGGL(rdg_tile_sort_lanes_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, n_tiles, ranges, comp,
-                           vals_out, kfull, (long long)capacity, num_rendered);
+                           vals_out, kfull, (long long)capacity, num_rendered, hv_header, hv_work);
         // lists above 1024 instances: a fixed grid walks the device-side work list (empty on an ordinary frame)
         hipLaunchKernelGGL(rdg_tile_sort_large_kernel, dim3(HL.max_work < 1024u ? HL.max_work : 1024u), dim3(256), 0, s,
                            ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header, hv_desc,

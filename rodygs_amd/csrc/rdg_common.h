@@ -86,13 +86,17 @@ static inline RdgSortLayout rdg_sort_layout(int64_t capacity) {
 // (chunk sort in LDS + a merge tree, rdg_binning.hip).  Everything is sized by the capacity alone: a heavy tile has
 // > RDG_TSORT_LDS instances, so there are < cap / RDG_TSORT_LDS of them and < 2 cap / RDG_TSORT_LDS chunks in all.
 #define RDG_TSORT_SMALL 1024
+#define RDG_TSORT_MID 4096     // lists up to here: 1024-instance chunks sorted by a wave each, merged in LDS by one workgroup
 #define RDG_TSORT_LDS 8192
 struct RdgHeavyDesc { uint32_t start, n, nchunks, node_base, tile, pad0, pad1, pad2; };
 struct RdgHeavyLayout {
     size_t header;   // uint32[64]: [0] = number of work items, [1] = number of heavy tiles
     size_t desc;     // RdgHeavyDesc[max_heavy]
-    size_t work;     // uint2[max_work]: (heavy tile index, chunk index), or (0x80000000 | tile, 0) for a tile of
-                     //                  RDG_TSORT_SMALL + 1 .. RDG_TSORT_LDS instances (one workgroup sorts it in LDS)
+    size_t work;     // uint2[max_work]: (heavy tile index, chunk index); (0x80000000 | tile, c) = chunk c of 1024 instances
+                     //                  of a tile of RDG_TSORT_SMALL + 1 .. RDG_TSORT_MID instances (a wave sorts the
+                     //                  chunk, the workgroup that takes item c = 0 merges the chunks in LDS);
+                     //                  (0x80000000 | tile, 0xffffffff) = a tile of RDG_TSORT_MID + 1 .. RDG_TSORT_LDS
+                     //                  instances (one workgroup sorts it in LDS)
     size_t nodes;    // uint32[2 * max_chunks]  arrival counters of the merge-tree nodes
     size_t total;
     uint32_t max_heavy, max_chunks, max_work;
@@ -102,7 +106,8 @@ static inline RdgHeavyLayout rdg_heavy_layout(int64_t capacity) {
     const size_t cap = (size_t)(capacity > 0 ? capacity : 1);
     L.max_heavy = (uint32_t)(cap / RDG_TSORT_LDS + 1);
     L.max_chunks = 2 * L.max_heavy;
-    L.max_work = L.max_chunks + (uint32_t)(cap / RDG_TSORT_SMALL + 1);
+    // chunk items of the mid tiles: every chunk but a tile's last is full, and a mid tile has > RDG_TSORT_SMALL instances
+    L.max_work = L.max_chunks + 2u * (uint32_t)(cap / RDG_TSORT_SMALL + 1);
     size_t o = 0;
     L.header = o;  o = rdg_align_up(o + 256, 256);
     L.desc = o;    o = rdg_align_up(o + (size_t)L.max_heavy * sizeof(RdgHeavyDesc), 256);
@@ -216,7 +221,7 @@ struct RdgDev {
     float tanx, tany, fx, fy, smod;
     int32_t prefiltered, cov_grad, sh_grad, render_normal;
     int32_t bin_mode, nren_stats;
-    int32_t split_lists;       // RdgRasterSettings.split_lists: run the split compositing path for lists > RDG_SPLIT_MIN
+    int32_t list_hints;        // RdgRasterSettings.list_hints: bit 0 = split compositing path for lists > RDG_SPLIT_MIN
     int32_t tile_cnt_zeroed;   // internal: the per-tile counters were cleared by the per-Gaussian stage's scan kernel
 };
 

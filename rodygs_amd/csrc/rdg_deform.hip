@@ -466,14 +466,19 @@ __device__ __forceinline__ float rdg_dbt_sum(const float* __restrict__ d_table, 
 // entry and is left zero).  Where the birth-sorted sequence switches to index u: seg_start[u] (int32 [Tu + 1], the
 // host caches it with the permutation) or, without it, a binary search on the sequence itself (the sorted compact copy
 // carries the index in its 8th float; without the copy: time_ind[order[.]]) -- 20 dependent loads, 25 us at P = 1 M.
-__global__ void __launch_bounds__(128)
+#define RDG_DEF_FIN_GROUPS 8
+__global__ void __launch_bounds__(128 * RDG_DEF_FIN_GROUPS)
 rdg_deform_part_finalize_kernel(int P, int Tu, int per, const int* __restrict__ seg_start,
                                 const float* __restrict__ gs, const long long* __restrict__ time_ind,
                                 const int* __restrict__ order, const float* __restrict__ part,
                                 float* __restrict__ d_table, float* __restrict__ d_basis_t,
                                 uint32_t* __restrict__ counter) {
-    const int u = blockIdx.x, e = threadIdx.x;
+    // 8 groups of 128 threads: group g adds the slots w0 + g, w0 + g + 8, ... of element e, then the eight group totals
+    // are added in group order -- a fixed order (what makes the sum reproducible) with eight loads in flight per element
+    const int u = blockIdx.x, e = threadIdx.x & 127, grp = threadIdx.x >> 7;
     __shared__ uint32_t sOld;
+    __shared__ float sPart[RDG_DEF_FIN_GROUPS][128];
+    float acc = 0.0f;
     if (e < 16 * RDG_DEF_K) {
         int bound[2];
         if (seg_start) {
@@ -490,40 +495,37 @@ rdg_deform_part_finalize_kernel(int P, int Tu, int per, const int* __restrict__ 
                 bound[q] = lo;
             }
         }
-        float acc = 0.0f;
         if (bound[1] > bound[0]) {
             const int w0 = bound[0] / per, w1 = (bound[1] - 1) / per;
-            // eight independent loads in flight, added in wave order (the order is what makes the sum reproducible)
-            int w = w0;
-            for (; w + 7 <= w1; w += 8) {
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(w + q + u) * (16 * RDG_DEF_K) + e];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc += v[q];
-            }
-            for (; w <= w1; ++w) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
+            for (int w = w0 + grp; w <= w1; w += RDG_DEF_FIN_GROUPS) acc += part[(size_t)(w + u) * (16 * RDG_DEF_K) + e];
         }
-        if (counter[1] != 0u) acc = __int_as_float(0x7fc00000);   // `order` was not sorted by birth index: poison, loudly
-        d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -acc;
+    }
+    sPart[grp][e] = acc;
+    __syncthreads();
+    if (grp == 0 && e < 16 * RDG_DEF_K) {
+        float tot = sPart[0][e];
+#pragma unroll
+        for (int g = 1; g < RDG_DEF_FIN_GROUPS; ++g) tot += sPart[g][e];
+        if (counter[1] != 0u) tot = __int_as_float(0x7fc00000);   // `order` was not sorted by birth index: poison, loudly
+        d_table[(size_t)u * (16 * RDG_DEF_K) + e] = -tot;
     }
     // publish this row (agent-scope release), count the finished workgroups; the last one acquires and reduces over u
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (e == 0) {
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         sOld = atomicAdd(counter, 1u);
     }
     __syncthreads();
     if (sOld != (uint32_t)(Tu - 1)) return;
-    if (e == 0) {
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         *counter = 0u;
     }
     __syncthreads();
-    if (e < 16 * RDG_DEF_K) d_basis_t[e] = -rdg_dbt_sum(d_table, Tu, 16 * RDG_DEF_K, e);
+    if (grp == 0 && e < 16 * RDG_DEF_K) d_basis_t[e] = -rdg_dbt_sum(d_table, Tu, 16 * RDG_DEF_K, e);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -964,7 +966,7 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
                                table ? 1 : 0, d_basis_t, d_table, use_gs ? (const float*)sorted_ws : (const float*)nullptr,
                                part);
             if (part)
-                hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P, Tu,
+                hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128 * RDG_DEF_FIN_GROUPS), 0, st, P, Tu,
                                    rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const int*)seg_start,
                                    use_gs ? (const float*)sorted_ws : (const float*)nullptr, (const long long*)time_ind,
                                    (const int*)order, (const float*)part, d_table, d_basis_t, counter);
@@ -1029,7 +1031,7 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
         hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(RDG_DEF_ACC_BLOCKS), dim3(256), 0, st, P, coeff,
                            (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,
                            spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws, part);
-        hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128), 0, st, P, Tu,
+        hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128 * RDG_DEF_FIN_GROUPS), 0, st, P, Tu,
                            rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const int*)seg_start,
                            (const float*)sorted_ws, (const long long*)time_ind, (const int*)order, (const float*)part,
                            d_table, d_basis_t, counter);

@@ -334,7 +334,7 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
 //   pass 3  one workgroup per split tile adds the partial sums in list order and writes the pixels.
 // Against the one-workgroup walk only the association of the transmittance product differs (last bits).
 // The work lists are built on the device by the binning stage (rdg_split_build); the three launches happen only when
-// the previous frame of this shape had a list above the threshold (RdgRasterSettings.split_lists, a host hint that
+// the previous frame of this shape had a list above the threshold (RdgRasterSettings.list_hints bit 0, a host hint that
 // decides speed, never the result: without it the whole-tile kernel walks every list itself).
 // ---------------------------------------------------------------------------------------------------------
 // per (segment, pixel) record, planar: RDG_SEG_F floats x 256 pixels
@@ -548,14 +548,14 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
     uint32_t* n_contrib = (uint32_t*)(im + I.n_contrib);
     // zeroed by the binning stage (rdg_launch_bin), which always runs before this launch
     unsigned long long* hitbits = (unsigned long long*)((char*)bin_ws + B.hit);
-    const int split_min = d.split_lists ? RDG_SPLIT_MIN : 0x7fffffff;
+    const int split_min = (d.list_hints & 1) ? RDG_SPLIT_MIN : 0x7fffffff;
 #define RDG_FWD_LAUNCH(NORMAL)                                                                                      \
     hipLaunchKernelGGL(rdg_render_fwd_kernel<NORMAL>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,       \
                        ranges, plist, rec, (long long)capacity, num_rendered, final_T, n_contrib,                    \
                        out_color, out_depth, out_normal, out_alpha, hitbits, split_min)
     if (d.render_normal) RDG_FWD_LAUNCH(true); else RDG_FWD_LAUNCH(false);
 #undef RDG_FWD_LAUNCH
-    if (d.split_lists) {
+    if ((d.list_hints & 1)) {
         // long lists: work lists from the ranges, then per-segment transmittance, per-segment composite, ordered combine
         int rc = rdg_launch_split_build(d, bin_ws, capacity, image_ws, num_rendered, s);
         if (rc) return rc;
@@ -633,7 +633,9 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], in
 // ---------------------------------------------------------------------------------------------------------
 // The backward's walk over one 64-slot word of staged splats (the scalar-instruction budget of rdg_fwd_walk applies).
 // jthr: per lane, the slot bit index above which the list position lies below the pixel's last contributor.
-template <bool HAS_DEPTH, bool CAPPED, bool DET>
+// ALLBELOW: every list position of this word lies below the last contributor of every pixel of the quadrant (the usual case:
+// pixels that never stopped early), so the per-lane position test drops out of the visit.
+template <bool HAS_DEPTH, bool CAPPED, bool DET, bool ALLBELOW>
 __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsigned long long cap, const int sbase,
                                              const char* sQ0, const char* sQ1, const char* sQ2, const float pixx,
                                              const float pixy, const int jthr, const float dLp0, const float dLp1,
@@ -661,7 +663,7 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
         // "power <= 0 and alpha >= 1/255" as one unsigned compare (see rdg_fwd_walk); "list position below the pixel's
         // last contributor" as a compare of the slot's bit index with a per-lane bound formed once per word
         const uint32_t key = (__float_as_uint(power) & 0x80000000u) | __float_as_uint(alpha);
-        const bool hit = (jb > jthr) && key >= RDG_THR_LIVE;
+        const bool hit = ALLBELOW ? key >= RDG_THR_LIVE : ((jb > jthr) && key >= RDG_THR_LIVE);
         if (!rdg_any(hit)) continue;
 #ifdef RDG_ABL_PREONLY   // ablation build: the walk + the blend test only
         if (G != 123.456f) continue;
@@ -852,14 +854,13 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
 #endif
             // list position of slot bit jb of this word: kbase - 64 s - jb; below last_contributor <=> jb > jthr
             const int jthr = kbase - s * 64 - last_contributor;
-            if (cap)
-                rdg_bwd_walk<HAS_DEPTH, true, DET>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
-                                                   pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, ring, flush_scale,
-                                                   flush_off, gdst, T, behind, ring_n);
-            else
-                rdg_bwd_walk<HAS_DEPTH, false, DET>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1, (const char*)sQ2,
-                                                    pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane, ring, flush_scale,
-                                                    flush_off, gdst, T, behind, ring_n);
+#define RDG_WALK(CAPPED, ALLB)                                                                                          \
+            rdg_bwd_walk<HAS_DEPTH, CAPPED, DET, ALLB>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1,          \
+                                                       (const char*)sQ2, pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane,   \
+                                                       ring, flush_scale, flush_off, gdst, T, behind, ring_n)
+            if (rdg_all(jthr < 0)) { if (cap) RDG_WALK(true, true); else RDG_WALK(false, true); }
+            else { if (cap) RDG_WALK(true, false); else RDG_WALK(false, false); }
+#undef RDG_WALK
         }
         __syncthreads();   // every wave is done with this round's staged records
     }
@@ -1020,7 +1021,7 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const int nblk = ((n_tiles + 7) / 8) * 8;
     const RdgSplitLayout SL = rdg_split_layout(capacity);
     const char* sp = b + B.split;
-    const int split_min = d.split_lists ? RDG_SPLIT_MIN : 0x7fffffff;
+    const int split_min = (d.list_hints & 1) ? RDG_SPLIT_MIN : 0x7fffffff;
     const unsigned gseg = SL.max_seg < 2048u ? SL.max_seg : 2048u;
 #define RDG_BWD_LAUNCH(DEPTH, DET, SEG, GRID, DST)                                                                 \
     hipLaunchKernelGGL((rdg_render_bwd_kernel<DEPTH, DET, SEG>), dim3(GRID), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg, \
@@ -1030,7 +1031,7 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
                        (const uint32_t*)(sp + SL.header), (const uint4*)(sp + SL.work), (const float*)(sp + SL.seg_pix))
     if (det) {
         if (g_depth) RDG_BWD_LAUNCH(true, true, false, nblk, det); else RDG_BWD_LAUNCH(false, true, false, nblk, det);
-        if (d.split_lists) {
+        if ((d.list_hints & 1)) {
             if (g_depth) RDG_BWD_LAUNCH(true, true, true, gseg, det); else RDG_BWD_LAUNCH(false, true, true, gseg, det);
         }
         if (d.P > 0)
@@ -1040,7 +1041,7 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
                                plist, (const float*)det, grow);
     } else {
         if (g_depth) RDG_BWD_LAUNCH(true, false, false, nblk, grow); else RDG_BWD_LAUNCH(false, false, false, nblk, grow);
-        if (d.split_lists) {
+        if ((d.list_hints & 1)) {
             if (g_depth) RDG_BWD_LAUNCH(true, false, true, gseg, grow); else RDG_BWD_LAUNCH(false, false, true, gseg, grow);
         }
     }

@@ -131,7 +131,7 @@ def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int) -> _lib.RdgRa
     s.render_normal = int(bool(RENDER_NORMAL))
     s.bin_mode = 0
     s.num_rendered_stats = 0
-    s.split_lists = 0
+    s.list_hints = 0
     return s
 
 
@@ -228,7 +228,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             cs.bin_mode = int(_BIN_HINT.get(key, 0))
             # deterministic mode: the choice must not depend on what the previous frame looked like (the split path
             # associates the transmittance product differently: same result to the last bits only)
-            cs.split_lists = 1 if DETERMINISTIC else int(_SPLIT_HINT.get(key, 0))
+            cs.list_hints = 1 if DETERMINISTIC else int(_SPLIT_HINT.get(key, 0))
             cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
             stream = _lib.stream_ptr()
             if GRAPH_CAPTURE and key not in _CAPACITY_HINT:

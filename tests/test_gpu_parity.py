@@ -2461,25 +2461,41 @@ def test_bin_mode_follows_the_largest_tile_of_the_previous_frame():
     ins = {k: sc[k].to(DEV) for k in NAMES}
     key = (P, H, W)
     rasterizer._BIN_HINT.pop(key, None)
+    rasterizer._SPLIT_HINT.pop(key, None)
+    # the 40 k list would also switch the COMPOSITING of the next frame to the split path (same image to the last bits
+    # only: test_split_compositing_of_long_tile_lists); held off here, this test is about the binning algorithm
+    monkey = rasterizer.SPLIT_ABOVE
+    rasterizer.SPLIT_ABOVE = 10 ** 9
 
     def fwd(src=ins):
         with torch.no_grad():
             return GaussianRasterizer(rs)(means3D=src["means3D"], means2D=torch.zeros(P, 3, device=DEV), shs=src["shs"],
                                           opacities=src["opacities"], scales=src["scales"], rotations=src["rotations"],
                                           viewmatrix=src["viewmatrix"])
-    a = fwd()                                   # bucket binning (multi-workgroup merge for the 40 k tile)
-    assert rasterizer._BIN_HINT.get(key) == 1
-    b = fwd()                                   # radix path, chosen by the hint
+    try:
+        a = fwd()                                   # bucket binning (multi-workgroup merge for the 40 k tile)
+        assert rasterizer._BIN_HINT.get(key) == 1 and key not in rasterizer._SPLIT_HINT
+        b = fwd()                                   # radix path, chosen by the hint
+        for i_ in (0, 1, 3):
+            assert torch.equal(a[i_], b[i_])
+        assert torch.equal(a[4], b[4])
+        # lists short again (opacity irrelevant: move the cluster behind the camera) -> back to bucket binning
+        far = dict(ins)
+        m3 = ins["means3D"].clone()
+        m3[:, 2] = torch.where(ins["opacities"][:, 0] < 0.035, -torch.ones_like(m3[:, 2]), m3[:, 2])
+        far["means3D"] = m3
+        fwd(far)
+        assert key not in rasterizer._BIN_HINT
+    finally:
+        rasterizer.SPLIT_ABOVE = monkey
+    # with the threshold back, the 40 k list switches the next frame's compositing to the split path
+    fwd()
+    assert rasterizer._SPLIT_HINT.get(key) == 1
+    c = fwd()
+    rasterizer._SPLIT_HINT.pop(key, None)
+    rasterizer._BIN_HINT.pop(key, None)
     for i_ in (0, 1, 3):
-        assert torch.equal(a[i_], b[i_])
-    assert torch.equal(a[4], b[4])
-    # lists short again (opacity irrelevant: move the cluster behind the camera) -> back to bucket binning
-    far = dict(ins)
-    m3 = ins["means3D"].clone()
-    m3[:, 2] = torch.where(ins["opacities"][:, 0] < 0.035, -torch.ones_like(m3[:, 2]), m3[:, 2])
-    far["means3D"] = m3
-    fwd(far)
-    assert key not in rasterizer._BIN_HINT
+        rel_ok(c[i_], a[i_], tol=2e-5, outliers=OUTLIER_FRAC, what="split path vs one workgroup per tile")
 
 
 def test_bench_runs_both_dp_formulations_the_way_the_driver_launches_it():
