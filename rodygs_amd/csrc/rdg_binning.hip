@@ -458,7 +458,12 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
     const uint32_t inc = rdg_wave_scan_incl(mine);
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
-    if (max_tile_out) atomicMax(&sMaxTile, big);
+    if (max_tile_out) {
+        // wave maximum first (1024 threads on one LDS atomic serialise)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o));
+        if (lane == 0) atomicMax(&sMaxTile, big);
+    }
     uint32_t run = inc - mine;
     for (uint32_t k = 0; k < w; ++k) run += wtot[k];
     uint32_t x2 = x_first, y2 = y_first;

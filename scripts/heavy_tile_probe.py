@@ -64,9 +64,40 @@ def main():
         _lib.timing_enable(False)
         return t, bool(rasterizer._BIN_HINT)
 
+    def timed_fwd_bwd(split: bool):
+        """forward + backward (photometric-style upstream gradient) with the long lists composited by one workgroup each
+        (split off) or by the split path (per-segment partial composites, several workgroups per list)"""
+        keep = rasterizer.SPLIT_ABOVE
+        rasterizer.SPLIT_ABOVE = keep if split else 10 ** 12
+        rasterizer._SPLIT_HINT.clear()
+        leaves = {k: ins[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        w = torch.rand(3, H, W, device=dev)
+
+        def step():
+            out = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=torch.zeros(P, 3, device=dev, requires_grad=True),
+                                         shs=leaves["shs"], opacities=leaves["opacities"], scales=leaves["scales"],
+                                         rotations=leaves["rotations"], viewmatrix=ins["viewmatrix"])
+            (out[0] * w).sum().backward()
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            _lib.timing_enable(True)
+            _lib.timing_reset()
+            for _ in range(args.reps):
+                step()
+            torch.cuda.synchronize()
+            t = {k: (ms / c if c else 0.0) for k, (ms, c) in _lib.stage_times().items()}
+            _lib.timing_enable(False)
+        finally:
+            rasterizer.SPLIT_ABOVE = keep
+            rasterizer._SPLIT_HINT.clear()
+        return {k: t[k] for k in ("render_fwd", "render_bwd")}
+
     default_above = rasterizer.BIN_RADIX_ABOVE
     st_b, _ = timed(1 << 40)              # hint disabled: bucket binning + merge tree on every frame
     st, radix_hint = timed(default_above)  # as shipped: the first frame's largest tile switches the next ones to radix
+    comp_split, comp_one = timed_fwd_bwd(True), timed_fwd_bwd(False)
     print(json.dumps({"workload": f"{P} Gaussians, {W}x{H}: one tile with {int(n[0])} instances, next {n[1:6].tolist()}",
                       "num_rendered_D": int(hs["D"]), "largest_tiles": n[:8].tolist(), "sorted_stream_bit_exact": exact,
                       "binning_ms": st["scan_dup"] + st["sort"] + st["ranges"],
@@ -74,6 +105,7 @@ def main():
                       "stage_ms": {k: st[k] for k in ("preprocess", "scan_dup", "sort", "ranges", "render_fwd")},
                       "bucket_only_binning_ms": st_b["scan_dup"] + st_b["sort"] + st_b["ranges"],
                       "bucket_only_stage_ms": {k: st_b[k] for k in ("scan_dup", "sort")},
+                      "compositing_ms_split_path": comp_split, "compositing_ms_one_workgroup_per_tile": comp_one,
                       "reps": args.reps, "bin_mode": os.environ.get("RDG_BIN_MODE", "bucket")}))
 
 

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Regenerates the measurement evidence under gpurun_out/prof_<tag>/ on the GPU box (copy what is to be judged into
-# profiles/): bench line, rocprofv3 kernel stats of the same command, one-step kernel timeline, PMC passes.
+# profiles/): bench line, rocprofv3 kernel stats of the same command, one-step kernel timeline, PMC passes, the two
+# extra scenes, the launch-bound regime with and without the captured graph, the long-list probe.
 #   usage: scripts/refresh_profiles.sh <tag>
 set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=$PWD
-T=${1:-r02}
+T=${1:-r03}
 O=$R/gpurun_out/prof_$T
 mkdir -p $O
 python3 bench.py > $O/${T}_bench.json 2> $O/bench.err
@@ -17,11 +18,23 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
 python3 scripts/pmc_hbm_traffic.py $O/pmc_fetch $O/pmc_write $O/${T}_pmc_hbm_traffic.json 1000000 1920 1080 > $O/pmc_traffic.txt 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_sq.err
-python3 scripts/pmc_summary.py $O/pmc_sq $O/${T}_pmc_sq_counters.json > /dev/null 2>&1
+python3 scripts/pmc_summary.py $O/pmc_sq $O/${T}_pmc_sq_counters.json 1000000 1920 1080 > /dev/null 2>&1
+# the two scenes the survey's generator never enters (not the headline): bench line + kernel table each
+for SC in sheets dense; do
+  python3 bench.py --scene $SC --no-cpu-baseline > $O/${T}_scene_${SC}_bench.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$SC -- python3 bench.py --scene $SC --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/kt_$SC.err
+  cp $(find $O/kt_$SC -name "*kernel_stats.csv" | head -1) $O/${T}_scene_${SC}_kernel_stats.csv
+  rm -rf $O/kt_$SC
+done
+# launch-bound regime (the reference's real clouds are ~100 k points): eager vs one captured graph per step
 python3 bench.py --points 100000 --no-cpu-baseline > $O/${T}_photometric_100k_bench.json 2>/dev/null
+python3 bench.py --points 100000 --no-cpu-baseline --graph > $O/${T}_photometric_100k_graph_bench.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --graph > $O/${T}_graph_bench.json 2>/dev/null
 python3 bench.py --points 4000000 --width 3840 --height 2160 --steps 10 --warmup 5 --gt-frames 4 --no-cpu-baseline > $O/${T}_photometric_4m_4k_bench.json 2>/dev/null
 python3 bench.py --full-losses --no-cpu-baseline > $O/${T}_full_losses_bench.json 2>/dev/null
 python3 bench.py --full-losses --points 4000000 --width 3840 --height 2160 --steps 10 --warmup 5 --gt-frames 4 --no-cpu-baseline > $O/${T}_full_losses_4m_4k_bench.json 2>/dev/null
+RDG_DETERMINISTIC=1 python3 bench.py --no-cpu-baseline > $O/${T}_deterministic_bench.json 2>/dev/null
+python3 scripts/heavy_tile_probe.py > $O/${T}_heavy_tile.json 2> $O/heavy.err
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
 tail -c 300 $O/${T}_bench.json
