@@ -74,6 +74,24 @@ def workload_label(P, W, H, frames, full_losses, world, variant="uniform"):
     return base + " (not a BASELINE config)"
 
 
+def wire_bytes(P, K, world, sharded, frames=100, mlp_params=68656):
+    """Payload each GPU puts on the wire per step (what the collectives are asked to move, before the algorithm's own
+    factor: a ring all-reduce sends 2 (N - 1) / N of its payload per GPU, an all-to-all (N - 1) / N):
+      allreduce: the flat gradient bucket of the replicated cloud -- (11 + 3 K + 16) floats per Gaussian -- plus the MLP
+                 and camera-pose bucket;
+      shard:     two all-to-alls of 64-byte rows (splat records out, gradient rows back) over the P / N Gaussians a rank
+                 owns x N cameras, plus the all-reduce of the MLP + pose bucket."""
+    small = (mlp_params + frames * 7) * 4
+    if not sharded:
+        payload = P * (11 + 3 * K + 16) * 4 + small
+        return {"all_reduce_payload_bytes": payload, "ring_bytes_sent_per_gpu": int(payload * 2 * (world - 1) / world)}
+    per = -(-P // world)
+    stride = (per + 255) // 256 * 256
+    a2a = stride * world * 64                       # one all-to-all's send buffer on a rank (all cameras of its slice)
+    return {"all_to_all_payload_bytes": 2 * a2a, "all_to_all_bytes_sent_per_gpu": int(2 * a2a * (world - 1) / world),
+            "all_reduce_payload_bytes": small}
+
+
 def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=False, radix_binning=False):
     """ALGORITHMIC HBM bytes per stage and step (SURVEY.md §8d formulas, adjusted to the algorithm that actually runs
     -- DESIGN.md §4 'Roofline accounting'):
@@ -497,7 +515,14 @@ def main():
             # every formulation that was timed (each EXACTLY --steps steps between barriers, max over ranks)
             res["dp_modes"] = {r["mode"] + ("" if r["sharded"] == (r["mode"] == "shard") else " (fell back to replicated)"):
                                {"value": args.steps * world / r["dt"], "unit": "frames/s",
-                                "ms_per_step": r["dt"] / args.steps * 1e3} for r in runs}
+                                "ms_per_step": r["dt"] / args.steps * 1e3,
+                                "wire": wire_bytes(P, 16, world, r["sharded"], args.frames)} for r in runs}
+            # what the process group really is (the first hardware run of N > 1 should explain itself)
+            res["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                    "rccl": (".".join(str(v) for v in torch.cuda.nccl.version())
+                                             if dist.get_backend() == "nccl" else None),
+                                    "devices_visible": torch.cuda.device_count(),
+                                    "one_device": bool(os.environ.get("RDG_ONE_DEVICE"))}
         if not args.no_cpu_baseline and world == 1:      # contract: the CPU leg runs at N = 1 only
             try:
                 res["cpu_baseline"] = cpu_baseline(scene, 3, budget_s=args.cpu_budget, threads=args.cpu_threads)

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -92,6 +93,30 @@ static int rdg_check_inputs(const RdgRasterSettings* s, const float* shs, const 
         return rdg_set_error("shs holds %d coefficients, sh_degree %d needs %d", s->M, s->sh_degree,
                              (s->sh_degree + 1) * (s->sh_degree + 1));
     return 0;
+}
+
+// Zero fill as a KERNEL, never hipMemsetAsync: a memset node inside a captured hipGraph was not ordered against the kernel
+// nodes next to it on this ROCm (the backward's gradient rows were only sometimes zero when the graph replayed: different
+// trajectories from run to run, NaN after another process had left other data in the memory; found with
+// torch.utils.deterministic.fill_uninitialized_memory, scripts/dbg_fill.py).  Same cost: the runtime's own memset is a
+// fill kernel too.
+__global__ void __launch_bounds__(256) rdg_zero16_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+__global__ void __launch_bounds__(256) rdg_zero4_kernel(uint32_t* __restrict__ p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+hipError_t rdg_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (((bytes | (uintptr_t)p) & 3) != 0) return hipMemsetAsync(p, 0, bytes, st);   // no caller does this
+    const bool wide = ((bytes | (uintptr_t)p) & 15) == 0;
+    const size_t n = wide ? bytes / 16 : bytes / 4;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (wide) hipLaunchKernelGGL(rdg_zero16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n);
+    else hipLaunchKernelGGL(rdg_zero4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n);
+    return hipGetLastError();
 }
 
 extern "C" {
@@ -193,7 +218,7 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
     float* grow = (float*)grad_ws;
     const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
     rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
-    hipError_t e = hipMemsetAsync(grow, 0, grow_bytes, st);
+    hipError_t e = rdg_zero_async(grow, grow_bytes, st);
     if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
                                    grad_out_alpha, grow, st);
@@ -218,7 +243,7 @@ int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg,
     rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
     // rows of positions no wave visits stay zero; the gradient rows themselves are written (not accumulated) by the
     // reduction, every one of them
-    hipError_t e = hipMemsetAsync(det_ws, 0, rdg_det_bytes(n_instances), st);
+    hipError_t e = rdg_zero_async(det_ws, rdg_det_bytes(n_instances), st);
     if (e != hipSuccess) return rdg_check_hip(e, "det row memset");
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
                                    grad_out_alpha, (float*)grad_ws, st, (float*)det_ws);

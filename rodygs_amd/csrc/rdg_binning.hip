@@ -1051,7 +1051,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         int zbits = 0;
         while (((size_t)1 << zbits) < rdg_cnt_entries(d.gx, d.gy)) ++zbits;
         if (!d.tile_cnt_zeroed) {
-            hipError_t em = hipMemsetAsync(tile_cnt, 0, rdg_cnt_entries(d.gx, d.gy) * 4, s);
+            hipError_t em = rdg_zero_async(tile_cnt, rdg_cnt_entries(d.gx, d.gy) * 4, s);
             if (em != hipSuccess) return rdg_check_hip(em, "tile_cnt memset");
         }
         if (d.P > 0)
@@ -1075,7 +1075,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                                (long long)capacity, num_rendered, (uint4*)(b + B.hit),
                                (long long)(rdg_hit_bytes(capacity, n_tiles) / 16));
         else {
-            hipError_t eh = hipMemsetAsync(b + B.hit, 0, rdg_hit_bytes(capacity, n_tiles), s);
+            hipError_t eh = rdg_zero_async(b + B.hit, rdg_hit_bytes(capacity, n_tiles), s);
             if (eh != hipSuccess) return rdg_check_hip(eh, "hit bits memset");
         }
         rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
@@ -1092,7 +1092,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     }
 
     {
-        hipError_t eh = hipMemsetAsync(b + B.hit, 0, rdg_hit_bytes(capacity, n_tiles), s);
+        hipError_t eh = rdg_zero_async(b + B.hit, rdg_hit_bytes(capacity, n_tiles), s);
         if (eh != hipSuccess) return rdg_check_hip(eh, "hit bits memset");
     }
     rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
@@ -1114,7 +1114,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     rdg_stage_end(RDG_STAGE_SORT, s);
     if (rc) return rc;
     rdg_stage_begin(RDG_STAGE_RANGES, s);
-    hipError_t e = hipMemsetAsync(ranges, 0, (size_t)n_tiles * sizeof(uint2), s);
+    hipError_t e = rdg_zero_async(ranges, (size_t)n_tiles * sizeof(uint2), s);
     if (e != hipSuccess) return rdg_check_hip(e, "ranges memset");
     hipLaunchKernelGGL(rdg_tile_ranges_kernel, dim3(2048), dim3(256), 0, s, in_b ? keys_b : keys_a,
                        (long long)capacity, num_rendered, ranges);

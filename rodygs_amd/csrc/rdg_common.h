@@ -228,6 +228,8 @@ struct RdgDev {
 // ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------
 int rdg_set_error(const char* fmt, ...);
 int rdg_check_hip(hipError_t e, const char* what);
+// zero `bytes` at `p` on stream `st` with a kernel (not a memset node: see rdg_api.hip)
+hipError_t rdg_zero_async(void* p, size_t bytes, hipStream_t st);
 void rdg_stage_begin(int stage, hipStream_t s);
 void rdg_stage_end(int stage, hipStream_t s);
 

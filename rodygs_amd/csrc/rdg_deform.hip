@@ -915,8 +915,8 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
     hipStream_t st = (hipStream_t)stream;
     const int row = B * RDG_DEF_K;
     rdg_stage_begin(RDG_STAGE_DEFORM_BWD, st);
-    hipError_t e = hipMemsetAsync(d_basis_t, 0, (size_t)row * 4, st);
-    if (e == hipSuccess && table && d_table) e = hipMemsetAsync(d_table, 0, (size_t)Tu * row * 4, st);
+    hipError_t e = rdg_zero_async(d_basis_t, (size_t)row * 4, st);
+    if (e == hipSuccess && table && d_table) e = rdg_zero_async(d_table, (size_t)Tu * row * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "deform_bwd memset");
     if (P > 0) {
         const int Tu_eff = table ? Tu : 1;
@@ -958,7 +958,7 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
                                     ? (uint32_t*)((char*)sorted_ws + rdg_deform_gs_bytes(P)) : nullptr;
             float* part = counter ? (float*)((char*)counter + 256) : nullptr;
             if (counter) {
-                hipError_t ec = hipMemsetAsync(counter, 0, 8, st);
+                hipError_t ec = rdg_zero_async(counter, 8, st);
                 if (ec != hipSuccess) return rdg_check_hip(ec, "deform_bwd counter memset");
             }
             hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(table ? RDG_DEF_ACC_BLOCKS : 64), dim3(256), 0, st, P,
@@ -1016,7 +1016,7 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
     float* d_basis_t = d_bases + (size_t)Tu * 112;
     rdg_stage_begin(RDG_STAGE_DEFORM_BWD, st);
     if (P <= 0) {
-        hipError_t e = hipMemsetAsync(d_bases, 0, (size_t)(Tu + 1) * 112 * 4, st);
+        hipError_t e = rdg_zero_async(d_bases, (size_t)(Tu + 1) * 112 * 4, st);
         if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_bwd memset");
     }
     if (P > 0) {
@@ -1082,7 +1082,7 @@ int rdg_dyn_getter_views_backward(int32_t P, int32_t Tu, int32_t nviews, int32_t
         return rdg_set_error("dyn_getter_views: 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
     rdg_stage_begin(RDG_STAGE_DEFORM_BWD, st);
-    hipError_t e = hipMemsetAsync(d_bases_all, 0, (size_t)nviews * (Tu + 1) * 112 * 4, st);
+    hipError_t e = rdg_zero_async(d_bases_all, (size_t)nviews * (Tu + 1) * 112 * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "dyn_getter_views_bwd memset");
     if (P > 0) {
         int nb = (P + 511) / 512;

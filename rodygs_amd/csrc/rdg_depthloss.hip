@@ -120,12 +120,12 @@ int rdg_pearson_depth_forward(int32_t H, int32_t W, int32_t n_boxes, int32_t bh,
     if (rdg_pearson_check(H, W, n_boxes, bh, bw)) return -1;
     hipStream_t st = (hipStream_t)stream;
     if (n_boxes == 0) {
-        hipError_t e = hipMemsetAsync(loss_out, 0, 4, st);
+        hipError_t e = rdg_zero_async(loss_out, 4, st);
         return rdg_check_hip(e, "pearson memset");
     }
     double* stats = (double*)ws;
     float4* coef = (float4*)((char*)ws + rdg_align_up((size_t)n_boxes * RDG_PD_NSTAT * sizeof(double), 256));
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)n_boxes * RDG_PD_NSTAT * sizeof(double), st);
+    hipError_t e = rdg_zero_async(stats, (size_t)n_boxes * RDG_PD_NSTAT * sizeof(double), st);
     if (e != hipSuccess) return rdg_check_hip(e, "pearson memset");
     const int chunks = (bh * bw + RDG_PD_CHUNK - 1) / RDG_PD_CHUNK;
     hipLaunchKernelGGL(rdg_pearson_stats_kernel, dim3(n_boxes, chunks), dim3(256), 0, st, H, W, bh, bw, row0, col0, pred,
@@ -140,7 +140,7 @@ int rdg_pearson_depth_backward(int32_t H, int32_t W, int32_t n_boxes, int32_t bh
                                const void* ws, const float* g_loss, float* d_pred, void* stream) {
     if (rdg_pearson_check(H, W, n_boxes, bh, bw)) return -1;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(d_pred, 0, (size_t)H * W * 4, st);
+    hipError_t e = rdg_zero_async(d_pred, (size_t)H * W * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "pearson bwd memset");
     if (n_boxes == 0) return 0;
     const float4* coef = (const float4*)((const char*)ws + rdg_align_up((size_t)n_boxes * RDG_PD_NSTAT * sizeof(double), 256));

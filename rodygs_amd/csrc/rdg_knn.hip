@@ -461,8 +461,8 @@ int rdg_knn_points_backward(int32_t Pq, int32_t Pt, int32_t K, const float* quer
     if (Pq <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipSuccess;
-    if (d_queries) e = hipMemsetAsync(d_queries, 0, (size_t)Pq * 12, st);
-    if (e == hipSuccess && d_targets && d_targets != d_queries) e = hipMemsetAsync(d_targets, 0, (size_t)Pt * 12, st);
+    if (d_queries) e = rdg_zero_async(d_queries, (size_t)Pq * 12, st);
+    if (e == hipSuccess && d_targets && d_targets != d_queries) e = rdg_zero_async(d_targets, (size_t)Pt * 12, st);
     if (e != hipSuccess) return rdg_check_hip(e, "knn_points_bwd memset");
     hipLaunchKernelGGL(rdg_knn_points_bwd_kernel, dim3((Pq + 255) / 256), dim3(256), 0, st, Pq, K, queries, targets,
                        (const long long*)idx, g_dists, d_queries, d_targets);
@@ -481,7 +481,7 @@ int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const
                             void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (n_src_rows > 0 && U > 0) {
-        hipError_t e = hipMemsetAsync(d_x, 0, (size_t)n_src_rows * U * 4, st);
+        hipError_t e = rdg_zero_async(d_x, (size_t)n_src_rows * U * 4, st);
         if (e != hipSuccess) return rdg_check_hip(e, "knn_gather_bwd memset");
     }
     if (n_rows <= 0 || U <= 0) return 0;
@@ -576,8 +576,8 @@ extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const f
     if (n <= 0 || K <= 0 || nt <= 0) return rdg_set_error("rigidity_dp: bad sizes");
     if ((((uintptr_t)pos_t4) | ((uintptr_t)G_t4)) & 15) return rdg_set_error("rigidity_dp: buffers must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(loss_sum, 0, 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_d2, 0, (size_t)n * K * 4, st);
+    hipError_t e = rdg_zero_async(loss_sum, 8, st);
+    if (e == hipSuccess) e = rdg_zero_async(d_d2, (size_t)n * K * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "rigidity_dp memset");
     const long long total = n * nt;
     if (K == 8)

@@ -220,8 +220,8 @@ int rdg_activate_backward(int32_t P, int32_t K, const float* scaling, const floa
     } else if (g_shs) {
         hipLaunchKernelGGL(rdg_sh_split_kernel, dim3(4096), dim3(256), 0, st, n, K * 3, g_shs, d_fdc, d_frest);
     } else {
-        hipError_t e = hipMemsetAsync(d_fdc, 0, (size_t)P * 3 * 4, st);
-        if (e == hipSuccess && K > 1) e = hipMemsetAsync(d_frest, 0, (size_t)P * (K - 1) * 3 * 4, st);
+        hipError_t e = rdg_zero_async(d_fdc, (size_t)P * 3 * 4, st);
+        if (e == hipSuccess && K > 1) e = rdg_zero_async(d_frest, (size_t)P * (K - 1) * 3 * 4, st);
         if (e != hipSuccess) return rdg_check_hip(e, "activate_bwd memset");
     }
     return rdg_check_hip(hipGetLastError(), "activate_bwd launch");

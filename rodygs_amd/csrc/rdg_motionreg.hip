@@ -80,7 +80,7 @@ int rdg_motion_reg_forward(int64_t P, int32_t B, const float* coeff, double* sum
     if (B != RDG_MR_B) return rdg_set_error("motion_reg: B must be %d", RDG_MR_B);
     if (((uintptr_t)coeff) & 15) return rdg_set_error("motion_reg: 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums2, 0, 2 * sizeof(double), st);
+    hipError_t e = rdg_zero_async(sums2, 2 * sizeof(double), st);
     if (e != hipSuccess) return rdg_check_hip(e, "motion_reg memset");
     if (P <= 0) return 0;
     long long nb = (P + 255) / 256;
@@ -237,9 +237,9 @@ int rdg_basis_reg(int32_t Tu, int32_t B, int32_t transl_degree, int32_t rot_degr
     const int n = Tu * RDG_MR_B;
     float* R_ws = (float*)ws;
     float* dR_ws = R_ws + (size_t)n * 9;
-    hipError_t e = hipMemsetAsync(dR_ws, 0, (size_t)n * 9 * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_table, 0, (size_t)n * 7 * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(loss, 0, sizeof(double), st);
+    hipError_t e = rdg_zero_async(dR_ws, (size_t)n * 9 * 4, st);
+    if (e == hipSuccess) e = rdg_zero_async(d_table, (size_t)n * 7 * 4, st);
+    if (e == hipSuccess) e = rdg_zero_async(loss, sizeof(double), st);
     if (e != hipSuccess) return rdg_check_hip(e, "basis_reg memset");
     hipLaunchKernelGGL(rdg_basis_R_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, table, R_ws);
     int nb = (n + 255) / 256;

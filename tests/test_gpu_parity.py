@@ -1332,6 +1332,50 @@ def test_graph_replay_of_the_train_step_is_bit_identical_to_the_eager_step():
     assert torch.isfinite(b.train_step(n, perm=perm))
 
 
+def test_train_step_and_graph_replay_with_nan_filled_workspaces():
+    """Every ``torch.empty`` filled with NaN / 0xFF (torch.utils.deterministic.fill_uninitialized_memory): a kernel that
+    reads a workspace before writing it, or a zero-fill that does not happen where the stream order says, turns the step
+    into NaN.  (How the memset nodes of a captured hipGraph were caught racing the kernels next to them: the library
+    zero-fills with its own kernel since.)  Eager photometric and full-loss steps stay finite; the float-atomic graph
+    replay follows the eager twin step by step."""
+    import torch.utils.deterministic as TD
+    from rodygs_amd.trainstep import DynamicScene, GraphedStep
+    prev = (torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled(),
+            TD.fill_uninitialized_memory)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    TD.fill_uninitialized_memory = True
+    try:
+        sc = O.synthetic_scene(30000, 640, 360, 3, seed=5)
+        tgt = O.synthetic_scene(8000, 640, 360, 3, seed=6)
+        perm = [0, 3, 5, 6, 1, 7]
+
+        def fresh(**kw):
+            ds = DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True, **kw)
+            ds.make_ground_truth(tgt, range(8))
+            return ds
+
+        def finite(ds):
+            torch.cuda.synchronize()
+            return all(bool(torch.isfinite(f[k]).all()) and bool(torch.isfinite(f[k].grad).all())
+                       for f in (ds.fp, ds.sp) for k in f.names)
+
+        a = fresh()
+        la = [float(a.train_step(s_, perm=perm)) for s_ in range(14)]
+        assert finite(a) and all(np.isfinite(la))
+        b = fresh()
+        gs = GraphedStep(b, perm, warmup=2)
+        lb = [float(gs.step()) for _ in range(12)]
+        assert finite(b) and gs.check() > 0
+        gs.close()
+        assert np.allclose(lb, la[2:], rtol=2e-3, atol=0), (la[2:], lb)       # float atomics: same curve, not the same bits
+        c = fresh(full_losses=True)
+        lc = [float(c.train_step(s_, perm=perm)) for s_ in range(6)]          # step 0 and 5 are rigidity steps
+        assert finite(c) and all(np.isfinite(lc))
+    finally:
+        torch.use_deterministic_algorithms(prev[0], warn_only=prev[1])
+        TD.fill_uninitialized_memory = prev[2]
+
+
 def test_full_loss_train_step_runs_and_reduces_loss():
     """Config-5 loss set in the loop: photometric + Pearson depth (global + local) + motion regularisers + rigidity on
     the HIP K-NN every 5th step; gradients of several losses accumulate into the same flat segments."""
