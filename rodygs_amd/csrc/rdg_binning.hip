@@ -419,20 +419,20 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
                      uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered,
                      uint32_t* __restrict__ hv_header, RdgHeavyDesc* __restrict__ hv_desc, uint2* __restrict__ hv_work,
                      uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_chunks, uint32_t max_work,
-                     int32_t* __restrict__ max_tile_out) {
+                     int32_t* __restrict__ max_tile_out, uint2* __restrict__ hv_chunk_work, uint32_t max_chunk_items) {
     if ((long long)(*num_rendered) > capacity) {
         if (threadIdx.x == 0 && max_tile_out) *max_tile_out = 0;
         // capacity overflow: leave EVERY tile empty, so the compositing kernels (forward and backward) see a valid,
         // empty scene (background image, zero gradients) instead of stale ranges; the host detects D > capacity
         for (int i = threadIdx.x; i < n_tiles; i += 1024) { ranges[i] = make_uint2(0u, 0u); tile_fill[i] = 0u; }
-        if (threadIdx.x == 0) { hv_header[0] = 0u; hv_header[1] = 0u; }
+        if (threadIdx.x == 0) { hv_header[0] = 0u; hv_header[1] = 0u; hv_header[2] = 0u; }
         return;
     }
     // every thread owns a run of consecutive tiles (local sums), ONE block-level scan of the 1024 run totals, then the
     // runs are written out: two barriers in all instead of two per 1024 tiles
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t sHeavy, sWork, sChunks, sMaxTile;
-    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; sChunks = 0u; sMaxTile = 0u; }
+    __shared__ uint32_t sHeavy, sWork, sChunks, sMaxTile, sChunkItems;
+    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; sChunks = 0u; sMaxTile = 0u; sChunkItems = 0u; }
     for (uint32_t i = threadIdx.x; i < 2u * max_chunks; i += 1024) hv_nodes[i] = 0u;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int per = (n_tiles + 1023) / 1024;
@@ -497,10 +497,13 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
             const uint32_t wb = atomicAdd(&sWork, 1u);
             if (wb < max_work) hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0xffffffffu);
         } else if (v > RDG_TSORT_SMALL) {
+            // chunk items for the waves of the register-block sort, ONE merge item for the workgroup kernel after it
             const uint32_t nch = (v + RDG_TSORT_SMALL - 1) / RDG_TSORT_SMALL;
-            const uint32_t wb = atomicAdd(&sWork, nch);
-            if (wb + nch <= max_work)
-                for (uint32_t c = 0; c < nch; ++c) hv_work[wb + c] = make_uint2(0x80000000u | (uint32_t)i, c);
+            const uint32_t cb = atomicAdd(&sChunkItems, nch), wb = atomicAdd(&sWork, 1u);
+            if (cb + nch <= max_chunk_items && wb < max_work) {
+                for (uint32_t c = 0; c < nch; ++c) hv_chunk_work[cb + c] = make_uint2((uint32_t)i, c);
+                hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0u);
+            }
         }
         run += v;
       }
@@ -508,6 +511,7 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
     __syncthreads();
     if (threadIdx.x == 0) {
         hv_header[0] = min(sWork, max_work); hv_header[1] = min(sHeavy, max_heavy);
+        hv_header[2] = min(sChunkItems, max_chunk_items);
         if (max_tile_out) *max_tile_out = (int32_t)sMaxTile;
     }
 }
@@ -751,11 +755,10 @@ rdg_tile_sort_lanes_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64
         if (n != 0 && n <= RDG_TSORT_SMALL)
             rdg_tile_sort_lanes_n<false>(comp + rg.x, n, rg.x, (uint32_t)tile, a, lane, vals_out, keys_full_out);
     }
-    const uint32_t n_work = hv_header[0];
+    const uint32_t n_work = hv_header[2];
     for (uint32_t wi = blockIdx.x * 4 + wv; wi < n_work; wi += gridDim.x * 4) {
-        const uint2 item = hv_work[wi];
-        if (!(item.x & 0x80000000u) || item.y == 0xffffffffu) continue;
-        const uint2 rg = ranges[item.x & 0x7fffffffu];
+        const uint2 item = hv_work[wi];           // (tile, chunk)
+        const uint2 rg = ranges[item.x];
         const uint32_t lo = item.y * RDG_TSORT_SMALL;
         const uint32_t nc = min((uint32_t)RDG_TSORT_SMALL, rg.y - rg.x - lo);
         rdg_tile_sort_lanes_n<true>(comp + rg.x + lo, nc, 0u, 0u, a, lane, nullptr, nullptr);
@@ -919,6 +922,9 @@ __device__ __forceinline__ void rdg_tile_merge_chunks(const uint64_t* __restrict
                                                       uint32_t tile, uint64_t* sK, uint32_t tid,
                                                       uint32_t* __restrict__ vals_out,
                                                       uint64_t* __restrict__ keys_full_out) {
+    // (A merge by RANK -- every element binary-searches the other run, 16 searches side by side per thread -- was built
+    // and measured: 426 us on the dense scene against 162 us for this merge path; its 12 x 16 random 8-byte LDS reads per
+    // thread and level cost more than the dependent chain they replace.)
     uint64_t* src = sK;
     uint64_t* dst = sK + RDG_TSORT_MID;
     for (uint32_t i = tid; i < n; i += 256) src[i] = g[i];
@@ -931,16 +937,19 @@ __device__ __forceinline__ void rdg_tile_merge_chunks(const uint64_t* __restrict
             uint32_t base = d0 / (2 * len) * (2 * len);
             uint32_t nA = min(len, n - base), nB = min(len, n - base - nA);
             uint32_t i = rdg_merge_path(src + base, nA, src + base + nA, nB, d0 - base), j = d0 - base - i;
+            // the heads of the two runs stay in registers: one LDS read per output (the consumed side's next element)
+            uint64_t x = i < nA ? src[base + i] : ~0ull, y = j < nB ? src[base + nA + j] : ~0ull;
             for (uint32_t d = d0; d < d1; ++d) {
                 if (d - base == nA + nB) {        // next pair
                     base += 2 * len;
                     nA = min(len, n - base); nB = min(len, n - base - nA);
                     i = 0; j = 0;
+                    x = nA ? src[base] : ~0ull; y = nB ? src[base + nA] : ~0ull;
                 }
-                const uint64_t x = i < nA ? src[base + i] : ~0ull, y = j < nB ? src[base + nA + j] : ~0ull;
                 const bool ta = x < y;
                 dst[d] = ta ? x : y;
-                i += ta ? 1u : 0u; j += ta ? 0u : 1u;
+                if (ta) { ++i; x = i < nA ? src[base + i] : ~0ull; }
+                else { ++j; y = j < nB ? src[base + nA + j] : ~0ull; }
             }
         }
         __syncthreads();
@@ -976,8 +985,8 @@ rdg_tile_sort_large_kernel(const uint2* __restrict__ ranges, uint64_t* __restric
             const uint2 rg = ranges[tile];
             const uint32_t n = rg.y - rg.x;
             if (item.y != 0xffffffffu) {
-                // chunk item of a mid list: the workgroup that holds chunk 0 merges the tile's sorted chunks
-                if (item.y == 0u) rdg_tile_merge_chunks(comp + rg.x, n, rg.x, tile, sK, tid, vals_out, keys_full_out);
+                // a mid list whose chunks the launch before has sorted: merge them
+                rdg_tile_merge_chunks(comp + rg.x, n, rg.x, tile, sK, tid, vals_out, keys_full_out);
                 continue;
             }
             uint32_t N2 = 2;
@@ -1067,7 +1076,8 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         uint32_t* hv_nodes = (uint32_t*)(hv + HL.nodes);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered, hv_header, hv_desc, hv_work, hv_nodes, HL.max_heavy,
-                           HL.max_chunks, HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr);
+                           HL.max_chunks, HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr,
+                           (uint2*)(hv + HL.chunks), HL.max_chunk_items);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
@@ -1082,7 +1092,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         rdg_stage_begin(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
         hipLaunchKernelGGL(rdg_tile_sort_lanes_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, n_tiles, ranges, comp,
-                           vals_out, kfull, (long long)capacity, num_rendered, hv_header, hv_work);
+                           vals_out, kfull, (long long)capacity, num_rendered, hv_header, (const uint2*)(hv + HL.chunks));
         // lists above 1024 instances: a fixed grid walks the device-side work list (empty on an ordinary frame)
         hipLaunchKernelGGL(rdg_tile_sort_large_kernel, dim3(HL.max_work < 1024u ? HL.max_work : 1024u), dim3(256), 0, s,
                            ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header, hv_desc,

@@ -92,26 +92,29 @@ struct RdgHeavyDesc { uint32_t start, n, nchunks, node_base, tile, pad0, pad1, p
 struct RdgHeavyLayout {
     size_t header;   // uint32[64]: [0] = number of work items, [1] = number of heavy tiles
     size_t desc;     // RdgHeavyDesc[max_heavy]
-    size_t work;     // uint2[max_work]: (heavy tile index, chunk index); (0x80000000 | tile, c) = chunk c of 1024 instances
-                     //                  of a tile of RDG_TSORT_SMALL + 1 .. RDG_TSORT_MID instances (a wave sorts the
-                     //                  chunk, the workgroup that takes item c = 0 merges the chunks in LDS);
-                     //                  (0x80000000 | tile, 0xffffffff) = a tile of RDG_TSORT_MID + 1 .. RDG_TSORT_LDS
-                     //                  instances (one workgroup sorts it in LDS)
+    size_t work;     // uint2[max_work]: items of rdg_tile_sort_large_kernel: (heavy tile index, chunk index);
+                     //                  (0x80000000 | tile, 0) = a tile of RDG_TSORT_SMALL + 1 .. RDG_TSORT_MID instances whose
+                     //                  1024-instance chunks are sorted: merge them in LDS; (0x80000000 | tile, 0xffffffff) =
+                     //                  a tile of RDG_TSORT_MID + 1 .. RDG_TSORT_LDS instances (one workgroup sorts it in LDS)
+    size_t chunks;   // uint2[max_chunk_items]: (tile, c) = chunk c of 1024 instances of a mid tile, sorted in place by a
+                     //                  wave of rdg_tile_sort_lanes_kernel (header[2] = their number)
     size_t nodes;    // uint32[2 * max_chunks]  arrival counters of the merge-tree nodes
     size_t total;
-    uint32_t max_heavy, max_chunks, max_work;
+    uint32_t max_heavy, max_chunks, max_work, max_chunk_items;
 };
 static inline RdgHeavyLayout rdg_heavy_layout(int64_t capacity) {
     RdgHeavyLayout L;
     const size_t cap = (size_t)(capacity > 0 ? capacity : 1);
     L.max_heavy = (uint32_t)(cap / RDG_TSORT_LDS + 1);
     L.max_chunks = 2 * L.max_heavy;
+    L.max_work = L.max_chunks + (uint32_t)(cap / RDG_TSORT_SMALL + 1);
     // chunk items of the mid tiles: every chunk but a tile's last is full, and a mid tile has > RDG_TSORT_SMALL instances
-    L.max_work = L.max_chunks + 2u * (uint32_t)(cap / RDG_TSORT_SMALL + 1);
+    L.max_chunk_items = 2u * (uint32_t)(cap / RDG_TSORT_SMALL + 1);
     size_t o = 0;
     L.header = o;  o = rdg_align_up(o + 256, 256);
     L.desc = o;    o = rdg_align_up(o + (size_t)L.max_heavy * sizeof(RdgHeavyDesc), 256);
     L.work = o;    o = rdg_align_up(o + (size_t)L.max_work * 8, 256);
+    L.chunks = o;  o = rdg_align_up(o + (size_t)L.max_chunk_items * 8, 256);
     L.nodes = o;   o = rdg_align_up(o + (size_t)L.max_chunks * 2 * 4, 256);
     L.total = o;
     return L;
