@@ -325,12 +325,17 @@ def test_eval_pose_helpers_against_reference_golden():
     assert torch.allclose(cam.world_view_transform.detach(), torch.from_numpy(g["cam_w2c"]), atol=1e-6)
 
 
+def bench_metric(P, W, H):
+    import bench
+    return bench.metric_label(P, W, H)
+
+
 def test_committed_bench_line_honours_the_contract():
     """The bench line committed under profiles/ (printed by `python bench.py` on the GPU box) carries every field of
     the measurement contract: the driver's keys, `roofline` for the dominant kernel and `cpu_baseline`; no stage is
     credited with more bytes than 8 TB/s could move in its time; the workload label is derived, not hard-coded."""
     import json
-    d = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r03_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -340,6 +345,10 @@ def test_committed_bench_line_honours_the_contract():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and (r["traffic"] is None or r["traffic"] > 0)
+    assert isinstance(r["traffic_source"], str) and r["second_roofline"]["bound"] == "valu_issue"
+    assert d["metric"] == bench_metric(d["config"]["points"], d["config"]["width"], d["config"]["height"])
+    for k in ("deferred_overflow_check", "one_device", "graph_replay", "deterministic_backward", "scene"):
+        assert k in d["config"], k
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert "no extrapolation" in c["sample"] and c["c2_full"]["value"] > 0 and len(c["c2_full"]["runs_s"]) == 3
