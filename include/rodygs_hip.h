@@ -116,7 +116,10 @@ int rdg_rasterize_forward(const RdgRasterSettings* s_host, const float* bg, cons
 
 /* Backward.  grad_out_* may be NULL (treated as zero).  All dL_* outputs must be zero-initialised by the
  * caller EXCEPT none: the library zeroes what it accumulates into.  dL_dmeans2D is [P,3] (z unused = 0),
- * dL_dviewmatrix is [16] in the same glm storage as viewmatrix.  grad_ws: rdg_grad_bytes(P) scratch.        */
+ * dL_dviewmatrix is [16] in the same glm storage as viewmatrix.  grad_ws: rdg_grad_bytes(P) scratch.
+ * grad_out_normal [3,H,W]: the per-Gaussian normals are constants of the graph, so a gradient of the normal image
+ * reaches the inputs only through the compositing weights (opacity, conic, position); it needs a forward that
+ * composited normals (render_normal = 1).                                                                    */
 size_t rdg_grad_bytes(int32_t P);
 int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, const float* means3D,
                            const float* shs, const float* colors_precomp, const float* opacities,
@@ -124,7 +127,8 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
                            const float* viewmatrix, const float* projmatrix, const int32_t* radii,
                            const void* geom_ws, const void* binning_ws, int64_t capacity, const void* image_ws,
                            const float* grad_out_color, const float* grad_out_depth,
-                           const float* grad_out_alpha, void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D,
+                           const float* grad_out_alpha, const float* grad_out_normal, void* grad_ws,
+                           float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dshs, float* dL_dcolors, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3D, float* dL_dviewmatrix, void* stream);
 
@@ -149,7 +153,7 @@ int rdg_composite_forward(const RdgRasterSettings* s_host, const float* bg, cons
 int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
                            const void* binning_ws, int64_t capacity, const void* image_ws,
                            const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
-                           void* grad_ws, void* stream);
+                           const float* grad_out_normal, void* grad_ws, void* stream);
 /* Deterministic form of rdg_composite_backward (SURVEY.md section 5b "deterministic mode: no float atomics -> bit-
  * reproducible"; the reference's un-vendored rasterizer accumulates with float atomics, whose order changes from run to
  * run): every wave STORES its per-(tile, splat) totals to its own quarter of a 256-B row per list position in det_ws
@@ -160,7 +164,8 @@ size_t rdg_det_bytes(int64_t n_instances);
 int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
                                const void* binning_ws, int64_t capacity, const void* image_ws,
                                const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
-                               void* grad_ws, void* det_ws, int64_t n_instances, void* stream);
+                               const float* grad_out_normal, void* grad_ws, void* det_ws, int64_t n_instances,
+                               void* stream);
 /* gradient rows (grad_ws) -> input gradients; geom_ws / radii are those of THIS rank's rdg_preprocess_forward      */
 int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3D, const float* shs,
                             const float* colors_precomp, const float* opacities, const float* scales,

@@ -54,13 +54,13 @@ _SIGS = {
     "rdg_sort_tmp_bytes": (C.c_size_t, [C.c_int64]),
     "rdg_knn_tmp_bytes": (C.c_size_t, [C.c_int32]),
     "rdg_rasterize_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 12 + [C.c_int64] + [_vp] * 8),
-    "rdg_rasterize_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13 + [C.c_int64] + [_vp] * 15),
+    "rdg_rasterize_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13 + [C.c_int64] + [_vp] * 16),
     "rdg_preprocess_forward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 13),
     "rdg_geom_from_records": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 4),
     "rdg_composite_forward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, _vp, C.c_int64] + [_vp] * 7),
-    "rdg_composite_backward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6),
+    "rdg_composite_backward": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 7),
     "rdg_det_bytes": (C.c_size_t, [C.c_int64]),
-    "rdg_composite_backward_det": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 6 +
+    "rdg_composite_backward_det": (C.c_int, [C.POINTER(RdgRasterSettings), _vp, _vp, _vp, C.c_int64] + [_vp] * 7 +
                                    [C.c_int64, _vp]),
     "rdg_preprocess_backward": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 22),
     "rdg_preprocess_backward_adam": (C.c_int, [C.POINTER(RdgRasterSettings)] + [_vp] * 18 + [C.c_int32] + [C.c_float] * 2 +

@@ -211,7 +211,7 @@ int rdg_rasterize_forward(const RdgRasterSettings* s_host, const float* bg, cons
 int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
                            const void* binning_ws, int64_t capacity, const void* image_ws,
                            const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
-                           void* grad_ws, void* stream) {
+                           const float* grad_out_normal, void* grad_ws, void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
     hipStream_t st = (hipStream_t)stream;
@@ -221,7 +221,7 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
     hipError_t e = rdg_zero_async(grow, grow_bytes, st);
     if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
-                                   grad_out_alpha, grow, st);
+                                   grad_out_alpha, grow, st, nullptr, grad_out_normal);
     rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
     return rc;
 }
@@ -233,7 +233,8 @@ size_t rdg_det_bytes(int64_t n_instances) {
 int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,
                                const void* binning_ws, int64_t capacity, const void* image_ws,
                                const float* grad_out_color, const float* grad_out_depth, const float* grad_out_alpha,
-                               void* grad_ws, void* det_ws, int64_t n_instances, void* stream) {
+                               const float* grad_out_normal, void* grad_ws, void* det_ws, int64_t n_instances,
+                               void* stream) {
     RdgDev d;
     if (rdg_make_dev(s_host, &d)) return -1;
     if (!det_ws || !grad_ws) return rdg_set_error("rdg_composite_backward_det: NULL workspace");
@@ -246,7 +247,7 @@ int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg,
     hipError_t e = rdg_zero_async(det_ws, rdg_det_bytes(n_instances), st);
     if (e != hipSuccess) return rdg_check_hip(e, "det row memset");
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
-                                   grad_out_alpha, (float*)grad_ws, st, (float*)det_ws);
+                                   grad_out_alpha, (float*)grad_ws, st, (float*)det_ws, grad_out_normal);
     rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
     return rc;
 }
@@ -344,13 +345,13 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                            const float* projmatrix, const int32_t* radii, const void* geom_ws, const void* binning_ws,
                            int64_t capacity, const void* image_ws, const float* grad_out_color,
-                           const float* grad_out_depth, const float* grad_out_alpha, void* grad_ws,
-                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                           const float* grad_out_depth, const float* grad_out_alpha, const float* grad_out_normal,
+                           void* grad_ws, float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                            float* dL_dopacities, float* dL_dscales, float* dL_drotations, float* dL_dcov3D,
                            float* dL_dviewmatrix, void* stream) {
     if (rdg_check_inputs(s_host, shs, colors_precomp, scales, rotations, cov3D_precomp)) return -1;
     int rc = rdg_composite_backward(s_host, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color,
-                                    grad_out_depth, grad_out_alpha, grad_ws, stream);
+                                    grad_out_depth, grad_out_alpha, grad_out_normal, grad_ws, stream);
     if (rc) return rc;
     return rdg_preprocess_backward(s_host, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    viewmatrix, projmatrix, radii, geom_ws, grad_ws, dL_dmeans3D, dL_dmeans2D, dL_dshs,

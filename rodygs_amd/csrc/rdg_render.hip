@@ -635,11 +635,15 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], in
 // jthr: per lane, the slot bit index above which the list position lies below the pixel's last contributor.
 // ALLBELOW: every list position of this word lies below the last contributor of every pixel of the quadrant (the usual case:
 // pixels that never stopped early), so the per-lane position test drops out of the visit.
-template <bool HAS_DEPTH, bool CAPPED, bool DET, bool ALLBELOW>
+// HAS_NORMAL: an upstream gradient for the normal image.  The per-Gaussian normals are constants of the graph (the oracle
+// detaches them), so the normal channels act like three more colour channels in dL/dalpha and nothing is accumulated for
+// the normals themselves.
+template <bool HAS_DEPTH, bool CAPPED, bool DET, bool ALLBELOW, bool HAS_NORMAL>
 __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsigned long long cap, const int sbase,
-                                             const char* sQ0, const char* sQ1, const char* sQ2, const float pixx,
-                                             const float pixy, const int jthr, const float dLp0, const float dLp1,
-                                             const float dLp2, const float dLd, const int lane,
+                                             const char* sQ0, const char* sQ1, const char* sQ2, const char* sQ3,
+                                             const float pixx, const float pixy, const int jthr, const float dLp0,
+                                             const float dLp1, const float dLp2, const float dLd, const float dLn0,
+                                             const float dLn1, const float dLn2, const int lane,
                                              float (*ring)[16][RDG_RING_Q], const float flush_scale, const int flush_off,
                                              float* __restrict__ grow, float& T, float& behind, int& ring_n) {
     while (mask) {
@@ -686,6 +690,10 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
         const float dch = aeff * T;
         float s_ = q2.x * dLp0 + q2.y * dLp1 + q2.z * dLp2;
         if (HAS_DEPTH) s_ += q1.z * dLd;
+        if (HAS_NORMAL) {
+            const float4 q3 = *(const float4*)(sQ3 + aj);
+            s_ += q3.x * dLn0 + q3.y * dLn1 + q3.z * dLn2;
+        }
         const float e_ = s_ - behind;
         behind = fmaf(aeff, e_, behind);
         const float dL_dalpha = e_ * T;
@@ -793,13 +801,14 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
 // whole-tile kernel calls it with (0, largest last contributor of the tile), the split path with one segment.
 // m0..m3: per quadrant, the largest last contributor of its pixels.  T / behind: the pixel's transmittance after, and the
 // (normalised) colour-gradient product behind, list position k_top - 1.
-template <bool HAS_DEPTH, bool DET>
+template <bool HAS_DEPTH, bool DET, bool HAS_NORMAL>
 __device__ __forceinline__ void
 rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int m0, const int m1, const int m2, const int m3,
                   const int last_contributor, const float pixx, const float pixy, const float dLp0, const float dLp1,
-                  const float dLp2, const float dLd, const uint32_t* __restrict__ point_list,
+                  const float dLp2, const float dLd, const float dLn0, const float dLn1, const float dLn2,
+                  const uint32_t* __restrict__ point_list,
                   const RdgRec* __restrict__ rec, const unsigned long long* __restrict__ hit, float4* sQ0, float4* sQ1,
-                  float4* sQ2, unsigned long long (*sMask)[4], unsigned long long* sCap, float (*ring)[16][RDG_RING_Q],
+                  float4* sQ2, float4* sQ3, unsigned long long (*sMask)[4], unsigned long long* sCap, float (*ring)[16][RDG_RING_Q],
                   const float flush_scale, const int flush_off, float* __restrict__ gdst, float& T, float& behind,
                   int& ring_n) {
     const int tid = threadIdx.x;
@@ -829,6 +838,7 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                     sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
                     sQ1[tid] = make_float4(cs.gam, q1.y, q1.z, 0.0f);
                     sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(DET ? range.x + (uint32_t)k : id));
+                    if (HAS_NORMAL) sQ3[tid] = p->q3;
                     over_cap = q1.y > RDG_ALPHA_CAP;
                 }
             }
@@ -855,8 +865,9 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
             // list position of slot bit jb of this word: kbase - 64 s - jb; below last_contributor <=> jb > jthr
             const int jthr = kbase - s * 64 - last_contributor;
 #define RDG_WALK(CAPPED, ALLB)                                                                                          \
-            rdg_bwd_walk<HAS_DEPTH, CAPPED, DET, ALLB>(mask, cap, s * 1024, (const char*)sQ0, (const char*)sQ1,          \
-                                                       (const char*)sQ2, pixx, pixy, jthr, dLp0, dLp1, dLp2, dLd, lane,   \
+            rdg_bwd_walk<HAS_DEPTH, CAPPED, DET, ALLB, HAS_NORMAL>(mask, cap, s * 1024, (const char*)sQ0,                \
+                                                       (const char*)sQ1, (const char*)sQ2, (const char*)sQ3, pixx, pixy,  \
+                                                       jthr, dLp0, dLp1, dLp2, dLd, dLn0, dLn1, dLn2, lane,               \
                                                        ring, flush_scale, flush_off, gdst, T, behind, ring_n)
             if (rdg_all(jthr < 0)) { if (cap) RDG_WALK(true, true); else RDG_WALK(false, true); }
             else { if (cap) RDG_WALK(true, false); else RDG_WALK(false, false); }
@@ -870,17 +881,18 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
 // of the per-pair arithmetic and of the reduction.
 // SEG: the split path (see the forward): one work item = one segment of a long list; the pixel's transmittance after
 // the segment is the one the forward stored, and what lies behind it is rebuilt from the later segments' partial sums.
-template <bool HAS_DEPTH, bool DET, bool SEG>
+template <bool HAS_DEPTH, bool DET, bool SEG, bool HAS_NORMAL>
 __global__ void __launch_bounds__(256)
 rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict__ bg,
                       const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const RdgRec* __restrict__ rec, const float* __restrict__ final_T,
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ g_color,
                       const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
-                      float* __restrict__ grow, const unsigned long long* __restrict__ hitbits, int split_min,
+                      const float* __restrict__ g_normal, float* __restrict__ grow, const unsigned long long* __restrict__ hitbits, int split_min,
                       const uint32_t* __restrict__ sp_header, const uint4* __restrict__ sp_work,
                       const float* __restrict__ seg_pix) {
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
+    __shared__ float4 sQ3[HAS_NORMAL ? RDG_BATCH : 1];                  // normals, only with a normal gradient
     __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
     __shared__ unsigned long long sMask[4][4];
     __shared__ unsigned long long sCap[4];   // per staging wave: splats whose opacity exceeds the alpha cap
@@ -912,11 +924,12 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         const unsigned long long* const hit = hitbits + ((size_t)(range.x >> 6) + (size_t)tile) * 4;
         const float T_final = inside ? final_T[pid] : 0.0f;
         const int last_contributor = inside ? (int)n_contrib[pid] : 0;
-        float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f;
+        float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLd = 0.f, dLa = 0.f, dLn0 = 0.f, dLn1 = 0.f, dLn2 = 0.f;
         if (inside) {
             if (g_color) { dLp0 = g_color[pid]; dLp1 = g_color[hw + pid]; dLp2 = g_color[2 * hw + pid]; }
             if (HAS_DEPTH) dLd = g_depth[pid];
             if (g_alpha) dLa = g_alpha[pid];
+            if (HAS_NORMAL) { dLn0 = g_normal[pid]; dLn1 = g_normal[hw + pid]; dLn2 = g_normal[2 * hw + pid]; }
         }
         // What lies BEHIND the last splat of a pixel, in units of "colour . dL/dpixel": the background, and the alpha
         // output (alpha_out = 1 - T_final) as a colour of -dL/dalpha_out.  Starting the behind-value recurrence from it
@@ -938,6 +951,9 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                     far += b2[(RDG_SEG_C + 0) * RDG_TILE_PIX] * dLp0 + b2[(RDG_SEG_C + 1) * RDG_TILE_PIX] * dLp1 +
                            b2[(RDG_SEG_C + 2) * RDG_TILE_PIX] * dLp2;
                     if (HAS_DEPTH) far += b2[(RDG_SEG_C + 3) * RDG_TILE_PIX] * dLd;
+                    if (HAS_NORMAL)
+                        far += b2[(RDG_SEG_C + 4) * RDG_TILE_PIX] * dLn0 + b2[(RDG_SEG_C + 5) * RDG_TILE_PIX] * dLn1 +
+                               b2[(RDG_SEG_C + 6) * RDG_TILE_PIX] * dLn2;
                 }
                 T = seg_pix[((size_t)(item.w + item.y) * RDG_SEG_F + RDG_SEG_TOUT) * RDG_TILE_PIX + tid];
                 behind = far / T;
@@ -956,9 +972,10 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         const int kmax = max(max(m0, m1), max(m2, m3));
         const int k_top = min(kmax, k_hi);
         int ring_n = 0;   // wave-uniform fill level of this wave's ring
-        rdg_bwd_composite<HAS_DEPTH, DET>(k_lo, k_top, range, m0, m1, m2, m3, last_contributor, pixx, pixy, dLp0, dLp1, dLp2,
-                                          dLd, point_list, rec, hit, sQ0, sQ1, sQ2, sMask, sCap, sRing[wv], flush_scale,
-                                          flush_off, gdst, T, behind, ring_n);
+        rdg_bwd_composite<HAS_DEPTH, DET, HAS_NORMAL>(k_lo, k_top, range, m0, m1, m2, m3, last_contributor, pixx, pixy, dLp0,
+                                                      dLp1, dLp2, dLd, dLn0, dLn1, dLn2, point_list, rec, hit, sQ0, sQ1, sQ2,
+                                                      sQ3, sMask, sCap, sRing[wv], flush_scale, flush_off, gdst, T, behind,
+                                                      ring_n);
         rdg_ring_flush<HAS_DEPTH, DET>(sRing[wv], ring_n, lane, flush_scale, flush_off, gdst);
     }
 }
@@ -1009,7 +1026,7 @@ rdg_det_reduce_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec, con
 // det != nullptr: deterministic mode -- `det` holds 4 * RDG_GROW floats per list position (zeroed by the caller)
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
                           int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
-                          const float* g_alpha, float* grow, hipStream_t s, float* det) {
+                          const float* g_alpha, float* grow, hipStream_t s, float* det, const float* g_normal) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const int n_tiles = d.gx * d.gy;
     const RdgBinLayout B = rdg_bin_layout(capacity, n_tiles);
@@ -1023,12 +1040,16 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
     const char* sp = b + B.split;
     const int split_min = (d.list_hints & 1) ? RDG_SPLIT_MIN : 0x7fffffff;
     const unsigned gseg = SL.max_seg < 2048u ? SL.max_seg : 2048u;
-#define RDG_BWD_LAUNCH(DEPTH, DET, SEG, GRID, DST)                                                                 \
-    hipLaunchKernelGGL((rdg_render_bwd_kernel<DEPTH, DET, SEG>), dim3(GRID), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg, \
+    // the split path's normal partial sums exist only if the forward composited normals
+    if (g_normal && !d.render_normal) return rdg_set_error("render_bwd: a normal gradient needs render_normal in the forward");
+#define RDG_BWD_LAUNCH4(DEPTH, DET, SEG, NRM, GRID, DST)                                                           \
+    hipLaunchKernelGGL((rdg_render_bwd_kernel<DEPTH, DET, SEG, NRM>), dim3(GRID), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg, \
                        (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),        \
                        (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
-                       g_alpha, DST, (const unsigned long long*)(b + B.hit), split_min,                            \
+                       g_alpha, g_normal, DST, (const unsigned long long*)(b + B.hit), split_min,                  \
                        (const uint32_t*)(sp + SL.header), (const uint4*)(sp + SL.work), (const float*)(sp + SL.seg_pix))
+#define RDG_BWD_LAUNCH(DEPTH, DET, SEG, GRID, DST)                                                                 \
+    do { if (g_normal) RDG_BWD_LAUNCH4(DEPTH, DET, SEG, true, GRID, DST); else RDG_BWD_LAUNCH4(DEPTH, DET, SEG, false, GRID, DST); } while (0)
     if (det) {
         if (g_depth) RDG_BWD_LAUNCH(true, true, false, nblk, det); else RDG_BWD_LAUNCH(false, true, false, nblk, det);
         if ((d.list_hints & 1)) {
@@ -1046,5 +1067,6 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
         }
     }
 #undef RDG_BWD_LAUNCH
+#undef RDG_BWD_LAUNCH4
     return rdg_check_hip(hipGetLastError(), "render_bwd launch");
 }

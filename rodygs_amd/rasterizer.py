@@ -151,12 +151,12 @@ def _empty(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return None if (t is None or t.numel() == 0) else t
 
 
-def _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws):
+def _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws, g_normal=None):
     """The compositing half of backward: float-atomic accumulation, or the deterministic two-pass form."""
     if not DETERMINISTIC:
         _lib.check(L.rdg_composite_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
                                             ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
-                                            _lib.ptr(g_alpha), _lib.ptr(gws), _lib.stream_ptr()),
+                                            _lib.ptr(g_alpha), _lib.ptr(g_normal), _lib.ptr(gws), _lib.stream_ptr()),
                    "rdg_composite_backward")
         return
     # D is known on the host except in deferred-overflow mode, where the capacity bounds it
@@ -164,7 +164,7 @@ def _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_al
     det = torch.empty(L.rdg_det_bytes(n_inst), dtype=torch.uint8, device=gws.device)
     _lib.check(L.rdg_composite_backward_det(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
                                             ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
-                                            _lib.ptr(g_alpha), _lib.ptr(gws), _lib.ptr(det), n_inst,
+                                            _lib.ptr(g_alpha), _lib.ptr(g_normal), _lib.ptr(gws), _lib.ptr(det), n_inst,
                                             _lib.stream_ptr()), "rdg_composite_backward_det")
 
 
@@ -283,13 +283,10 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_color, g_depth, g_normal, g_alpha, g_radii, g_extra):
-        if g_normal is not None:
-            # rendered_normal is composited from per-Gaussian normals that are constants of the graph, and no reference
-            # caller differentiates it (src/trainer/rodygs.py:272-309): its backward is not built.  A silent zero would
-            # be the wrong failure mode.
-            raise RuntimeError("rodygs_amd rasterizer: rendered_normal received an upstream gradient, but its backward "
-                               "is not implemented (no RoDyGS loss reads it); detach it before using it in a loss")
-        if ctx.empty_cloud or (g_color is None and g_depth is None and g_alpha is None):
+        if g_normal is not None and not ctx.cs.render_normal:
+            raise RuntimeError("rodygs_amd rasterizer: rendered_normal received an upstream gradient, but the forward ran "
+                               "with rasterizer.RENDER_NORMAL = False (the image is all zeros and has no graph)")
+        if ctx.empty_cloud or (g_color is None and g_depth is None and g_alpha is None and g_normal is None):
             return (None,) * 11
         L = _lib.lib()
         m3, shs, col, op, sc, ro, cov, vm, pm, bg, radii, geom, binning, image = ctx.saved_tensors
@@ -300,7 +297,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         def gc(t):
             return None if t is None else t.to(torch.float32).contiguous()
 
-        g_color, g_depth, g_alpha = gc(g_color), gc(g_depth), gc(g_alpha)
+        # rendered_normal is composited from per-Gaussian normals that are constants of the graph: its gradient reaches the
+        # inputs through the compositing weights only (no RoDyGS loss reads it, src/trainer/rodygs.py:272-309)
+        g_color, g_depth, g_alpha, g_normal = gc(g_color), gc(g_depth), gc(g_alpha), gc(g_normal)
         with torch.cuda.device(dev):
             gws = torch.empty(L.rdg_grad_bytes(P), dtype=torch.uint8, device=dev)
             d_m3 = torch.empty(P, 3, **f32)
@@ -337,7 +336,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 prm = fused["param"]
                 if prm.data_ptr() != shs.data_ptr() or prm.numel() != shs.numel():
                     raise RuntimeError("grad_sinks['shs_adam']['param'] must be the storage passed to the rasterizer as shs")
-                _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws)
+                _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws, g_normal)
                 if fused.get("step_scalars") is not None:
                     # graph replay: the bias corrections are read from device memory (RdgStepScalars)
                     _lib.check(L.rdg_preprocess_backward_adam_dev(
@@ -359,7 +358,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     step, _lib.stream_ptr()), "rdg_preprocess_backward_adam")
                 return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None
             if DETERMINISTIC:
-                _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws)
+                _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws, g_normal)
                 rc = L.rdg_preprocess_backward(C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col), _lib.ptr(op),
                                                _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm), _lib.ptr(pm),
                                                _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(gws), _lib.ptr(d_m3),
@@ -372,7 +371,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                               _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm),
                                               _lib.ptr(pm), _lib.ptr(radii), _lib.ptr(geom), _lib.ptr(binning),
                                               ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
-                                              _lib.ptr(g_alpha), _lib.ptr(gws), _lib.ptr(d_m3), _lib.ptr(d_m2),
+                                              _lib.ptr(g_alpha), _lib.ptr(g_normal), _lib.ptr(gws), _lib.ptr(d_m3),
+                                              _lib.ptr(d_m2),
                                               _lib.ptr(d_sh), _lib.ptr(d_col), _lib.ptr(d_op), _lib.ptr(d_sc),
                                               _lib.ptr(d_ro), _lib.ptr(d_cov), _lib.ptr(d_vm), _lib.stream_ptr())
                 _lib.check(rc, "rdg_rasterize_backward")

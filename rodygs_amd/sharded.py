@@ -440,8 +440,8 @@ class ShardedDynamicScene:
                 g_depth, loss = depth_leaf.grad.contiguous(), loss + ld.detach()
             _lib.check(L.rdg_composite_backward(C.byref(self.cs_cam), _lib.ptr(self.bg), _lib.ptr(self.geom_cam),
                                                 _lib.ptr(self._binning), self._capacity, _lib.ptr(self.image_ws),
-                                                _lib.ptr(self.d_img), _lib.ptr(g_depth), None, _lib.ptr(self.grad_cam),
-                                                st), "rdg_composite_backward")
+                                                _lib.ptr(self.d_img), _lib.ptr(g_depth), None, None,
+                                                _lib.ptr(self.grad_cam), st), "rdg_composite_backward")
         return loss
 
     def phase_owner_backward(self) -> None:
