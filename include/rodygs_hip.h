@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RDG_ABI_VERSION 3
+#define RDG_ABI_VERSION 4
 #define RDG_MAX_VIEWS 16   /* cameras per step in the *_views entry points */
 
 /* Mirror of GaussianRasterizationSettings (renderer.py:50-63) + sizes. Host struct, passed by pointer. */
@@ -71,6 +71,15 @@ typedef struct RdgRasterSettings {
                               *          follows: keep the struct) by several workgroups each -- per-segment partial
                               *          composites + an ordered combine (three extra launches); 0: one workgroup walks
                               *          every list.  Same result up to the association of the transmittance product.  */
+    int32_t grad_rows_zeroed; /* backward calls only: 1 = the per-Gaussian gradient rows at the head of grad_ws are already
+                              * zero (the forward of this frame cleared them, zero_grad_ws below), so the backward does not
+                              * launch its own fill; 0: the backward clears them itself (a repeated backward through the
+                              * same graph must say 0: the first one consumed the zeros)                               */
+    int32_t reserved0;
+    void* zero_grad_ws;      /* forward calls only, optional: an rdg_grad_bytes(P) workspace whose gradient rows the
+                              * compositing forward clears while it runs -- that kernel is instruction-bound and its memory
+                              * pipeline idle, so the fill is free there, against a 12 us launch of its own at the head of
+                              * the backward (P = 1 M).  NULL: off.                                                   */
 } RdgRasterSettings;
 
 /* stage ids for rdg_stage_time_ms() */
@@ -93,6 +102,8 @@ enum {
 };
 
 int rdg_abi_version(void);
+/* sizeof(RdgRasterSettings) as this library was compiled: a binding checks its own mirror of the struct against it */
+size_t rdg_settings_bytes(void);
 const char* rdg_last_error(void);
 
 /* ---- workspace sizes (bytes) -------------------------------------------------------------------------- */

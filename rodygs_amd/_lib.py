@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RDG_LIB_PATH: load another build of the same ABI (A/B runs of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("RDG_LIB_PATH") or os.path.join(_HERE, "csrc", "librodygs_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _lock = threading.Lock()
@@ -24,6 +24,7 @@ class RdgRasterSettings(C.Structure):
         ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("enable_cov_grad", C.c_int32), ("enable_sh_grad", C.c_int32), ("render_normal", C.c_int32),
         ("bin_mode", C.c_int32), ("num_rendered_stats", C.c_int32), ("list_hints", C.c_int32),
+        ("grad_rows_zeroed", C.c_int32), ("reserved0", C.c_int32), ("zero_grad_ws", C.c_void_p),
     ]
 
 
@@ -46,6 +47,7 @@ STAGES = {
 _vp = C.c_void_p
 _SIGS = {
     "rdg_abi_version": (C.c_int, []),
+    "rdg_settings_bytes": (C.c_size_t, []),
     "rdg_last_error": (C.c_char_p, []),
     "rdg_geom_bytes": (C.c_size_t, [C.c_int32]),
     "rdg_binning_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
@@ -150,6 +152,8 @@ def lib():
             fn.argtypes = args
         if h.rdg_abi_version() != ABI_VERSION:
             raise RuntimeError("rodygs_amd: librodygs_hip.so ABI version mismatch -- rebuild")
+        if h.rdg_settings_bytes() != C.sizeof(RdgRasterSettings):
+            raise RuntimeError("rodygs_amd: RdgRasterSettings of the library and of this binding differ -- rebuild")
         _lib = h
     return _lib
 

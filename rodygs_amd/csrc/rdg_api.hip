@@ -78,6 +78,7 @@ static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     d->prefiltered = s->prefiltered; d->cov_grad = s->enable_cov_grad; d->sh_grad = s->enable_sh_grad;
     d->render_normal = s->render_normal;
     d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats; d->list_hints = s->list_hints;
+    d->grad_rows_zeroed = s->grad_rows_zeroed; d->zero_grad_ws = s->zero_grad_ws;
     d->tile_cnt_zeroed = 0;
     return 0;
 }
@@ -122,6 +123,7 @@ hipError_t rdg_zero_async(void* p, size_t bytes, hipStream_t st) {
 extern "C" {
 
 int rdg_abi_version(void) { return RDG_ABI_VERSION; }
+size_t rdg_settings_bytes(void) { return sizeof(RdgRasterSettings); }
 const char* rdg_last_error(void) { return g_err; }
 
 size_t rdg_geom_bytes(int32_t P) { return rdg_geom_layout(P).total; }
@@ -218,8 +220,10 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
     float* grow = (float*)grad_ws;
     const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
     rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
-    hipError_t e = rdg_zero_async(grow, grow_bytes, st);
-    if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
+    if (!d.grad_rows_zeroed) {          // else: cleared by this frame's compositing forward (zero_grad_ws)
+        hipError_t e = rdg_zero_async(grow, grow_bytes, st);
+        if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
+    }
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
                                    grad_out_alpha, grow, st, nullptr, grad_out_normal);
     rdg_stage_end(RDG_STAGE_RENDER_BWD, st);

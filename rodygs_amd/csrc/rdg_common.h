@@ -226,6 +226,8 @@ struct RdgDev {
     int32_t bin_mode, nren_stats;
     int32_t list_hints;        // RdgRasterSettings.list_hints: bit 0 = split compositing path for lists > RDG_SPLIT_MIN
     int32_t tile_cnt_zeroed;   // internal: the per-tile counters were cleared by the per-Gaussian stage's scan kernel
+    int32_t grad_rows_zeroed;  // RdgRasterSettings.grad_rows_zeroed (backward)
+    void* zero_grad_ws;        // RdgRasterSettings.zero_grad_ws (forward): gradient rows cleared by the compositing kernel
 };
 
 // ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------

@@ -194,10 +194,44 @@ rdg_deform_dcoeff16_kernel(int P, int Tu, const long long* __restrict__ time_ind
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void rdg_diff16_to_lds(float* sm, int Tu, const float* __restrict__ bases) {
     const float* bt = bases + (size_t)Tu * 112;          // packed bases: Tu table rows, then B(t)
-    for (int k = threadIdx.x; k < Tu * 112; k += blockDim.x) {
-        const int u = k / 112, c = k - u * 112;
-        sm[u * RDG_DC_STRIDE + c] = bt[c] - bases[(size_t)u * 112 + c];
+    // four elements per thread and trip, every load issued before the first LDS store: written as the plain loop the
+    // compiler waited for each pair of loads in turn (11 dependent L2 round trips at Tu = 100 before the kernel began)
+    const int n = Tu * 112;
+    for (int k0 = threadIdx.x; k0 < n; k0 += 4 * blockDim.x) {
+        float a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = min(k0 + q * (int)blockDim.x, n - 1);
+            const int u = k / 112, c = k - u * 112;
+            a[q] = bt[c]; b[q] = bases[(size_t)u * 112 + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = k0 + q * (int)blockDim.x;
+            if (k < n) { const int u = k / 112, c = k - u * 112; sm[u * RDG_DC_STRIDE + c] = a[q] - b[q]; }
+        }
     }
+}
+
+// The coefficient-gradient rows (64 B per Gaussian) leave the backward kernel through a wave-private LDS stage: written
+// by a lane directly, one instruction stores 16 B of each of 64 different rows (256 write requests of 16 B per wave);
+// through the stage every store instruction moves 1 KB contiguous (-11 us at P = 1 M).  The forward's coefficient READS
+// gained nothing from the same stage (+4 us: the lines of a row stay in the L1 between its four loads) and go direct.
+// Stage row stride 20 floats: 16-B aligned, and 8 consecutive rows cover all 32 banks.
+#define RDG_DG_STAGE 20
+#define RDG_DG_STAGE_BYTES (64 * RDG_DG_STAGE * 4)                  // per wave
+__device__ __forceinline__ void rdg_stage_rows16_out(float* __restrict__ dst, long long first_row, long long n_rows,
+                                                     float* stage, int lane, const float4 in[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(stage + lane * RDG_DG_STAGE + 4 * i) = in[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long long r = first_row + 16 * i + (lane >> 2);
+        const float4 v = *reinterpret_cast<const float4*>(stage + (16 * i + (lane >> 2)) * RDG_DG_STAGE + 4 * (lane & 3));
+        if (r < n_rows) reinterpret_cast<float4*>(dst)[r * 4 + (lane & 3)] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Single-camera forward (the 1-GPU train step): the difference table sits in LDS, so a Gaussian costs 28 row reads and
@@ -212,11 +246,18 @@ rdg_dyn_getter_fwd_kernel(int P, int Tu, const float* __restrict__ coeff, const 
     rdg_diff16_to_lds(smem_dg, Tu, bases);
     __syncthreads();
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        // every global load of the Gaussian before the first use (one round trip to memory per Gaussian: written in
+        // program order "load, use, store, load ..." the compiler kept that order across the stores)
         const int u = (int)time_ind[p];
         const float4* c4 = reinterpret_cast<const float4*>(coeff + (size_t)p * 16);
-        float c[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const float4 t = c4[q]; c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w; }
+        const float4 c0 = c4[0], c1 = c4[1], c2 = c4[2], c3 = c4[3];
+        float x0 = xyz[3 * p], x1 = xyz[3 * p + 1], x2 = xyz[3 * p + 2];
+        float s0 = scaling[3 * p], s1 = scaling[3 * p + 1], s2 = scaling[3 * p + 2];
+        float4 q = reinterpret_cast<const float4*>(rotation)[p];
+        float op = opacity[p];
+        asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(op), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(s0), "+v"(s1),
+                     "+v"(s2));
+        const float c[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
         const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
         float acc[RDG_DEF_K];
 #pragma unroll
@@ -231,16 +272,14 @@ rdg_dyn_getter_fwd_kernel(int P, int Tu, const float* __restrict__ coeff, const 
                 acc[e % 7] = __fmaf_rn(c[e / 7], vv[e4], acc[e % 7]);   // written out: same bits as the views kernel
             }
         }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            means3D[3 * p + k] = __fmaf_rn(acc[k], scale, xyz[3 * p + k]);
-            scales[3 * p + k] = __expf(scaling[3 * p + k]);
-        }
-        const float4 q = reinterpret_cast<const float4*>(rotation)[p];
+        means3D[3 * p] = __fmaf_rn(acc[0], scale, x0);
+        means3D[3 * p + 1] = __fmaf_rn(acc[1], scale, x1);
+        means3D[3 * p + 2] = __fmaf_rn(acc[2], scale, x2);
+        scales[3 * p] = __expf(s0); scales[3 * p + 1] = __expf(s1); scales[3 * p + 2] = __expf(s2);
         const float inv = 1.0f / fmaxf(sqrtf(__fmaf_rn(q.w, q.w, __fmaf_rn(q.z, q.z, __fmaf_rn(q.y, q.y, q.x * q.x)))), 1e-12f);
         reinterpret_cast<float4*>(rots)[p] = make_float4(__fmaf_rn(q.x, inv, acc[3]), __fmaf_rn(q.y, inv, acc[4]),
                                                          __fmaf_rn(q.z, inv, acc[5]), __fmaf_rn(q.w, inv, acc[6]));
-        opac[p] = 1.0f / (1.0f + __expf(-opacity[p]));
+        opac[p] = 1.0f / (1.0f + __expf(-op));
     }
 }
 
@@ -258,26 +297,48 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero; k += gridDim.x * blockDim.x) zero_out[k] = 0u;
     rdg_diff16_to_lds(smem_dg, Tu, bases);
     __syncthreads();
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const int u = (int)time_ind[p];
-        float g[RDG_DEF_K] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // an absent upstream gradient reads the parameter of the same shape instead (any valid address) and is replaced by
+    // zero afterwards: no branch between the loads, so all of a Gaussian's loads are in flight together (with the four
+    // null tests as branches the loop made ten dependent round trips to memory per Gaussian: 2.7 TB/s)
+    const bool has_m = g_means3D != nullptr, has_s = g_scales != nullptr, has_r = g_rots != nullptr, has_o = g_opac != nullptr;
+    const float* pm = has_m ? g_means3D : scaling;
+    const float* ps = has_s ? g_scales : scaling;
+    const float4* pr = reinterpret_cast<const float4*>(has_r ? g_rots : rotation);
+    const float* po = has_o ? g_opac : opacity;
+    const int lane = threadIdx.x & 63;
+    float* stage = smem_dg + Tu * RDG_DC_STRIDE + (threadIdx.x >> 6) * (64 * RDG_DG_STAGE);
+    for (int p0 = (blockIdx.x * blockDim.x + threadIdx.x) - lane; p0 < P; p0 += gridDim.x * blockDim.x) {
+        const int p = p0 + lane;
+        const bool live = p < P;
+        const int pc = live ? p : P - 1;
+        const int u = (int)time_ind[pc];
+        const size_t sidx = (size_t)inv_order[pc];
+        float gm[3], gsc[3], sc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gm[k] = pm[3 * pc + k]; gsc[k] = ps[3 * pc + k]; sc[k] = scaling[3 * pc + k]; }
+        const float4 q = reinterpret_cast<const float4*>(rotation)[pc];
+        float4 gr = pr[pc];
+        const float opv = opacity[pc];
+        float gop = po[pc];
+        // loaded here, not behind a branch further down
+        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(gr.x), "+v"(gr.y), "+v"(gr.z), "+v"(gr.w), "+v"(gop));
+        float qx = q.x, qy = q.y, qz = q.z, qw = q.w;
+        asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gm[k] = has_m ? gm[k] : 0.0f; gsc[k] = has_s ? gsc[k] : 0.0f; }
+        gr = has_r ? gr : make_float4(0.f, 0.f, 0.f, 0.f);
+        gop = has_o ? gop : 0.0f;
+        float g[RDG_DEF_K];
         // ---- activations backward (as rdg_activate_bwd_kernel) ----
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float gm = g_means3D ? g_means3D[3 * p + k] : 0.0f;
-            d_xyz[3 * p + k] = gm;
-            g[k] = gm * scale;
-            d_scaling[3 * p + k] = g_scales ? g_scales[3 * p + k] * __expf(scaling[3 * p + k]) : 0.0f;
-        }
+        for (int k = 0; k < 3; ++k) g[k] = gm[k] * scale;
+        g[3] = gr.x; g[4] = gr.y; g[5] = gr.z; g[6] = gr.w;
         float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g_rots) {
-            const float4 q = reinterpret_cast<const float4*>(rotation)[p];
-            const float4 gr = reinterpret_cast<const float4*>(g_rots)[p];
-            g[3] = gr.x; g[4] = gr.y; g[5] = gr.z; g[6] = gr.w;
-            const float nn = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (has_r) {
+            const float nn = sqrtf(qx * qx + qy * qy + qz * qz + qw * qw);
             if (nn > 1e-12f) {
                 const float inv = 1.0f / nn;
-                const float yx = q.x * inv, yy = q.y * inv, yz = q.z * inv, yw = q.w * inv;
+                const float yx = qx * inv, yy = qy * inv, yz = qz * inv, yw = qw * inv;
                 const float dot = yx * gr.x + yy * gr.y + yz * gr.z + yw * gr.w;
                 dq = make_float4((gr.x - yx * dot) * inv, (gr.y - yy * dot) * inv, (gr.z - yz * dot) * inv,
                                  (gr.w - yw * dot) * inv);
@@ -285,15 +346,21 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
                 dq = make_float4(gr.x * 1e12f, gr.y * 1e12f, gr.z * 1e12f, gr.w * 1e12f);
             }
         }
-        reinterpret_cast<float4*>(d_rotation)[p] = dq;
-        const float sg = 1.0f / (1.0f + __expf(-opacity[p]));
-        d_opacity[p] = g_opac ? g_opac[p] * sg * (1.0f - sg) : 0.0f;
-        // ---- deformation backward: sorted compact copy for the dB reduction + dL/dcoeff ----
-        if (gs) {
-            const size_t sidx = (size_t)inv_order[p];
+        const float sg = 1.0f / (1.0f + __expf(-opv));
+        // ---- the stores that do not wait for the table row: issued first, their registers are free for the row loop ----
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d_xyz[3 * p + k] = gm[k];
+                d_scaling[3 * p + k] = has_s ? gsc[k] * __expf(sc[k]) : 0.0f;
+            }
+            reinterpret_cast<float4*>(d_rotation)[p] = dq;
+            d_opacity[p] = has_o ? gop * sg * (1.0f - sg) : 0.0f;
+            // sorted compact copy (scaled gradient, birth index) for the dB reduction
             gs[2 * sidx] = make_float4(g[0], g[1], g[2], g[3]);
             gs[2 * sidx + 1] = make_float4(g[4], g[5], g[6], __int_as_float(u));
         }
+        // ---- deformation backward: dL/dcoeff ----
         const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
         float sacc[16];
 #pragma unroll
@@ -307,10 +374,12 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
                 const int e = 4 * j + e4;
                 sacc[e / 7] += g[e % 7] * vv[e4];
             }
+            if ((j & 3) == 3) asm volatile("" ::: "memory");   // at most four row reads hoisted: 112 live registers otherwise (spills)
         }
-        float4* dc = reinterpret_cast<float4*>(d_coeff + (size_t)p * 16);
+        float4 dc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dc[q] = make_float4(sacc[4 * q], sacc[4 * q + 1], sacc[4 * q + 2], sacc[4 * q + 3]);
+        for (int q4 = 0; q4 < 4; ++q4) dc[q4] = make_float4(sacc[4 * q4], sacc[4 * q4 + 1], sacc[4 * q4 + 2], sacc[4 * q4 + 3]);
+        rdg_stage_rows16_out(d_coeff, p0, P, stage, lane, dc);
     }
 }
 
@@ -981,6 +1050,12 @@ int rdg_deform_backward(int32_t P, int32_t B, int32_t Tu, const float* coeff, co
 
 
 int rdg_dyn_getter_supported(int32_t B, int32_t Tu) { return B == 16 && Tu >= 1 && ((size_t)Tu * RDG_DC_STRIDE + 112) * 4 <= 64 * 1024; }
+// LDS of the single-camera backward kernel: the difference table + one coefficient-gradient stage per wave (above the
+// 64 KB a kernel gets without asking: the attribute is set once)
+static size_t rdg_getter_lds(int32_t Tu) { return (size_t)Tu * RDG_DC_STRIDE * 4 + 16 * RDG_DG_STAGE_BYTES; }
+static hipError_t rdg_getter_lds_attr(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rdg_getter_lds(141));
+}
 
 int rdg_dyn_getter_forward(int32_t P, int32_t Tu, const float* coeff, const int64_t* time_ind, const float* bases,
                            float spatial_scale, const float* xyz, const float* scaling, const float* rotation,
@@ -1023,7 +1098,9 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
         int nb = (P + 1023) / 1024;
         if (nb > rdg_getter_grid_cap()) nb = rdg_getter_grid_cap();
         uint32_t* counter = (uint32_t*)((char*)sorted_ws + rdg_deform_gs_bytes(P));
-        hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), (size_t)Tu * RDG_DC_STRIDE * 4, st, P, Tu,
+        static const hipError_t attr = rdg_getter_lds_attr((const void*)rdg_dyn_getter_bwd_kernel);
+        if (attr != hipSuccess) return rdg_check_hip(attr, "dyn_getter_bwd LDS attribute");
+        hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), rdg_getter_lds(Tu), st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
                            (const int*)inv_order, (float4*)sorted_ws, counter, 2);

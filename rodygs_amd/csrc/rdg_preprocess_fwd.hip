@@ -242,7 +242,8 @@ __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __r
     for (int i = threadIdx.x; i < zero_words; i += 1024) zero_buf[i] = 0u;
     __shared__ uint32_t wtot[16];
     __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    __shared__ unsigned long long total64;     // the same total without wrap-around: D >= 2^31 must not pass for a small D
+    if (threadIdx.x == 0) { carry_s = 0; total64 = 0ull; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int base = 0; base < nblk; base += 1024) {
@@ -256,12 +257,21 @@ __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __r
         const uint32_t carry = carry_s;
         if (i < nblk) block_sums[i] = carry + woff + inc - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == 1023) {
+            carry_s = carry + woff + inc;
+            unsigned long long t = total64;
+            for (int k = 0; k < 16; ++k) t += wtot[k];      // a wave's total fits 32 bits (64 x tiles of the grid), a sweep's need not
+            total64 = t;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        block_sums[nblk] = carry_s;
-        *num_rendered = (int32_t)carry_s;
+        // every later kernel of the frame compares *num_rendered with the capacity of the instance buffers and leaves
+        // when it is larger: 2^31 - 1 instances or more (garbage scales: every Gaussian on every tile) saturate, so the
+        // frame is skipped and the host raises instead of indexing with a wrapped 32-bit count
+        const bool fits = total64 < 0x7fffffffull;
+        block_sums[nblk] = fits ? carry_s : 0x7fffffffu;
+        *num_rendered = fits ? (int32_t)carry_s : 0x7fffffff;
     }
 }
 

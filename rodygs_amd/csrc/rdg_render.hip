@@ -271,7 +271,16 @@ rdg_render_fwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                       const RdgRec* __restrict__ rec, long long capacity, const int32_t* __restrict__ num_rendered,
                       float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
                       float* __restrict__ out_depth, float* __restrict__ out_normal, float* __restrict__ out_alpha,
-                      unsigned long long* __restrict__ hitbits, int split_min) {
+                      unsigned long long* __restrict__ hitbits, int split_min, uint4* __restrict__ zero_buf,
+                      long long zero_n16) {
+    // optional (RdgRasterSettings.zero_grad_ws): the gradient rows of the backward that follows are cleared from here.
+    // This kernel is instruction-bound and stores nothing until its last lines: the fill rides along for free (a
+    // launch of its own at the head of the backward: 12 us at P = 1 M).  Every workgroup, before any early exit.
+    if (zero_buf) {
+        const long long per = (zero_n16 + gridDim.x - 1) / gridDim.x;
+        const long long z0 = per * blockIdx.x, z1 = z0 + per < zero_n16 ? z0 + per : zero_n16;
+        for (long long i = z0 + threadIdx.x; i < z1; i += 256) zero_buf[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // on capacity overflow the binning stage has emptied every tile range: this kernel then renders the background
     const int tile = rdg_tile_of_block(blockIdx.x, n_tiles);
     if (tile >= n_tiles) return;
@@ -552,7 +561,9 @@ int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws,
 #define RDG_FWD_LAUNCH(NORMAL)                                                                                      \
     hipLaunchKernelGGL(rdg_render_fwd_kernel<NORMAL>, dim3(nblk), dim3(256), 0, s, d.W, d.H, d.gx, n_tiles, bg,       \
                        ranges, plist, rec, (long long)capacity, num_rendered, final_T, n_contrib,                    \
-                       out_color, out_depth, out_normal, out_alpha, hitbits, split_min)
+                       out_color, out_depth, out_normal, out_alpha, hitbits, split_min, (uint4*)d.zero_grad_ws,     \
+                       zero_n16)
+    const long long zero_n16 = (long long)(rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256) / 16);
     if (d.render_normal) RDG_FWD_LAUNCH(true); else RDG_FWD_LAUNCH(false);
 #undef RDG_FWD_LAUNCH
     if ((d.list_hints & 1)) {

@@ -26,6 +26,7 @@ from . import _lib
 
 # module-level knobs (not part of the reference surface)
 RENDER_NORMAL = True          # composite the (unused-by-RoDyGS) normal channels
+PREZERO_GRAD_ROWS = os.environ.get("RDG_PREZERO_GRAD_ROWS", "1") != "0"   # the forward clears the backward's gradient rows
 _CAPACITY_HINT = {}           # (P, H, W) -> last num_rendered, to size the binning workspace without a sync
 _BIN_HINT = {}                # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
 # Bucket binning (count / scan / scatter + per-tile sort) is the fast path on ordinary frames, but its cost grows with
@@ -80,6 +81,14 @@ def _note_largest_tile(key, largest: int) -> None:
         _SPLIT_HINT.pop(key, None)
 
 
+_INSTANCE_LIMIT = 2 ** 31 - 1      # the device saturates its (tile, Gaussian) instance count here (rdg_scan_block_sums_kernel)
+
+
+def _too_many(key) -> str:
+    return (f"rasterizer forward for (P,H,W)={key}: 2^31 - 1 or more (tile, Gaussian) instances -- the instance index is "
+            "32 bits wide, as upstream's; the frame was rendered empty.  Scales this large usually mean a diverged run")
+
+
 def poll_overflow(block: bool = False) -> None:
     """Deferred mode: check the instance counts of forwards whose copy has landed (all of them if ``block``)."""
     while _PENDING:
@@ -90,6 +99,8 @@ def poll_overflow(block: bool = False) -> None:
         n = int(host[0])
         _PENDING.pop(0)
         _PINNED_FREE.append(host)
+        if n >= _INSTANCE_LIMIT:
+            raise RuntimeError(_too_many(key))
         _CAPACITY_HINT[key] = max(n, int(_CAPACITY_HINT.get(key, 0) * 0.9))
         _note_largest_tile(key, int(host[1]))
         if n > cap:
@@ -219,6 +230,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             normal = torch.empty(3, H, W, dtype=torch.float32, device=dev)
             alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
             radii = torch.empty(P, dtype=torch.int32, device=dev)
+            # a backward will follow: its gradient rows are cleared by the compositing forward (RdgRasterSettings
+            # .zero_grad_ws: free there, a 12 us launch at the head of the backward otherwise)
+            gws = None
+            if PREZERO_GRAD_ROWS and P > 0 and not DETERMINISTIC and any(ctx.needs_input_grad):
+                gws = torch.empty(L.rdg_grad_bytes(P), **u8)
+                cs.zero_grad_ws = gws.data_ptr()
             # [0] = D (instances), [1] = largest tile list: both written by the forward on every path (the block-sum scan
             # writes [0] even for an empty cloud, the tile scan / tile max kernels write [1] also on capacity overflow),
             # so no fill launch
@@ -261,6 +278,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                     break
                 # one host read AFTER the whole forward is queued (upstream stalls mid-pipeline instead)
                 n, largest = (int(v) for v in nren.tolist())
+                if n >= _INSTANCE_LIMIT:
+                    raise RuntimeError(_too_many(key))
                 _CAPACITY_HINT[key] = n
                 _note_largest_tile(key, largest)
                 if n <= cap:
@@ -273,6 +292,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = raster_settings
         ctx.empty_cloud = (P == 0)
         ctx.cs = cs
+        ctx.gws = gws                 # zeroed gradient rows for the FIRST backward through this graph
         ctx.capacity = cap
         ctx.num_rendered = n
         ctx.has = (shs is not None, col is not None, sc is not None, cov is not None)
@@ -301,7 +321,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         # inputs through the compositing weights only (no RoDyGS loss reads it, src/trainer/rodygs.py:272-309)
         g_color, g_depth, g_alpha, g_normal = gc(g_color), gc(g_depth), gc(g_alpha), gc(g_normal)
         with torch.cuda.device(dev):
-            gws = torch.empty(L.rdg_grad_bytes(P), dtype=torch.uint8, device=dev)
+            gws, ctx.gws = ctx.gws, None          # the rows the forward cleared serve one backward
+            ctx.cs.grad_rows_zeroed = 1 if (gws is not None and not DETERMINISTIC) else 0
+            if gws is None:
+                gws = torch.empty(L.rdg_grad_bytes(P), dtype=torch.uint8, device=dev)
             d_m3 = torch.empty(P, 3, **f32)
             d_m2 = torch.empty(P, 3, **f32)
             d_op = torch.empty_like(op)

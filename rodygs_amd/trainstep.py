@@ -547,6 +547,8 @@ class GraphedStep:
         """Instance count of the last replayed frame (synchronises); raises if it exceeded the captured capacity."""
         from . import rasterizer
         n, largest = (int(v) for v in self._nren.tolist())
+        if n >= rasterizer._INSTANCE_LIMIT:
+            raise RuntimeError(rasterizer._too_many(self._key))
         rasterizer._CAPACITY_HINT[self._key] = max(n, int(rasterizer._CAPACITY_HINT.get(self._key, 0) * 0.9))
         if n > self._cap:
             rasterizer._CAPACITY_HINT[self._key] = n

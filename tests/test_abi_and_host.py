@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
         assert hasattr(raw, n), f"{n} declared in include/rodygs_hip.h but not exported"
     # and the ctypes binding table covers the whole header
     assert set(names) == set(_lib.EXPORTED_SYMBOLS)
-    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 3
+    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_workspace_sizes(hip_lib):
@@ -43,7 +43,10 @@ def test_workspace_sizes(hip_lib):
 def test_c_struct_matches_header():
     import ctypes
     from rodygs_amd._lib import RdgRasterSettings
-    assert ctypes.sizeof(RdgRasterSettings) == 16 * 4
+    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 8
+    from rodygs_amd import _lib
+    assert _lib.lib().rdg_settings_bytes() == ctypes.sizeof(RdgRasterSettings)      # the compiled header's sizeof
+    assert RdgRasterSettings.zero_grad_ws.offset == 72
     assert [f[0] for f in RdgRasterSettings._fields_][:8] == [
         "P", "M", "sh_degree", "image_height", "image_width", "tanfovx", "tanfovy", "scale_modifier"]
 

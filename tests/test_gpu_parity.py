@@ -382,6 +382,32 @@ def test_capacity_overflow_retries_and_retain_graph():
     rel_ok(out[0], oc[0], outliers=OUTLIER_FRAC, what="color after retry")
 
 
+def test_instance_count_beyond_32_bits_raises_instead_of_indexing_with_a_wrapped_count():
+    """Garbage scales (a diverged run, an uninitialised buffer): every Gaussian covers every tile and the (tile, Gaussian)
+    instance count passes 2^31.  The device total saturates (rdg_scan_block_sums_kernel), every later kernel of the
+    frame leaves, and the host raises -- a wrapped 32-bit count would have passed the capacity check and indexed out of
+    bounds.  The next, sane frame renders normally."""
+    from rodygs_amd import GaussianRasterizer, rasterizer
+    import hip_stages as HS
+    P, W, H = 300000, 1920, 1080                               # 300 k x 8160 tiles = 2.4e9 instances
+    sc = O.synthetic_scene(P, W, H, 0, seed=5)
+    rs = HS.make_settings(sc, 0)
+    ins = {k: sc[k].clone().to(DEV) for k in NAMES}
+    big = dict(ins, scales=torch.full_like(ins["scales"], 1.0e4))
+    rasterizer._CAPACITY_HINT.pop((P, H, W), None)
+
+    def fwd(d):
+        return GaussianRasterizer(rs)(means3D=d["means3D"], means2D=torch.zeros(P, 3, device=DEV), shs=d["shs"],
+                                      opacities=d["opacities"], scales=d["scales"], rotations=d["rotations"],
+                                      viewmatrix=d["viewmatrix"])
+    with pytest.raises(RuntimeError, match="2\\^31 - 1 or more"):
+        fwd(big)
+    torch.cuda.synchronize()
+    out = fwd(ins)
+    assert 0 < rasterizer._CAPACITY_HINT[(P, H, W)] < 2 ** 31 - 1
+    assert bool(torch.isfinite(out[0]).all()) and float(out[0].abs().max()) > 0
+
+
 def test_render_wrapper_returns_reference_dict():
     """render() mirror of /root/reference/src/trainer/renderer.py:17-114: keys, shapes, and every VALUE of the dict
     (plus the gradients that flow back through it) against the oracle rendering the same camera."""
