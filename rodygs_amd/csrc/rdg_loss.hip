@@ -63,11 +63,17 @@ static RdgWin rdg_make_window() {
 
 #define RDG_LOSS_HITEMS ((LWY * (LTX / RB) + 255) / 256)   // horizontal-pass work items per thread (2)
 
-__global__ void __launch_bounds__(256)
+// four waves per SIMD (<= 128 registers): with the 35 KB of LDS that is four workgroups per CU
+__global__ void __launch_bounds__(256, 4)
 rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
                     float* __restrict__ maps, float* __restrict__ sums) {
+    // 35.1 KB instead of 41.4 KB -- four workgroups per CU instead of three (the phases of a workgroup are separated by
+    // barriers; other workgroups fill the gaps): the fifth filtered map reuses the halo tile of x, its horizontal results
+    // waiting in registers until every thread has read its inputs
     __shared__ float sx[LWY][LWX + 1], sy[LWY][LWX + 1];
-    __shared__ float sh[5][LWY][LTX];
+    __shared__ float sh4[4][LWY][LTX];
+    float (*sh5)[LTX] = (float (*)[LTX])&sx[0][0];
+    static_assert(LWY * LTX <= LWY * (LWX + 1), "the fifth map must fit the halo tile it reuses");
     __shared__ float sred[2][4];
     const int tid = threadIdx.x;
     int ox, oy, c; size_t bid;
@@ -98,37 +104,58 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
         }
     }
     __syncthreads();
+    // vertical-pass coordinates: thread = column tx, RB rows starting at ty0; its |x - y| terms are taken now, while the
+    // halo tile of x is still in LDS
+    const int tx = tid % LTX, ty0 = (tid / LTX) * RB;
+    const int px = ox + tx;
+    float l1v[RB];
+#pragma unroll
+    for (int o = 0; o < RB; ++o) l1v[o] = fabsf(sx[ty0 + o + LH][tx + LH] - sy[ty0 + o + LH][tx + LH]);
     // horizontal pass: LWY rows x (LTX / RB) groups of RB outputs
-    for (int item = tid; item < LWY * (LTX / RB); item += 256) {
-        const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
-        float xs[RB + 10], ys[RB + 10];
+    float h4reg[RDG_LOSS_HITEMS][RB];
 #pragma unroll
-        for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
+    for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
+        const int item = tid + 256 * hi;
+        if (item < LWY * (LTX / RB)) {
+            const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+            float xs[RB + 10], ys[RB + 10];
 #pragma unroll
-        for (int o = 0; o < RB; ++o) {
-            float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+            for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
 #pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float xv = xs[o + k], yv = ys[o + k];
-                const float wx = w[k] * xv, wy = w[k] * yv;
-                h0 += wx; h1 += wy; h2 += wx * xv; h3 += wy * yv; h4 += wx * yv;
+            for (int o = 0; o < RB; ++o) {
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float xv = xs[o + k], yv = ys[o + k];
+                    const float wx = w[k] * xv, wy = w[k] * yv;
+                    h0 += wx; h1 += wy; h2 += wx * xv; h3 += wy * yv; h4 += wx * yv;
+                }
+                sh4[0][r][c0 + o] = h0; sh4[1][r][c0 + o] = h1; sh4[2][r][c0 + o] = h2; sh4[3][r][c0 + o] = h3;
+                h4reg[hi][o] = h4;
             }
-            sh[0][r][c0 + o] = h0; sh[1][r][c0 + o] = h1; sh[2][r][c0 + o] = h2; sh[3][r][c0 + o] = h3;
-            sh[4][r][c0 + o] = h4;
+        }
+        asm volatile("" ::: "memory");      // one work item's reads at a time (the second item's 28 loads hoisted: +28 registers)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
+        const int item = tid + 256 * hi;
+        if (item < LWY * (LTX / RB)) {
+            const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+#pragma unroll
+            for (int o = 0; o < RB; ++o) sh5[r][c0 + o] = h4reg[hi][o];
         }
     }
     __syncthreads();
-    // vertical pass: thread = column tx, RB rows starting at ty0
-    const int tx = tid % LTX, ty0 = (tid / LTX) * RB;
-    const int px = ox + tx;
     float l1 = 0.f, ms = 0.f;
     float mu1[RB], mu2[RB], e11[RB], e22[RB], e12[RB];
 #pragma unroll
     for (int o = 0; o < RB; ++o) { mu1[o] = 0.f; mu2[o] = 0.f; e11[o] = 0.f; e22[o] = 0.f; e12[o] = 0.f; }
 #pragma unroll
     for (int rr = 0; rr < RB + 10; ++rr) {
-        const float a0 = sh[0][ty0 + rr][tx], a1 = sh[1][ty0 + rr][tx], a2 = sh[2][ty0 + rr][tx],
-                    a3 = sh[3][ty0 + rr][tx], a4 = sh[4][ty0 + rr][tx];
+        const float a0 = sh4[0][ty0 + rr][tx], a1 = sh4[1][ty0 + rr][tx], a2 = sh4[2][ty0 + rr][tx],
+                    a3 = sh4[3][ty0 + rr][tx], a4 = sh5[ty0 + rr][tx];
+        if ((rr & 1) == 1) asm volatile("" ::: "memory");   // ten row reads in flight, not seventy (registers: occupancy 4)
 #pragma unroll
         for (int o = 0; o < RB; ++o) {
             const int k = rr - o;
@@ -157,7 +184,7 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
             maps[stride + c * hw + p] = de11;
             maps[2 * stride + c * hw + p] = de12;
             ms += m;
-            l1 += fabsf(sx[ty0 + o + LH][tx + LH] - sy[ty0 + o + LH][tx + LH]);
+            l1 += l1v[o];
         }
     }
     l1 = rdg_wave_sum_to63(l1);
