@@ -80,6 +80,10 @@ typedef struct RdgRasterSettings {
                               * compositing forward clears while it runs -- that kernel is instruction-bound and its memory
                               * pipeline idle, so the fill is free there, against a 12 us launch of its own at the head of
                               * the backward (P = 1 M).  NULL: off.                                                   */
+    int32_t* num_rendered_host; /* forward calls only, optional, with num_rendered_stats = 1: a device-accessible HOST
+                              * int32[2] (pinned memory) that the binning stage also writes (D, largest tile list) -- a
+                              * caller that checks D after the fact (no host wait per frame) presets it to -1 and polls it;
+                              * no copy, no event on the stream.  NULL: off.                                            */
 } RdgRasterSettings;
 
 /* stage ids for rdg_stage_time_ms() */

@@ -25,6 +25,7 @@ class RdgRasterSettings(C.Structure):
         ("enable_cov_grad", C.c_int32), ("enable_sh_grad", C.c_int32), ("render_normal", C.c_int32),
         ("bin_mode", C.c_int32), ("num_rendered_stats", C.c_int32), ("list_hints", C.c_int32),
         ("grad_rows_zeroed", C.c_int32), ("reserved0", C.c_int32), ("zero_grad_ws", C.c_void_p),
+        ("num_rendered_host", C.c_void_p),
     ]
 
 

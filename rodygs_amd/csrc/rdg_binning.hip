@@ -419,9 +419,11 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
                      uint32_t* __restrict__ tile_fill, long long capacity, const int32_t* __restrict__ num_rendered,
                      uint32_t* __restrict__ hv_header, RdgHeavyDesc* __restrict__ hv_desc, uint2* __restrict__ hv_work,
                      uint32_t* __restrict__ hv_nodes, uint32_t max_heavy, uint32_t max_chunks, uint32_t max_work,
-                     int32_t* __restrict__ max_tile_out, uint2* __restrict__ hv_chunk_work, uint32_t max_chunk_items) {
+                     int32_t* __restrict__ max_tile_out, uint2* __restrict__ hv_chunk_work, uint32_t max_chunk_items,
+                     int32_t* __restrict__ host_mirror) {
     if ((long long)(*num_rendered) > capacity) {
         if (threadIdx.x == 0 && max_tile_out) *max_tile_out = 0;
+        if (threadIdx.x == 0 && host_mirror) { host_mirror[1] = 0; __threadfence_system(); host_mirror[0] = *num_rendered; }
         // capacity overflow: leave EVERY tile empty, so the compositing kernels (forward and backward) see a valid,
         // empty scene (background image, zero gradients) instead of stale ranges; the host detects D > capacity
         for (int i = threadIdx.x; i < n_tiles; i += 1024) { ranges[i] = make_uint2(0u, 0u); tile_fill[i] = 0u; }
@@ -513,6 +515,8 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
         hv_header[0] = min(sWork, max_work); hv_header[1] = min(sHeavy, max_heavy);
         hv_header[2] = min(sChunkItems, max_chunk_items);
         if (max_tile_out) *max_tile_out = (int32_t)sMaxTile;
+        // host mirror (RdgRasterSettings.num_rendered_host): [1] first, [0] last -- the host polls [0]
+        if (host_mirror) { host_mirror[1] = (int32_t)sMaxTile; __threadfence_system(); host_mirror[0] = *num_rendered; }
     }
 }
 
@@ -1008,7 +1012,8 @@ rdg_tile_sort_large_kernel(const uint2* __restrict__ ranges, uint64_t* __restric
 
 // largest tile list of the radix path (the bucket path gets it from its scan kernel): num_rendered[1]
 __global__ void __launch_bounds__(1024)
-rdg_tile_max_kernel(int n_tiles, const uint2* __restrict__ ranges, long long capacity, int32_t* __restrict__ num_rendered) {
+rdg_tile_max_kernel(int n_tiles, const uint2* __restrict__ ranges, long long capacity, int32_t* __restrict__ num_rendered,
+                    int32_t* __restrict__ host_mirror) {
     __shared__ uint32_t sMax;
     if (threadIdx.x == 0) sMax = 0u;
     __syncthreads();
@@ -1017,7 +1022,10 @@ rdg_tile_max_kernel(int n_tiles, const uint2* __restrict__ ranges, long long cap
         for (int i = threadIdx.x; i < n_tiles; i += 1024) { const uint2 r = ranges[i]; m = max(m, r.y - r.x); }
     atomicMax(&sMax, m);
     __syncthreads();
-    if (threadIdx.x == 0) num_rendered[1] = (int32_t)sMax;
+    if (threadIdx.x == 0) {
+        num_rendered[1] = (int32_t)sMax;
+        if (host_mirror) { host_mirror[1] = (int32_t)sMax; __threadfence_system(); host_mirror[0] = num_rendered[0]; }
+    }
 }
 
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
@@ -1077,7 +1085,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered, hv_header, hv_desc, hv_work, hv_nodes, HL.max_heavy,
                            HL.max_chunks, HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr,
-                           (uint2*)(hv + HL.chunks), HL.max_chunk_items);
+                           (uint2*)(hv + HL.chunks), HL.max_chunk_items, d.nren_host);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
@@ -1130,7 +1138,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                        (long long)capacity, num_rendered, ranges);
     if (d.nren_stats)
         hipLaunchKernelGGL(rdg_tile_max_kernel, dim3(1), dim3(1024), 0, s, n_tiles, ranges, (long long)capacity,
-                           num_rendered);
+                           num_rendered, d.nren_host);
     rdg_stage_end(RDG_STAGE_RANGES, s);
     return rdg_check_hip(hipGetLastError(), "bin launch");
 }

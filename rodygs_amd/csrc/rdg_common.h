@@ -228,6 +228,7 @@ struct RdgDev {
     int32_t tile_cnt_zeroed;   // internal: the per-tile counters were cleared by the per-Gaussian stage's scan kernel
     int32_t grad_rows_zeroed;  // RdgRasterSettings.grad_rows_zeroed (backward)
     void* zero_grad_ws;        // RdgRasterSettings.zero_grad_ws (forward): gradient rows cleared by the compositing kernel
+    int32_t* nren_host;        // RdgRasterSettings.num_rendered_host (forward): host mirror of num_rendered[0..1]
 };
 
 // ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------

@@ -27,6 +27,7 @@ from . import _lib
 # module-level knobs (not part of the reference surface)
 RENDER_NORMAL = True          # composite the (unused-by-RoDyGS) normal channels
 PREZERO_GRAD_ROWS = os.environ.get("RDG_PREZERO_GRAD_ROWS", "1") != "0"   # the forward clears the backward's gradient rows
+NREN_HOST_MIRROR = os.environ.get("RDG_NREN_MIRROR", "1") != "0"           # deferred check: the device writes D to pinned memory
 _CAPACITY_HINT = {}           # (P, H, W) -> last num_rendered, to size the binning workspace without a sync
 _BIN_HINT = {}                # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
 # Bucket binning (count / scan / scatter + per-tile sort) is the fast path on ordinary frames, but its cost grows with
@@ -56,7 +57,7 @@ GRAPH_CAPTURE = False
 _LAST_NREN = [None]               # (nren int32[2] device tensor, key, capacity) of the most recent forward
 
 DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
-_PENDING = []                     # (event, pinned int32[1], key, capacity) of forwards not yet checked
+_PENDING = []                     # (stream, pinned int32[2], key, capacity, device pair) of forwards not yet checked
 _PINNED_FREE = []
 
 
@@ -92,10 +93,13 @@ def _too_many(key) -> str:
 def poll_overflow(block: bool = False) -> None:
     """Deferred mode: check the instance counts of forwards whose copy has landed (all of them if ``block``)."""
     while _PENDING:
-        ev, host, key, cap = _PENDING[0]
-        if not block and not ev.query():
-            return
-        ev.synchronize()
+        stream, host, key, cap, nren = _PENDING[0]
+        if int(host[0]) < 0:                  # the binning stage of that forward has not written its mirror yet
+            if not block:
+                return
+            stream.synchronize()
+            if int(host[0]) < 0:              # (a path that does not mirror: read the device pair)
+                host[0], host[1] = (int(v) for v in nren.tolist())
         n = int(host[0])
         _PENDING.pop(0)
         _PINNED_FREE.append(host)
@@ -253,6 +257,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             deferred = DEFERRED_OVERFLOW_CHECK and key in _CAPACITY_HINT and not GRAPH_CAPTURE
             if deferred:
                 poll_overflow(block=False)
+            host = None
+            if deferred:
+                # D and the largest list are ALSO written to pinned host memory by the binning stage itself
+                # (RdgRasterSettings.num_rendered_host): no copy and no event on the stream; -1 = not there yet
+                host = _pinned_slot()
+                host[0], host[1] = -1, -1
+                if NREN_HOST_MIRROR:
+                    cs.num_rendered_host = host.data_ptr()
             while True:
                 binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), **u8)
                 rc = L.rdg_rasterize_forward(C.byref(cs), _lib.ptr(bg), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col),
@@ -269,11 +281,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                     # opt-in: no host wait at all.  D goes to pinned memory asynchronously and is checked by
                     # poll_overflow() at the next forward / on demand; on overflow the device has rendered an
                     # empty scene (every tile range zero) and RasterizerCapacityOverflow is raised then.
-                    host = _pinned_slot()
-                    host.copy_(nren, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    _PENDING.append((ev, host, key, cap))
+                    if not NREN_HOST_MIRROR:           # the copy-engine form: a blit and an event on the stream per frame
+                        host.copy_(nren, non_blocking=True)
+                    _PENDING.append((torch.cuda.current_stream(dev), host, key, cap, nren))
                     n = -1
                     break
                 # one host read AFTER the whole forward is queued (upstream stalls mid-pipeline instead)

@@ -361,6 +361,11 @@ class ShardedDynamicScene:
         if deferred:
             rasterizer.poll_overflow(block=False)
         st = _lib.stream_ptr()
+        host = None
+        if deferred:                # the binning stage mirrors (D, largest list) into pinned memory: rasterizer.poll_overflow
+            host = rasterizer._pinned_slot()
+            host[0], host[1] = -1, -1
+        self.cs_cam.num_rendered_host = None if host is None else host.data_ptr()
         while True:
             if self._binning is None or self._capacity != cap:
                 self._binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), dtype=torch.uint8, device=dev)
@@ -373,11 +378,7 @@ class ShardedDynamicScene:
                                                _lib.ptr(self.depth), _lib.ptr(self.normal), _lib.ptr(self.alpha), st),
                        "rdg_composite_forward")
             if deferred:
-                host = rasterizer._pinned_slot()
-                host.copy_(self.nren, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                rasterizer._PENDING.append((ev, host, self.key, cap))
+                rasterizer._PENDING.append((torch.cuda.current_stream(dev), host, self.key, cap, self.nren))
                 break
             D, largest = (int(v) for v in self.nren.tolist())
             hint[self.key] = D

@@ -43,7 +43,7 @@ def test_workspace_sizes(hip_lib):
 def test_c_struct_matches_header():
     import ctypes
     from rodygs_amd._lib import RdgRasterSettings
-    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 8
+    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 16
     from rodygs_amd import _lib
     assert _lib.lib().rdg_settings_bytes() == ctypes.sizeof(RdgRasterSettings)      # the compiled header's sizeof
     assert RdgRasterSettings.zero_grad_ws.offset == 72
