@@ -1098,8 +1098,15 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
         int nb = (P + 1023) / 1024;
         if (nb > rdg_getter_grid_cap()) nb = rdg_getter_grid_cap();
         uint32_t* counter = (uint32_t*)((char*)sorted_ws + rdg_deform_gs_bytes(P));
-        static const hipError_t attr = rdg_getter_lds_attr((const void*)rdg_dyn_getter_bwd_kernel);
-        if (attr != hipSuccess) return rdg_check_hip(attr, "dyn_getter_bwd LDS attribute");
+        // once per device of this process (the attribute belongs to the function ON a device)
+        static bool attr_set[64] = {};
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
+            const hipError_t attr = rdg_getter_lds_attr((const void*)rdg_dyn_getter_bwd_kernel);
+            if (attr != hipSuccess) return rdg_check_hip(attr, "dyn_getter_bwd LDS attribute");
+            if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+        }
         hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), rdg_getter_lds(Tu), st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
