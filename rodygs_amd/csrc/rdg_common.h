@@ -450,25 +450,36 @@ __device__ __forceinline__ void rdg_adam_elem(float& p, float g, float& m, float
 }
 
 
-// p[rows] <- Adam(p, g = S): the update form of rdg_lds_to_rows (same chunking; head_len leading floats of a row take
-// step_head, the rest step_tail)
-__device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const RdgShAdam ad, long long first_row,
-                                                  long long n_rows, int row, int stride, const float* S, int lane) {
+// ---- factored SH gradient rows -------------------------------------------------------------------------------------
+// dL/dsh[k][ch] of a Gaussian is basis_k(direction) * dL/dcolour[ch] (clamped channels: 0): 16 + 3 numbers instead of
+// 48.  The per-Gaussian backward leaves them in a small LDS tile (F: 64 rows of RDG_FAC floats -- basis values at 0..15,
+// the three colour gradients at 16..18) next to the tile S that still holds the SH VALUES it staged at its start, so the
+// optimizer-in-backward step below needs no second trip to memory for the parameters (192 B per Gaussian at 16
+// coefficients, 13 % of that kernel's bytes).  g = F[k] * F[16 + ch] is the same product the unfactored form stored.
+#define RDG_FAC 20
+__device__ __forceinline__ float rdg_fac_grad(const float* Frow, int idx) {
+    const int k = (idx * 171) >> 9;              // idx / 3 for idx < 171 (rows hold <= 48 floats)
+    return Frow[k] * Frow[16 + (idx - 3 * k)];
+}
+// p[rows] <- Adam(p = S (the staged values), g = factored): the update form of rdg_lds_to_rows (same chunking; head_len
+// leading floats of a row take step_head, the rest step_tail).  RDG_ADAM_UNROLL chunks per trip with every load issued
+// before the first use: the kernel that calls this runs two waves per SIMD, so the bytes in flight per CU -- not the
+// arithmetic -- set its rate
+__device__ __forceinline__ void rdg_lds_adam_rows_fac(float* __restrict__ p, const RdgShAdam ad, long long first_row,
+                                                      long long n_rows, int row, int stride, const float* S,
+                                                      const float* F, int lane) {
     const long long base = first_row * row, total = n_rows * row;
     const float inv_row = 1.0f / (float)row;
     typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
     if ((row & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)ad.m) | ((uintptr_t)ad.v)) & 15) == 0) {
-        // RDG_ADAM_UNROLL chunks per trip with every load issued before the first use: the kernel that calls this runs
-        // two waves per SIMD (186 VGPRs), so the bytes in flight per CU -- not the arithmetic -- set its rate
 #define RDG_ADAM_UNROLL 4
         for (int v0 = lane; v0 < 16 * row; v0 += 64 * RDG_ADAM_UNROLL) {
-            rdg_nt4 pp[RDG_ADAM_UNROLL], mm[RDG_ADAM_UNROLL], vv[RDG_ADAM_UNROLL];
+            rdg_nt4 mm[RDG_ADAM_UNROLL], vv[RDG_ADAM_UNROLL];
 #pragma unroll
             for (int u = 0; u < RDG_ADAM_UNROLL; ++u) {
                 const int v = v0 + 64 * u;
                 const long long e = base + 4ll * v;
                 if (v < 16 * row && e < total) {
-                    pp[u] = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(p + e));
                     mm[u] = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.m + e));
                     vv[u] = __builtin_nontemporal_load(reinterpret_cast<const rdg_nt4*>(ad.v + e));
                 }
@@ -481,12 +492,14 @@ __device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const R
                     const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
                     const int col = 4 * v - gi * row;
                     const float* src = S + gi * stride + col;
-                    float P4[4] = {pp[u].x, pp[u].y, pp[u].z, pp[u].w}, M4[4] = {mm[u].x, mm[u].y, mm[u].z, mm[u].w};
+                    const float* Frow = F + gi * RDG_FAC;
+                    float P4[4] = {src[0], src[1], src[2], src[3]}, M4[4] = {mm[u].x, mm[u].y, mm[u].z, mm[u].w};
                     float V4[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        rdg_adam_elem(P4[c], src[c], M4[c], V4[c], (col + c) < ad.head_len ? ad.step_head : ad.step_tail,
-                                      ad.b1, ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
+                        rdg_adam_elem(P4[c], rdg_fac_grad(Frow, col + c), M4[c], V4[c],
+                                      (col + c) < ad.head_len ? ad.step_head : ad.step_tail, ad.b1, ad.b2, ad.omb1, ad.omb2,
+                                      ad.eps, ad.bc2_sqrt);
                     __builtin_nontemporal_store(rdg_nt4{P4[0], P4[1], P4[2], P4[3]}, reinterpret_cast<rdg_nt4*>(p + e));
                     __builtin_nontemporal_store(rdg_nt4{M4[0], M4[1], M4[2], M4[3]}, reinterpret_cast<rdg_nt4*>(ad.m + e));
                     __builtin_nontemporal_store(rdg_nt4{V4[0], V4[1], V4[2], V4[3]}, reinterpret_cast<rdg_nt4*>(ad.v + e));
@@ -500,10 +513,38 @@ __device__ __forceinline__ void rdg_lds_adam_rows(float* __restrict__ p, const R
             if (e < total) {
                 const int gi = (int)(((float)idx + 0.5f) * inv_row);
                 const int col = idx - gi * row;
-                float pi = p[e], mi = ad.m[e], vi = ad.v[e];
-                rdg_adam_elem(pi, S[gi * stride + col], mi, vi, col < ad.head_len ? ad.step_head : ad.step_tail, ad.b1,
-                              ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
+                float pi = S[gi * stride + col], mi = ad.m[e], vi = ad.v[e];
+                rdg_adam_elem(pi, rdg_fac_grad(F + gi * RDG_FAC, col), mi, vi, col < ad.head_len ? ad.step_head : ad.step_tail,
+                              ad.b1, ad.b2, ad.omb1, ad.omb2, ad.eps, ad.bc2_sqrt);
                 p[e] = pi; ad.m[e] = mi; ad.v[e] = vi;
+            }
+        }
+    }
+}
+// g[rows] = factored gradient: the store form (no optimizer in the kernel)
+__device__ __forceinline__ void rdg_lds_to_rows_fac(float* __restrict__ g, long long first_row, long long n_rows, int row,
+                                                    const float* F, int lane) {
+    const long long base = first_row * row, total = n_rows * row;
+    const float inv_row = 1.0f / (float)row;
+    if ((row & 3) == 0 && (((uintptr_t)g) & 15) == 0) {
+        for (int v = lane; v < 16 * row; v += 64) {
+            const long long e = base + 4ll * v;
+            if (e < total) {
+                const int gi = (int)(((float)(4 * v) + 0.5f) * inv_row);
+                const int col = 4 * v - gi * row;
+                const float* Frow = F + gi * RDG_FAC;
+                typedef float rdg_nt4 __attribute__((ext_vector_type(4)));
+                const rdg_nt4 val = {rdg_fac_grad(Frow, col), rdg_fac_grad(Frow, col + 1), rdg_fac_grad(Frow, col + 2),
+                                     rdg_fac_grad(Frow, col + 3)};
+                __builtin_nontemporal_store(val, reinterpret_cast<rdg_nt4*>(g + e));
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 64 * row; idx += 64) {
+            const long long e = base + idx;
+            if (e < total) {
+                const int gi = (int)(((float)idx + 0.5f) * inv_row);
+                g[e] = rdg_fac_grad(F + gi * RDG_FAC, idx - gi * row);
             }
         }
     }

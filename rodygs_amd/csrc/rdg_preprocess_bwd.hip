@@ -44,6 +44,10 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
     // its own row IN PLACE -- every coefficient is read before its slot is overwritten with the gradient.
     __shared__ float sSH[NW][64 * 49];
     __shared__ float sGR[MULTI ? NW : 1][MULTI ? 64 * 49 : 1];
+    // single camera: the SH gradient of a Gaussian stays FACTORED (16 basis values + 3 colour gradients, rdg_common.h) and
+    // the staged SH values stay where they are -- the optimizer step at the end reads its parameters from LDS
+    __shared__ __attribute__((aligned(16))) float sFac[MULTI ? 1 : NW][MULTI ? 4 : 64 * RDG_FAC];
+    float* const myFac = MULTI ? nullptr : sFac[threadIdx.x >> 6] + (threadIdx.x & 63) * RDG_FAC;
     const int sh_row = d.M * 3, sh_stride = sh_row | 1;
     float* const mySH = sSH[threadIdx.x >> 6] + (threadIdx.x & 63) * sh_stride;
     float* const myGR = MULTI ? sGR[threadIdx.x >> 6] + (threadIdx.x & 63) * sh_stride : mySH;
@@ -224,13 +228,19 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                 const float il = 1.0f / ln;
                 const float ux = ox * il, uy = oy * il, uz = oz * il;
                 const float* sh = mySH;
-                float* dsh = myGR;          // single camera: in place (every coefficient is read before it is overwritten)
-#define RDG_DSH(idx, val) do { if (MULTI) dsh[idx] += (val); else dsh[idx] = (val); } while (0)
+                float* dsh = myGR;          // several cameras: accumulated over them in the second tile
+                // single camera: only the basis values are kept (bk), the gradient is their product with gcol
+                float bk[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) bk[k] = 0.0f;
+                bk[0] = SH_C0;
+#define RDG_DSH(idx, val) do { if (MULTI) dsh[idx] += (val); } while (0)
                 float dRx = 0.f, dRy = 0.f, dRz = 0.f;  // dL/d(unit dir)
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) RDG_DSH(ch, SH_C0 * gcol[ch]);
                 if (d.deg > 0) {
                     const float b1 = -SH_C1 * uy, b2 = SH_C1 * uz, b3 = -SH_C1 * ux;
+                    bk[1] = b1; bk[2] = b2; bk[3] = b3;
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
                         const float g = gcol[ch];
@@ -244,6 +254,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                         const float xx = ux * ux, yy = uy * uy, zz = uz * uz, xy = ux * uy, yz = uy * uz, xz = ux * uz;
                         const float b4 = BSH_C2[0] * xy, b5 = BSH_C2[1] * yz, b6 = BSH_C2[2] * (2.0f * zz - xx - yy),
                                     b7 = BSH_C2[3] * xz, b8 = BSH_C2[4] * (xx - yy);
+                        bk[4] = b4; bk[5] = b5; bk[6] = b6; bk[7] = b7; bk[8] = b8;
 #pragma unroll
                         for (int ch = 0; ch < 3; ++ch) {
                             const float g = gcol[ch];
@@ -263,6 +274,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                                         b12 = BSH_C3[3] * uz * (2.0f * zz - 3.0f * xx - 3.0f * yy),
                                         b13 = BSH_C3[4] * ux * (4.0f * zz - xx - yy), b14 = BSH_C3[5] * uz * (xx - yy),
                                         b15 = BSH_C3[6] * ux * (xx - 3.0f * yy);
+                            bk[9] = b9; bk[10] = b10; bk[11] = b11; bk[12] = b12; bk[13] = b13; bk[14] = b14; bk[15] = b15;
 #pragma unroll
                             for (int ch = 0; ch < 3; ++ch) {
                                 const float g = gcol[ch];
@@ -286,11 +298,13 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                         }
                     }
                 }
-                // zero the inactive-degree coefficients of this Gaussian
-                if (!MULTI)
-                    for (int k = (d.deg + 1) * (d.deg + 1); k < d.M; ++k) {
-                        dsh[3 * k + 0] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f;
-                    }
+                // (the basis values of the inactive degrees stay 0: their coefficients get a zero gradient)
+                if (!MULTI) {
+                    float4* f4 = reinterpret_cast<float4*>(myFac);
+                    f4[0] = make_float4(bk[0], bk[1], bk[2], bk[3]);     f4[1] = make_float4(bk[4], bk[5], bk[6], bk[7]);
+                    f4[2] = make_float4(bk[8], bk[9], bk[10], bk[11]);   f4[3] = make_float4(bk[12], bk[13], bk[14], bk[15]);
+                    f4[4] = make_float4(gcol[0], gcol[1], gcol[2], 0.0f);
+                }
 #undef RDG_DSH
                 // unit-vector normalisation backward
                 const float dotg = ux * dRx + uy * dRy + uz * dRz;
@@ -337,8 +351,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                 dq3 = 2.0f * (-2.0f * qz * dR00 - qr * dR01 + qx * dR02 + qr * dR10 - 2.0f * qz * dR11 + qy * dR12 +
                               qx * dR20 + qy * dR21);
             }
-        } else if (shs && !MULTI) {
-            for (int k = 0; k < sh_row; ++k) mySH[k] = 0.f;
+        }
+        if (shs && !MULTI && (!live || colors)) {     // no SH gradient for this Gaussian: all factors zero
+            float4* f4 = reinterpret_cast<float4*>(myFac);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) f4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         dmeans3D[3 * i + 0] = dmx; dmeans3D[3 * i + 1] = dmy; dmeans3D[3 * i + 2] = dmz;
         dmeans2D[3 * i + 0] = gnx; dmeans2D[3 * i + 1] = gny; dmeans2D[3 * i + 2] = 0.f;
@@ -356,12 +373,13 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
     }
     if (shs && wave_first < d.P && vw == nviews - 1) {
         rdg_wave_lds_sync();
-        const float* tile = MULTI ? sGR[threadIdx.x >> 6] : sSH[threadIdx.x >> 6];
-        if (!MULTI && sh_adam.m)       // optimizer in backward: the SH parameters are updated from the LDS tile
-            rdg_lds_adam_rows(const_cast<float*>(shs), rdg_sh_adam_resolve(sh_adam), wave_first, d.P, sh_row, sh_stride, tile,
-                              threadIdx.x & 63);
+        if (MULTI)
+            rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, sGR[threadIdx.x >> 6], threadIdx.x & 63);
+        else if (sh_adam.m)            // optimizer in backward: parameters from the staged tile, gradient from the factors
+            rdg_lds_adam_rows_fac(const_cast<float*>(shs), rdg_sh_adam_resolve(sh_adam), wave_first, d.P, sh_row, sh_stride,
+                                  sSH[threadIdx.x >> 6], sFac[threadIdx.x >> 6], threadIdx.x & 63);
         else
-            rdg_lds_to_rows(dshs, wave_first, d.P, sh_row, sh_stride, tile, threadIdx.x & 63);
+            rdg_lds_to_rows_fac(dshs, wave_first, d.P, sh_row, sFac[threadIdx.x >> 6], threadIdx.x & 63);
     }
     // pose-gradient reduction: DPP wave sums -> LDS -> ONE partial row per workgroup (no atomics: 16 k waves
     // hammering the same 19 addresses ran 20x slower than the rest of the kernel, and this form is deterministic)
