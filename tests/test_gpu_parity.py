@@ -2733,7 +2733,7 @@ def test_psnr_delta_through_the_real_train_step():
         of the oracle at step 100 and 0.1 dB at the densification (all HIP runs within 0.12 dB of each other there),
         SH-Adam-in-backward == separate launch bit for bit;
       * chaotic part -- 4 float-atomic runs: same early gates per run; at the end the oracle (one more draw of the same
-        process) within 0.05 dB + 2 standard errors of their mean."""
+        process) within 0.05 dB + 2 standard errors of their mean, the spread taken as at least 0.1 dB."""
     import importlib.util
     spec = importlib.util.spec_from_file_location(
         "psnr_delta", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "psnr_delta.py"))
@@ -2759,8 +2759,14 @@ def test_psnr_delta_through_the_real_train_step():
         # and the HIP runs -- which share everything but the float-atomic order -- must agree among themselves
         assert abs(d) <= 0.1, (k, d, res["delta_db_at_step"])
     assert max(at250.values()) - min(at250.values()) <= 0.12, at250          # measured: up to 0.062 (seed 11, 8 atomic runs)
-    assert abs(sm["mean_delta_db"]) <= 0.05 + 2.0 * sm["mean_delta_se_db"], sm
-    assert sm["hip_std_end_db"] < 0.2, sm
+    # End of the free runs: chaos on BOTH sides.  The oracle's end value is one draw of the same process and moves with the
+    # host (24.68 ... 24.80 dB on four boxes of the pool for this seed: its CPU reductions follow the thread count); four
+    # runs give a poor estimate of the spread (0.045 ... 0.15 dB seen), so the standard error uses at least the 0.1 dB the
+    # process is known to have.  This is a sanity bar for gross errors -- the 0.05 dB statement is the teacher-forced gate.
+    n_runs = sm["n_atomic_runs"]
+    se = max(sm["hip_std_end_db"], 0.1) * (1.0 + 1.0 / n_runs) ** 0.5
+    assert abs(sm["mean_delta_db"]) <= 0.05 + 2.0 * se, sm
+    assert sm["hip_std_end_db"] < 0.3, sm
 
 
 def test_teacher_forced_psnr_drift_detects_a_one_percent_gradient_error():
