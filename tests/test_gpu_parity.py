@@ -632,7 +632,9 @@ def test_deterministic_backward_full_size_1m_1080p():
         assert torch.equal(a[k], b[k]), f"deterministic mode at 1 M: d_{k} differs between two runs"
     at = _hip_grads(sc, 3, (0.0, 0.0, 0.0), False)
     for k in a:
-        rel_ok(a[k], at[k], tol=2e-5, what=f"deterministic vs atomic at 1 M: d_{k}")
+        # summation order only: <= 2e-5 of the column's scale, up to a handful of the 1 M rows just above it (seen: one
+        # quaternion component at 2.2e-5 on one run of the float-atomic path), none above 1e-4
+        rel_ok(a[k], at[k], tol=2e-5, outliers=1e-5, cap=1e-4, what=f"deterministic vs atomic at 1 M: d_{k}")
 
 
 def _tile_counts(ranges):
