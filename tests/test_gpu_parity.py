@@ -351,7 +351,7 @@ def test_render_without_the_normal_channels_is_the_same_frame():
         assert torch.equal(with_n[i], without[i]), i
     assert float(without[2].detach().abs().max()) == 0.0 and float(with_n[2].detach().abs().max()) > 0.0
     for k in ("means3D", "opacities", "scales", "rotations", "viewmatrix"):
-        rel_ok(ins_w[k].grad, ins_n[k].grad, tol=1e-5, what="d_" + k)     # float atomics: not bitwise
+        rel_ok(ins_w[k].grad, ins_n[k].grad, tol=1e-5, outliers=1e-4, cap=1e-4, what="d_" + k)     # float atomics: not bitwise
 
 
 def test_capacity_overflow_retries_and_retain_graph():
@@ -374,7 +374,7 @@ def test_capacity_overflow_retries_and_retain_graph():
     g1 = ins["means3D"].grad.clone()
     ins["means3D"].grad = None
     loss.backward()
-    rel_ok(ins["means3D"].grad, g1, tol=1e-5, what="repeat backward")
+    rel_ok(ins["means3D"].grad, g1, tol=1e-5, outliers=1e-4, cap=1e-4, what="repeat backward")     # float atomics: summation order
     st = O.OracleSettings(240, 320, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 1)
     with torch.no_grad():
         oc = O.rasterize(sc["means3D"], torch.zeros(3000, 3), sc["opacities"], sc["viewmatrix"], st, shs=sc["shs"],
@@ -612,7 +612,7 @@ def test_deterministic_backward_is_bit_reproducible(scene):
         assert bool(torch.isfinite(a[k]).all())
     at = _hip_grads(sc, 3, bg, False, depth)
     for k in a:
-        rel_ok(a[k], at[k], tol=1e-5, what=f"deterministic vs atomic d_{k}")
+        rel_ok(a[k], at[k], tol=1e-5, outliers=1e-4, cap=1e-4, what=f"deterministic vs atomic d_{k}")
     if scene == "uniform":
         res = run_pair(sc, 3, bg, seed=11)     # same loss weights (seed) as _hip_grads
         oi, om2 = res[3], res[4]
@@ -810,7 +810,7 @@ def test_full_size_properties_1m_1080p():
     gw = torch.rand(3, H, W, device=DEV)
     g1 = torch.autograd.grad(a[0], ins["shs"], gw, retain_graph=True)[0]
     g2 = torch.autograd.grad(a[0], ins["shs"], 2.5 * gw)[0]
-    rel_ok(g2, 2.5 * g1, tol=2e-5, what="backward linearity")      # float atomics: order-dependent rounding only
+    rel_ok(g2, 2.5 * g1, tol=2e-5, outliers=1e-4, cap=2e-4, what="backward linearity")      # float atomics: order-dependent rounding only
 
 
 @pytest.mark.parametrize("P,W,H,n_sample", [(100000, 1920, 1080, 20),       # BASELINE configs[1]
