@@ -1,6 +1,7 @@
 // rdg_api.hip -- the extern "C" surface of librodygs_hip.so (declared in include/rodygs_hip.h).
 // No torch headers, no exceptions across the ABI, no device allocation: plain pointers, sizes and a stream.
 #include "rdg_common.h"
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -45,7 +46,36 @@ static void rdg_timing_drain() {
     }
     g_npending = 0;
 }
+// ---- named ranges for rocprofv3 --marker-trace: RDG_ROCTX=1 in the environment ---------------
+// roctx is looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so): the library has no link-time
+// dependency on a profiler.  Ranges are host-side push / pop pairs around the launches of a stage.
+typedef int (*rdg_roctx_push_t)(const char*);
+typedef int (*rdg_roctx_pop_t)(void);
+static rdg_roctx_push_t g_roctx_push = nullptr;
+static rdg_roctx_pop_t g_roctx_pop = nullptr;
+static int g_roctx = -1;      // -1: not looked at yet, 0: off, 1: on
+static const char* const g_stage_names[RDG_STAGE_COUNT] = {
+    "rdg:preprocess", "rdg:scan_dup", "rdg:sort", "rdg:ranges", "rdg:render_fwd", "rdg:render_bwd", "rdg:preprocess_bwd",
+    "rdg:deform_fwd", "rdg:deform_bwd", "rdg:adam", "rdg:loss_fwd", "rdg:loss_bwd", "rdg:mlp_fwd", "rdg:mlp_bwd"};
+static bool rdg_roctx_on() {
+    if (g_roctx < 0) {
+        g_roctx = 0;
+        const char* e = getenv("RDG_ROCTX");
+        if (e && e[0] == '1') {
+            void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                g_roctx_push = (rdg_roctx_push_t)dlsym(h, "roctxRangePushA");
+                g_roctx_pop = (rdg_roctx_pop_t)dlsym(h, "roctxRangePop");
+                if (g_roctx_push && g_roctx_pop) g_roctx = 1;
+            }
+        }
+    }
+    return g_roctx == 1;
+}
+
 void rdg_stage_begin(int stage, hipStream_t s) {
+    if (rdg_roctx_on() && stage >= 0 && stage < RDG_STAGE_COUNT) (void)g_roctx_push(g_stage_names[stage]);
     if (!g_timing || !((g_timing_mask >> stage) & 1u)) return;
     if (g_npending >= RDG_MAX_PENDING) rdg_timing_drain();
     hipEvent_t e;
@@ -54,6 +84,7 @@ void rdg_stage_begin(int stage, hipStream_t s) {
     g_open[stage] = e;
 }
 void rdg_stage_end(int stage, hipStream_t s) {
+    if (g_roctx == 1) (void)g_roctx_pop();
     if (!g_timing || !g_open[stage]) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;

@@ -10,7 +10,7 @@ make -j8 > /dev/null
 cp $2.o /tmp/$2.keep.o
 rm -f $2.o
 make EXTRA="$3" $2.o > /dev/null
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 *.o -o variants/$1.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 *.o -ldl -o variants/$1.so
 cp /tmp/$2.keep.o $2.o
 touch $2.o
 echo "built variants/$1.so ($2 with $3)"
