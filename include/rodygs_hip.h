@@ -172,8 +172,9 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
 /* Deterministic form of rdg_composite_backward (SURVEY.md section 5b "deterministic mode: no float atomics -> bit-
  * reproducible"; the reference's un-vendored rasterizer accumulates with float atomics, whose order changes from run to
  * run): every wave STORES its per-(tile, splat) totals to its own quarter of a 256-B row per list position in det_ws
- * (rdg_det_bytes(n_instances) bytes, n_instances >= the frame's num_rendered; zeroed by this call), then one pass adds
- * them up per Gaussian in the order of its tile rectangle.  Same gradient rows as rdg_composite_backward up to the
+ * (rdg_det_bytes(n_instances) bytes, n_instances >= the frame's num_rendered; zeroed by this call; rows in Gaussian-major
+ * order, addressed through an exclusive scan of tiles_touched kept at the end of grad_ws), then one pass adds them up per
+ * Gaussian in the order of its tile rectangle.  Same gradient rows as rdg_composite_backward up to the
  * rounding of a different summation order; two calls on the same inputs give the same bits.                          */
 size_t rdg_det_bytes(int64_t n_instances);
 int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg, const void* geom_ws,

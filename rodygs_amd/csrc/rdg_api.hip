@@ -161,12 +161,14 @@ const char* rdg_last_error(void) { return g_err; }
 size_t rdg_geom_bytes(int32_t P) { return rdg_geom_layout(P).total; }
 size_t rdg_binning_bytes(int64_t capacity, int32_t n_tiles) { return rdg_bin_layout(capacity, n_tiles).total; }
 size_t rdg_image_bytes(int32_t H, int32_t W) { return rdg_image_layout(H, W).total; }
+// deterministic mode: first-instance index of every Gaussian (uint32 [P]), the LAST piece of the gradient workspace
+static size_t rdg_det_off_bytes(int32_t P) { return rdg_align_up((size_t)(P > 0 ? P : 1) * 4, 256); }
 size_t rdg_grad_bytes(int32_t P) {
     const size_t Pp = (size_t)(P > 0 ? P : 1);
     // gradient rows + one pose partial row per per-Gaussian workgroup + 32 second-level pose partial rows
     // (one set of second-level rows per camera for the *_views entry points)
     return rdg_align_up(Pp * RDG_GROW * 4, 256) + rdg_align_up(((Pp + 127) / 128) * 19 * 4, 256) + 4096 +
-           (size_t)RDG_MAX_VIEWS * 32 * 19 * 4;
+           (size_t)RDG_MAX_VIEWS * 32 * 19 * 4 + rdg_det_off_bytes(P);
 }
 size_t rdg_sort_tmp_bytes(int64_t capacity) {
     // alternate key/value buffers + tables
@@ -282,8 +284,10 @@ int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg,
     // reduction, every one of them
     hipError_t e = rdg_zero_async(det_ws, rdg_det_bytes(n_instances), st);
     if (e != hipSuccess) return rdg_check_hip(e, "det row memset");
+    uint32_t* det_off = (uint32_t*)((char*)grad_ws + rdg_grad_bytes(d.P) - rdg_det_off_bytes(d.P));
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
-                                   grad_out_alpha, (float*)grad_ws, st, (float*)det_ws, grad_out_normal);
+                                   grad_out_alpha, (float*)grad_ws, st, (float*)det_ws, grad_out_normal, det_off,
+                                   (long long)n_instances);
     rdg_stage_end(RDG_STAGE_RENDER_BWD, st);
     return rc;
 }

@@ -285,7 +285,7 @@ int rdg_launch_split_build(const RdgDev& d, void* bin_ws, int64_t capacity, cons
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
                           int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
                           const float* g_alpha, float* grow, hipStream_t s, float* det = nullptr,
-                          const float* g_normal = nullptr);
+                          const float* g_normal = nullptr, uint32_t* det_off = nullptr, long long n_instances = 0);
 int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, const int32_t* radii, const void* geom_ws,

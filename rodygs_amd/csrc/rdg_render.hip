@@ -821,7 +821,7 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                   const RdgRec* __restrict__ rec, const unsigned long long* __restrict__ hit, float4* sQ0, float4* sQ1,
                   float4* sQ2, float4* sQ3, unsigned long long (*sMask)[4], unsigned long long* sCap, float (*ring)[16][RDG_RING_Q],
                   const float flush_scale, const int flush_off, float* __restrict__ gdst, float& T, float& behind,
-                  int& ring_n) {
+                  int& ring_n, const uint32_t* __restrict__ det_off, const int gx, const int gy, const int tx, const int ty) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int rounds = (k_top - k_lo + RDG_BATCH - 1) / RDG_BATCH;
@@ -848,7 +848,19 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                     const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
                     sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
                     sQ1[tid] = make_float4(cs.gam, q1.y, q1.z, 0.0f);
-                    sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(DET ? range.x + (uint32_t)k : id));
+                    uint32_t row = id;
+                    if (DET) {
+                        // deterministic mode: the row of this (tile, Gaussian) instance in Gaussian-major order -- the
+                        // Gaussian's first instance (det_off, exclusive scan of tiles_touched) + the tile's ordinal inside
+                        // the Gaussian's rectangle (the rectangle rule of the binning stage, restated on the record): the
+                        // reduction then reads a Gaussian's rows one after the other, no search
+                        const float r_ = (float)__float_as_int(q1.w);
+                        const int x0 = min(gx, max(0, (int)((q0.x - r_) / (float)RDG_TILE)));
+                        const int y0 = min(gy, max(0, (int)((q0.y - r_) / (float)RDG_TILE)));
+                        const int x1 = min(gx, max(0, (int)((((q0.x + r_) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+                        row = det_off[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+                    }
+                    sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(row));
                     if (HAS_NORMAL) sQ3[tid] = p->q3;
                     over_cap = q1.y > RDG_ALPHA_CAP;
                 }
@@ -901,7 +913,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                       const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
                       const float* __restrict__ g_normal, float* __restrict__ grow, const unsigned long long* __restrict__ hitbits, int split_min,
                       const uint32_t* __restrict__ sp_header, const uint4* __restrict__ sp_work,
-                      const float* __restrict__ seg_pix) {
+                      const float* __restrict__ seg_pix, const uint32_t* __restrict__ det_off, int gy) {
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
     __shared__ float4 sQ3[HAS_NORMAL ? RDG_BATCH : 1];                  // normals, only with a normal gradient
     __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
@@ -986,50 +998,48 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         rdg_bwd_composite<HAS_DEPTH, DET, HAS_NORMAL>(k_lo, k_top, range, m0, m1, m2, m3, last_contributor, pixx, pixy, dLp0,
                                                       dLp1, dLp2, dLd, dLn0, dLn1, dLn2, point_list, rec, hit, sQ0, sQ1, sQ2,
                                                       sQ3, sMask, sCap, sRing[wv], flush_scale, flush_off, gdst, T, behind,
-                                                      ring_n);
+                                                      ring_n, det_off, gx, gy, tx, ty);
         rdg_ring_flush<HAS_DEPTH, DET>(sRing[wv], ring_n, lane, flush_scale, flush_off, gdst);
     }
 }
 
-// Deterministic mode, second half: one 16-lane group per Gaussian, lane c = component c of the 64-B gradient row.  The
-// group walks the Gaussian's tile rectangle in row-major order (the order its instances were emitted in), finds the
-// instance's position in the tile's sorted list by binary search on the composite (depth bits, index) -- the order of
-// every tile list in both binning modes (rdg_binning.hip) -- and adds the four per-wave partial rows of that position in
-// a fixed order.  Every float addition of the accumulation therefore happens in an order fixed by the geometry alone.
+// Deterministic mode, first step: det_off[g] = index of Gaussian g's first (tile, Gaussian) instance in Gaussian-major
+// order = exclusive scan of tiles_touched (the per-block part is the binning stage's block_sums).
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_det_offsets_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ block_sums,
+                       uint32_t* __restrict__ det_off) {
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / 64];
+    const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    const uint32_t mine = i < P ? tiles_touched[i] : 0u;
+    const uint32_t inc = rdg_wave_scan_incl(mine);
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = block_sums[blockIdx.x];
+    for (uint32_t k = 0; k < w; ++k) base += wsum[k];
+    if (i < P) det_off[i] = base + inc - mine;
+}
+
+// Deterministic mode, last step: one 16-lane group per Gaussian, lane c = component c of the 64-B gradient row.  The
+// Gaussian's instances sit in rows det_off[g] .. + tiles_touched[g] in the row-major order of its tile rectangle (the
+// staging of the compositing backward addressed them that way); the group adds the four per-wave partial rows of each
+// in a fixed order.  Every float addition of the accumulation therefore happens in an order fixed by the geometry alone
+// -- and the rows are read one after the other (the first form of this kernel found each instance by a binary search in
+// its tile's sorted list: 9 dependent loads per instance, 1.7 ms at D = 4 M).
 __global__ void __launch_bounds__(256)
-rdg_det_reduce_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
-                      const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const float* __restrict__ det, float* __restrict__ grow) {
+rdg_det_reduce_kernel(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ det_off,
+                      long long n_instances, const float* __restrict__ det, float* __restrict__ grow) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int g = (int)(t >> 4), c = (int)(t & 15);
     if (g >= P) return;
     float acc = 0.0f;
-    if (tiles_touched[g] > 0) {
-        const float4 q0 = rec[g].q0, q1 = rec[g].q1;
-        const int radius = __float_as_int(q1.w);
-        const unsigned long long want = ((unsigned long long)__float_as_uint(q1.z) << 32) | (unsigned long long)(uint32_t)g;
-        // the rectangle rule of the binning stage (rdg_rect_dup, rdg_binning.hip), restated on the record
-        const float r = (float)radius;
-        const int x0 = min(gx, max(0, (int)((q0.x - r) / (float)RDG_TILE)));
-        const int y0 = min(gy, max(0, (int)((q0.y - r) / (float)RDG_TILE)));
-        const int x1 = min(gx, max(0, (int)((((q0.x + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
-        const int y1 = min(gy, max(0, (int)((((q0.y + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
-        for (int ty = y0; ty < y1; ++ty)
-            for (int tx = x0; tx < x1; ++tx) {
-                const uint2 rg = ranges[ty * gx + tx];
-                uint32_t lo = rg.x, hi = rg.y;      // first position whose composite is >= want
-                while (lo < hi) {
-                    const uint32_t mid = lo + ((hi - lo) >> 1);
-                    const uint32_t id = point_list[mid];
-                    const unsigned long long have =
-                        ((unsigned long long)__float_as_uint(rec[id].q1.z) << 32) | (unsigned long long)id;
-                    if (have < want) lo = mid + 1; else hi = mid;
-                }
-                if (lo < rg.y && point_list[lo] == (uint32_t)g) {
-                    const float* row = det + (size_t)lo * (4 * RDG_GROW) + c;
-                    acc += (row[0] + row[RDG_GROW]) + (row[2 * RDG_GROW] + row[3 * RDG_GROW]);
-                }
-            }
+    const uint32_t n = tiles_touched[g], first = det_off[g];
+    // (an overflowed frame has empty tile lists and meaningless offsets: nothing beyond the workspace is read)
+    if ((long long)first + n <= n_instances) {
+        for (uint32_t j = 0; j < n; ++j) {
+            const float* row = det + (size_t)(first + j) * (4 * RDG_GROW) + c;
+            acc += (row[0] + row[RDG_GROW]) + (row[2 * RDG_GROW] + row[3 * RDG_GROW]);
+        }
     }
     grow[(size_t)g * RDG_GROW + c] = acc;
 }
@@ -1037,7 +1047,8 @@ rdg_det_reduce_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec, con
 // det != nullptr: deterministic mode -- `det` holds 4 * RDG_GROW floats per list position (zeroed by the caller)
 int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws, const void* bin_ws,
                           int64_t capacity, const void* image_ws, const float* g_color, const float* g_depth,
-                          const float* g_alpha, float* grow, hipStream_t s, float* det, const float* g_normal) {
+                          const float* g_alpha, float* grow, hipStream_t s, float* det, const float* g_normal,
+                          uint32_t* det_off, long long n_instances) {
     const RdgGeomLayout G = rdg_geom_layout(d.P);
     const int n_tiles = d.gx * d.gy;
     const RdgBinLayout B = rdg_bin_layout(capacity, n_tiles);
@@ -1058,19 +1069,24 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
                        (const uint2*)(im + I.ranges), plist, (const RdgRec*)((const char*)geom_ws + G.rec),        \
                        (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
                        g_alpha, g_normal, DST, (const unsigned long long*)(b + B.hit), split_min,                  \
-                       (const uint32_t*)(sp + SL.header), (const uint4*)(sp + SL.work), (const float*)(sp + SL.seg_pix))
+                       (const uint32_t*)(sp + SL.header), (const uint4*)(sp + SL.work), (const float*)(sp + SL.seg_pix), \
+                       (const uint32_t*)det_off, d.gy)
 #define RDG_BWD_LAUNCH(DEPTH, DET, SEG, GRID, DST)                                                                 \
     do { if (g_normal) RDG_BWD_LAUNCH4(DEPTH, DET, SEG, true, GRID, DST); else RDG_BWD_LAUNCH4(DEPTH, DET, SEG, false, GRID, DST); } while (0)
     if (det) {
+        if (!det_off) return rdg_set_error("render_bwd: the deterministic mode needs the instance-offset buffer");
+        if (d.P > 0)
+            hipLaunchKernelGGL(rdg_det_offsets_kernel, dim3((d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK), dim3(RDG_PRE_BLOCK), 0, s,
+                               d.P, (const uint32_t*)((const char*)geom_ws + G.tiles_touched),
+                               (const uint32_t*)((const char*)geom_ws + G.block_sums), det_off);
         if (g_depth) RDG_BWD_LAUNCH(true, true, false, nblk, det); else RDG_BWD_LAUNCH(false, true, false, nblk, det);
         if ((d.list_hints & 1)) {
             if (g_depth) RDG_BWD_LAUNCH(true, true, true, gseg, det); else RDG_BWD_LAUNCH(false, true, true, gseg, det);
         }
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_det_reduce_kernel, dim3((unsigned)(((long long)d.P * 16 + 255) / 256)), dim3(256), 0, s,
-                               d.P, d.gx, d.gy, (const RdgRec*)((const char*)geom_ws + G.rec),
-                               (const uint32_t*)((const char*)geom_ws + G.tiles_touched), (const uint2*)(im + I.ranges),
-                               plist, (const float*)det, grow);
+                               d.P, (const uint32_t*)((const char*)geom_ws + G.tiles_touched), (const uint32_t*)det_off,
+                               n_instances, (const float*)det, grow);
     } else {
         if (g_depth) RDG_BWD_LAUNCH(true, false, false, nblk, grow); else RDG_BWD_LAUNCH(false, false, false, nblk, grow);
         if ((d.list_hints & 1)) {

@@ -47,7 +47,7 @@ SPLIT_BELOW = 3072
 
 # Deterministic backward (RDG_DETERMINISTIC=1 or set at run time): the compositing backward stores
 # per-(wave, list position) partial rows and reduces them per Gaussian in a fixed order instead of accumulating with float
-# atomics (rdg_composite_backward_det) -- two runs give the same bits; ~2x the backward time and 256 B per instance.
+# atomics (rdg_composite_backward_det) -- two runs give the same bits; ~2x the compositing backward (1.3x the train step) and 256 B per instance.
 DETERMINISTIC = os.environ.get("RDG_DETERMINISTIC", "0") == "1"
 
 # hipGraph capture (rodygs_amd.trainstep.GraphedStep sets it around capture): the forward touches nothing on the host --
