@@ -170,8 +170,19 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_RAW_STREAM = None
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  Called once per library launch: the raw-stream query
+    (what torch's own compiled code uses) costs ~1 us, torch.cuda.current_stream() builds a Stream object through several
+    Python layers for ~11 us -- 0.08 ms per train step at the sizes where the step is host-bound."""
+    global _RAW_STREAM
     import torch
+    if _RAW_STREAM is None:
+        _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _RAW_STREAM:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

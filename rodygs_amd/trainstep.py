@@ -75,9 +75,29 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
     L = _lib.lib()
     if advance:
         fp.step_count += 1
+    for f in extra:
+        f.step_count = fp.step_count
+    # the segment table only depends on the layout and the rates: built once per distinct call shape (it is ~60 us of
+    # Python per step otherwise -- a tenth of the whole step at the sizes where the step is host-bound)
+    key = (tuple(names) if names is not None else None, lr_scale, tuple(sorted(lr_override.items())) if lr_override else None,
+           tuple(sorted((k, tuple(v)) for k, v in row_lr.items())) if row_lr else None,
+           tuple((id(f), f.flat.data_ptr(), f.flat_grad.data_ptr(), f.exp_avg.data_ptr(), f.exp_avg_sq.data_ptr(),
+                  tuple(f.lr.values())) for f in (fp, *extra)))
+    cache = fp.__dict__.setdefault("_adam_segs", {})
+    hit = cache.get(key)
+    if hit is not None:
+        segs, n_ent = hit
+        if n_ent == 0:
+            return
+        if step_scalars is not None:
+            _lib.check(L.rdg_adam_step_multi_dev(n_ent, segs, betas[0], betas[1], eps, _lib.ptr(step_scalars),
+                                                 _lib.stream_ptr()), "rdg_adam_step_multi_dev")
+        else:
+            _lib.check(L.rdg_adam_step_multi(n_ent, segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
+                       "rdg_adam_step_multi")
+        return
     entries = []   # (flat-params, first offset, element count, lr, row_len, head_len, lr_tail)
     for f in (fp, *extra):
-        f.step_count = fp.step_count
         for k in f.names:
             if f is fp and names is not None and k not in names:
                 entries.append(None)      # a gap: the neighbours must not be merged across it
@@ -91,7 +111,10 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
             else:
                 entries.append((f, o, n, lr_k, row_len, head_len, lr_tail))
     entries = [e for e in entries if e is not None]
+    if len(cache) > 64:
+        cache.clear()
     if not entries:
+        cache[key] = (None, 0)
         return
     segs = (_lib.RdgAdamSeg * len(entries))()
     for i, (f, o, n, lr, row_len, head_len, lr_tail) in enumerate(entries):
@@ -105,6 +128,7 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
         segs[i].lr_tail = lr_tail * lr_scale
         segs[i].row_len = row_len
         segs[i].head_len = head_len
+    cache[key] = (segs, len(entries))
     if step_scalars is not None:
         _lib.check(L.rdg_adam_step_multi_dev(len(entries), segs, betas[0], betas[1], eps, _lib.ptr(step_scalars),
                                              _lib.stream_ptr()), "rdg_adam_step_multi_dev")
