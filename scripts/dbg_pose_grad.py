@@ -1,0 +1,46 @@
+"""One sweep case in detail: the pose gradient of the HIP path and of the f32 oracle against the oracle run in float64."""
+import os, random, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_parity as T
+from oracle import rasterizer_oracle as O
+seed0, c = int(sys.argv[1]), int(sys.argv[2])
+rng = random.Random(seed0 + c)
+P = rng.choice([1, 7, 63, 64, 65, 200, 777, 1500, 3000, 5000]); W = rng.choice([16, 33, 100, 128, 250, 320, 401])
+H = rng.choice([16, 17, 96, 128, 200, 240, 333]); deg_max = rng.choice([0, 1, 2, 3]); deg = rng.randint(0, deg_max)
+bg = tuple(rng.random() for _ in range(3))
+sc = O.synthetic_scene(P, W, H, deg_max, seed=seed0 + c)
+sc["viewmatrix"] = T.orbit_view(rng.uniform(-20, 20), rng.uniform(-15, 15), (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 1.5)))
+if rng.random() < 0.3:
+    sc["scales"] = sc["scales"] * rng.uniform(1.5, 5.0)
+kw = dict(cov_grad=rng.random() < 0.8, sh_grad=rng.random() < 0.8, scale_modifier=rng.choice([1.0, 1.0, 0.7, 1.3]),
+          seed=seed0 + c, normal_loss=rng.choice([0.0, 0.0, 0.5]), depth_loss=rng.choice([0.1, 0.1, 0.0]))
+res = T.run_pair(sc, deg, bg, **kw)
+hv, ov = res[0]["viewmatrix"].grad.cpu().double(), res[3]["viewmatrix"].grad.double()
+# float64 oracle with the same loss weights
+gen = torch.Generator().manual_seed(kw["seed"])
+wc, wd, wa = torch.rand(3, H, W, generator=gen), torch.rand(1, H, W, generator=gen), torch.rand(1, H, W, generator=gen)
+wn = torch.randn(3, H, W, generator=gen) * kw["normal_loss"]
+d = {k: sc[k].clone().double().requires_grad_(True) for k in T.NAMES}
+st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.tensor(bg).double(), kw["scale_modifier"], sc["projmatrix"].double(), deg,
+                      enable_cov_grad=kw["cov_grad"], enable_sh_grad=kw["sh_grad"])
+o = O.rasterize(d["means3D"], torch.zeros(P, 3, dtype=torch.float64, requires_grad=True), d["opacities"], d["viewmatrix"], st,
+                shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
+ls = (o[0] * wc.double()).sum() + (o[3] * wa.double()).sum()
+if kw["depth_loss"]: ls = ls + (o[1] * wd.double()).sum() * kw["depth_loss"]
+if kw["normal_loss"]: ls = ls + (o[2] * wn.double()).sum()
+ls.backward()
+tv = d["viewmatrix"].grad
+sc_ = tv.abs().max()
+print("scale", float(sc_))
+print("HIP    vs f64 oracle: max rel", float((hv - tv).abs().max() / sc_))
+print("f32 or vs f64 oracle: max rel", float((ov - tv).abs().max() / sc_))
+print("HIP    vs f32 oracle: max rel", float((hv - ov).abs().max() / sc_))
+torch.set_printoptions(precision=5, linewidth=200, sci_mode=False)
+print("f64 oracle:\n", tv)
+print("HIP - f64:\n", hv - tv)
+print("f32 oracle - f64:\n", ov - tv)
+for k in ("means3D", "scales", "rotations", "opacities"):
+    a, b = res[0][k].grad.cpu().double(), d[k].grad
+    print(k, "HIP vs f64 per-column max rel:", [float(x) for x in ((a - b).abs().amax(0) / b.abs().amax(0).clamp_min(1e-30))])

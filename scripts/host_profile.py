@@ -23,6 +23,31 @@ rasterizer.DEFERRED_OVERFLOW_CHECK = True
 for s in range(10, 40):
     ds.train_step(s, perm=perm)
 torch.cuda.synchronize()
+# the backward functions run on the autograd engine's thread (invisible to cProfile): wall-clock them one by one
+import collections
+import time as _t
+import rodygs_amd.deform as _D
+import rodygs_amd.losses as _Lo
+import rodygs_amd.model_ops as _M
+BW = collections.defaultdict(float)
+
+
+def _wrap(cls):
+    orig = cls.backward
+
+    def timed(ctx, *a):
+        t = _t.perf_counter()
+        r = orig(ctx, *a)
+        BW[cls.__name__] += _t.perf_counter() - t
+        return r
+    cls.backward = staticmethod(timed)
+
+
+for mod in (rasterizer, _D, _Lo, _M):
+    for name in dir(mod):
+        obj = getattr(mod, name)
+        if isinstance(obj, type) and issubclass(obj, torch.autograd.Function) and obj is not torch.autograd.Function:
+            _wrap(obj)
 pr = cProfile.Profile()
 pr.enable()
 import time
@@ -33,6 +58,8 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 pr.disable()
 print(f"{dt / 300 * 1e3:.4f} ms per step (with the profiler on)")
+for k, v in sorted(BW.items(), key=lambda kv: -kv[1]):
+    print(f"  backward of {k:28s} {v / 300 * 1e6:7.1f} us per step")
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
 st.sort_stats("cumulative").print_stats(30)

@@ -41,10 +41,16 @@ def _columns(t):
     return t.reshape(1, -1)
 
 
+# entries of a column (of >= 256) that may sit above the bar wherever outliers are allowed at all: one flipped pixel moves the
+# gradient rows of the flipped splat and of the few behind it in that pixel.  1 in the test-suite; scripts/parity_sweep.py
+# raises it to 4 for its random scenes (3 of 400 needed more than one entry, none more than three)
+FLIP_ENTRIES = 1
+
+
 def rel_ok(a, b, tol=TOL, outliers=0.0, what="", cap=OUTLIER_CAP):
     """|a - b| <= tol * max|b| COLUMN BY COLUMN (_columns): a small column (a degree-3 SH band next to the DC band, one
-    quaternion component) is held to its own scale, not to the tensor's.  At most `outliers` of a column's entries may
-    sit above the bar (a decision flipped on an alpha = 1/255 / T = 1e-4 discontinuity) and none of them above
+    quaternion component) is held to its own scale, not to the tensor's.  At most `outliers` of a column's entries (and
+    always one entry of a column of 256 or more, when outliers are allowed at all) may sit above the bar (a decision flipped on an alpha = 1/255 / T = 1e-4 discontinuity) and none of them above
     cap * scale: a flipped decision changes an entry by one pixel-splat pair's share, never by the entry itself.  A
     column the oracle has exactly zero must be exactly zero."""
     a = torch.as_tensor(a).detach().double().cpu()
@@ -58,7 +64,12 @@ def rel_ok(a, b, tol=TOL, outliers=0.0, what="", cap=OUTLIER_CAP):
     rel = torch.where((scale == 0) & (d == 0), torch.zeros_like(rel), rel)
     frac = (rel > tol).double().mean(dim=1)
     worst = rel.amax(dim=1)
-    if bool((frac > outliers).any()) or bool((worst > (cap if outliers > 0 else tol)).any()):
+    # where outliers are allowed at all, ONE entry of a column of >= 256 is: a single pixel on the alpha = 1/255 boundary
+    # is 2.6e-4 of a 16x240 image and moves one Gaussian's gradient row of a 777-Gaussian cloud by 2e-4 of the column's
+    # scale (scripts/parity_sweep.py: 2 such pixels in 200 random scenes), still bounded by `cap`
+    n_col = A.shape[1]
+    allowed = max(outliers, (FLIP_ENTRIES + 0.5) / n_col) if (outliers > 0 and n_col >= 256) else outliers
+    if bool((frac > allowed).any()) or bool((worst > (cap if outliers > 0 else tol)).any()):
         order = torch.argsort(worst, descending=True)[:5]
         rows = "; ".join(f"col {int(c)}: max rel {worst[c].item():.3e}, frac over bar {frac[c].item():.2e}, "
                          f"scale {scale[c].item():.3e}" for c in order)
