@@ -16,6 +16,9 @@ if rng.random() < 0.3:
     sc["scales"] = sc["scales"] * rng.uniform(1.5, 5.0)
 kw = dict(cov_grad=rng.random() < 0.8, sh_grad=rng.random() < 0.8, scale_modifier=rng.choice([1.0, 1.0, 0.7, 1.3]),
           seed=seed0 + c, normal_loss=rng.choice([0.0, 0.0, 0.5]), depth_loss=rng.choice([0.1, 0.1, 0.0]))
+for a in sys.argv[3:]:                                    # e.g. cov_grad=0 sh_grad=0 normal_loss=0 depth_loss=0
+    k_, v_ = a.split("="); kw[k_] = type(kw[k_])(float(v_))
+print(P, W, H, deg, deg_max, kw)
 res = T.run_pair(sc, deg, bg, **kw)
 hv, ov = res[0]["viewmatrix"].grad.cpu().double(), res[3]["viewmatrix"].grad.double()
 # float64 oracle with the same loss weights
