@@ -328,6 +328,9 @@ __device__ __forceinline__ uint32_t rdg_zidx(uint32_t x, uint32_t y) {
 // rank an instance keeps is therefore exactly what a per-instance atomic would have handed out, with as many atomics
 // as there are DISTINCT tiles among the wave's 64 slots: spatially coherent clouds (Morton-ordered scenes, densified
 // clusters, one tile holding 200 k instances) issue a fraction of the atomics and no longer serialise on one address.
+#ifndef RDG_BUCKET_PIPE
+#define RDG_BUCKET_PIPE 1
+#endif
 template <int MODE>  // 0 = count, 1 = scatter
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
 rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restrict__ rec,
@@ -343,70 +346,105 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restric
              i += (long long)gridDim.x * RDG_PRE_BLOCK)
             zero16[i] = make_uint4(0u, 0u, 0u, 0u);
     if ((long long)(*num_rendered) > capacity) return;
-    __shared__ uint32_t sOff[RDG_PRE_BLOCK];
-    __shared__ uint32_t sDepth[RDG_PRE_BLOCK];
-    __shared__ uint16_t sX0[RDG_PRE_BLOCK], sY0[RDG_PRE_BLOCK], sW[RDG_PRE_BLOCK];
+    // Load-balanced expansion, one WAVE at a time: the wave's 64 Gaussians own T_w consecutive instance slots (their
+    // rectangles' tiles, row by row), handled 64 slots per step.  The owner of a slot is found without a search: every
+    // Gaussian drops its lane number at the slot its run starts on (one LDS store per Gaussian and frame), a running
+    // maximum along the 64 slots fills the runs in (DPP scan), and the owner's rectangle comes over by ds_bpermute.
+    // (The earlier form was a binary search over the workgroup's 256 offsets, eight dependent LDS reads per slot; this one
+    // is 2-3 us faster per pass on the bench frame and shorter -- both passes are bound by the memory side, see below.)
+    // Marks of earlier steps need no clearing: they name lanes <= the owner carried over from the previous step, which
+    // the maximum ignores.
+    __shared__ uint32_t sMark[RDG_PRE_BLOCK];
     __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * RDG_PRE_BLOCK + tid;
-    uint32_t t = 0;
+    uint32_t t = 0, xy0 = 0, wd0 = 1, dep = 0;
     if (i < P) {
         t = tiles_touched[i];
         if (t > 0) {
             const float4 q0 = rec[i].q0;
-            const float4 q1 = rec[i].q1;
             int x0, y0, x1, y1;
             rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
-            sX0[tid] = (uint16_t)x0; sY0[tid] = (uint16_t)y0; sW[tid] = (uint16_t)(x1 - x0);
-            sDepth[tid] = __float_as_uint(q1.z);
+            xy0 = (uint32_t)x0 | ((uint32_t)y0 << 16); wd0 = (uint32_t)(x1 - x0);
+            if (MODE == 1) dep = __float_as_uint(rec[i].q1.z);
         }
     }
     const uint32_t inc = rdg_wave_scan_incl(t);
     const uint32_t lane = tid & 63, w = tid >> 6;
+    const uint32_t excl = inc - t;
+    sMark[tid] = 0u;
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t k = 0; k < w; ++k) woff += wsum[k];
-    sOff[tid] = woff + inc - t;
-    __syncthreads();
-    const uint32_t first = block_sums[blockIdx.x];
-    const uint32_t total = block_sums[blockIdx.x + 1] - first;
+    const uint32_t total = wsum[w];                                // wave-uniform trip count: the ballots need every lane
+    const uint32_t first = block_sums[blockIdx.x] + woff;          // the wave's first slot in the frame's instance order
+    uint32_t* __restrict__ mark = sMark + (w << 6);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t k0 = 0; k0 < total; k0 += RDG_PRE_BLOCK) {     // block-uniform trip count: the ballots need every lane
-        const uint32_t k = k0 + tid;
-        const bool act = k < total;
-        int lo = 0;
-        uint32_t tx = 0, ty = 0;
-        if (act) {
-            int hi = RDG_PRE_BLOCK - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (sOff[mid] <= k) lo = mid; else hi = mid - 1;
-            }
-            const uint32_t j = k - sOff[lo];
-            const uint32_t wd = sW[lo];
+    uint32_t carry = 0;
+    // U steps can be taken together (their returning atomics / loads all in flight before the first result is needed).
+    // Measured on the bench frame: U = 2 and 4 change nothing (count + scan + scatter 87-88 us in every form) -- with
+    // 8 workgroups per CU the round trips of different waves already overlap; what bounds the two passes is the rate
+    // of ~10 M returning atomics on 8 k counters (count) and of ~10 M scattered 8-B stores (scatter).  U stays 1.
+    constexpr int U = RDG_BUCKET_PIPE;
+    for (uint32_t k0 = 0; k0 < total; k0 += RDG_WAVE * U) {
+        bool act[U];
+        uint32_t kk[U], tx[U], ty[U], own_lane[U], odep[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t kb = k0 + (uint32_t)(RDG_WAVE * u);
+            kk[u] = kb + lane;
+            act[u] = kk[u] < total;
+            if (t > 0 && excl - kb < (uint32_t)RDG_WAVE) mark[excl - kb] = lane + 1u;  // (excl < kb wraps: no store)
+            rdg_wave_lds_sync();
+            const uint32_t own = max(rdg_wave_scan_max_incl(mark[lane]), carry);       // 1 + lane of the slot's Gaussian
+            rdg_wave_lds_sync();
+            carry = (uint32_t)__builtin_amdgcn_readlane((int)own, 63);
+            own_lane[u] = (own - 1u) & 63u;
+            const int src = (int)own_lane[u] << 2;
+            const uint32_t oxy = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)xy0);
+            const uint32_t wd = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)wd0);
+            const uint32_t oex = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)excl);
+            odep[u] = MODE == 1 ? (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)dep) : 0u;
+            const uint32_t j = act[u] ? kk[u] - oex : 0u;
             const uint32_t ry = j / wd, rx = j - ry * wd;
-            tx = (uint32_t)sX0[lo] + rx; ty = (uint32_t)sY0[lo] + ry;
+            tx[u] = (oxy & 0xffffu) + rx; ty[u] = (oxy >> 16) + ry;
         }
         if (MODE == 0) {
-            const uint32_t z = rdg_zidx(tx, ty);
-            unsigned long long m = __ballot(act);
-            if (m == 0ull) continue;
-            for (int bit = 0; bit < zbits; ++bit) {
-                const bool bset = (z >> bit) & 1u;
-                const unsigned long long bal = __ballot(act && bset);
-                m &= bset ? bal : ~bal;
+            uint32_t below[U], base[U];
+            int leader[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t z = rdg_zidx(tx[u], ty[u]);
+                unsigned long long m = __ballot(act[u]);
+                for (int bit = 0; bit < zbits; ++bit) {
+                    const bool bset = (z >> bit) & 1u;
+                    const unsigned long long bal = __ballot(act[u] && bset);
+                    m &= bset ? bal : ~bal;
+                }
+                below[u] = (uint32_t)__popcll(m & lt_mask);
+                base[u] = 0;
+                if (act[u] && below[u] == 0) base[u] = atomicAdd(&tile_cnt[z], (uint32_t)__popcll(m));
+                leader[u] = act[u] ? __ffsll((long long)m) - 1 : 0;
             }
-            const uint32_t below = (uint32_t)__popcll(m & lt_mask);
-            uint32_t base = 0;
-            if (act && below == 0) base = atomicAdd(&tile_cnt[z], (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, act ? __ffsll((long long)m) - 1 : 0);
-            // coalesced 4-B store in emission order; the scatter pass needs no second round of atomics
-            if (act) rank_buf[first + k] = base + below;
-        } else if (act) {
-            const uint32_t tile = ty * (uint32_t)gx + tx;
-            const uint32_t pos = ranges[tile].x + rank_buf[first + k];
-            comp[pos] = ((uint64_t)sDepth[lo] << 32) | (uint64_t)(blockIdx.x * RDG_PRE_BLOCK + lo);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t bs = (uint32_t)__shfl((int)base[u], leader[u]);
+                // coalesced 4-B store in emission order; the scatter pass needs no second round of atomics
+                if (act[u]) rank_buf[first + kk[u]] = bs + below[u];
+            }
+        } else {
+            uint32_t st[U], rk[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                st[u] = 0u; rk[u] = 0u;
+                if (act[u]) { st[u] = ranges[ty[u] * (uint32_t)gx + tx[u]].x; rk[u] = rank_buf[first + kk[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (act[u])
+                    comp[st[u] + rk[u]] = ((uint64_t)odep[u] << 32) |
+                                          (uint64_t)(blockIdx.x * RDG_PRE_BLOCK + (w << 6) + own_lane[u]);
         }
     }
 }
@@ -430,35 +468,49 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
         if (threadIdx.x == 0) { hv_header[0] = 0u; hv_header[1] = 0u; hv_header[2] = 0u; }
         return;
     }
-    // every thread owns a run of consecutive tiles (local sums), ONE block-level scan of the 1024 run totals, then the
-    // runs are written out: two barriers in all instead of two per 1024 tiles
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t sHeavy, sWork, sChunks, sMaxTile, sChunkItems;
-    if (threadIdx.x == 0) { sHeavy = 0u; sWork = 0u; sChunks = 0u; sMaxTile = 0u; sChunkItems = 0u; }
+    // Every WAVE owns a segment of consecutive tiles and walks it 64 tiles at a time, lane l on tile (step base + l):
+    // the stores of a step are then contiguous (512 B of ranges, 256 B of cursors per instruction) and its counter
+    // loads touch 16 lines of the Z-ordered array instead of 64.  (With a run of 8 consecutive tiles per THREAD every
+    // load and store instruction of this single workgroup touched 64 different cache lines -- ~32 k line transactions
+    // through one CU's address path, most of the kernel's 14 us on the critical path of every frame.)
+    // One pass for the segment totals, ONE barrier, one pass that scans (DPP) and writes.  The work-list and chunk-item
+    // slots come out of the same scans (they were LDS atomics on two addresses); only the rare > RDG_TSORT_LDS tiles
+    // still use atomics.
+    __shared__ uint32_t wtot[3][16];
+    __shared__ uint32_t sHeavy, sChunks, sMaxTile;
+    if (threadIdx.x == 0) { sHeavy = 0u; sChunks = 0u; sMaxTile = 0u; }
     for (uint32_t i = threadIdx.x; i < 2u * max_chunks; i += 1024) hv_nodes[i] = 0u;
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int per = (n_tiles + 1023) / 1024;
-    const int t0 = threadIdx.x * per, t1 = min(n_tiles, t0 + per);
-    // the counters of a thread's run are fetched 8 at a time with independent loads (one memory latency per 8 tiles,
-    // not per tile: this single workgroup sits on the critical path of every frame)
-    uint32_t mine = 0, big = 0;
-    // (x, y) of the run's first tile by ONE division; the rest by stepping along the row
-    const uint32_t x_first = (uint32_t)(t0 % gx), y_first = (uint32_t)(t0 / gx);
+    const int seg = (((n_tiles + 15) / 16) + 63) & ~63;
+    const int s0 = min(n_tiles, (int)w * seg), s1 = min(n_tiles, s0 + seg);
+    // (x, y) of the lane's first tile by ONE division; 64 tiles further by stepping along the rows
+    const uint32_t x_first = (uint32_t)((s0 + (int)lane) % gx), y_first = (uint32_t)((s0 + (int)lane) / gx);
+    uint32_t mine = 0, big = 0, my_work = 0, my_items = 0;
     {
         uint32_t x = x_first, y = y_first;
-        for (int c0 = t0; c0 < t1; c0 += 8) {
+        for (int c0 = s0; c0 < s1; c0 += 64 * 8) {           // 8 independent loads in flight per lane
             uint32_t vv[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                vv[q] = c0 + q < t1 ? tile_cnt[rdg_zidx(x, y)] : 0u;
-                if (++x == (uint32_t)gx) { x = 0; ++y; }
+                vv[q] = c0 + 64 * q + (int)lane < s1 ? tile_cnt[rdg_zidx(x, y)] : 0u;
+                x += 64u;
+                while (x >= (uint32_t)gx) { x -= (uint32_t)gx; ++y; }
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { mine += vv[q]; big = max(big, vv[q]); }
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t v = vv[q];
+                mine += v; big = max(big, v);
+                if (v > RDG_TSORT_LDS) my_work += (v + RDG_TSORT_LDS - 1) / RDG_TSORT_LDS;
+                else if (v > RDG_TSORT_MID) my_work += 1u;
+                else if (v > RDG_TSORT_SMALL) { my_work += 1u; my_items += (v + RDG_TSORT_SMALL - 1) / RDG_TSORT_SMALL; }
+            }
         }
     }
-    const uint32_t inc = rdg_wave_scan_incl(mine);
-    if (lane == 63) wtot[w] = inc;
+    {
+        const uint32_t inc = rdg_wave_scan_incl(mine);
+        const uint32_t inc_w = rdg_wave_scan_incl(my_work), inc_i = rdg_wave_scan_incl(my_items);
+        if (lane == 63) { wtot[0][w] = inc; wtot[1][w] = inc_w; wtot[2][w] = inc_i; }
+    }
     __syncthreads();
     if (max_tile_out) {
         // wave maximum first (1024 threads on one LDS atomic serialise)
@@ -466,28 +518,38 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
         for (int o = 32; o > 0; o >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, o));
         if (lane == 0) atomicMax(&sMaxTile, big);
     }
-    uint32_t run = inc - mine;
-    for (uint32_t k = 0; k < w; ++k) run += wtot[k];
+    uint32_t run0 = 0, work0 = 0, item0 = 0;                  // the segment's first slots (wave-uniform)
+    for (uint32_t k = 0; k < w; ++k) { run0 += wtot[0][k]; work0 += wtot[1][k]; item0 += wtot[2][k]; }
     uint32_t x2 = x_first, y2 = y_first;
-    for (int c0 = t0; c0 < t1; c0 += 8) {
+    for (int c0 = s0; c0 < s1; c0 += 64 * 8) {
       uint32_t vv[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-          vv[q] = c0 + q < t1 ? tile_cnt[rdg_zidx(x2, y2)] : 0u;
-          if (++x2 == (uint32_t)gx) { x2 = 0; ++y2; }
+          vv[q] = c0 + 64 * q + (int)lane < s1 ? tile_cnt[rdg_zidx(x2, y2)] : 0u;
+          x2 += 64u;
+          while (x2 >= (uint32_t)gx) { x2 -= (uint32_t)gx; ++y2; }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int i = c0 + q;
-        if (i >= t1) break;
+        if (c0 + 64 * q >= s1) break;                         // wave-uniform
+        const int i = c0 + 64 * q + (int)lane;
         const uint32_t v = vv[q];
+        uint32_t wk = 0, it = 0;
+        if (v > RDG_TSORT_LDS) wk = (v + RDG_TSORT_LDS - 1) / RDG_TSORT_LDS;
+        else if (v > RDG_TSORT_MID) wk = 1u;
+        else if (v > RDG_TSORT_SMALL) { wk = 1u; it = (v + RDG_TSORT_SMALL - 1) / RDG_TSORT_SMALL; }
+        const uint32_t sc_v = rdg_wave_scan_incl(v), sc_w = rdg_wave_scan_incl(wk), sc_i = rdg_wave_scan_incl(it);
+        const uint32_t run = run0 + sc_v - v, wb = work0 + sc_w - wk, cb_items = item0 + sc_i - it;
+        run0 += (uint32_t)__builtin_amdgcn_readlane((int)sc_v, 63);
+        work0 += (uint32_t)__builtin_amdgcn_readlane((int)sc_w, 63);
+        item0 += (uint32_t)__builtin_amdgcn_readlane((int)sc_i, 63);
+        if (i >= s1) continue;
         ranges[i] = v ? make_uint2(run, run + v) : make_uint2(0u, 0u);
         tile_fill[i] = 0u;
         if (v > RDG_TSORT_LDS) {
-            const uint32_t nch = (v + RDG_TSORT_LDS - 1) / RDG_TSORT_LDS;
+            const uint32_t nch = wk;
             const uint32_t h = atomicAdd(&sHeavy, 1u);
             const uint32_t cb = atomicAdd(&sChunks, nch);
-            const uint32_t wb = atomicAdd(&sWork, nch);
             // sized by construction (rdg_heavy_layout): the three bounds always hold
             if (h < max_heavy && cb + nch <= max_chunks && wb + nch <= max_work) {
                 RdgHeavyDesc d; d.start = run; d.n = v; d.nchunks = nch; d.node_base = 2u * cb; d.tile = (uint32_t)i;
@@ -496,24 +558,23 @@ rdg_tile_scan_kernel(int n_tiles, int gx, const uint32_t* __restrict__ tile_cnt,
                 for (uint32_t c = 0; c < nch; ++c) hv_work[wb + c] = make_uint2(h, c);
             }
         } else if (v > RDG_TSORT_MID) {
-            const uint32_t wb = atomicAdd(&sWork, 1u);
             if (wb < max_work) hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0xffffffffu);
         } else if (v > RDG_TSORT_SMALL) {
             // chunk items for the waves of the register-block sort, ONE merge item for the workgroup kernel after it
-            const uint32_t nch = (v + RDG_TSORT_SMALL - 1) / RDG_TSORT_SMALL;
-            const uint32_t cb = atomicAdd(&sChunkItems, nch), wb = atomicAdd(&sWork, 1u);
-            if (cb + nch <= max_chunk_items && wb < max_work) {
-                for (uint32_t c = 0; c < nch; ++c) hv_chunk_work[cb + c] = make_uint2((uint32_t)i, c);
+            const uint32_t nch = it;
+            if (cb_items + nch <= max_chunk_items && wb < max_work) {
+                for (uint32_t c = 0; c < nch; ++c) hv_chunk_work[cb_items + c] = make_uint2((uint32_t)i, c);
                 hv_work[wb] = make_uint2(0x80000000u | (uint32_t)i, 0u);
             }
         }
-        run += v;
       }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        hv_header[0] = min(sWork, max_work); hv_header[1] = min(sHeavy, max_heavy);
-        hv_header[2] = min(sChunkItems, max_chunk_items);
+        uint32_t n_work = 0, n_items = 0;
+        for (int k = 0; k < 16; ++k) { n_work += wtot[1][k]; n_items += wtot[2][k]; }
+        hv_header[0] = min(n_work, max_work); hv_header[1] = min(sHeavy, max_heavy);
+        hv_header[2] = min(n_items, max_chunk_items);
         if (max_tile_out) *max_tile_out = (int32_t)sMaxTile;
         // host mirror (RdgRasterSettings.num_rendered_host): [1] first, [0] last -- the host polls [0]
         if (host_mirror) { host_mirror[1] = (int32_t)sMaxTile; __threadfence_system(); host_mirror[0] = *num_rendered; }

@@ -563,4 +563,14 @@ __device__ __forceinline__ uint32_t rdg_wave_scan_incl(uint32_t x) {
     t = rdg_dpp_u<0x143, 0xc>(x); x += t;          // row_bcast:31 -> rows 2,3
     return x;
 }
+// inclusive running maximum over the 64 lanes (uint32; lanes shifted in from outside a row read 0)
+__device__ __forceinline__ uint32_t rdg_wave_scan_max_incl(uint32_t x) {
+    x = max(x, rdg_dpp_u<0x111>(x));
+    x = max(x, rdg_dpp_u<0x112>(x));
+    x = max(x, rdg_dpp_u<0x114>(x));
+    x = max(x, rdg_dpp_u<0x118>(x));
+    x = max(x, rdg_dpp_u<0x142, 0xa>(x));
+    x = max(x, rdg_dpp_u<0x143, 0xc>(x));
+    return x;
+}
 #endif

@@ -233,38 +233,48 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
 }
 
 // Exclusive scan of block_sums[0..nblk) in place by ONE 1024-thread block; block_sums[nblk] and *num_rendered
-// receive the total (D).  nblk <= 16384 at P = 4 M, i.e. <= 16 sweeps.
+// receive the total (D).  nblk <= 16384 at P = 4 M, i.e. runs of <= 16 entries per thread.
 __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblk,
                                                                    int32_t* __restrict__ num_rendered,
                                                                    uint32_t* __restrict__ zero_buf, int zero_words) {
     // optional: clear the binning stage's per-tile counters here (this block is otherwise idle most of its life; saves
     // a memset launch and a stream boundary per frame)
     for (int i = threadIdx.x; i < zero_words; i += 1024) zero_buf[i] = 0u;
+    // every thread owns a run of consecutive block sums: ONE block scan of the 1024 run totals and two barriers in all
+    // (a sweep of 1024 entries at a time took three barriers per sweep, four sweeps at 1 M Gaussians)
     __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    __shared__ unsigned long long total64;     // the same total without wrap-around: D >= 2^31 must not pass for a small D
-    if (threadIdx.x == 0) { carry_s = 0; total64 = 0ull; }
-    __syncthreads();
+    __shared__ unsigned long long wtot64[16];  // the same totals without wrap-around: D >= 2^31 must not pass for a small D
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < nblk; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nblk ? block_sums[i] : 0u;
-        uint32_t inc = rdg_wave_scan_incl(v);
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
-        const uint32_t carry = carry_s;
-        if (i < nblk) block_sums[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) {
-            carry_s = carry + woff + inc;
-            unsigned long long t = total64;
-            for (int k = 0; k < 16; ++k) t += wtot[k];      // a wave's total fits 32 bits (64 x tiles of the grid), a sweep's need not
-            total64 = t;
-        }
-        __syncthreads();
+    const int per = (nblk + 1023) / 1024;
+    const int t0 = min(nblk, (int)threadIdx.x * per), t1 = min(nblk, t0 + per);
+    uint32_t mine = 0;
+    unsigned long long mine64 = 0ull;
+    for (int c0 = t0; c0 < t1; c0 += 8) {
+        uint32_t vv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vv[q] = c0 + q < t1 ? block_sums[c0 + q] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mine += vv[q]; mine64 += vv[q]; }
     }
+    const uint32_t inc = rdg_wave_scan_incl(mine);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine64 += __shfl_xor(mine64, o);
+    if (lane == 63) { wtot[w] = inc; wtot64[w] = mine64; }
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (uint32_t k = 0; k < w; ++k) run += wtot[k];
+    for (int c0 = t0; c0 < t1; c0 += 8) {
+        uint32_t vv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) vv[q] = c0 + q < t1 ? block_sums[c0 + q] : 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (c0 + q < t1) { block_sums[c0 + q] = run; run += vv[q]; }
+    }
+    uint32_t carry_s = 0;
+    unsigned long long total64 = 0ull;
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 16; ++k) { carry_s += wtot[k]; total64 += wtot64[k]; }
     if (threadIdx.x == 0) {
         // every later kernel of the frame compares *num_rendered with the capacity of the instance buffers and leaves
         // when it is larger: 2^31 - 1 instances or more (garbage scales: every Gaussian on every tile) saturate, so the
