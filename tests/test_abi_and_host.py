@@ -430,3 +430,25 @@ def test_bin_mode_hint_has_hysteresis():
     assert key not in R._BIN_HINT
     R._note_largest_tile(key, R.BIN_BUCKET_BELOW + 5)           # between the thresholds from below: still bucket
     assert key not in R._BIN_HINT
+
+
+def test_measurement_scripts_and_entry_points_parse_and_stay_off_the_oracle_in_the_product():
+    """Every script the profiles / DESIGN numbers come from must at least parse (they only run on the GPU box), and
+    nothing under rodygs_amd/ may import the oracle (prompt rule 3: the oracle is test infrastructure)."""
+    import ast
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "scripts", "*.py")) + [os.path.join(root, "bench.py"),
+                                                                os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        ast.parse(open(f).read(), filename=f)
+    for f in glob.glob(os.path.join(root, "rodygs_amd", "**", "*.py"), recursive=True):
+        tree = ast.parse(open(f).read(), filename=f)
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{f} imports the oracle"
