@@ -351,7 +351,7 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restric
     // Gaussian drops its lane number at the slot its run starts on (one LDS store per Gaussian and frame), a running
     // maximum along the 64 slots fills the runs in (DPP scan), and the owner's rectangle comes over by ds_bpermute.
     // (The earlier form was a binary search over the workgroup's 256 offsets, eight dependent LDS reads per slot; this one
-    // is 2-3 us faster per pass on the bench frame and shorter -- both passes are bound by the memory side, see below.)
+    // is shorter and 2-3 us faster in the count pass on the bench frame -- what the passes are bound by: see below.)
     // Marks of earlier steps need no clearing: they name lanes <= the owner carried over from the previous step, which
     // the maximum ignores.
     __shared__ uint32_t sMark[RDG_PRE_BLOCK];
@@ -383,9 +383,12 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restric
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t carry = 0;
     // U steps can be taken together (their returning atomics / loads all in flight before the first result is needed).
-    // Measured on the bench frame: U = 2 and 4 change nothing (count + scan + scatter 87-88 us in every form) -- with
-    // 8 workgroups per CU the round trips of different waves already overlap; what bounds the two passes is the rate
-    // of ~10 M returning atomics on 8 k counters (count) and of ~10 M scattered 8-B stores (scatter).  U stays 1.
+    // Measured on the bench frame: U = 2 and 4 change nothing (count + scan + scatter 87-88 us in every form; the ISA
+    // at U = 4 does hold four atomics in flight) -- with 8 workgroups per CU the round trips of different waves
+    // already overlap.  The atomics are not the bound either: PMC (scripts/atomic_probe.sh) counts 0.33 M atomic
+    // requests per frame for 10 M instances (the wave aggregation on a Z-ordered cloud).  The count pass moves ~100 MB
+    // (records in, 4-B ranks out) in 36 us and runs ~240 mostly scalar instructions of tile matching per step; the
+    // scatter pass moves ~170 MB, 80 MB of it as scattered 8-B stores, in 33 us (5 TB/s).  U stays 1.
     constexpr int U = RDG_BUCKET_PIPE;
     for (uint32_t k0 = 0; k0 < total; k0 += RDG_WAVE * U) {
         bool act[U];
