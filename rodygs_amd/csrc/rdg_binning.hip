@@ -386,9 +386,11 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restric
     // Measured on the bench frame: U = 2 and 4 change nothing (count + scan + scatter 87-88 us in every form; the ISA
     // at U = 4 does hold four atomics in flight) -- with 8 workgroups per CU the round trips of different waves
     // already overlap.  The atomics are not the bound either: PMC (scripts/atomic_probe.sh) counts 0.33 M atomic
-    // requests per frame for 10 M instances (the wave aggregation on a Z-ordered cloud).  The count pass moves ~100 MB
-    // (records in, 4-B ranks out) in 36 us and runs ~240 mostly scalar instructions of tile matching per step; the
-    // scatter pass moves ~170 MB, 80 MB of it as scattered 8-B stores, in 33 us (5 TB/s).  U stays 1.
+    // requests per frame for 10 M instances (the wave aggregation on a Z-ordered cloud).  Nor is the tile matching:
+    // matching on the index bits that differ inside the wave only was bit-exact and not a microsecond faster.  A wave
+    // of the count pass lives 12.5 us for ~1 000 vector instructions (SQ counters): the pass is each workgroup's chain
+    // of dependent memory trips (tile count -> record -> scan -> per step: atomic -> store) at ~100 MB / 36 us; the
+    // scatter pass moves ~170 MB, 80 MB of it as scattered 8-B stores, in 33 us (5 TB/s).  U stays 1.  
     constexpr int U = RDG_BUCKET_PIPE;
     for (uint32_t k0 = 0; k0 < total; k0 += RDG_WAVE * U) {
         bool act[U];
