@@ -33,13 +33,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SQ_FILE = "r03_pmc_sq_counters.json"     # rocprofv3 --pmc SQ_* pass of this bench command (scripts/pmc_summary.py)
+SQ_FILE = "r04_pmc_sq_counters.json"     # rocprofv3 --pmc SQ_* pass of this bench command (scripts/pmc_summary.py)
 N_SIMD = 1024                            # 256 CUs x 4 SIMDs
 # measured issue cost of a wave64 VALU instruction with every SIMD saturated (scripts/valu_probe.hip,
 # profiles/r02_valu_issue_cost.txt), in cycles per instruction and SIMD
 VALU_ISSUE_CLASSES = {"f32 mul/add/fma/mov with VGPR sources": 2.3, "every other VALU instruction": 4.2,
                       "transcendental": 8.4}
-PMC_FILE = "r03_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
+PMC_FILE = "r04_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
 
 
 def kernel_source_hash(files=("rdg_render.hip", "rdg_common.h")):
@@ -92,7 +92,8 @@ def wire_bytes(P, K, world, sharded, frames=100, mlp_params=68656):
             "all_reduce_payload_bytes": small}
 
 
-def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=False, radix_binning=False):
+def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=False, radix_binning=False,
+                densify_stats=False):
     """ALGORITHMIC HBM bytes per stage and step (SURVEY.md §8d formulas, adjusted to the algorithm that actually runs
     -- DESIGN.md §4 'Roofline accounting'):
       * binning: bucket binning moves, per tile instance, a 4-B rank (written by the count pass, read by the scatter
@@ -101,7 +102,9 @@ def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=Fa
         6-pass radix formula applies only under RDG_BIN_MODE=radix;
       * optimizer in backward: the SH features' Adam step happens inside the per-Gaussian backward kernel -- their
         28 B/float leave the Adam launch; the kernel no longer writes dL/dshs (-12K B) and instead reads and writes the
-        parameter and both moments (24 B/float) of those 3K floats."""
+        parameter and both moments (24 B/float) of those 3K floats;
+      * densification statistics: the per-Gaussian backward reads and writes max_radii2D, xyz_gradient_accum and denom of
+        every visible Gaussian (24 B)."""
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     n_pass = (32 + max(tiles - 1, 1).bit_length() + 7) // 8
     n_adam = 59 + 16                                    # floats per Gaussian: 11 geometry + 3K SH (K=16) + 16 coeff
@@ -118,6 +121,8 @@ def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=Fa
     if sh_adam_in_backward:
         sb["adam"] -= 28 * 3 * K * own
         sb["preprocess_bwd"] += (24 * 3 * K - 12 * K) * P
+    if densify_stats:
+        sb["preprocess_bwd"] += 24 * V
     return sb
 
 
@@ -208,6 +213,11 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     spatial_order = os.environ.get("RDG_SPATIAL_ORDER", "1") != "0"
     ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, full_losses=args.full_losses,
                       spatial_order=spatial_order)
+    # the statistics every reference iteration below densify_until_iter keeps (max_radii2D, xyz_gradient_accum, denom:
+    # /root/reference/src/trainer/rodygs.py:316-341) are part of the step: updated inside the per-Gaussian backward kernel
+    densify_stats = not args.no_densify_stats
+    if densify_stats:
+        ds.track_densification()
     n_gt = min(args.gt_frames * world, args.frames)
     perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
     ds.make_ground_truth(target, perm)
@@ -230,7 +240,10 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     else:
         train_step = lambda st_: ds.train_step(st_, rank, world, perm)          # noqa: E731
     graphed = None
-    use_graph = bool(args.graph and world == 1 and not sharded and not args.full_losses)
+    use_graph = bool(args.graph and world == 1 and not sharded)
+    if sharded and densify_stats:
+        ss.track_densification()
+    rstate = rasterizer.DEFAULT_STATE if sharded else ds.raster_state     # whose frame-to-frame memory the steps use
 
     def sync():
         if world > 1:
@@ -256,6 +269,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         # capture after the warm-up (capacity and binning hints are known); the timed region replays the graph
         from rodygs_amd.trainstep import GraphedStep
         rasterizer.DEFERRED_OVERFLOW_CHECK = False
+        rstate.poll_overflow(block=True)
         graphed = GraphedStep(ds, perm, warmup=2, first_step=step)
         step = graphed.next_step
         train_step_eager = train_step
@@ -271,6 +285,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     import gc
     gc.collect()
     gc.freeze()
+    deferred_in_timed_region = bool(rasterizer.DEFERRED_OVERFLOW_CHECK)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -279,11 +294,11 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     sync()
     dt = time.perf_counter() - t0
     if graphed is not None:
-        graphed.check()                      # raises if a replayed frame outgrew the captured capacity
+        graphed.check()                      # raises if ANY replayed frame outgrew the captured capacity (sticky record)
         step = graphed.next_step
         graphed.close()
         train_step = train_step_eager
-    rasterizer.poll_overflow(block=True)
+    rstate.poll_overflow(block=True)
     dom = _lib.stage_times()["render_bwd"]
     _lib.timing_enable(True)
     _lib.timing_reset()
@@ -291,7 +306,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         train_step(step)
         step += 1
     sync()
-    rasterizer.poll_overflow(block=True)
+    rstate.poll_overflow(block=True)
     stages = _lib.stage_times()
     if graphed is None:
         stages["render_bwd"] = dom
@@ -302,14 +317,14 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     out = {"mode": mode, "sharded": sharded, "dt": dt, "loss": float(loss.item()), "spatial_order": spatial_order,
-           "graph": graphed is not None,
+           "graph": graphed is not None, "densify_stats": densify_stats, "deferred": deferred_in_timed_region,
            "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
         if sharded:
-            out["D"] = int(rasterizer._CAPACITY_HINT.get(ss.key, 0))
+            out["D"] = int(rstate.capacity_hint.get(ss.key, 0))
             out["V"] = ss.visible_count()
             with torch.no_grad():
-                _, n_contrib = rasterizer.last_compositing_state()
+                _, n_contrib = rasterizer.last_compositing_state(rstate)
                 out["S"] = int(n_contrib.sum(dtype=torch.int64).item())
         else:
             # D, V and S: means over the frames the timed region cycles through (each forward reads its instance count
@@ -319,8 +334,8 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
                 for f in perm:
                     o, _ = ds.render(f)
                     vsum += int((o[4] > 0).sum().item())
-                    dsum += int(rasterizer._CAPACITY_HINT.get((P, H, W), 0))
-                    _, n_contrib = rasterizer.last_compositing_state()
+                    dsum += int(rstate.capacity_hint.get((P, H, W), 0))
+                    _, n_contrib = rasterizer.last_compositing_state(rstate)
                     ssum += int(n_contrib.sum(dtype=torch.int64).item())
             out["D"], out["V"], out["S"] = dsum // len(perm), vsum // len(perm), ssum // len(perm)
     del ds, ss, train_step
@@ -347,10 +362,13 @@ def main():
                     help="rodygs_amd.synthetic variant: 'uniform' = the SURVEY 8d generator (the headline workload); "
                          "'sheets' = opaque depth sheets (early termination); 'dense' = 3x the projected sigma (D ~ 9x)")
     ap.add_argument("--graph", action="store_true", default=os.environ.get("RDG_GRAPH", "0") == "1",
-                    help="N = 1, photometric: replay the step as ONE captured hipGraph (trainstep.GraphedStep) instead of "
+                    help="N = 1: replay the step as ONE captured hipGraph (trainstep.GraphedStep) instead of "
                          "launching its ~50 kernels from Python -- what makes the step kernel-bound at the size of the "
                          "reference's real clouds (~100 k points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-densify-stats", action="store_true",
+                    help="leave the per-iteration densification statistics (max_radii2D, xyz_gradient_accum, denom) out of "
+                         "the step; by default they are part of it, as in every reference iteration below densify_until_iter")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads of the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=60.0,
                     help="seconds of CPU compositing the cpu_baseline leg may spend on the bench frame before it "
@@ -440,9 +458,9 @@ def main():
         K = 16
         sh_adam_in_backward = bool(world == 1 and not sharded and not args.full_losses
                                    and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")
-        radix_binning = os.environ.get("RDG_BIN_MODE", "")[:1] == "r"
+        radix_binning = bool(rasterizer_mod._FORCE_RADIX)
         sb = stage_bytes(P, K, V, D, H, W, world=world, sharded=sharded, sh_adam_in_backward=sh_adam_in_backward,
-                         radix_binning=radix_binning)
+                         radix_binning=radix_binning, densify_stats=best["densify_stats"])
         sms = dict(per_stage)
         sms["binning"] = per_stage["scan_dup"] + per_stage["sort"] + per_stage["ranges"]
         stage_roofline = {k: {"algorithmic_bytes": b, "ms": sms[k],
@@ -496,10 +514,12 @@ def main():
                        # switches that shape the number: no read-back of the instance count inside the timed steps
                        # (capacity from the warm-up; an overflow renders that frame empty and raises afterwards), and
                        # whether every rank shares one device (functional check of the N > 1 flow, not a measurement)
-                       "deferred_overflow_check": True, "untimed_settle_steps": args.settle, "one_device": bool(os.environ.get("RDG_ONE_DEVICE")),
+                       "deferred_overflow_check": best["deferred"], "untimed_settle_steps": args.settle, "one_device": bool(os.environ.get("RDG_ONE_DEVICE")),
                        # True: the timed steps are replays of ONE captured hipGraph (trainstep.GraphedStep); the
                        # dominant kernel's avg_ms then comes from eager steps after the timed region
                        "graph_replay": graph_replay,
+                       # the statistics of /root/reference/src/trainer/rodygs.py:316-341 are kept by every timed step
+                       "densify_stats": best["densify_stats"],
                        "deterministic_backward": bool(rasterizer_mod.DETERMINISTIC),
                        "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",

@@ -40,8 +40,9 @@
 extern "C" {
 #endif
 
-#define RDG_ABI_VERSION 4
+#define RDG_ABI_VERSION 5
 #define RDG_MAX_VIEWS 16   /* cameras per step in the *_views entry points */
+#define RDG_ADAM_MAX_SEGS 12 /* parameter groups per rdg_adam_step_multi launch */
 
 /* Mirror of GaussianRasterizationSettings (renderer.py:50-63) + sizes. Host struct, passed by pointer. */
 typedef struct RdgRasterSettings {
@@ -58,8 +59,8 @@ typedef struct RdgRasterSettings {
     int32_t enable_cov_grad; /* pose-gradient gates (SURVEY.md §7 open question 4)           */
     int32_t enable_sh_grad;
     int32_t render_normal;   /* 1: composite the normal channels (default); 0: leave them zero */
-    int32_t bin_mode;        /* tile binning algorithm of THIS forward: 0 = bucket binning (default; RDG_BIN_MODE=radix in the
-                              * environment overrides), 1 = stable LSD radix sort of (tile | depth) keys.  Same result bit
+    int32_t bin_mode;        /* tile binning algorithm of THIS forward: 0 = bucket binning (default),
+                              * 1 = stable LSD radix sort of (tile | depth) keys.  Same result bit
                               * for bit; bucket binning is faster on ordinary frames, the radix sort has no atomics and no
                               * per-tile work, so its time does not depend on how the instances are spread over the tiles
                               * (a tile holding 200 k instances).  Callers pick it from num_rendered[1] of the previous frame. */
@@ -75,7 +76,7 @@ typedef struct RdgRasterSettings {
                               * zero (the forward of this frame cleared them, zero_grad_ws below), so the backward does not
                               * launch its own fill; 0: the backward clears them itself (a repeated backward through the
                               * same graph must say 0: the first one consumed the zeros)                               */
-    int32_t reserved0;
+    int32_t densify_row0;    /* backward calls only: first Gaussian row the densify_* arrays below cover (see there)   */
     void* zero_grad_ws;      /* forward calls only, optional: an rdg_grad_bytes(P) workspace whose gradient rows the
                               * compositing forward clears while it runs -- that kernel is instruction-bound and its memory
                               * pipeline idle, so the fill is free there, against a 12 us launch of its own at the head of
@@ -84,6 +85,28 @@ typedef struct RdgRasterSettings {
                               * int32[2] (pinned memory) that the binning stage also writes (D, largest tile list) -- a
                               * caller that checks D after the fact (no host wait per frame) presets it to -1 and polls it;
                               * no copy, no event on the stream.  NULL: off.                                            */
+    /* Backward calls only, optional (any of the three may be NULL): the per-iteration densification statistics of the
+     * reference's train loop, updated by the per-Gaussian backward kernel, which holds dL/dmean2D and the radius of every
+     * Gaussian in registers -- no extra pass, no host sync, no boolean-mask indexing.  For every Gaussian i with
+     * radii[i] > 0 (the reference's visibility_filter, /root/reference/src/trainer/renderer.py:111) and
+     * densify_row0 <= i < densify_row0 + densify_rows, with j = i - densify_row0:
+     *     densify_max_radii[j]  = max(densify_max_radii[j], (float)radii[i])   (src/trainer/rodygs.py:334-338)
+     *     densify_grad_accum[j] += hypot(dL/dmean2D[i].x, dL/dmean2D[i].y)       (rodygs.py:322-324, rodygs_static.py:317-318)
+     *     densify_denom[j]      += 1                                            (rodygs_static.py:319)
+     * The row window is the reference's slicing of the concatenated static || dynamic cloud (rodygs.py:320-332): the static
+     * sub-step keeps rows [0, n_static), the dynamic one rows [n_static, P).  The arrays are float32 [densify_rows] (the
+     * reference's [P,1] accumulators are the same memory).  One update per backward CALL: a caller that runs backward
+     * twice through one graph (retain_graph) passes them once.  rdg_densify_stats() is the stand-alone form.          */
+    float* densify_grad_accum;
+    float* densify_denom;
+    float* densify_max_radii;
+    int32_t densify_rows;
+    int32_t reserved1;
+    int32_t* num_rendered_max; /* forward calls only, optional: a device int32 that receives max(itself, D) of every forward
+                              * handed the same pointer -- a STICKY record for callers that do not look at every frame's
+                              * num_rendered (a captured hipGraph replays the forward many times into one num_rendered_dev;
+                              * a frame in the middle that outgrew the capacity was rendered empty and would go unnoticed).
+                              * The caller zeroes it, reads it when it likes and compares with the capacity.  NULL: off. */
 } RdgRasterSettings;
 
 /* stage ids for rdg_stage_time_ms() */
@@ -354,6 +377,16 @@ int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const fl
 int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float* xyz, const float* scaling,
                        const float* rotation, const float* z, float* xyz_out, float* scaling_out, void* stream);
 
+/* The per-iteration densification statistics as a stand-alone launch, for a caller that follows the reference's flow
+ * (viewspace_point_tensor.grad and radii in hand after loss.backward(), /root/reference/src/trainer/rodygs.py:316-341,
+ * add_densification_stats /root/reference/src/trainer/rodygs_static.py:317-319): for the n rows starting at row0 of
+ * dL_dmeans2D [P,3] / radii [P] (the static or the dynamic part of the concatenated cloud), where radii > 0:
+ * max_radii[j] = max(max_radii[j], radii), grad_accum[j] += |dL_dmeans2D[:2]|, denom[j] += 1 (j = row - row0; float32 [n]
+ * each, any may be NULL).  Replaces five boolean-mask indexing ops (each a nonzero + host sync in the framework).  The
+ * same update rides along in rdg_preprocess_backward* for free (RdgRasterSettings.densify_*).                          */
+int rdg_densify_stats(int64_t n, int64_t row0, const float* dL_dmeans2D, const int32_t* radii, float* grad_accum,
+                      float* denom, float* max_radii, void* stream);
+
 /* ThreeDGSTrainer.reset_opacity (/root/reference/src/trainer/rodygs_static.py:151-160) with the optimizer surgery of
  * replace_tensor_to_optimizer (/root/reference/src/trainer/utils.py:15-32), in place on a flat-bucket segment:
  * opacity_logit[i] = inverse_sigmoid(min(sigmoid(opacity_logit[i]), max_opacity)) (reference: 0.01), and both Adam
@@ -434,7 +467,6 @@ int rdg_adam_step_rows(int64_t n, float* param, const float* grad, float* exp_av
                        float eps, int32_t step, void* stream);
 
 /* All parameter groups in ONE launch (the reference steps ~8 groups per sub-step, rodygs_static.py:106-141).     */
-#define RDG_ADAM_MAX_SEGS 12
 typedef struct RdgAdamSeg {
     int64_t n;              /* floats in this segment                                   */
     float* param;
@@ -490,17 +522,24 @@ int rdg_pose_views_backward(int32_t T, int32_t nviews, const int32_t* frames_hos
                             const float* cam_t, const float* g_views, float* d_q, float* d_t, void* stream);
 
 /* ---- per-step scalars in device memory (hipGraph replay of a train step, rodygs_amd/trainstep.py GraphedStep) --------
- * A captured graph bakes every by-value kernel argument.  The three values of a train step that change from step to step
- * -- Adam's two bias corrections and the index of the rendered frame -- can instead be read from this 16-byte device
- * struct, which the host refreshes (one small H2D copy) before each replay.  The *_dev entry points below are the
+ * A captured graph bakes every by-value kernel argument.  The values of a train step that change from step to step
+ * -- Adam's two bias corrections, the index of the rendered frame and (optionally) the learning rates -- can instead be
+ * read from this 128-byte device struct, which the host refreshes (one small H2D copy) before each replay.  The *_dev entry points below are the
  * by-pointer forms of rdg_pose_view_forward / _backward, rdg_adam_step_multi and rdg_preprocess_backward_adam; same
  * arithmetic, same bits (the host computes the corrections exactly as the by-value forms do).                       */
 typedef struct RdgStepScalars {
     float inv_bias_correction1;    /* (float)(1 / (1 - beta1^step))    */
     float sqrt_bias_correction2;   /* (float)sqrt(1 - beta2^step)      */
     int32_t frame;                 /* row of the camera tables to render */
-    int32_t reserved;
-} RdgStepScalars;
+    int32_t lr_from_table;         /* != 0: the learning rates below replace the by-value ones of the *_dev calls -- the
+                                    * reference re-sets the xyz (and deform) learning rate every iteration
+                                    * (/root/reference/src/trainer/rodygs_static.py:143-149); a captured graph would replay
+                                    * the rates it was captured with                                                   */
+    float seg_lr_head[RDG_ADAM_MAX_SEGS]; /* rdg_adam_step_multi_dev: lr_head / lr_tail of segment i of that launch     */
+    float seg_lr_tail[RDG_ADAM_MAX_SEGS];
+    float sh_lr_head, sh_lr_tail;  /* rdg_preprocess_backward_adam_dev                                                  */
+    int32_t reserved[2];
+} RdgStepScalars;                  /* 128 bytes */
 int rdg_pose_view_forward_dev(int32_t T, const RdgStepScalars* dev, const float* cam_q, const float* cam_t,
                               float* out_view16, void* stream);
 int rdg_pose_view_backward_dev(int32_t T, const RdgStepScalars* dev, const float* cam_q, const float* cam_t,

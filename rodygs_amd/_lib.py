@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RDG_LIB_PATH: load another build of the same ABI (A/B runs of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("RDG_LIB_PATH") or os.path.join(_HERE, "csrc", "librodygs_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 _lock = threading.Lock()
@@ -24,8 +24,10 @@ class RdgRasterSettings(C.Structure):
         ("scale_modifier", C.c_float), ("prefiltered", C.c_int32), ("debug", C.c_int32),
         ("enable_cov_grad", C.c_int32), ("enable_sh_grad", C.c_int32), ("render_normal", C.c_int32),
         ("bin_mode", C.c_int32), ("num_rendered_stats", C.c_int32), ("list_hints", C.c_int32),
-        ("grad_rows_zeroed", C.c_int32), ("reserved0", C.c_int32), ("zero_grad_ws", C.c_void_p),
-        ("num_rendered_host", C.c_void_p),
+        ("grad_rows_zeroed", C.c_int32), ("densify_row0", C.c_int32), ("zero_grad_ws", C.c_void_p),
+        ("num_rendered_host", C.c_void_p), ("densify_grad_accum", C.c_void_p), ("densify_denom", C.c_void_p),
+        ("densify_max_radii", C.c_void_p), ("densify_rows", C.c_int32), ("reserved1", C.c_int32),
+        ("num_rendered_max", C.c_void_p),
     ]
 
 
@@ -37,7 +39,11 @@ class RdgAdamSeg(C.Structure):
 
 class RdgStepScalars(C.Structure):
     _fields_ = [("inv_bias_correction1", C.c_float), ("sqrt_bias_correction2", C.c_float), ("frame", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("lr_from_table", C.c_int32), ("seg_lr_head", C.c_float * 12), ("seg_lr_tail", C.c_float * 12),
+                ("sh_lr_head", C.c_float), ("sh_lr_tail", C.c_float), ("reserved", C.c_int32 * 2)]
+
+
+STEP_SCALARS_FLOATS = C.sizeof(RdgStepScalars) // 4      # a device RdgStepScalars as a float32 tensor of this many words
 
 
 STAGES = {
@@ -94,6 +100,7 @@ _SIGS = {
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_gather_rows": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),
     "rdg_split_children": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
+    "rdg_densify_stats": (C.c_int, [C.c_int64, C.c_int64] + [_vp] * 6),
     "rdg_reset_opacity": (C.c_int, [C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "rdg_rigidity_dp_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32] + [_vp] * 6 + [C.c_float] + [_vp] * 4),
     "rdg_motion_reg_forward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp]),

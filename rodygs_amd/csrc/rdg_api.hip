@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -29,11 +30,15 @@ static int g_timing = 0;
 static uint32_t g_timing_mask = 0xFFFFFFFFu;
 static RdgPending g_pending[RDG_MAX_PENDING];
 static int g_npending = 0;
-static hipEvent_t g_open[RDG_STAGE_COUNT];
+// A stage is opened and closed by the thread that launches it (begin / end pair inside one entry point), so the open
+// events are per thread; the list of finished brackets and the totals are shared by the threads of the process (the
+// autograd engine runs backward on a thread of its own) and guarded by one mutex -- taken only while timing is on.
+static thread_local hipEvent_t g_open[RDG_STAGE_COUNT];
 static double g_total_ms[RDG_STAGE_COUNT];
 static int64_t g_count[RDG_STAGE_COUNT];
+static std::mutex g_timing_mu;
 
-static void rdg_timing_drain() {
+static void rdg_timing_drain() {   // caller holds g_timing_mu
     for (int i = 0; i < g_npending; ++i) {
         float ms = 0.f;
         if (hipEventSynchronize(g_pending[i].b) == hipSuccess &&
@@ -76,19 +81,20 @@ static bool rdg_roctx_on() {
 
 void rdg_stage_begin(int stage, hipStream_t s) {
     if (rdg_roctx_on() && stage >= 0 && stage < RDG_STAGE_COUNT) (void)g_roctx_push(g_stage_names[stage]);
-    if (!g_timing || !((g_timing_mask >> stage) & 1u)) return;
-    if (g_npending >= RDG_MAX_PENDING) rdg_timing_drain();
+    if (!g_timing || stage < 0 || stage >= RDG_STAGE_COUNT || !((g_timing_mask >> stage) & 1u)) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, s);
     g_open[stage] = e;
 }
 void rdg_stage_end(int stage, hipStream_t s) {
-    if (g_roctx == 1) (void)g_roctx_pop();
-    if (!g_timing || !g_open[stage]) return;
+    if (g_roctx == 1 && stage >= 0 && stage < RDG_STAGE_COUNT) (void)g_roctx_pop();
+    if (stage < 0 || stage >= RDG_STAGE_COUNT || !g_open[stage]) return;
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
+    if (hipEventCreate(&e) != hipSuccess) { (void)hipEventDestroy(g_open[stage]); g_open[stage] = nullptr; return; }
     (void)hipEventRecord(e, s);
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (g_npending >= RDG_MAX_PENDING) rdg_timing_drain();
     g_pending[g_npending].a = g_open[stage];
     g_pending[g_npending].b = e;
     g_pending[g_npending].stage = stage;
@@ -111,6 +117,11 @@ static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats; d->list_hints = s->list_hints;
     d->grad_rows_zeroed = s->grad_rows_zeroed; d->zero_grad_ws = s->zero_grad_ws;
     d->nren_host = s->num_rendered_stats ? s->num_rendered_host : nullptr;
+    d->nren_max = s->num_rendered_max;
+    d->dn_accum = s->densify_grad_accum; d->dn_denom = s->densify_denom; d->dn_maxr = s->densify_max_radii;
+    d->dn_row0 = s->densify_row0; d->dn_rows = s->densify_rows;
+    if ((d->dn_accum || d->dn_denom || d->dn_maxr) && (d->dn_row0 < 0 || d->dn_rows < 0))
+        return rdg_set_error("densify_row0 / densify_rows must not be negative");
     d->tile_cnt_zeroed = 0;
     return 0;
 }
@@ -150,6 +161,17 @@ hipError_t rdg_zero_async(void* p, size_t bytes, hipStream_t st) {
     if (wide) hipLaunchKernelGGL(rdg_zero16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint4*)p, n);
     else hipLaunchKernelGGL(rdg_zero4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n);
     return hipGetLastError();
+}
+
+// zero the first min(*n_dev, cap) rows of row16 * 16 bytes each: the deterministic backward's per-instance rows, of which
+// only the frame's own D are ever read (the workspace is sized by the capacity when the host does not know D)
+__global__ void __launch_bounds__(256) rdg_zero_rows_dev_kernel(uint4* __restrict__ p, unsigned row16,
+                                                               const uint32_t* __restrict__ n_dev, long long cap) {
+    long long n = (long long)*n_dev;
+    if (n > cap) n = cap;
+    const size_t n16 = (size_t)n * row16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 extern "C" {
@@ -256,7 +278,7 @@ int rdg_composite_backward(const RdgRasterSettings* s_host, const float* bg, con
     rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
     if (!d.grad_rows_zeroed) {          // else: cleared by this frame's compositing forward (zero_grad_ws)
         hipError_t e = rdg_zero_async(grow, grow_bytes, st);
-        if (e != hipSuccess) return rdg_check_hip(e, "grad row memset");
+        if (e != hipSuccess) { rdg_stage_end(RDG_STAGE_RENDER_BWD, st); return rdg_check_hip(e, "grad row memset"); }
     }
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
                                    grad_out_alpha, grow, st, nullptr, grad_out_normal);
@@ -282,8 +304,16 @@ int rdg_composite_backward_det(const RdgRasterSettings* s_host, const float* bg,
     rdg_stage_begin(RDG_STAGE_RENDER_BWD, st);
     // rows of positions no wave visits stay zero; the gradient rows themselves are written (not accumulated) by the
     // reduction, every one of them
-    hipError_t e = rdg_zero_async(det_ws, rdg_det_bytes(n_instances), st);
-    if (e != hipSuccess) return rdg_check_hip(e, "det row memset");
+    // (only the rows of the frame's own D instances, read on the device from the per-Gaussian stage's scan total)
+    {
+        const RdgGeomLayout G = rdg_geom_layout(d.P);
+        const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+        const uint32_t* d_dev = (const uint32_t*)((const char*)geom_ws + G.block_sums) + (d.P > 0 ? nblk : 0);
+        hipLaunchKernelGGL(rdg_zero_rows_dev_kernel, dim3(4096), dim3(256), 0, st, (uint4*)det_ws,
+                           (unsigned)(4 * RDG_GROW * 4 / 16), d_dev, (long long)n_instances);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { rdg_stage_end(RDG_STAGE_RENDER_BWD, st); return rdg_check_hip(e, "det row fill"); }
+    }
     uint32_t* det_off = (uint32_t*)((char*)grad_ws + rdg_grad_bytes(d.P) - rdg_det_off_bytes(d.P));
     int rc = rdg_launch_render_bwd(d, bg, geom_ws, binning_ws, capacity, image_ws, grad_out_color, grad_out_depth,
                                    grad_out_alpha, (float*)grad_ws, st, (float*)det_ws, grad_out_normal, det_off,
@@ -422,9 +452,8 @@ int rdg_preprocess_forward_views_rows(const RdgRasterSettings* s_host, int32_t n
     rdg_stage_begin(RDG_STAGE_PREPROCESS, st);
     int rc = rdg_launch_preprocess_fwd_views(d, nviews, stride_rows, row0, means3D, shs, opacities, scales, rotations,
                                              viewmatrices, projmatrix, geom_ws, radii, st);
-    if (rc) return rc;
     rdg_stage_end(RDG_STAGE_PREPROCESS, st);
-    return 0;
+    return rc;
 }
 
 int rdg_preprocess_forward_views(const RdgRasterSettings* s_host, int32_t nviews, int32_t stride_rows,
@@ -448,7 +477,7 @@ int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nview
     const int32_t total = nviews * stride_rows;
     const size_t grow_bytes = rdg_align_up((size_t)total * RDG_GROW * 4, 256);
     float* posebuf = (float*)((char*)grad_ws + grow_bytes);
-    rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
+    RdgStageScope scope(RDG_STAGE_PREPROCESS_BWD, st);
     {
         int rc = rdg_launch_preprocess_bwd_views(d, nviews, stride_rows, means3D, shs, opacities, scales, rotations,
                                                  viewmatrices, projmatrix, radii, geom_ws, (const float*)grad_ws, posebuf,
@@ -464,7 +493,6 @@ int rdg_preprocess_backward_views(const RdgRasterSettings* s_host, int32_t nview
                                               dL_dviewmatrices, st);
         if (rc) return rc;
     }
-    rdg_stage_end(RDG_STAGE_PREPROCESS_BWD, st);
     return 0;
 }
 
@@ -575,9 +603,19 @@ int rdg_sort_pairs(uint64_t* keys, uint32_t* vals, int64_t capacity, const int32
     return rdg_check_hip(hipGetLastError(), "sort_pairs");
 }
 
+int rdg_densify_stats(int64_t n, int64_t row0, const float* dL_dmeans2D, const int32_t* radii, float* grad_accum,
+                      float* denom, float* max_radii, void* stream) {
+    if (n < 0 || row0 < 0) return rdg_set_error("rdg_densify_stats: n and row0 must not be negative");
+    if (n == 0) return 0;
+    if (!radii || (grad_accum && !dL_dmeans2D)) return rdg_set_error("rdg_densify_stats: radii (and dL_dmeans2D) required");
+    return rdg_launch_densify_stats((long long)n, (long long)row0, dL_dmeans2D, radii, grad_accum, denom, max_radii,
+                                    (hipStream_t)stream);
+}
+
 int rdg_timing_enable(int32_t on) { g_timing = on ? 1 : 0; return 0; }
 int rdg_timing_select(uint32_t stage_mask) { g_timing_mask = stage_mask; return 0; }
 int rdg_timing_reset(void) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
     rdg_timing_drain();
     memset(g_total_ms, 0, sizeof(g_total_ms));
     memset(g_count, 0, sizeof(g_count));
@@ -585,6 +623,7 @@ int rdg_timing_reset(void) {
 }
 int rdg_stage_time_ms(int32_t stage, double* total_ms, int64_t* count) {
     if (stage < 0 || stage >= RDG_STAGE_COUNT) return rdg_set_error("bad stage id");
+    std::lock_guard<std::mutex> lk(g_timing_mu);
     rdg_timing_drain();
     if (total_ms) *total_ms = g_total_ms[stage];
     if (count) *count = g_count[stage];

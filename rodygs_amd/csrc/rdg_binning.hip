@@ -1109,9 +1109,9 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     const int n_tiles = d.gx * d.gy;
     uint2* ranges = (uint2*)((char*)image_ws + I.ranges);
 
-    static int radix_mode = -1;   // RDG_BIN_MODE=radix selects the LSD radix path (kept for A/B runs)
-    if (radix_mode < 0) { const char* ev = getenv("RDG_BIN_MODE"); radix_mode = (ev && ev[0] == 'r') ? 1 : 0; }
-    if (!radix_mode && d.bin_mode != 1) {
+    // RdgRasterSettings.bin_mode alone picks the algorithm (the Python host turns RDG_BIN_MODE=radix into bin_mode = 1
+    // when it loads: no process-global switch in the library)
+    if (d.bin_mode != 1) {
         const int npass = (rdg_key_bits(n_tiles) + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
         uint32_t* vals_out = (npass & 1) ? vals_b : vals_a;      // where the compositing kernels look
         uint64_t* keys_out = (npass & 1) ? keys_b : keys_a;      // full (tile | depth) keys, tests only
@@ -1130,7 +1130,14 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
             hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_out, vscr, keys_unsorted_copy,
                                vals_unsorted_copy, (long long)capacity, num_rendered);
         }
-        rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
+        const RdgHeavyLayout HL = rdg_heavy_layout(capacity);
+        char* hv = b + B.heavy;
+        uint32_t* hv_header = (uint32_t*)(hv + HL.header);
+        RdgHeavyDesc* hv_desc = (RdgHeavyDesc*)(hv + HL.desc);
+        uint2* hv_work = (uint2*)(hv + HL.work);
+        uint32_t* hv_nodes = (uint32_t*)(hv + HL.nodes);
+        {
+        RdgStageScope scope(RDG_STAGE_SCAN_DUP, s);
         int zbits = 0;
         while (((size_t)1 << zbits) < rdg_cnt_entries(d.gx, d.gy)) ++zbits;
         if (!d.tile_cnt_zeroed) {
@@ -1142,12 +1149,6 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                                (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered, (uint4*)nullptr, 0ll);
-        const RdgHeavyLayout HL = rdg_heavy_layout(capacity);
-        char* hv = b + B.heavy;
-        uint32_t* hv_header = (uint32_t*)(hv + HL.header);
-        RdgHeavyDesc* hv_desc = (RdgHeavyDesc*)(hv + HL.desc);
-        uint2* hv_work = (uint2*)(hv + HL.work);
-        uint32_t* hv_nodes = (uint32_t*)(hv + HL.nodes);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
                            (long long)capacity, num_rendered, hv_header, hv_desc, hv_work, hv_nodes, HL.max_heavy,
                            HL.max_chunks, HL.max_work, d.nren_stats ? num_rendered + 1 : nullptr,
@@ -1162,8 +1163,8 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
             hipError_t eh = rdg_zero_async(b + B.hit, rdg_hit_bytes(capacity, n_tiles), s);
             if (eh != hipSuccess) return rdg_check_hip(eh, "hit bits memset");
         }
-        rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
-        rdg_stage_begin(RDG_STAGE_SORT, s);
+        }
+        RdgStageScope scope(RDG_STAGE_SORT, s);
         uint64_t* kfull = radix_export_keys ? keys_out : nullptr;
         hipLaunchKernelGGL(rdg_tile_sort_lanes_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, s, n_tiles, ranges, comp,
                            vals_out, kfull, (long long)capacity, num_rendered, hv_header, (const uint2*)(hv + HL.chunks));
@@ -1171,7 +1172,6 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         hipLaunchKernelGGL(rdg_tile_sort_large_kernel, dim3(HL.max_work < 1024u ? HL.max_work : 1024u), dim3(256), 0, s,
                            ranges, comp, vals_out, kfull, (long long)capacity, num_rendered, keys_out, hv_header, hv_desc,
                            hv_work, hv_nodes);
-        rdg_stage_end(RDG_STAGE_SORT, s);
         return rdg_check_hip(hipGetLastError(), "bucket bin launch");
     }
 
@@ -1197,7 +1197,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                              b + B.sort_tmp, &in_b, s);
     rdg_stage_end(RDG_STAGE_SORT, s);
     if (rc) return rc;
-    rdg_stage_begin(RDG_STAGE_RANGES, s);
+    RdgStageScope scope(RDG_STAGE_RANGES, s);
     hipError_t e = rdg_zero_async(ranges, (size_t)n_tiles * sizeof(uint2), s);
     if (e != hipSuccess) return rdg_check_hip(e, "ranges memset");
     hipLaunchKernelGGL(rdg_tile_ranges_kernel, dim3(2048), dim3(256), 0, s, in_b ? keys_b : keys_a,
@@ -1205,6 +1205,5 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     if (d.nren_stats)
         hipLaunchKernelGGL(rdg_tile_max_kernel, dim3(1), dim3(1024), 0, s, n_tiles, ranges, (long long)capacity,
                            num_rendered, d.nren_host);
-    rdg_stage_end(RDG_STAGE_RANGES, s);
     return rdg_check_hip(hipGetLastError(), "bin launch");
 }

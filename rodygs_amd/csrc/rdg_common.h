@@ -229,6 +229,10 @@ struct RdgDev {
     int32_t grad_rows_zeroed;  // RdgRasterSettings.grad_rows_zeroed (backward)
     void* zero_grad_ws;        // RdgRasterSettings.zero_grad_ws (forward): gradient rows cleared by the compositing kernel
     int32_t* nren_host;        // RdgRasterSettings.num_rendered_host (forward): host mirror of num_rendered[0..1]
+    int32_t* nren_max;         // RdgRasterSettings.num_rendered_max (forward): sticky maximum of D over forwards
+    // RdgRasterSettings.densify_* (backward): densification statistics updated by the per-Gaussian backward kernel
+    float* dn_accum; float* dn_denom; float* dn_maxr;
+    int32_t dn_row0, dn_rows;
 };
 
 // ---- error + timing plumbing (rdg_api.hip) ---------------------------------------------------------------
@@ -238,6 +242,15 @@ int rdg_check_hip(hipError_t e, const char* what);
 hipError_t rdg_zero_async(void* p, size_t bytes, hipStream_t st);
 void rdg_stage_begin(int stage, hipStream_t s);
 void rdg_stage_end(int stage, hipStream_t s);
+// begin / end as a scope: every return path between them, the error returns included, closes the stage (its timing
+// bracket and its roctx range)
+struct RdgStageScope {
+    int stage; hipStream_t s;
+    RdgStageScope(int stage_, hipStream_t s_) : stage(stage_), s(s_) { rdg_stage_begin(stage_, s_); }
+    ~RdgStageScope() { rdg_stage_end(stage, s); }
+    RdgStageScope(const RdgStageScope&) = delete;
+    RdgStageScope& operator=(const RdgStageScope&) = delete;
+};
 
 // Adam state of the SH-feature segment handed to the per-Gaussian backward kernel ("optimizer in backward",
 // rdg_preprocess_backward_adam): the kernel has a wave's 64 gradient rows in LDS -- instead of writing them out for
@@ -256,8 +269,9 @@ struct RdgShAdam {
 __device__ __forceinline__ RdgShAdam rdg_sh_adam_resolve(RdgShAdam ad) {
     if (ad.dev) {
         const float inv = ad.dev->inv_bias_correction1;
-        ad.step_head = ad.lr_head * inv;
-        ad.step_tail = ad.lr_tail * inv;
+        const bool tab = ad.dev->lr_from_table != 0;
+        ad.step_head = (tab ? ad.dev->sh_lr_head : ad.lr_head) * inv;
+        ad.step_tail = (tab ? ad.dev->sh_lr_tail : ad.lr_tail) * inv;
         ad.bc2_sqrt = ad.dev->sqrt_bias_correction2;
     }
     return ad;
@@ -269,6 +283,9 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, void* geom_ws, int32_t* radii,
                               int32_t* num_rendered, hipStream_t s, uint32_t* zero_buf = nullptr, size_t zero_words = 0);
+// rdg_densify.hip: the statistics update as its own launch (rdg_densify_stats)
+int rdg_launch_densify_stats(long long n, long long row0, const float* dmeans2D, const int32_t* radii, float* accum,
+                             float* denom, float* maxr, hipStream_t s);
 int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii, int32_t* num_rendered,
                                  hipStream_t s);
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,

@@ -940,9 +940,13 @@ template <int VAR>
 __global__ void __launch_bounds__(256)
 rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float omb1, float omb2, float eps,
                       float bc2_sqrt, const RdgStepScalars* __restrict__ dev) {
-    if (dev) { inv_bc1 = dev->inv_bias_correction1; bc2_sqrt = dev->sqrt_bias_correction2; }   // graph replay
     const RdgAdamSeg sg = segs.s[blockIdx.y];
-    rdg_adam_segment<VAR>(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, sg.lr_head * inv_bc1, sg.lr_tail * inv_bc1,
+    float lr_head = sg.lr_head, lr_tail = sg.lr_tail;
+    if (dev) {                                                  // graph replay
+        inv_bc1 = dev->inv_bias_correction1; bc2_sqrt = dev->sqrt_bias_correction2;
+        if (dev->lr_from_table) { lr_head = dev->seg_lr_head[blockIdx.y]; lr_tail = dev->seg_lr_tail[blockIdx.y]; }
+    }
+    rdg_adam_segment<VAR>(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, lr_head * inv_bc1, lr_tail * inv_bc1,
                      sg.row_len, sg.head_len, b1, b2, omb1, omb2, eps, bc2_sqrt);
 }
 

@@ -55,6 +55,29 @@ __global__ void rdg_reset_opacity_kernel(long long n, float cap, float* __restri
     v[i] = 0.0f;
 }
 
+// Densification statistics of one iteration as their own launch (rdg_densify_stats; the per-Gaussian backward does the
+// same update in passing, rdg_preprocess_bwd.hip): rows [row0, row0 + n) of the concatenated cloud, visible = radius > 0
+// (/root/reference/src/trainer/rodygs.py:316-341, rodygs_static.py:317-319).
+__global__ void __launch_bounds__(256)
+rdg_densify_stats_kernel(long long n, long long row0, const float* __restrict__ dm2, const int32_t* __restrict__ radii,
+                         float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ maxr) {
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const long long i = row0 + j;
+    const int32_t r = radii[i];
+    if (r <= 0) return;
+    if (maxr) maxr[j] = fmaxf(maxr[j], (float)r);
+    if (accum) { const float gx = dm2[3 * i], gy = dm2[3 * i + 1]; accum[j] += sqrtf(gx * gx + gy * gy); }
+    if (denom) denom[j] += 1.0f;
+}
+
+int rdg_launch_densify_stats(long long n, long long row0, const float* dmeans2D, const int32_t* radii, float* accum,
+                             float* denom, float* maxr, hipStream_t s) {
+    hipLaunchKernelGGL(rdg_densify_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, row0, dmeans2D,
+                       radii, accum, denom, maxr);
+    return rdg_check_hip(hipGetLastError(), "densify_stats launch");
+}
+
 extern "C" {
 
 int rdg_reset_opacity(int64_t n, float max_opacity, float* opacity_logit, float* exp_avg, float* exp_avg_sq,

@@ -357,6 +357,14 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
 #pragma unroll
             for (int q = 0; q < 5; ++q) f4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (!MULTI && live && (unsigned)(i - d.dn_row0) < (unsigned)d.dn_rows) {
+            // densification statistics of the reference's train loop (RdgRasterSettings.densify_*): dL/dmean2D and the
+            // radius are in registers here -- 12 B of read-modify-write per visible Gaussian instead of a pass of its own
+            const int j = i - d.dn_row0;
+            if (d.dn_maxr) d.dn_maxr[j] = fmaxf(d.dn_maxr[j], (float)radii[i]);
+            if (d.dn_accum) d.dn_accum[j] += sqrtf(gnx * gnx + gny * gny);
+            if (d.dn_denom) d.dn_denom[j] += 1.0f;
+        }
         dmeans3D[3 * i + 0] = dmx; dmeans3D[3 * i + 1] = dmy; dmeans3D[3 * i + 2] = dmz;
         dmeans2D[3 * i + 0] = gnx; dmeans2D[3 * i + 1] = gny; dmeans2D[3 * i + 2] = 0.f;
         dopac[i] = gop;

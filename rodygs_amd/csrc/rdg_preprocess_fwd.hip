@@ -236,7 +236,8 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
 // receive the total (D).  nblk <= 16384 at P = 4 M, i.e. runs of <= 16 entries per thread.
 __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __restrict__ block_sums, int nblk,
                                                                    int32_t* __restrict__ num_rendered,
-                                                                   uint32_t* __restrict__ zero_buf, int zero_words) {
+                                                                   uint32_t* __restrict__ zero_buf, int zero_words,
+                                                                   int32_t* __restrict__ nren_max) {
     // optional: clear the binning stage's per-tile counters here (this block is otherwise idle most of its life; saves
     // a memset launch and a stream boundary per frame)
     for (int i = threadIdx.x; i < zero_words; i += 1024) zero_buf[i] = 0u;
@@ -282,6 +283,8 @@ __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __r
         const bool fits = total64 < 0x7fffffffull;
         block_sums[nblk] = fits ? carry_s : 0x7fffffffu;
         *num_rendered = fits ? (int32_t)carry_s : 0x7fffffff;
+        // sticky record (RdgRasterSettings.num_rendered_max): one thread per frame, the frames of a stream in order
+        if (nren_max) { const int32_t n = fits ? (int32_t)carry_s : 0x7fffffff; if (n > *nren_max) *nren_max = n; }
     }
 }
 
@@ -327,7 +330,7 @@ int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii,
         hipLaunchKernelGGL(rdg_geom_from_records_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
                            (const RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), block_sums, radii);
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
-                       num_rendered, (uint32_t*)nullptr, 0);
+                       num_rendered, (uint32_t*)nullptr, 0, d.nren_max);
     return rdg_check_hip(hipGetLastError(), "geom_from_records launch");
 }
 
@@ -345,7 +348,7 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
                            (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0, 0);
     }
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
-                       num_rendered, zero_buf, (int)zero_words);
+                       num_rendered, zero_buf, (int)zero_words, d.nren_max);
     return rdg_check_hip(hipGetLastError(), "preprocess_fwd launch");
 }
 

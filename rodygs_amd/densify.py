@@ -37,14 +37,41 @@ class DensifyStats:
                             torch.zeros(P, device=device))
 
     def add(self, viewspace_grad: torch.Tensor, update_filter: torch.Tensor, radii: Optional[torch.Tensor] = None):
-        """add_densification_stats (rodygs_static.py:317-319) with the gradient norm of rodygs.py:319-341, and the
-        running max of the screen radii (rodygs.py:334-337)."""
+        """The reference's own expression -- add_densification_stats (rodygs_static.py:317-319) with the gradient norm of
+        rodygs.py:319-341 and the running max of the screen radii (rodygs.py:334-337) -- five boolean-mask indexing ops,
+        each a nonzero + host sync.  Kept as the statement the parity tests compare the kernels with; the train step uses
+        ``sink()`` (inside the per-Gaussian backward kernel) or ``add_frame`` (one launch)."""
         g = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True)
         self.xyz_gradient_accum[update_filter] += g[update_filter]
         self.denom[update_filter] += 1
         if radii is not None:
             self.max_radii2D[update_filter] = torch.max(self.max_radii2D[update_filter],
                                                         radii[update_filter].to(self.max_radii2D.dtype))
+
+    def add_frame(self, viewspace_grad: torch.Tensor, radii: torch.Tensor, row0: int = 0) -> None:
+        """One iteration's update as ONE HIP launch (rdg_densify_stats), for a caller that follows the reference's flow
+        (``viewspace_point_tensor.grad`` and ``radii`` in hand after ``loss.backward()``): rows [row0, row0 + P_stats) of
+        the concatenated cloud, visible = radii > 0 (the reference's ``visibility_filter``).  No host sync."""
+        if not (viewspace_grad.is_cuda and radii.is_cuda and self.denom.is_cuda):
+            raise RuntimeError("DensifyStats.add_frame: tensors must be on the GPU (no CPU fallback exists)")
+        n = self.denom.numel()
+        g = viewspace_grad.detach()
+        if g.dtype != torch.float32 or not g.is_contiguous() or g.dim() != 2 or g.shape[1] != 3:
+            raise RuntimeError("DensifyStats.add_frame: viewspace gradient must be a contiguous float32 [P,3] tensor")
+        if radii.dtype != torch.int32 or not radii.is_contiguous():
+            raise RuntimeError("DensifyStats.add_frame: radii must be the rasterizer's contiguous int32 [P] tensor")
+        if row0 < 0 or row0 + n > radii.numel() or g.shape[0] != radii.numel():
+            raise RuntimeError("DensifyStats.add_frame: the statistics rows do not lie inside the rendered cloud")
+        with torch.cuda.device(g.device):
+            _lib.check(_lib.lib().rdg_densify_stats(n, row0, _lib.ptr(g), _lib.ptr(radii),
+                                                    _lib.ptr(self.xyz_gradient_accum), _lib.ptr(self.denom),
+                                                    _lib.ptr(self.max_radii2D), _lib.stream_ptr()), "rdg_densify_stats")
+
+    def sink(self, row0: int = 0) -> dict:
+        """``grad_sinks["densify"]`` entry for the rasterizer: the per-Gaussian backward kernel applies the update itself
+        (no launch, no extra pass: dL/dmean2D and the radius are in its registers)."""
+        return {"grad_accum": self.xyz_gradient_accum, "denom": self.denom, "max_radii": self.max_radii2D,
+                "row0": int(row0), "rows": int(self.denom.numel())}
 
 
 def allreduce_stats_(stats: "DensifyStats") -> None:

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import NamedTuple, Optional
 
 import torch
@@ -28,8 +29,6 @@ from . import _lib
 RENDER_NORMAL = True          # composite the (unused-by-RoDyGS) normal channels
 PREZERO_GRAD_ROWS = os.environ.get("RDG_PREZERO_GRAD_ROWS", "1") != "0"   # the forward clears the backward's gradient rows
 NREN_HOST_MIRROR = os.environ.get("RDG_NREN_MIRROR", "1") != "0"           # deferred check: the device writes D to pinned memory
-_CAPACITY_HINT = {}           # (P, H, W) -> last num_rendered, to size the binning workspace without a sync
-_BIN_HINT = {}                # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
 # Bucket binning (count / scan / scatter + per-tile sort) is the fast path on ordinary frames, but its cost grows with
 # the longest tile list (same-address atomics in the count pass, a merge tree in the sort); the LSD radix path does not
 # care how instances are spread.  Same result bit for bit, so the choice is made per frame from the PREVIOUS frame's
@@ -40,25 +39,23 @@ BIN_BUCKET_BELOW = 16384
 # 200 k-instance tile: 15 ms).  Lists above 4096 instances can be cut into segments composited by a workgroup each
 # (csrc/rdg_render.hip "split path"; the backward follows the forward's choice) -- three extra launches in the forward and
 # one in the backward, so, like the binning algorithm, the choice is made per frame from the previous frame's largest list.
-_SPLIT_HINT = {}              # (P, H, W) -> 1 while the largest tile list of the last frame calls for the split path
 SPLIT_ABOVE = 4096            # = RDG_SPLIT_MIN of the library: shorter lists are never split
 SPLIT_BELOW = 3072
-
+# RDG_BIN_MODE=radix in the environment: every forward takes the radix binning (A/B switch; read once, here)
+_FORCE_RADIX = os.environ.get("RDG_BIN_MODE", "") == "radix"
 
 # Deterministic backward (RDG_DETERMINISTIC=1 or set at run time): the compositing backward stores
 # per-(wave, list position) partial rows and reduces them per Gaussian in a fixed order instead of accumulating with float
 # atomics (rdg_composite_backward_det) -- two runs give the same bits; ~2x the compositing backward (1.3x the train step) and 256 B per instance.
 DETERMINISTIC = os.environ.get("RDG_DETERMINISTIC", "0") == "1"
 
-# hipGraph capture (rodygs_amd.trainstep.GraphedStep sets it around capture): the forward touches nothing on the host --
-# capacity and binning mode come from the hints of the warm-up steps, the instance count stays on the device
-# (last_num_rendered()) and is checked by the owner of the graph between replays.
+# hipGraph capture (rodygs_amd.trainstep.GraphedStep sets RasterState.graph_capture around capture; the module flag is the
+# same switch for every state): the forward touches nothing on the host -- capacity and binning mode come from the hints
+# of the warm-up steps, the instance count stays on the device (last_num_rendered()) and is checked by the owner of the
+# graph between replays.
 GRAPH_CAPTURE = False
-_LAST_NREN = [None]               # (nren int32[2] device tensor, key, capacity) of the most recent forward
 
 DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
-_PENDING = []                     # (stream, pinned int32[2], key, capacity, device pair) of forwards not yet checked
-_PINNED_FREE = []
 
 
 class RasterizerCapacityOverflow(RuntimeError):
@@ -67,19 +64,79 @@ class RasterizerCapacityOverflow(RuntimeError):
     has been raised, so re-running the frame succeeds."""
 
 
-def _pinned_slot() -> torch.Tensor:
-    return _PINNED_FREE.pop() if _PINNED_FREE else torch.empty(2, dtype=torch.int32).pin_memory()
+class RasterState:
+    """What the rasterizer remembers from one frame to the next, owned by the CALLER ("reentrant per
+    workspace; no global mutable state"): the instance count of the last frame of every (P, H, W) -- it sizes the next
+    frame's binning workspace without a host wait --, the two speed hints derived from the last frame's largest tile list
+    (binning algorithm, split compositing), the forwards whose instance count has not been checked yet (deferred mode)
+    and the workspaces of the most recent forward.  None of it changes a result; all of it decides speed, so two scenes of
+    equal (P, H, W) -- a static and a dynamic model, a training and an evaluation renderer -- should not share one: give
+    each its own ``RasterState`` (``GaussianRasterizer(settings, state=...)``; ``DynamicScene``, ``PoseOptimizer`` and the
+    sharded scenes do).  A caller that builds a rasterizer per call without one, as the reference does
+    (/root/reference/src/trainer/renderer.py:65), gets ``DEFAULT_STATE``.  Safe to use from several threads: the host
+    bookkeeping of a forward runs under the state's lock (the launches themselves do not)."""
+
+    def __init__(self):
+        self.capacity_hint = {}       # (P, H, W) -> last num_rendered
+        self.bin_hint = {}            # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
+        self.split_hint = {}          # (P, H, W) -> 1 while it calls for the split compositing path
+        self.pending = []             # (stream, pinned int32[2], key, capacity, device pair) of forwards not yet checked
+        self.pinned_free = []
+        self.last_nren = None         # (nren int32[2] device tensor, key, capacity) of the most recent forward
+        self.last_image = None        # (image workspace, H, W) of the most recent forward
+        self.graph_capture = False
+        self.nren_max = None          # optional device int32[1]: sticky maximum of D (RdgRasterSettings.num_rendered_max)
+        self.det_ws = None            # deterministic mode: the per-instance row workspace, kept across steps
+        self.lock = threading.RLock()
+
+    def pinned_slot(self) -> torch.Tensor:
+        return self.pinned_free.pop() if self.pinned_free else torch.empty(2, dtype=torch.int32).pin_memory()
+
+    def note_largest_tile(self, key, largest: int) -> None:
+        if largest > BIN_RADIX_ABOVE:
+            self.bin_hint[key] = 1
+        elif largest < BIN_BUCKET_BELOW:
+            self.bin_hint.pop(key, None)
+        if largest > SPLIT_ABOVE:
+            self.split_hint[key] = 1
+        elif largest < SPLIT_BELOW:
+            self.split_hint.pop(key, None)
+
+    def poll_overflow(self, block: bool = False) -> None:
+        """Deferred mode: check the instance counts of forwards whose count has landed (all of them if ``block``)."""
+        with self.lock:
+            while self.pending:
+                stream, host, key, cap, nren = self.pending[0]
+                if int(host[0]) < 0:                  # the binning stage of that forward has not written its mirror yet
+                    if not block:
+                        return
+                    stream.synchronize()
+                    if int(host[0]) < 0:              # (a path that does not mirror: read the device pair)
+                        host[0], host[1] = (int(v) for v in nren.tolist())
+                n = int(host[0])
+                self.pending.pop(0)
+                self.pinned_free.append(host)
+                if n >= _INSTANCE_LIMIT:
+                    raise RuntimeError(_too_many(key))
+                self.capacity_hint[key] = max(n, int(self.capacity_hint.get(key, 0) * 0.9))
+                self.note_largest_tile(key, int(host[1]))
+                if n > cap:
+                    self.capacity_hint[key] = n
+                    raise RasterizerCapacityOverflow(
+                        f"rasterizer forward for (P,H,W)={key} needed {n} instances, workspace held {cap}: that frame "
+                        f"was rendered empty; re-run it (the capacity hint is now {n})")
+
+
+DEFAULT_STATE = RasterState()
+# the default state's tables under their historical module names (tests and scripts reach for them)
+_CAPACITY_HINT = DEFAULT_STATE.capacity_hint
+_BIN_HINT = DEFAULT_STATE.bin_hint
+_SPLIT_HINT = DEFAULT_STATE.split_hint
+_PENDING = DEFAULT_STATE.pending
 
 
 def _note_largest_tile(key, largest: int) -> None:
-    if largest > BIN_RADIX_ABOVE:
-        _BIN_HINT[key] = 1
-    elif largest < BIN_BUCKET_BELOW:
-        _BIN_HINT.pop(key, None)
-    if largest > SPLIT_ABOVE:
-        _SPLIT_HINT[key] = 1
-    elif largest < SPLIT_BELOW:
-        _SPLIT_HINT.pop(key, None)
+    DEFAULT_STATE.note_largest_tile(key, largest)
 
 
 _INSTANCE_LIMIT = 2 ** 31 - 1      # the device saturates its (tile, Gaussian) instance count here (rdg_scan_block_sums_kernel)
@@ -90,28 +147,8 @@ def _too_many(key) -> str:
             "32 bits wide, as upstream's; the frame was rendered empty.  Scales this large usually mean a diverged run")
 
 
-def poll_overflow(block: bool = False) -> None:
-    """Deferred mode: check the instance counts of forwards whose copy has landed (all of them if ``block``)."""
-    while _PENDING:
-        stream, host, key, cap, nren = _PENDING[0]
-        if int(host[0]) < 0:                  # the binning stage of that forward has not written its mirror yet
-            if not block:
-                return
-            stream.synchronize()
-            if int(host[0]) < 0:              # (a path that does not mirror: read the device pair)
-                host[0], host[1] = (int(v) for v in nren.tolist())
-        n = int(host[0])
-        _PENDING.pop(0)
-        _PINNED_FREE.append(host)
-        if n >= _INSTANCE_LIMIT:
-            raise RuntimeError(_too_many(key))
-        _CAPACITY_HINT[key] = max(n, int(_CAPACITY_HINT.get(key, 0) * 0.9))
-        _note_largest_tile(key, int(host[1]))
-        if n > cap:
-            _CAPACITY_HINT[key] = n
-            raise RasterizerCapacityOverflow(
-                f"rasterizer forward for (P,H,W)={key} needed {n} instances, workspace held {cap}: that frame was "
-                f"rendered empty; re-run it (the capacity hint is now {n})")
+def poll_overflow(block: bool = False, state: Optional[RasterState] = None) -> None:
+    (state or DEFAULT_STATE).poll_overflow(block)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -144,7 +181,7 @@ def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int) -> _lib.RdgRa
     s.enable_cov_grad = int(bool(rs.enable_cov_grad))
     s.enable_sh_grad = int(bool(rs.enable_sh_grad))
     s.render_normal = int(bool(RENDER_NORMAL))
-    s.bin_mode = 0
+    s.bin_mode = 1 if _FORCE_RADIX else 0
     s.num_rendered_stats = 0
     s.list_hints = 0
     return s
@@ -174,21 +211,66 @@ def _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_al
                                             _lib.ptr(g_alpha), _lib.ptr(g_normal), _lib.ptr(gws), _lib.stream_ptr()),
                    "rdg_composite_backward")
         return
-    # D is known on the host except in deferred-overflow mode, where the capacity bounds it
+    # D is known on the host except in deferred-overflow mode and under graph capture, where the capacity bounds it (the
+    # library clears only the rows of the frame's own instances: it reads D on the device).  The workspace is kept on
+    # the state and reused while it is large enough -- 256 B per instance is 1 GB at P = 1 M
     n_inst = ctx.num_rendered if 0 <= ctx.num_rendered <= ctx.capacity else ctx.capacity
-    det = torch.empty(L.rdg_det_bytes(n_inst), dtype=torch.uint8, device=gws.device)
+    need = L.rdg_det_bytes(n_inst)
+    st = ctx.state
+    det = st.det_ws
+    if det is None or det.numel() < need or det.device != gws.device or st.graph_capture or GRAPH_CAPTURE:
+        det = torch.empty(need, dtype=torch.uint8, device=gws.device)
+        if not (st.graph_capture or GRAPH_CAPTURE):
+            st.det_ws = det
     _lib.check(L.rdg_composite_backward_det(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
                                             ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
                                             _lib.ptr(g_alpha), _lib.ptr(g_normal), _lib.ptr(gws), _lib.ptr(det), n_inst,
                                             _lib.stream_ptr()), "rdg_composite_backward_det")
 
 
+def _bind_densify_stats(ctx, P: int) -> None:
+    """grad_sinks["densify"] = {"grad_accum", "denom", "max_radii" (float32, `rows` elements each, any may be missing),
+    "row0" (default 0), "rows" (default: the arrays' length)}: the per-Gaussian backward kernel updates the densification
+    statistics of the reference's train loop (/root/reference/src/trainer/rodygs.py:316-341, rodygs_static.py:317-319)
+    itself -- RdgRasterSettings.densify_*.  Applied by the FIRST backward through a forward only: a second backward
+    through the same graph (retain_graph) must not count the frame twice."""
+    cs = ctx.cs
+    cs.densify_grad_accum = cs.densify_denom = cs.densify_max_radii = None
+    cs.densify_rows = cs.densify_row0 = 0
+    sink = None if ctx.grad_sinks is None else ctx.grad_sinks.get("densify")
+    if sink is None or getattr(ctx, "densify_done", False):
+        return
+    ctx.densify_done = True
+    row0 = int(sink.get("row0", 0))
+    arrs = {k: sink.get(k) for k in ("grad_accum", "denom", "max_radii")}
+    rows = sink.get("rows")
+    for k, t in arrs.items():
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError(f"grad_sinks['densify']['{k}'] must be a contiguous float32 GPU tensor")
+        rows = t.numel() if rows is None else rows
+        if t.numel() != rows:
+            raise RuntimeError("grad_sinks['densify']: the statistics arrays must all hold `rows` elements")
+    if rows is None:
+        return
+    rows = int(rows)
+    if row0 < 0 or row0 + rows > P:
+        raise RuntimeError(f"grad_sinks['densify']: rows [{row0}, {row0 + rows}) do not lie inside the {P} Gaussians")
+    cs.densify_grad_accum = _lib.ptr(arrs["grad_accum"])
+    cs.densify_denom = _lib.ptr(arrs["denom"])
+    cs.densify_max_radii = _lib.ptr(arrs["max_radii"])
+    cs.densify_row0, cs.densify_rows = row0, rows
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
-                raster_settings, grad_sinks=None):
+                raster_settings, grad_sinks=None, state=None):
         L = _lib.lib()
         ctx.grad_sinks = grad_sinks
+        state = state if state is not None else DEFAULT_STATE
+        ctx.state = state
         dev = means3D.device
         sh, colors_precomp = _empty(sh), _empty(colors_precomp)
         scales, rotations, cov3Ds_precomp = _empty(scales), _empty(rotations), _empty(cov3Ds_precomp)
@@ -246,25 +328,29 @@ class _RasterizeGaussians(torch.autograd.Function):
             nren = torch.empty(2, dtype=torch.int32, device=dev)
             key = (P, H, W)
             cs.num_rendered_stats = 1
-            cs.bin_mode = int(_BIN_HINT.get(key, 0))
-            # deterministic mode: the choice must not depend on what the previous frame looked like (the split path
-            # associates the transmittance product differently: same result to the last bits only)
-            cs.list_hints = 1 if DETERMINISTIC else int(_SPLIT_HINT.get(key, 0))
-            cap = max(int(_CAPACITY_HINT.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
+            capture = GRAPH_CAPTURE or state.graph_capture
             stream = _lib.stream_ptr()
-            if GRAPH_CAPTURE and key not in _CAPACITY_HINT:
-                raise RuntimeError("rasterizer.GRAPH_CAPTURE needs a warm-up forward of this (P, H, W) first")
-            deferred = DEFERRED_OVERFLOW_CHECK and key in _CAPACITY_HINT and not GRAPH_CAPTURE
-            if deferred:
-                poll_overflow(block=False)
-            host = None
-            if deferred:
-                # D and the largest list are ALSO written to pinned host memory by the binning stage itself
-                # (RdgRasterSettings.num_rendered_host): no copy and no event on the stream; -1 = not there yet
-                host = _pinned_slot()
-                host[0], host[1] = -1, -1
-                if NREN_HOST_MIRROR:
-                    cs.num_rendered_host = host.data_ptr()
+            with state.lock:
+                cs.bin_mode = max(int(cs.bin_mode), int(state.bin_hint.get(key, 0)))
+                # deterministic mode: the choice must not depend on what the previous frame looked like (the split path
+                # associates the transmittance product differently: same result to the last bits only)
+                cs.list_hints = 1 if DETERMINISTIC else int(state.split_hint.get(key, 0))
+                cap = max(int(state.capacity_hint.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
+                if capture and key not in state.capacity_hint:
+                    raise RuntimeError("graph capture needs a warm-up forward of this (P, H, W) on the same RasterState first")
+                deferred = DEFERRED_OVERFLOW_CHECK and key in state.capacity_hint and not capture
+                if deferred:
+                    state.poll_overflow(block=False)
+                host = None
+                if deferred:
+                    # D and the largest list are ALSO written to pinned host memory by the binning stage itself
+                    # (RdgRasterSettings.num_rendered_host): no copy and no event on the stream; -1 = not there yet
+                    host = state.pinned_slot()
+                    host[0], host[1] = -1, -1
+                    if NREN_HOST_MIRROR:
+                        cs.num_rendered_host = host.data_ptr()
+                if state.nren_max is not None:
+                    cs.num_rendered_max = state.nren_max.data_ptr()     # sticky maximum of D (graph replay)
             while True:
                 binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), **u8)
                 rc = L.rdg_rasterize_forward(C.byref(cs), _lib.ptr(bg), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col),
@@ -273,8 +359,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                              _lib.ptr(color), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(alpha),
                                              _lib.ptr(radii), _lib.ptr(nren), stream)
                 _lib.check(rc, "rdg_rasterize_forward")
-                _LAST_NREN[0] = (nren, key, cap)
-                if GRAPH_CAPTURE:
+                state.last_nren = (nren, key, cap)
+                if capture:
                     n = -1
                     break
                 if deferred:
@@ -283,19 +369,21 @@ class _RasterizeGaussians(torch.autograd.Function):
                     # empty scene (every tile range zero) and RasterizerCapacityOverflow is raised then.
                     if not NREN_HOST_MIRROR:           # the copy-engine form: a blit and an event on the stream per frame
                         host.copy_(nren, non_blocking=True)
-                    _PENDING.append((torch.cuda.current_stream(dev), host, key, cap, nren))
+                    with state.lock:
+                        state.pending.append((torch.cuda.current_stream(dev), host, key, cap, nren))
                     n = -1
                     break
                 # one host read AFTER the whole forward is queued (upstream stalls mid-pipeline instead)
                 n, largest = (int(v) for v in nren.tolist())
                 if n >= _INSTANCE_LIMIT:
                     raise RuntimeError(_too_many(key))
-                _CAPACITY_HINT[key] = n
-                _note_largest_tile(key, largest)
+                with state.lock:
+                    state.capacity_hint[key] = n
+                    state.note_largest_tile(key, largest)
                 if n <= cap:
                     break
                 cap = int(n * 1.25) + 4096
-        _LAST_IMAGE_WS[0] = (image, H, W)
+        state.last_image = (image, H, W)
         # outputs the loss never touched (normal, alpha, usually depth) arrive as None in backward instead of as
         # zero-filled images the kernel would then read
         ctx.set_materialize_grads(False)
@@ -317,7 +405,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("rodygs_amd rasterizer: rendered_normal received an upstream gradient, but the forward ran "
                                "with rasterizer.RENDER_NORMAL = False (the image is all zeros and has no graph)")
         if ctx.empty_cloud or (g_color is None and g_depth is None and g_alpha is None and g_normal is None):
-            return (None,) * 11
+            return (None,) * 12
         L = _lib.lib()
         m3, shs, col, op, sc, ro, cov, vm, pm, bg, radii, geom, binning, image = ctx.saved_tensors
         dev = m3.device
@@ -332,6 +420,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_color, g_depth, g_alpha, g_normal = gc(g_color), gc(g_depth), gc(g_alpha), gc(g_normal)
         with torch.cuda.device(dev):
             gws, ctx.gws = ctx.gws, None          # the rows the forward cleared serve one backward
+            _bind_densify_stats(ctx, P)
             ctx.cs.grad_rows_zeroed = 1 if (gws is not None and not DETERMINISTIC) else 0
             if gws is None:
                 gws = torch.empty(L.rdg_grad_bytes(P), dtype=torch.uint8, device=dev)
@@ -380,7 +469,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                         float(fused["lr_head"]), float(fused["lr_tail"]), float(fused["betas"][0]),
                         float(fused["betas"][1]), float(fused["eps"]), _lib.ptr(fused["step_scalars"]),
                         _lib.stream_ptr()), "rdg_preprocess_backward_adam_dev")
-                    return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None
+                    return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None, None
                 step = fused["step"]() if callable(fused["step"]) else int(fused["step"])
                 _lib.check(L.rdg_preprocess_backward_adam(
                     C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(op), _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(vm),
@@ -389,7 +478,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _lib.ptr(fused["exp_avg_sq"]), int(fused["head_len"]), float(fused["lr_head"]),
                     float(fused["lr_tail"]), float(fused["betas"][0]), float(fused["betas"][1]), float(fused["eps"]),
                     step, _lib.stream_ptr()), "rdg_preprocess_backward_adam")
-                return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None
+                return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None, None
             if DETERMINISTIC:
                 _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws, g_normal)
                 rc = L.rdg_preprocess_backward(C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col), _lib.ptr(op),
@@ -414,27 +503,26 @@ class _RasterizeGaussians(torch.autograd.Function):
             ready = ctx.grad_sinks.get("on_shs_ready")
             if ready is not None:
                 ready()          # the sink now holds the final dL/dshs (stream-ordered): e.g. start its all-reduce
-        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_ro, d_cov, d_vm, None, None
+        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_ro, d_cov, d_vm, None, None, None
 
 
-_LAST_IMAGE_WS = [None]
-
-
-def last_num_rendered():
-    """(nren, key, capacity): the device tensor [D, largest tile list] the most recent forward wrote, the (P, H, W) key
-    of its hints and the capacity it ran with.  The owner of a captured graph reads it between replays: D > capacity
-    means that frame was rendered empty and the graph must be re-captured with the raised hint."""
-    if _LAST_NREN[0] is None:
+def last_num_rendered(state: Optional[RasterState] = None):
+    """(nren, key, capacity): the device tensor [D, largest tile list] the most recent forward (of ``state``) wrote, the
+    (P, H, W) key of its hints and the capacity it ran with.  The owner of a captured graph reads it between replays:
+    D > capacity means that frame was rendered empty and the graph must be re-captured with the raised hint."""
+    state = state or DEFAULT_STATE
+    if state.last_nren is None:
         raise RuntimeError("no rasterizer forward has run yet")
-    return _LAST_NREN[0]
+    return state.last_nren
 
 
-def last_compositing_state():
+def last_compositing_state(state: Optional[RasterState] = None):
     """(final_T[H,W] float32, n_contrib[H,W] int32) of the most recent forward -- the per-pixel state the backward
     replays from (``rdg_image_export``).  sum(n_contrib) is S, the pixel-splat pairs the forward walked."""
-    if _LAST_IMAGE_WS[0] is None:
+    state = state or DEFAULT_STATE
+    if state.last_image is None:
         raise RuntimeError("no rasterizer forward has run yet")
-    image, H, W = _LAST_IMAGE_WS[0]
+    image, H, W = state.last_image
     with torch.cuda.device(image.device):
         final_T = torch.empty(H, W, dtype=torch.float32, device=image.device)
         n_contrib = torch.empty(H, W, dtype=torch.int32, device=image.device)
@@ -444,15 +532,18 @@ def last_compositing_state():
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
-                        raster_settings, grad_sinks=None):
+                        raster_settings, grad_sinks=None, state=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, viewmatrix, raster_settings, grad_sinks)
+                                     cov3Ds_precomp, viewmatrix, raster_settings, grad_sinks, state)
 
 
 class GaussianRasterizer(nn.Module):
-    def __init__(self, raster_settings: GaussianRasterizationSettings):
+    def __init__(self, raster_settings: GaussianRasterizationSettings, state: Optional[RasterState] = None):
+        """``state`` (outside the reference surface): the caller-owned ``RasterState`` this rasterizer's frame-to-frame
+        memory lives in; None = the process default (what the reference's rasterizer-per-call pattern gets)."""
         super().__init__()
         self.raster_settings = raster_settings
+        self.state = state
 
     def markVisible(self, positions: torch.Tensor, viewmatrix: torch.Tensor) -> torch.Tensor:
         """Frustum test of the upstream API (no reference caller): view-space z > 0.2."""
@@ -468,7 +559,8 @@ class GaussianRasterizer(nn.Module):
         {"shs_adam": {param, exp_avg, exp_avg_sq, head_len, lr_head, lr_tail, betas, eps, step}} makes backward apply
         the Adam step of the SH features itself (``rdg_preprocess_backward_adam``) -- the parameters change DURING
         backward, so use it only where backward runs exactly once per optimiser step and nothing else needs dL/dshs
-        (rodygs_amd/trainstep.py does, for the single-GPU photometric step)."""
+        (rodygs_amd/trainstep.py does, for the single-GPU photometric step); {"densify": {...}} makes backward update
+        the densification statistics of the train loop (see ``_bind_densify_stats``)."""
         if extra_attrs is not None:
             raise NotImplementedError("extra_attrs is not used by RoDyGS and is not implemented")
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
@@ -479,4 +571,4 @@ class GaussianRasterizer(nn.Module):
         if viewmatrix is None:
             raise Exception("viewmatrix must be given (it is a differentiable forward argument in the pose branch)")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                   viewmatrix, self.raster_settings, grad_sinks)
+                                   viewmatrix, self.raster_settings, grad_sinks, self.state)

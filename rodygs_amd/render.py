@@ -1,71 +1,46 @@
-"""``render()`` glue with the reference's signature and return dict
-(/root/reference/src/trainer/renderer.py:17-114; clones at src/model/rodygs_static.py:184-296 and
-src/evaluator/eval.py:84-191), calling the MI355X-native rasterizer."""
+"""``render()`` glue: the reference's signature and return dictionary
+(/root/reference/src/trainer/renderer.py:17-114; the same glue is repeated at src/model/rodygs_static.py:184-296 and
+src/evaluator/eval.py:84-191) in front of the MI355X-native rasterizer.
+
+Contract kept from the reference (callers depend on it): the positional / keyword arguments, the eight keys of the
+result, ``viewspace_points`` receiving dL/dmean2D in ``.grad`` after backward (read at src/trainer/rodygs.py:322-324),
+``visibility_filter = radii > 0``, transposed ("glm storage") camera matrices, and the crossed gradient gates
+(renderer.py:61-62 hands ``enable_sh_grad`` to the rasterizer's ``enable_cov_grad`` and the other way round; every
+shipped caller passes equal flags)."""
 from __future__ import annotations
 
 import math
+from typing import Optional
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterState
+
+_IMAGE_KEYS = ("rendered_image", "rendered_depth", "rendered_normal", "rendered_alpha")
+
+
+def camera_settings(camera, bg: torch.Tensor, sh_degree: int, scale_modifier: float, cov_gate: bool,
+                    sh_gate: bool) -> GaussianRasterizationSettings:
+    """Rasterizer settings of a camera object with the FixedCameraTorch surface
+    (/root/reference/src/data/utils.py:105-170): FoVx, FoVy, image_height, image_width, projection_matrix."""
+    return GaussianRasterizationSettings(
+        int(camera.image_height), int(camera.image_width), math.tan(0.5 * camera.FoVx), math.tan(0.5 * camera.FoVy), bg,
+        scale_modifier, camera.projection_matrix.t(), sh_degree, False, False, cov_gate, sh_gate)
 
 
 def render(xyz, active_sh_degree, opacity, scaling, rotation, features, viewpoint_camera, bg_color: torch.Tensor,
-           scaling_modifier=1, override_color=None, enable_sh_grad=False, enable_cov_grad=False):
-    """Render the scene.  ``viewpoint_camera`` needs FoVx, FoVy, image_height, image_width, projection_matrix
-    and world_view_transform (the FixedCameraTorch surface, /root/reference/src/data/utils.py:105-170)."""
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
-
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-
-    # NOTE: the reference passes enable_cov_grad=enable_sh_grad and enable_sh_grad=enable_cov_grad
-    # (renderer.py:61-62, names swapped; harmless there because callers pass equal flags).  Reproduced as is.
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height),
-        image_width=int(viewpoint_camera.image_width),
-        tanfovx=tanfovx,
-        tanfovy=tanfovy,
-        bg=bg_color,
-        scale_modifier=scaling_modifier,
-        projmatrix=viewpoint_camera.projection_matrix.transpose(0, 1),  # glm storage
-        sh_degree=active_sh_degree,
-        prefiltered=False,
-        debug=False,
-        enable_cov_grad=enable_sh_grad,
-        enable_sh_grad=enable_cov_grad,
-    )
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
-    shs = None
-    colors_precomp = None
-    if override_color is None:
-        shs = features
-    else:
-        colors_precomp = override_color
-
-    rendered_image, rendered_depth, rendered_normal, rendered_alpha, radii, extra = rasterizer(
-        means3D=xyz,
-        means2D=screenspace_points,
-        shs=shs,
-        colors_precomp=colors_precomp,
-        opacities=opacity,
-        scales=scaling,
-        rotations=rotation,
-        cov3Ds_precomp=None,
-        viewmatrix=viewpoint_camera.world_view_transform.transpose(0, 1),  # glm storage
-    )
-    return {
-        "rendered_image": rendered_image,
-        "rendered_depth": rendered_depth,
-        "rendered_normal": rendered_normal,
-        "rendered_alpha": rendered_alpha,
-        "viewspace_points": screenspace_points,
-        "visibility_filter": radii > 0,
-        "radii": radii,
-        "extra": extra,
-    }
+           scaling_modifier=1, override_color=None, enable_sh_grad=False, enable_cov_grad=False,
+           raster_state: Optional[RasterState] = None):
+    """One differentiable render of the cloud from ``viewpoint_camera``.  ``raster_state`` (outside the reference
+    surface): the caller's ``RasterState``; None = the process default."""
+    settings = camera_settings(viewpoint_camera, bg_color, active_sh_degree, scaling_modifier,
+                               cov_gate=enable_sh_grad, sh_gate=enable_cov_grad)
+    # the 2-D means carry no value into the rasterizer; the tensor exists to collect dL/dmean2D
+    mean2d_sink = xyz.new_zeros(xyz.shape).requires_grad_()
+    colour = {"colors_precomp": override_color} if override_color is not None else {"shs": features}
+    *images, radii, extra = GaussianRasterizer(settings, state=raster_state)(
+        means3D=xyz, means2D=mean2d_sink, opacities=opacity, scales=scaling, rotations=rotation,
+        viewmatrix=viewpoint_camera.world_view_transform.t(), **colour)
+    out = dict(zip(_IMAGE_KEYS, images))
+    out.update(viewspace_points=mean2d_sink, visibility_filter=radii > 0, radii=radii, extra=extra)
+    return out

@@ -363,7 +363,7 @@ class ShardedDynamicScene:
         st = _lib.stream_ptr()
         host = None
         if deferred:                # the binning stage mirrors (D, largest list) into pinned memory: rasterizer.poll_overflow
-            host = rasterizer._pinned_slot()
+            host = rasterizer.DEFAULT_STATE.pinned_slot()
             host[0], host[1] = -1, -1
         self.cs_cam.num_rendered_host = None if host is None else host.data_ptr()
         while True:
@@ -386,7 +386,7 @@ class ShardedDynamicScene:
             if D <= cap:
                 break
             cap = int(D * 1.5) + 4096
-        rasterizer._LAST_IMAGE_WS[0] = (self.image_ws, self.H, self.W)
+        rasterizer.DEFAULT_STATE.last_image = (self.image_ws, self.H, self.W)
 
     # private random stream of this rank (Pearson boxes, rigidity sample): lets several virtual ranks in one process draw
     # exactly what they would draw in their own processes

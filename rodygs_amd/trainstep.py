@@ -1,6 +1,5 @@
 """Minimal RoDyGS dynamic train step around the hot path ("build re-states a minimal train
-step for configs 3-5; full trainer out of scope").  It is the caller bench.py times, not a trainer replacement:
-no densification, no LR schedule, photometric loss only.
+step for configs 3-5; full trainer out of scope").  It is the caller bench.py times, not a trainer replacement.
 
 One step = what /root/reference/src/trainer/rodygs.py:198-369 does for a dynamic sub-step on one camera:
   time-deformation (MLP basis in torch + HIP per-Gaussian contraction, rodygs_dynamic.py:122-138)
@@ -23,7 +22,7 @@ from .deform import (MLPBasisNetwork, dynamic_gaussians, dynamic_getter_supporte
 from .dp import BucketedAllReduce, FlatParams, allreduce_sum_, frame_for
 from .losses import fused_photometric_loss
 from .model_ops import activate_gaussians, pose_view_matrix
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, RasterState
 
 
 def quaternion_to_matrix(q: torch.Tensor) -> torch.Tensor:
@@ -80,60 +79,61 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
     # the segment table only depends on the layout and the rates: built once per distinct call shape (it is ~60 us of
     # Python per step otherwise -- a tenth of the whole step at the sizes where the step is host-bound)
     key = (tuple(names) if names is not None else None, lr_scale, tuple(sorted(lr_override.items())) if lr_override else None,
-           tuple(sorted((k, tuple(v)) for k, v in row_lr.items())) if row_lr else None,
+           tuple(sorted((k, tuple(v)) for k, v in row_lr.items())) if row_lr else None, step_scalars is not None,
            tuple((id(f), f.flat.data_ptr(), f.flat_grad.data_ptr(), f.exp_avg.data_ptr(), f.exp_avg_sq.data_ptr(),
                   tuple(f.lr.values())) for f in (fp, *extra)))
     cache = fp.__dict__.setdefault("_adam_segs", {})
     hit = cache.get(key)
-    if hit is not None:
-        segs, n_ent = hit
-        if n_ent == 0:
-            return
-        if step_scalars is not None:
-            _lib.check(L.rdg_adam_step_multi_dev(n_ent, segs, betas[0], betas[1], eps, _lib.ptr(step_scalars),
-                                                 _lib.stream_ptr()), "rdg_adam_step_multi_dev")
-        else:
-            _lib.check(L.rdg_adam_step_multi(n_ent, segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
-                       "rdg_adam_step_multi")
-        return
-    entries = []   # (flat-params, first offset, element count, lr, row_len, head_len, lr_tail)
-    for f in (fp, *extra):
-        for k in f.names:
-            if f is fp and names is not None and k not in names:
-                entries.append(None)      # a gap: the neighbours must not be merged across it
-                continue
-            o, n = f.offsets[k]
-            lr_k = float(lr_override[k]) if (f is fp and lr_override and k in lr_override) else f.lr[k]
-            row_len, head_len, lr_tail = ((row_lr or {}).get(k, (1, 1, lr_k)) if f is fp else (1, 1, lr_k))
-            last = entries[-1] if entries else None
-            if last is not None and last[0] is f and last[4] == 1 and row_len == 1 and last[3] == lr_k:
-                entries[-1] = (f, last[1], o + n - last[1], last[3], 1, 1, last[6])
-            else:
-                entries.append((f, o, n, lr_k, row_len, head_len, lr_tail))
-    entries = [e for e in entries if e is not None]
-    if len(cache) > 64:
-        cache.clear()
-    if not entries:
-        cache[key] = (None, 0)
-        return
-    segs = (_lib.RdgAdamSeg * len(entries))()
-    for i, (f, o, n, lr, row_len, head_len, lr_tail) in enumerate(entries):
-        b = o * 4
-        segs[i].n = n
-        segs[i].param = f.flat.data_ptr() + b
-        segs[i].grad = f.flat_grad.data_ptr() + b
-        segs[i].exp_avg = f.exp_avg.data_ptr() + b
-        segs[i].exp_avg_sq = f.exp_avg_sq.data_ptr() + b
-        segs[i].lr_head = lr * lr_scale
-        segs[i].lr_tail = lr_tail * lr_scale
-        segs[i].row_len = row_len
-        segs[i].head_len = head_len
-    cache[key] = (segs, len(entries))
+    if hit is None:
+        entries = []   # [flat-params, first offset, element count, lr, row_len, head_len, lr_tail, names]
+        for f in (fp, *extra):
+            for k in f.names:
+                if f is fp and names is not None and k not in names:
+                    entries.append(None)      # a gap: the neighbours must not be merged across it
+                    continue
+                o, n = f.offsets[k]
+                lr_k = float(lr_override[k]) if (f is fp and lr_override and k in lr_override) else f.lr[k]
+                row_len, head_len, lr_tail = ((row_lr or {}).get(k, (1, 1, lr_k)) if f is fp else (1, 1, lr_k))
+                last = entries[-1] if entries else None
+                # graph replay: the groups of ``fp`` keep a segment each -- their rates are refreshed per step from device
+                # memory (RdgStepScalars.seg_lr_*), and a schedule may move one of two groups that share a rate today
+                mergeable = step_scalars is None or f is not fp
+                if (mergeable and last is not None and last[0] is f and last[4] == 1 and row_len == 1
+                        and last[3] == lr_k):
+                    last[2] = o + n - last[1]
+                    last[7].append(k)
+                else:
+                    entries.append([f, o, n, lr_k, row_len, head_len, lr_tail, [k]])
+        entries = [e for e in entries if e is not None]
+        if len(cache) > 64:
+            cache.clear()
+        segs = None
+        if entries:
+            segs = (_lib.RdgAdamSeg * len(entries))()
+            for i, (f, o, n, lr, row_len, head_len, lr_tail, _) in enumerate(entries):
+                b = o * 4
+                segs[i].n = n
+                segs[i].param = f.flat.data_ptr() + b
+                segs[i].grad = f.flat_grad.data_ptr() + b
+                segs[i].exp_avg = f.exp_avg.data_ptr() + b
+                segs[i].exp_avg_sq = f.exp_avg_sq.data_ptr() + b
+                segs[i].lr_head = lr * lr_scale
+                segs[i].lr_tail = lr_tail * lr_scale
+                segs[i].row_len = row_len
+                segs[i].head_len = head_len
+        # (bucket, names of the groups merged into the segment, name whose row_lr gives the tail rate or None)
+        layout = [(e[0], tuple(e[7]), e[7][0] if e[4] > 1 else None) for e in entries]
+        hit = cache[key] = (segs, len(entries), layout)
+    segs, n_ent, layout = hit
     if step_scalars is not None:
-        _lib.check(L.rdg_adam_step_multi_dev(len(entries), segs, betas[0], betas[1], eps, _lib.ptr(step_scalars),
+        fp.__dict__["_adam_graph_layout"] = (layout, lr_scale)      # GraphedStep fills the device rate table from it
+    if n_ent == 0:
+        return
+    if step_scalars is not None:
+        _lib.check(L.rdg_adam_step_multi_dev(n_ent, segs, betas[0], betas[1], eps, _lib.ptr(step_scalars),
                                              _lib.stream_ptr()), "rdg_adam_step_multi_dev")
         return
-    _lib.check(L.rdg_adam_step_multi(len(entries), segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
+    _lib.check(L.rdg_adam_step_multi(n_ent, segs, betas[0], betas[1], eps, fp.step_count, _lib.stream_ptr()),
                "rdg_adam_step_multi")
 
 
@@ -251,15 +251,16 @@ class DynamicScene:
         self.gt = {}
         self.gt_depth = {}
         self.stats = None        # DensifyStats once track_densification() is called
+        self.raster_state = RasterState()    # this scene's frame-to-frame rasterizer memory (capacity / binning hints)
         # full_losses: the whole loss set of the reference's dynamic sub-step (config 5,
         # configs/train/train_kubric_mrig.yaml:186-232): photometric + motion L1 / sparsity / basis regularisers +
         # global and local Pearson depth + rigidity every 5th step.  Several losses then feed the same parameters, so
         # only the SH features keep an overwriting gradient sink; the other segments are zeroed and accumulated.
         self.full_losses = full_losses
         # optimizer-in-backward for the SH features (see render()); train_step switches it on for the single-GPU
-        # photometric step only -- gradient exchange, densification statistics and extra losses need the plain path
+        # step only -- a gradient exchange needs dL/dshs itself
         self.fuse_sh_adam = False
-        self._graph_inputs = None    # GraphedStep: (time-embedding rows, ground truth, RdgStepScalars) at fixed addresses
+        self._graph_inputs = None    # GraphedStep: (time-embedding rows, ground truth, RdgStepScalars, depth ground truth) at fixed addresses
         self._grad_one = None
         self._plain_full = False     # full_losses on a step without rigidity: the photometric step's fused kernels
         if full_losses:
@@ -323,8 +324,12 @@ class DynamicScene:
                                   "lr_head": self.fp.lr["features"], "lr_tail": lr_tail, "betas": (0.9, 0.999),
                                   "eps": 1e-15, "step": lambda: self.fp.step_count + 1,
                                   "step_scalars": None if gi is None else gi[2]}}
-        out = GaussianRasterizer(self.settings())(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
-                                                  rotations=rot, viewmatrix=vm, grad_sinks=sinks)
+        if self.stats is not None and torch.is_grad_enabled():
+            # densification statistics of the iteration (rodygs.py:316-341): updated by the per-Gaussian backward kernel
+            sinks["densify"] = self.stats.sink()
+        out = GaussianRasterizer(self.settings(), state=self.raster_state)(
+            means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling, rotations=rot, viewmatrix=vm,
+            grad_sinks=sinks)
         self._last_radii = out[4]
         return out, m2
 
@@ -359,7 +364,7 @@ class DynamicScene:
             for f in frames:
                 vm = pose_view_matrix(self.cam_q, self.cam_t, int(f))
                 z = torch.zeros_like(target_scene["means3D"])
-                out = GaussianRasterizer(self.settings())(
+                out = GaussianRasterizer(self.settings(), state=self.raster_state)(
                     means3D=target_scene["means3D"].to(dev), means2D=z.to(dev), shs=target_scene["shs"].to(dev),
                     opacities=target_scene["opacities"].to(dev), scales=target_scene["scales"].to(dev),
                     rotations=target_scene["rotations"].to(dev), viewmatrix=vm)
@@ -425,11 +430,13 @@ class DynamicScene:
             def get_total_motion_table():
                 return allb[:-1]
 
-        loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
+        gi = self._graph_inputs
+        loss = fused_photometric_loss(out[0], self.gt[frame] if gi is None else gi[1], 0.2)
         w, mod = self.loss_terms["motion_basis_reg"]
         loss = loss + w * mod(_Model)
+        gt_depth = self.gt_depth[frame] if gi is None else gi[3]
         for w, mod in self.depth_terms:
-            loss = loss + w * mod(out[1], self.gt_depth[frame])
+            loss = loss + w * mod(out[1], gt_depth)
 
         def after():
             reg = fused_motion_l1_sparsity(fp["motion_coeff"], self.loss_terms["motion_l1"][0],
@@ -462,9 +469,7 @@ class DynamicScene:
         loss.backward(self._grad_one)
         if after is not None:
             loss = loss.detach() + after()
-        if self.stats is not None:
-            # add_densification_stats: screen-space gradient norm of the Gaussians visible in this frame
-            self.stats.add(self.m2.grad, self._last_radii > 0, self._last_radii)
+        # (densification statistics, when tracked: updated inside backward by the per-Gaussian kernel, see render())
         if world > 1:
             # overlapped exchange: pieces arrive in issue order; Adam steps each piece while the next one is in flight
             self.sync.finish()
@@ -486,55 +491,69 @@ class DynamicScene:
 
 
 class GraphedStep:
-    """hipGraph replay of ``DynamicScene.train_step`` (single GPU, photometric loss): ONE graph launch per step instead of
-    ~50 kernel launches, ~30 allocations and ten autograd nodes driven from Python.  At the size of the reference's real
-    clouds (<= 120 k points per cloud, /root/reference/configs/train/train_kubric_mrig.yaml:42,102) the eager step is
-    host-bound; the graph runs at the speed of its kernels.
+    """hipGraph replay of ``DynamicScene.train_step`` (single GPU; the photometric step, with or without densification
+    statistics, and the config-5 loss set on its steps without rigidity): ONE graph launch per step instead of ~50 kernel
+    launches, ~30 allocations and ten autograd nodes driven from Python.  At the size of the reference's real clouds
+    (<= 120 k points per cloud, /root/reference/configs/train/train_kubric_mrig.yaml:42,102) the eager step is host-bound;
+    the graph runs at the speed of its kernels.
 
     What changes from step to step lives in device memory at fixed addresses, refreshed before each replay: the frame's
-    time-embedding rows and ground-truth image (two device copies), and a 16-byte ``RdgStepScalars`` (Adam's two bias
-    corrections, computed on the host exactly as the eager path does, and the frame index for the camera-pose kernels)
-    -- one small H2D copy out of a ring of pinned slots.  Same kernels, same arithmetic, same bits as the eager step.
-    The instance count of a frame stays on the device; ``check()`` reads it (one sync) and raises
-    ``RasterizerCapacityOverflow`` if a frame outgrew the capacity the graph was captured with (re-build the GraphedStep
-    then; also after a densification, which changes every buffer)."""
+    time-embedding rows and ground truth (device copies), and a 128-byte ``RdgStepScalars`` -- Adam's two bias corrections
+    (computed on the host exactly as the eager path does), the frame index for the camera-pose kernels and the LEARNING
+    RATES of every parameter group (``fp.lr`` / ``sp.lr`` as they stand when the step is staged, or ``step(lr_override=)``:
+    the reference re-sets the xyz rate every iteration, /root/reference/src/trainer/rodygs_static.py:143-149) -- one small
+    H2D copy out of a ring of pinned slots.  Same kernels, same arithmetic, same bits as the eager step.
+    The instance count of every replayed frame is folded into a STICKY device maximum (RdgRasterSettings
+    .num_rendered_max); ``check()`` reads it (one sync) and raises ``RasterizerCapacityOverflow`` if ANY frame since the
+    last check outgrew the capacity the graph was captured with -- such a frame was rendered empty and its Adam step ran
+    on zero gradients (re-build the GraphedStep then; also after a densification, which changes every buffer)."""
 
     RING = 256
 
     def __init__(self, ds: "DynamicScene", perm, warmup: int = 2, first_step: int = 0):
-        from . import rasterizer
-        if ds.full_losses or ds.stats is not None:
-            raise NotImplementedError("GraphedStep covers the photometric step without densification statistics")
+        if ds.full_losses and not _PLAIN_FULL_FAST:
+            raise NotImplementedError("GraphedStep needs the fused plain full-loss step (RDG_PLAIN_FULL_FAST=1)")
         self.ds, self.perm = ds, list(perm)
         dev = ds.device
-        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)                    # RdgStepScalars
-        self.ring = torch.zeros(self.RING, 4, dtype=torch.float32).pin_memory()
+        W = _lib.STEP_SCALARS_FLOATS
+        self.scal = torch.zeros(W, dtype=torch.float32, device=dev)                    # RdgStepScalars
+        self.ring = torch.zeros(self.RING, W, dtype=torch.float32).pin_memory()
         self.ring_i32 = self.ring.view(torch.int32)
         self.emb_in = torch.empty_like(ds.emb_rows[0])
         self.gt_in = torch.empty_like(ds.gt[self.perm[0]])
+        self.gt_depth_in = torch.empty_like(ds.gt_depth[self.perm[0]]) if ds.full_losses else None
         self._slot, self._fence = 0, []
-        ds._graph_inputs = (self.emb_in, self.gt_in, self.scal)
+        ds._graph_inputs = (self.emb_in, self.gt_in, self.scal, self.gt_depth_in)
+        st = ds.raster_state
+        st.nren_max = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky maximum of D over the replays
         step = first_step
+        if ds.full_losses and step % ds.rigidity[1] == 0:
+            step += 1                            # a rigidity step is not part of the graph (see step())
         for _ in range(max(1, warmup)):          # eager, on the same staged inputs: hints, caches, lazy initialisation
+            if ds.full_losses and step % ds.rigidity[1] == 0:
+                step += 1
             self._stage(step)
             ds.train_step(step, 0, 1, self.perm)
+            step += 1
+        if ds.full_losses and step % ds.rigidity[1] == 0:
             step += 1
         self.next_step = step
         torch.cuda.synchronize(dev)
         counts = (ds.fp.step_count, ds.sp.step_count)
         self.graph = torch.cuda.CUDAGraph()
-        rasterizer.GRAPH_CAPTURE = True
+        st.graph_capture = True
         try:
             self._stage(step)
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(self.graph):
                 self.loss = ds.train_step(step, 0, 1, self.perm)       # recorded, not executed
         finally:
-            rasterizer.GRAPH_CAPTURE = False
+            st.graph_capture = False
         ds.fp.step_count, ds.sp.step_count = counts                    # capture advanced the host counters only
-        self._nren, self._key, self._cap = rasterizer.last_num_rendered()
+        self._nren, self._key, self._cap = st.last_nren
+        st.nren_max.zero_()
 
-    def _stage(self, step: int) -> int:
+    def _stage(self, step: int, lr_override=None) -> int:
         ds = self.ds
         frame = frame_for(step, 0, 1, self.perm)
         k = ds.fp.step_count + 1
@@ -548,19 +567,55 @@ class GraphedStep:
             ev = torch.cuda.Event()
             ev.record()
             self._fence.append(ev)
+        row = self.ring[i]
         # float(1 / bc1) and float(sqrt(bc2)) from doubles: what rdg_adam_step_multi computes on the host
-        self.ring[i, 0] = 1.0 / (1.0 - 0.9 ** k)
-        self.ring[i, 1] = math.sqrt(1.0 - 0.999 ** k)
+        row[0] = 1.0 / (1.0 - 0.9 ** k)
+        row[1] = math.sqrt(1.0 - 0.999 ** k)
         self.ring_i32[i, 2] = frame
-        self.scal.copy_(self.ring[i], non_blocking=True)
+        # learning rates: the segment table of the (captured) Adam launch, in its order; 0 until the first eager step of
+        # this object has recorded the layout (the by-value rates of that very step are then the current ones anyway)
+        rec = ds.fp.__dict__.get("_adam_graph_layout")
+        self.ring_i32[i, 3] = 0
+        if rec is not None:
+            layout, lr_scale = rec
+            for j, (f, names, row_name) in enumerate(layout):
+                rates = {float(lr_override[n]) if (f is ds.fp and lr_override and n in lr_override) else f.lr[n]
+                         for n in names}
+                if len(rates) != 1:
+                    raise RuntimeError(f"GraphedStep: the parameter groups {names} were merged into one Adam segment at "
+                                       "capture and now have different learning rates; re-build the GraphedStep")
+                lr = rates.pop()
+                row[4 + j] = lr * lr_scale
+                row[16 + j] = (ds.row_lr[row_name][2] if row_name is not None else lr) * lr_scale
+            lr_f = (float(lr_override["features"]) if lr_override and "features" in lr_override
+                    else ds.fp.lr["features"])
+            row[28] = lr_f
+            row[29] = ds.row_lr["features"][2]
+            self.ring_i32[i, 3] = 1
+        self.scal.copy_(row, non_blocking=True)
         self.emb_in.copy_(ds.emb_rows[frame])
         self.gt_in.copy_(ds.gt[frame])
+        if self.gt_depth_in is not None:
+            self.gt_depth_in.copy_(ds.gt_depth[frame])
         return frame
 
-    def step(self) -> torch.Tensor:
-        """Stage the step's inputs, replay the graph; returns the (device) loss of the step."""
+    def step(self, lr_override=None) -> torch.Tensor:
+        """Stage the step's inputs, replay the graph; returns the (device) loss of the step.  ``lr_override``: {group
+        name: lr} for this step only, as ``fused_adam_``; groups not named take ``fp.lr`` as it stands now.  With the
+        config-5 loss set, every ``freq``-th step carries the rigidity loss (host-side sampling, K-NN): that step runs
+        eagerly on the same staged inputs, the four steps between them replay the graph."""
         ds = self.ds
-        self._stage(self.next_step)
+        if ds.full_losses and self.next_step % ds.rigidity[1] == 0:
+            if lr_override:
+                raise NotImplementedError("lr_override on an eager rigidity step")
+            gi, ds._graph_inputs = ds._graph_inputs, None
+            try:
+                loss = ds.train_step(self.next_step, 0, 1, self.perm)
+            finally:
+                ds._graph_inputs = gi
+            self.next_step += 1
+            return loss
+        self._stage(self.next_step, lr_override)
         self.graph.replay()
         self.next_step += 1
         ds.fp.step_count += 1
@@ -568,18 +623,23 @@ class GraphedStep:
         return self.loss
 
     def check(self) -> int:
-        """Instance count of the last replayed frame (synchronises); raises if it exceeded the captured capacity."""
+        """Largest instance count of ANY frame replayed since the last check (synchronises); raises if it exceeded the
+        captured capacity -- that frame was rendered empty."""
         from . import rasterizer
-        n, largest = (int(v) for v in self._nren.tolist())
+        st = self.ds.raster_state
+        n = int(st.nren_max.item())
+        st.nren_max.zero_()
         if n >= rasterizer._INSTANCE_LIMIT:
             raise RuntimeError(rasterizer._too_many(self._key))
-        rasterizer._CAPACITY_HINT[self._key] = max(n, int(rasterizer._CAPACITY_HINT.get(self._key, 0) * 0.9))
+        with st.lock:
+            st.capacity_hint[self._key] = max(n, int(st.capacity_hint.get(self._key, 0) * 0.9))
         if n > self._cap:
-            rasterizer._CAPACITY_HINT[self._key] = n
             raise rasterizer.RasterizerCapacityOverflow(
                 f"a replayed frame needed {n} instances, the graph was captured with {self._cap}: that frame was "
-                f"rendered empty; re-build the GraphedStep (the capacity hint is now {n})")
+                f"rendered empty and its optimiser step ran on zero gradients; re-build the GraphedStep (the capacity "
+                f"hint is now {n})")
         return n
 
     def close(self) -> None:
         self.ds._graph_inputs = None
+        self.ds.raster_state.nren_max = None

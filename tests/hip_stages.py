@@ -16,14 +16,17 @@ def make_settings(sc, sh_degree, bg=None, dev="cuda", cov_grad=True, sh_grad=Tru
         debug=False, enable_cov_grad=cov_grad, enable_sh_grad=sh_grad)
 
 
-def run_stages(sc, sh_degree, dev="cuda", capacity=None):
-    """preprocess -> export -> bin (with copies) on the GPU; returns numpy views of every intermediate."""
+def run_stages(sc, sh_degree, dev="cuda", capacity=None, bin_mode=None):
+    """preprocess -> export -> bin (with copies) on the GPU; returns numpy views of every intermediate.
+    bin_mode: 0 = bucket binning, 1 = LSD radix sort (RdgRasterSettings.bin_mode); None = the default of the settings."""
     L = _lib.lib()
     rs = make_settings(sc, sh_degree, dev=dev)
     m3 = sc["means3D"].to(dev).contiguous()
     P = m3.shape[0]
     shs = sc["shs"].to(dev).contiguous()
     cs = _c_settings(rs, P, shs.shape[1])
+    if bin_mode is not None:
+        cs.bin_mode = int(bin_mode)
     H, W = sc["H"], sc["W"]
     n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     u8 = dict(dtype=torch.uint8, device=dev)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
         assert hasattr(raw, n), f"{n} declared in include/rodygs_hip.h but not exported"
     # and the ctypes binding table covers the whole header
     assert set(names) == set(_lib.EXPORTED_SYMBOLS)
-    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 4
+    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_workspace_sizes(hip_lib):
@@ -40,10 +40,18 @@ def test_workspace_sizes(hip_lib):
     assert hip_lib.rdg_sort_tmp_bytes(1000) > 0 and hip_lib.rdg_knn_tmp_bytes(1000) > 0
 
 
+def _lib_mod():
+    from rodygs_amd import _lib
+    return _lib
+
+
 def test_c_struct_matches_header():
     import ctypes
     from rodygs_amd._lib import RdgRasterSettings
-    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 16
+    # 18 int32 / float fields, two pointers, the three statistics pointers + (rows, reserved), the sticky-count pointer
+    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 16 + 24 + 8 + 8
+    assert ctypes.sizeof(_lib_mod().RdgStepScalars) == 128 == 4 * _lib_mod().STEP_SCALARS_FLOATS
+    assert RdgRasterSettings.densify_grad_accum.offset == 88 and RdgRasterSettings.num_rendered_max.offset == 120
     from rodygs_amd import _lib
     assert _lib.lib().rdg_settings_bytes() == ctypes.sizeof(RdgRasterSettings)      # the compiled header's sizeof
     assert RdgRasterSettings.zero_grad_ws.offset == 72
