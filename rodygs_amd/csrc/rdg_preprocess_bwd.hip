@@ -174,13 +174,22 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                 dvy += Pm[4] * dhx + Pm[5] * dhy + Pm[7] * dhw;
                 dvz += Pm[8] * dhx + Pm[9] * dhy + Pm[11] * dhw;
             }
-            // (3) conic -> cov2D
+            // (3) conic -> cov2D.  conic = (c, -b, a) / det, differentiated in the association reverse-mode differentiation
+            // of those three quotients produces (through 1 / det, then det = a c - b^2), NOT as the closed forms
+            // da = (-c^2 gca + b c gcb - b^2 gcc) / det^2 ...: for a needle-shaped footprint (b^2 close to a c: det / (a c) = 0.03
+            // on the Gaussian that decided sweep case 40000 / 353) the closed forms add three terms of the size of
+            // c^2 g that cancel to a fraction of it, and what is left of their rounding errors is then amplified again
+            // when the covariance path cancels against the projection path in dL/dmean -- 7.5e-4 of the column's largest
+            // entry on that Gaussian, 2e-4 on the pose gradient; this form: 2.5e-5 / 6e-6, the float32 oracle's own level
+            // (scripts/dbg_pose_rows.py)
             float da = 0.f, db = 0.f, dc = 0.f;
             if (det != 0.0f) {
-                const float d2 = 1.0f / (det * det);
-                da = d2 * (-c * c * gca + b * c * gcb - b * b * gcc);
-                db = d2 * (2.0f * b * c * gca - (a * c + b * b) * gcb + 2.0f * a * b * gcc);
-                dc = d2 * (-b * b * gca + a * b * gcb - a * a * gcc);
+                const float di = 1.0f / det;
+                const float ddi = (gca * c - gcb * b) + gcc * a;          // dL/d(1/det)
+                const float ddet = -(ddi * di) * di;
+                da = gcc * di + ddet * c;
+                dc = gca * di + ddet * a;
+                db = -gcb * di - 2.0f * b * ddet;
             }
             // (4) cov2D -> Sigma3D (6-vector grads count both off-diagonal entries) and T
             dS[0] = T00 * T00 * da + T00 * T10 * db + T10 * T10 * dc;

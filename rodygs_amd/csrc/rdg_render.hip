@@ -649,17 +649,6 @@ __device__ __forceinline__ void rdg_ring_flush(float (*ring)[16][RDG_RING_Q], in
 // HAS_NORMAL: an upstream gradient for the normal image.  The per-Gaussian normals are constants of the graph (the oracle
 // detaches them), so the normal channels act like three more colour channels in dL/dalpha and nothing is accumulated for
 // the normals themselves.
-// precision probes of the two back-to-front recurrences (scripts/dbg_pose_rows.py; variant builds only)
-#ifdef RDG_DBG_T64
-typedef double rdg_tacc;
-#else
-typedef float rdg_tacc;
-#endif
-#ifdef RDG_DBG_B64
-typedef double rdg_bacc;
-#else
-typedef float rdg_bacc;
-#endif
 template <bool HAS_DEPTH, bool CAPPED, bool DET, bool ALLBELOW, bool HAS_NORMAL>
 __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsigned long long cap, const int sbase,
                                              const char* sQ0, const char* sQ1, const char* sQ2, const char* sQ3,
@@ -667,7 +656,7 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
                                              const float dLp1, const float dLp2, const float dLd, const float dLn0,
                                              const float dLn1, const float dLn2, const int lane,
                                              float (*ring)[16][RDG_RING_Q], const float flush_scale, const int flush_off,
-                                             float* __restrict__ grow, rdg_tacc& T_, rdg_bacc& behind, int& ring_n) {
+                                             float* __restrict__ grow, float& T, float& behind, int& ring_n) {
     while (mask) {
         const int jb = __builtin_ctzll(mask);
         asm("s_bitset0_b64 %0, %1" : "+s"(mask) : "s"(jb));
@@ -707,13 +696,8 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
             asm volatile("; opacity above the cap" ::: "memory");
             aeff = fminf(RDG_ALPHA_CAP, aeff);
         }
-#ifdef RDG_DBG_T64
-        T_ = T_ / (double)(1.0f - aeff);
-#else
         const float inv1ma = __builtin_amdgcn_rcpf(1.0f - aeff);
-        T_ = T_ * inv1ma;
-#endif
-        const float T = (float)T_;
+        T = T * inv1ma;
         const float dch = aeff * T;
         float s_ = q2.x * dLp0 + q2.y * dLp1 + q2.z * dLp2;
         if (HAS_DEPTH) s_ += q1.z * dLd;
@@ -721,14 +705,8 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
             const float4 q3 = *(const float4*)(sQ3 + aj);
             s_ += q3.x * dLn0 + q3.y * dLn1 + q3.z * dLn2;
         }
-#ifdef RDG_DBG_B64
-        const double e64 = (double)s_ - behind;
-        behind = behind + (double)aeff * e64;
-        const float e_ = (float)e64;
-#else
         const float e_ = s_ - behind;
         behind = fmaf(aeff, e_, behind);
-#endif
         const float dL_dalpha = e_ * T;
         // What leaves the lane: the weight t0 = G dL/dalpha (= dL/dopacity; G dL/dG = opacity * t0, the opacity
         // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 dx and
@@ -842,7 +820,7 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                   const uint32_t* __restrict__ point_list,
                   const RdgRec* __restrict__ rec, const unsigned long long* __restrict__ hit, float4* sQ0, float4* sQ1,
                   float4* sQ2, float4* sQ3, unsigned long long (*sMask)[4], unsigned long long* sCap, float (*ring)[16][RDG_RING_Q],
-                  const float flush_scale, const int flush_off, float* __restrict__ gdst, rdg_tacc& T, rdg_bacc& behind,
+                  const float flush_scale, const int flush_off, float* __restrict__ gdst, float& T, float& behind,
                   int& ring_n, const uint32_t* __restrict__ det_off, const int gx, const int gy, const int tx, const int ty) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -980,8 +958,8 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         // output (alpha_out = 1 - T_final) as a colour of -dL/dalpha_out.  Starting the behind-value recurrence from it
         // makes dL/dalpha_k = T_k (s_k - behind_k) exact with no separate T_final term.
         const float bgdot = bg[0] * dLp0 + bg[1] * dLp1 + bg[2] * dLp2;
-        rdg_tacc T = T_final;
-        rdg_bacc behind = bgdot - dLa;
+        float T = T_final;
+        float behind = bgdot - dLa;
         int k_lo = 0, k_hi = 0x7fffffff;
         if (SEG) {
             k_lo = (int)item.y * RDG_SPLIT_SEG;

@@ -92,6 +92,7 @@ def pre_bwd():
                                          gws.data_ptr(), dm3.data_ptr(), dm2.data_ptr(), dsh.data_ptr(), None, dop.data_ptr(),
                                          dsc.data_ptr(), dro.data_ptr(), None, dvm.data_ptr(), s_), "preprocess_backward")
     torch.cuda.synchronize()
+    pre_bwd.last = (dm3.cpu().double(), dsc.cpu().double(), dro.cpu().double())
     return dvm.cpu().double()
 
 
@@ -118,6 +119,24 @@ orow[:, 0], orow[:, 1] = m1x * inv_o, m1y * inv_o
 orow[:, 2:5] = gcon * inv_o.unsqueeze(1)
 orow[:, 6:9] = geom["rgb"].grad if geom["rgb"].grad is not None else 0.0
 orow = torch.where(vis.unsqueeze(1), orow, torch.zeros_like(orow))
+# the float32 oracle's own rows: what float32 autograd (every T_i kept from the forward) reaches
+d32 = {k: sc[k].clone().requires_grad_(True) for k in T.NAMES}
+st32 = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.tensor(bg), kw["scale_modifier"], sc["projmatrix"], deg,
+                        enable_cov_grad=kw["cov_grad"], enable_sh_grad=kw["sh_grad"])
+o32 = O.rasterize(d32["means3D"], torch.zeros(P, 3, requires_grad=True), d32["opacities"], d32["viewmatrix"], st32,
+                  shs=d32["shs"], scales=d32["scales"], rotations=d32["rotations"])
+g32 = o32[5]["geom"]
+for k in ("conic", "rgb"):
+    g32[k].retain_grad()
+((o32[0] * wc).sum() + (o32[3] * wa).sum() + (o32[1] * wd).sum() * kw["depth_loss"]).backward()
+r32 = torch.zeros(P, 16, dtype=torch.float64)
+r32[:, 2:5] = g32["conic"].grad.double() * inv_o.unsqueeze(1)
+r32[:, 6:9] = g32["rgb"].grad.double()
+print("(0) float32-oracle rows vs float64 oracle:")
+for name, sl in (("conic", slice(2, 5)), ("rgb", slice(6, 9))):
+    a, b = r32[vis][:, sl], orow[vis][:, sl]
+    print(f"    {name:8s}", [f"{float(x):.2e}" for x in ((a - b).abs().amax(0) / b.abs().amax(0).clamp_min(1e-300))])
+print(f"    float32-oracle pose gradient vs float64: max rel {err(d32['viewmatrix'].grad.double()):.3e}")
 hr = rows_hip.cpu().double()
 print("(1) HIP rows vs float64 oracle, max |diff| / max |oracle| per column (visible Gaussians):")
 for name, sl in (("moments", slice(0, 2)), ("conic", slice(2, 5)), ("rgb", slice(6, 9))):
@@ -129,3 +148,21 @@ for label, cols in list(groups.items()) + [("moments+conic+rgb", [0, 1, 2, 3, 4,
     rows[:, cols] = orow[:, cols].to(torch.float32).to(dev)
     print(f"(3) oracle-f64 {label:18s} in the rows:        max rel {err(pre_bwd()):.3e}")
 rows.copy_(rows_hip)
+
+# ---- per Gaussian: where the per-Gaussian backward itself (fed the float64 rows) is least accurate -----------------------
+rows[:, [0, 1, 2, 3, 4, 6, 7, 8]] = orow[:, [0, 1, 2, 3, 4, 6, 7, 8]].to(torch.float32).to(dev)
+pre_bwd()
+dm3, dsc, dro = pre_bwd.last
+rows.copy_(rows_hip)
+torch.set_printoptions(precision=4, linewidth=220, sci_mode=True)
+for name, hipg, org in (("means3D", dm3, d["means3D"].grad), ("scales", dsc, d["scales"].grad), ("rotations", dro, d["rotations"].grad)):
+    colmax = org.abs().amax(0)
+    e = ((hipg - org).abs() / colmax).amax(1)
+    worst = torch.argsort(e, descending=True)[:6]
+    print(f"per-Gaussian backward on float64 rows, d_{name}: worst Gaussians (error / column max)")
+    for i in worst.tolist():
+        a_, b_, c_ = [float(x) for x in cov2[i]]
+        det = a_ * c_ - b_ * b_
+        print(f"    #{i}: err {float(e[i]):.2e}  |grad|/colmax {float((org[i].abs() / colmax).max()):.2e}  depth {float(geom['depth'][i]):.3f} "
+              f"radius {int(geom['radii'][i])} opacity {float(op[i]):.3f} cov2D ({a_:.3e}, {b_:.3e}, {c_:.3e}) det/(ac) {det / (a_ * c_):.2e} "
+              f"tiles {int(geom['tiles_touched'][i])}")

@@ -1,9 +1,7 @@
 """Randomised parity sweep on the GPU box: HIP path vs oracle on N random small scenes (random size, ragged image sizes,
 SH degree, background, pose, scale modifier, gradient gates) with the per-column bar of the test-suite
 (tests/test_gpu_parity.py::check_pair).  Prints one line per case and a summary; exit code 1 on any failure."""
-import math
 import os
-import random
 import sys
 
 import torch
@@ -12,27 +10,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as T  # noqa: E402
-from oracle import rasterizer_oracle as O  # noqa: E402
+from oracle import rasterizer_oracle as O  # noqa: E402,F401
+from sweep_cases import sweep_case  # noqa: E402
 
 T.FLIP_ENTRIES = int(os.environ.get("RDG_SWEEP_FLIP_ENTRIES", "4"))     # see tests/test_gpu_parity.py::FLIP_ENTRIES
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 bad = flips = 0
 for c in range(n_cases):
-    rng = random.Random(seed0 + c)
-    P = rng.choice([1, 7, 63, 64, 65, 200, 777, 1500, 3000, 5000])
-    W = rng.choice([16, 33, 100, 128, 250, 320, 401])
-    H = rng.choice([16, 17, 96, 128, 200, 240, 333])
-    deg_max = rng.choice([0, 1, 2, 3])
-    deg = rng.randint(0, deg_max)
-    bg = tuple(rng.random() for _ in range(3))
-    sc = O.synthetic_scene(P, W, H, deg_max, seed=seed0 + c)
-    sc["viewmatrix"] = T.orbit_view(rng.uniform(-20, 20), rng.uniform(-15, 15),
-                                    (rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 1.5)))
-    if rng.random() < 0.3:
-        sc["scales"] = sc["scales"] * rng.uniform(1.5, 5.0)          # long lists, overflow retries
-    kw = dict(cov_grad=rng.random() < 0.8, sh_grad=rng.random() < 0.8, scale_modifier=rng.choice([1.0, 1.0, 0.7, 1.3]),
-              seed=seed0 + c, normal_loss=rng.choice([0.0, 0.0, 0.5]), depth_loss=rng.choice([0.1, 0.1, 0.0]))
+    sc, deg, bg, kw = sweep_case(seed0, c)
+    P, W, H, deg_max = sc["means3D"].shape[0], sc["W"], sc["H"], int(round(sc["shs"].shape[1] ** 0.5)) - 1
     tag = f"case {c:3d}: P={P:5d} {W}x{H} deg {deg}/{deg_max} {kw}"
     res = None
     try:
