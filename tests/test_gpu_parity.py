@@ -2001,8 +2001,7 @@ def test_sharded_training_with_densification():
     for r in range(world):
         f = perm[(1 * world + r) % frames]
         out, m2 = ds.render(f)
-        fused_photometric_loss(out[0], ds.gt[f], 0.2).backward()
-        ds.stats.add(ds.m2.grad, ds._last_radii > 0, ds._last_radii)
+        fused_photometric_loss(out[0], ds.gt[f], 0.2).backward()      # the replica's statistics: updated inside backward
     run_virtual_step(shards, 1, perm)
     for name in ("xyz_gradient_accum", "denom", "max_radii2D"):
         got = torch.cat([getattr(sh.stats, name) for sh in shards])
