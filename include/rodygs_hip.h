@@ -398,14 +398,21 @@ int rdg_reset_opacity(int64_t n, float max_opacity, float* opacity_logit, float*
  * intermediates: pos_t4 [nt,n,4] = position (canonical + translation, w unused) of every sampled Gaussian at the
  * drawn times, nn_idx [n,K] (indices into the sample), d2 [n,K] squared neighbour distances, and the reverse
  * adjacency of nn_idx (rev_off [n+1], rev_edge [n*K] = edge ids i*K+k sorted by destination) so that every gradient
- * row is written once instead of through scattered atomics.  orig (optional, [n]): when the caller stores the sample
+ * row is written once instead of through scattered atomics.  rev_dst (optional, [n*K]): the destination of every entry
+ * of rev_edge (the sorted keys themselves); with it a wave shares out the edges arriving at its 64 Gaussians evenly
+ * among its lanes instead of each lane walking its own in-degree.  orig (optional, [n]): when the caller stores the sample
  * in another (cache-friendly) order, orig[s] = position of stored element s in the reference's sample order, which
  * defines the pairing f / nt; d2 / d_d2 stay in that original order.  Writes loss_sum[0] (f64) = sum over
- * (tau, i, k) of sqrt((gap - d2_flat[f / nt])^2 + eps^2), its unscaled gradient G_t4 [nt,n,4] w.r.t. pos_t4 (stored
- * order) and d_d2 [n,K].                                                                                          */
+ * (tau, i, k) of sqrt((gap - d2_flat[f / nt])^2 + eps^2), its unscaled gradient w.r.t. the positions -- G_t4 [nt,n,4]
+ * in stored order, or, when G3_orig is given (needs orig), G3_orig [nt,n,3] in the ORIGINAL sample order, i.e. already in
+ * the layout of the caller's position tensor (G_t4 may then be NULL) -- and d_d2 [n,K].                                                                                          */
 int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const float* pos_t4, const int64_t* nn_idx,
-                            const float* d2, const int64_t* rev_off, const int64_t* rev_edge, const int64_t* orig,
-                            float eps, double* loss_sum, float* G_t4, float* d_d2, void* stream);
+                            const float* d2, const int64_t* rev_off, const int64_t* rev_edge, const int64_t* rev_dst,
+                            const int64_t* orig, float eps, double* loss_sum, float* G_t4, float* d_d2, float* G3_orig,
+                            void* stream);
+/* pos4 [nt,n,4] = (pos3 [nt,n,3] rows taken in `order` [n], 0): the stored-order, 16-B-row copy of the sample's positions
+ * that rdg_rigidity_dp_forward gathers from, in one launch.                                                           */
+int rdg_rigidity_pack(int64_t n, int32_t nt, const float* pos3, const int64_t* order, float* pos4, void* stream);
 
 /* ---- Pearson depth losses (GlobalPearsonDepthLoss / LocalPearsonDepthLoss, /root/reference/src/trainer/losses.py:108-182;
  *      pearson_depth_loss, /root/reference/src/utils/loss_utils.py:100-117) -------------------------------------------

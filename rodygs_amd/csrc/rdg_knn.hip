@@ -504,61 +504,181 @@ int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const
 // pos_t = canon + own(tau) and the gradient G_t are laid out [nt][n] float4, one 16-B gather per edge end.
 // Outputs are the SUM of the terms and its unscaled gradients: G_t (w.r.t. pos_t) and d_d2 [n*K].
 // ---------------------------------------------------------------------------------------------------------
+// f / d for f < 2^52 through one double multiply and a correction step: the 64-bit integer division the compiler emits is
+// ~100 instructions, and the kernel below needs one per edge end (the reference's f / nt row pairing) -- a third of its
+// run time before (2.2 -> 1.4 ms at n = 500 k, nt = 25)
+__device__ __forceinline__ long long rdg_div_pos(long long f, long long d, double inv_d) {
+    long long q = (long long)((double)f * inv_d);
+    const long long r = f - q * d;
+    if (r < 0) --q; else if (r >= d) ++q;
+    return q;
+}
+
+// Time slabs a workgroup carries its 256 Gaussians through: the index data (neighbour lists, arriving edges) is read once
+// per group instead of once per slab.  Measured at n = 2 M, nt = 25 (scripts/rig_probe.py): 1 / 2 / 3 / 5 slabs per group
+// 9.4 / 9.1 / 9.0 / 9.2 ms -- the kernel is bound by the latency of its ~33 gathers per (time, Gaussian), not by the index
+// traffic; 2 keeps the LDS small.
+#ifndef RDG_RIG_TG
+#define RDG_RIG_TG 2
+#endif
 template <int KT>      // KT > 0: K known at compile time -- the K neighbour loads of a thread are issued together
 __global__ void __launch_bounds__(256)
 rdg_rigidity_dp_kernel(long long n, int K_rt, int nt, const float4* __restrict__ pos_t, const long long* __restrict__ nn_idx,
                        const float* __restrict__ d2, const long long* __restrict__ rev_off,
-                       const long long* __restrict__ rev_edge, const long long* __restrict__ orig, float eps2,
-                       double* __restrict__ loss_sum, float4* __restrict__ G_t, float* __restrict__ d_d2) {
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+                       const long long* __restrict__ rev_edge, const long long* __restrict__ rev_dst,
+                       const long long* __restrict__ orig, float eps2,
+                       double* __restrict__ loss_sum, float4* __restrict__ G_t, float* __restrict__ d_d2,
+                       float* __restrict__ G3_orig) {
+    // grid: (blocks over i, groups of RDG_RIG_TG time slabs) -- the 64 lanes of a wave are 64 consecutive sampled Gaussians
+    const int tau0 = blockIdx.y * RDG_RIG_TG;
+    const int ntg = min(RDG_RIG_TG, nt - tau0);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int K = KT > 0 ? KT : K_rt;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double inv_nt = 1.0 / (double)nt;
+    __shared__ float4 sP[4][RDG_RIG_TG][64];       // the wave's own positions per slab, for the edges that arrive at them
+    __shared__ float4 sC[4][64];                   // one chunk of 64 arriving edges: their gradient contributions
     double local = 0.0;
-    if (tid < n * nt) {
-        const long long tau = tid / n, i = tid - tau * n;
-        const float4* slab = pos_t + tau * n;          // positions of all sampled Gaussians at this time, 16 B each
-        const float4 p = slab[i];
-        // `orig` (optional): the sample is stored in a cache-friendly order (neighbours close in memory); the
-        // reference's pairing of gaps with d2 entries is defined on the ORIGINAL sample order, so rows use orig[]
-        const long long i_row = orig ? orig[i] : i;
-        float gx = 0.f, gy = 0.f, gz = 0.f;            // d/d(pos_i(tau))
-        // (1) edges leaving i: the loss terms themselves, -u on this end, the d2 gradient
-        long long row_prev = -1;
-        float row_acc = 0.f;
+    const bool act = i < n;
+    float gx[RDG_RIG_TG], gy[RDG_RIG_TG], gz[RDG_RIG_TG];    // d/d(pos_i(tau)) for the slabs of the group
+    // `orig` (optional): the sample is stored in a cache-friendly order (neighbours close in memory); the
+    // reference's pairing of gaps with d2 entries is defined on the ORIGINAL sample order, so rows use orig[]
+    const long long i_row = act ? (orig ? orig[i] : i) : 0;
+    long long nbr[KT > 0 ? KT : 1];
+    if (KT > 0 && act) {
 #pragma unroll
-        for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
-            const float4 q = slab[nn_idx[i * K + k]];
-            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-            const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-            const long long row = ((tau * n + i_row) * K + k) / nt;
-            const float diff = gap - d2[row];
-            const float term = sqrtf(diff * diff + eps2);
-            local += (double)term;
-            const float s = diff / term;                 // d term / d gap ;  d term / d y = -s
-            if (row != row_prev) {
-                if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
-                row_prev = row; row_acc = 0.f;
+        for (int k = 0; k < KT; ++k) nbr[k] = nn_idx[i * K + k];           // all K index loads in flight together
+    }
+    const long long n_rows = n * K;
+#pragma unroll
+    for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
+        gx[tg] = gy[tg] = gz[tg] = 0.f;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act && tg < ntg) {
+            const long long tau = tau0 + tg;
+            const float4* slab = pos_t + tau * n;      // positions of all sampled Gaussians at this time, 16 B each
+            p = slab[i];
+            // (1) edges leaving i: the loss terms themselves, -u on this end, the d2 gradient.  Their rows are
+            // (f0 + k) / nt for consecutive k: one division, then a running remainder
+            const long long f0 = (tau * n + i_row) * K;
+            long long row = rdg_div_pos(f0, nt, inv_nt);
+            int rem = (int)(f0 - row * nt);
+            // K consecutive flat entries touch at most two rows when nt >= K: two loads instead of K gathers
+            const bool two_rows = nt >= K;
+            const float y0 = d2[row], y1 = two_rows ? d2[row + 1 < n_rows ? row + 1 : row] : 0.f;
+            const long long row0 = row;
+            long long row_prev = -1;
+            float row_acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+            for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
+                const float4 q = slab[KT > 0 ? nbr[k] : nn_idx[i * K + k]];
+                const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+                const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float y = two_rows ? (row == row0 ? y0 : y1) : d2[row];
+                const float diff = gap - y;
+                const float term = sqrtf(diff * diff + eps2);
+                local += (double)term;
+                const float s = diff / term;                 // d term / d gap ;  d term / d y = -s
+                if (row != row_prev) {
+                    if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
+                    row_prev = row; row_acc = 0.f;
+                }
+                row_acc -= s;
+                const float ig = gap > 0.f ? s / gap : 0.f;  // torch.norm backward is 0 at the origin
+                ax -= ig * dx; ay -= ig * dy; az -= ig * dz;
+                if (++rem == nt) { rem = 0; ++row; }
             }
-            row_acc -= s;
-            const float ig = gap > 0.f ? s / gap : 0.f;  // torch.norm backward is 0 at the origin
-            gx -= ig * dx; gy -= ig * dy; gz -= ig * dz;
+            if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
+            gx[tg] = ax; gy[tg] = ay; gz[tg] = az;
         }
-        if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
-        // (2) edges arriving at i (reverse adjacency): the same terms recomputed, +u on this end -- instead of three
-        // scattered float atomics per (tau, edge), which ran at the 4-byte-atomic rate (13 ms at n = 500 k)
+        sP[wv][tg][lane] = p;
+    }
+    // (2) edges ARRIVING at i (reverse adjacency): the same terms recomputed, +u on this end -- instead of three
+    // scattered float atomics per (tau, edge), which ran at the 4-byte-atomic rate (13 ms at n = 500 k).
+    if (rev_dst) {
+        // Balanced form: the edges that arrive at the wave's 64 Gaussians are ONE contiguous stretch of the
+        // destination-sorted edge list; the lanes take them 64 at a time, one edge per lane whatever its destination (a
+        // lane walking its OWN arrivals made the wave wait for its largest in-degree: ~25 trips for an average of 8),
+        // park the edge's contribution in LDS, and every destination lane then adds its own run of the chunk (three
+        // LDS reads per edge: the heavy part -- two gathers, a division, two square roots -- is what got balanced).
+        const long long i_first = (long long)blockIdx.x * 256 + (wv << 6);
+        if (i_first < n) {
+            const long long i_end = i_first + 64 < n ? i_first + 64 : n;
+            const long long E0 = rev_off[i_first], E1 = rev_off[i_end];
+            const long long my0 = act ? rev_off[i] : 0, my1 = act ? rev_off[i + 1] : 0;
+            rdg_wave_lds_sync();
+            for (long long base = E0; base < E1; base += 64) {
+                const long long e = base + lane;
+                const bool ev = e < E1;
+                long long src = 0, fk = 0;
+                int dl = 0;
+                if (ev) {
+                    const long long edge = rev_edge[e];
+                    src = KT > 0 ? edge / KT : edge / K;
+                    fk = (orig ? orig[src] : src) * K + (edge - src * K);      // flat index of the edge inside a slab
+                    dl = (int)(rev_dst[e] - i_first);
+                }
+                const int a0 = (int)((my0 > base ? my0 : base) - base), a1 = (int)((my1 < base + 64 ? my1 : base + 64) - base);
+#pragma unroll
+                for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
+                    if (tg >= ntg) break;
+                    const long long tau = tau0 + tg;
+                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ev) {
+                        const float4 q = pos_t[tau * n + src];
+                        const float4 pd = sP[wv][tg][dl];
+                        const float dx = pd.x - q.x, dy = pd.y - q.y, dz = pd.z - q.z;
+                        const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+                        const long long rrow = rdg_div_pos(tau * n * K + fk, nt, inv_nt);
+                        const float diff = gap - d2[rrow];
+                        const float s = diff / sqrtf(diff * diff + eps2);
+                        const float ig = gap > 0.f ? s / gap : 0.f;
+                        c = make_float4(ig * dx, ig * dy, ig * dz, 0.f);
+                    }
+                    sC[wv][lane] = c;
+                    rdg_wave_lds_sync();
+                    float ax = 0.f, ay = 0.f, az = 0.f;
+                    for (int t = a0; t < a1; ++t) {
+                        const float4 v = sC[wv][t];
+                        ax += v.x; ay += v.y; az += v.z;
+                    }
+                    gx[tg] += ax; gy[tg] += ay; gz[tg] += az;
+                    rdg_wave_lds_sync();
+                }
+            }
+        }
+    } else if (act) {
         for (long long e = rev_off[i]; e < rev_off[i + 1]; ++e) {
             const long long edge = rev_edge[e];
-            const long long src = edge / K;
-            const int k = (int)(edge - src * K);
-            const float4 q = slab[src];
-            const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-            const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-            const long long row = ((tau * n + (orig ? orig[src] : src)) * K + k) / nt;
-            const float diff = gap - d2[row];
-            const float s = diff / sqrtf(diff * diff + eps2);
-            const float ig = gap > 0.f ? s / gap : 0.f;
-            gx += ig * dx; gy += ig * dy; gz += ig * dz;
+            const long long src = KT > 0 ? edge / KT : edge / K;
+            const long long fk = (orig ? orig[src] : src) * K + (edge - src * K);
+#pragma unroll
+            for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
+                if (tg >= ntg) break;
+                const long long tau = tau0 + tg;
+                const float4 q = pos_t[tau * n + src], p = sP[wv][tg][lane];
+                const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+                const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+                const long long rrow = rdg_div_pos(tau * n * K + fk, nt, inv_nt);
+                const float diff = gap - d2[rrow];
+                const float s = diff / sqrtf(diff * diff + eps2);
+                const float ig = gap > 0.f ? s / gap : 0.f;
+                gx[tg] += ig * dx; gy[tg] += ig * dy; gz[tg] += ig * dz;
+            }
         }
-        G_t[tau * n + i] = make_float4(gx, gy, gz, 0.f);
+    }
+    if (act) {
+#pragma unroll
+        for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
+            if (tg >= ntg) break;
+            const long long tau = tau0 + tg;
+            if (G3_orig) {            // the caller's own layout: [nt][n][3] in the ORIGINAL sample order
+                float* g3 = G3_orig + (tau * n + i_row) * 3;
+                g3[0] = gx[tg]; g3[1] = gy[tg]; g3[2] = gz[tg];
+            } else {
+                G_t[tau * n + i] = make_float4(gx[tg], gy[tg], gz[tg], 0.f);
+            }
+        }
     }
     // block sum of the terms (f64)
     __shared__ double sh[4];
@@ -569,24 +689,50 @@ rdg_rigidity_dp_kernel(long long n, int K_rt, int nt, const float4* __restrict__
     if (threadIdx.x == 0) atomicAdd(loss_sum, (sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
+// pos4[tau][s] = (pos3[tau][order[s]], 0): the sample re-laid along the curve order, padded to 16-B rows (what the
+// framework did as a zero fill + an advanced-indexing copy: 1.1 ms at n = 2 M, nt = 25)
+__global__ void __launch_bounds__(256)
+rdg_rigidity_pack_kernel(long long n, const float* __restrict__ pos3, const long long* __restrict__ order,
+                         float4* __restrict__ pos4) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const long long tau = blockIdx.y;
+    const float* src = pos3 + (tau * n + order[s]) * 3;
+    pos4[tau * n + s] = make_float4(src[0], src[1], src[2], 0.f);
+}
+
+extern "C" int rdg_rigidity_pack(int64_t n, int32_t nt, const float* pos3, const int64_t* order, float* pos4,
+                                 void* stream) {
+    if (n <= 0 || nt <= 0) return 0;
+    if (nt > 65535) return rdg_set_error("rigidity_pack: at most 65535 time samples");
+    if (((uintptr_t)pos4) & 15) return rdg_set_error("rigidity_pack: pos4 must be 16-B aligned");
+    hipLaunchKernelGGL(rdg_rigidity_pack_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nt), dim3(256), 0,
+                       (hipStream_t)stream, (long long)n, pos3, (const long long*)order, (float4*)pos4);
+    return rdg_check_hip(hipGetLastError(), "rigidity_pack launch");
+}
+
 extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const float* pos_t4, const int64_t* nn_idx,
                                        const float* d2, const int64_t* rev_off, const int64_t* rev_edge,
-                                       const int64_t* orig, float eps, double* loss_sum, float* G_t4, float* d_d2,
-                                       void* stream) {
+                                       const int64_t* rev_dst, const int64_t* orig, float eps, double* loss_sum,
+                                       float* G_t4, float* d_d2, float* G3_orig, void* stream) {
     if (n <= 0 || K <= 0 || nt <= 0) return rdg_set_error("rigidity_dp: bad sizes");
+    if (nt > 65535 * RDG_RIG_TG) return rdg_set_error("rigidity_dp: too many time samples");
+    if (!G_t4 && !G3_orig) return rdg_set_error("rigidity_dp: one of G_t4 / G3_orig is required");
     if ((((uintptr_t)pos_t4) | ((uintptr_t)G_t4)) & 15) return rdg_set_error("rigidity_dp: buffers must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = rdg_zero_async(loss_sum, 8, st);
     if (e == hipSuccess) e = rdg_zero_async(d_d2, (size_t)n * K * 4, st);
     if (e != hipSuccess) return rdg_check_hip(e, "rigidity_dp memset");
-    const long long total = n * nt;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((nt + RDG_RIG_TG - 1) / RDG_RIG_TG));
     if (K == 8)
-        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<8>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K,
+        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<8>, grid, dim3(256), 0, st, (long long)n, K,
                            nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
-                           (const long long*)rev_edge, (const long long*)orig, eps * eps, loss_sum, (float4*)G_t4, d_d2);
+                           (const long long*)rev_edge, (const long long*)rev_dst, (const long long*)orig, eps * eps,
+                           loss_sum, (float4*)G_t4, d_d2, G3_orig);
     else
-        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<0>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, K,
+        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<0>, grid, dim3(256), 0, st, (long long)n, K,
                            nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
-                           (const long long*)rev_edge, (const long long*)orig, eps * eps, loss_sum, (float4*)G_t4, d_d2);
+                           (const long long*)rev_edge, (const long long*)rev_dst, (const long long*)orig, eps * eps,
+                           loss_sum, (float4*)G_t4, d_d2, G3_orig);
     return rdg_check_hip(hipGetLastError(), "rigidity_dp launch");
 }

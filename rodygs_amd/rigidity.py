@@ -53,7 +53,28 @@ def _curve_order(p: torch.Tensor) -> torch.Tensor:
         v = (v | (v << 4)) & 0x030C30C3
         return (v | (v << 2)) & 0x09249249
 
-    return torch.argsort((spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2]))
+    code = (spread(q[:, 0]) << 2) | (spread(q[:, 1]) << 1) | spread(q[:, 2])
+    if code.is_cuda:
+        return _sort_by_key(code, 30)[1]
+    return torch.argsort(code)
+
+
+def _sort_by_key(keys: torch.Tensor, end_bit: int):
+    """Stable sort of non-negative int64 keys below 2^end_bit with the library's LSD radix sort (rdg_sort_pairs: one
+    8-bit pass per 8 key bits, where the framework's sort walks all 64 bits of an int64): (sorted keys, permutation)."""
+    from . import _lib
+    L = _lib.lib()
+    n = keys.numel()
+    k = keys.detach().to(torch.int64).clone().contiguous()
+    v = torch.arange(n, dtype=torch.int32, device=keys.device)
+    if n == 0:
+        return k, v.to(torch.int64)
+    with torch.cuda.device(keys.device):
+        nd = torch.full((1,), n, dtype=torch.int32, device=keys.device)
+        tmp = torch.empty(L.rdg_sort_tmp_bytes(n), dtype=torch.uint8, device=keys.device)
+        _lib.check(L.rdg_sort_pairs(_lib.ptr(k), _lib.ptr(v), n, _lib.ptr(nd), int(end_bit), _lib.ptr(tmp),
+                                    _lib.stream_ptr()), "rdg_sort_pairs")
+    return k, v.to(torch.int64)
 
 
 class _FusedDistancePreserving(torch.autograd.Function):
@@ -76,29 +97,30 @@ class _FusedDistancePreserving(torch.autograd.Function):
             rank = torch.empty_like(order)
             rank[order] = torch.arange(n, device=dev)
             ii = rank[ii[order]].contiguous()                       # neighbour lists in stored order
-            p4 = torch.zeros(nt, n, 4, dtype=torch.float32, device=dev)
-            p4[..., :3] = pos_t.detach()[:, order]
+            p3 = pos_t.detach().to(torch.float32).contiguous()
+            p4 = torch.empty(nt, n, 4, dtype=torch.float32, device=dev)
+            _lib.check(L.rdg_rigidity_pack(n, nt, _lib.ptr(p3), _lib.ptr(order), _lib.ptr(p4), _lib.stream_ptr()),
+                       "rdg_rigidity_pack")
             # reverse adjacency of the K-NN graph: edge ids (i*K + k) grouped by their destination
             flat = ii.reshape(-1)
-            srt, rev_edge = torch.sort(flat, stable=True)
-            rev_edge = rev_edge.contiguous()
+            srt, rev_edge = _sort_by_key(flat, max(1, (n - 1).bit_length()))     # destinations (sorted), edge ids
             # offsets of every destination in the sorted edge list (searchsorted instead of bincount + cumsum:
             # bincount reads its output size back to the host and stalls the stream of launches)
             rev_off = torch.searchsorted(srt, torch.arange(n + 1, device=dev)).contiguous()
             loss = torch.empty(1, dtype=torch.float64, device=dev)
-            G4 = torch.empty_like(p4)
+            G3 = torch.empty(nt, n, 3, dtype=torch.float32, device=dev)      # gradient in the caller's own row order
             d_d2 = torch.empty_like(dd)
             _lib.check(L.rdg_rigidity_dp_forward(n, K, nt, _lib.ptr(p4), _lib.ptr(ii), _lib.ptr(dd), _lib.ptr(rev_off),
-                                                 _lib.ptr(rev_edge), _lib.ptr(order), float(eps), _lib.ptr(loss),
-                                                 _lib.ptr(G4), _lib.ptr(d_d2), _lib.stream_ptr()),
+                                                 _lib.ptr(rev_edge), _lib.ptr(srt), _lib.ptr(order), float(eps), _lib.ptr(loss),
+                                                 None, _lib.ptr(d_d2), _lib.ptr(G3), _lib.stream_ptr()),
                        "rdg_rigidity_dp_forward")
-        ctx.save_for_backward(G4, d_d2, rank)
+        ctx.save_for_backward(G3, d_d2)
         return loss[0].to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        G4, d_d2, rank = ctx.saved_tensors
-        return G4[:, rank, :3] * g, None, d_d2 * g, None
+        G3, d_d2 = ctx.saved_tensors
+        return G3 * g, None, d_d2 * g, None
 
 
 class RigidityLoss(nn.Module):

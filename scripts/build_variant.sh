@@ -9,7 +9,7 @@ cd "$(dirname "$0")/../rodygs_amd/csrc"
 mkdir -p variants
 make -j8 > /dev/null
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -I../../include"
+COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed -I../../include"
 case "$2" in
   rdg_preprocess_fwd|rdg_binning) MODE="-ffp-contract=off" ;;
   rdg_render) MODE="-ffp-contract=fast -fno-slp-vectorize" ;;
