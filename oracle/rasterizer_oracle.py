@@ -307,9 +307,9 @@ def bin_and_sort(geom):
 
 
 def _composite_group(a, pixx, pixy, bgc):
-    """Front-to-back compositing of G tiles at once.  a [G,L,13] = (px, py, conic a b c, opacity, 7 features) per list
-    slot (padding slots: all zero -> alpha 0 -> never blended), pixx / pixy [G,256] pixel coordinates.
-    Returns (values [G,8,256] = colour(+bg) 3, depth 1, normal 3, alpha 1;  final_T [G,256];  n_contrib [G,256])."""
+    """Front-to-back compositing of G tiles at once.  a [G,L,13+E] = (px, py, conic a b c, opacity, 7 features, E extra
+    attributes) per list slot (padding slots: all zero -> alpha 0 -> never blended), pixx / pixy [G,256] pixel coordinates.
+    Returns (values [G,8+E,256] = colour(+bg) 3, depth 1, normal 3, extra E, alpha 1;  final_T [G,256];  n_contrib [G,256])."""
     dt = a.dtype
     dx = a[:, :, 0:1] - pixx.unsqueeze(1)
     dy = a[:, :, 1:2] - pixy.unsqueeze(1)
@@ -349,7 +349,8 @@ def render_tiles(geom, binning, bg, H, W, tile_subset=None, rows_per_group=8192)
     ranges = binning["ranges"].astype(np.int64)
     bgc = bg.to(dt).reshape(3)
     tiles = np.asarray(list(range(gx * gy) if tile_subset is None else tile_subset), dtype=np.int64)
-    out = torch.zeros(8, H * W, dtype=dt)
+    E = 0 if geom.get("extra") is None else int(geom["extra"].shape[1])
+    out = torch.zeros(8 + E, H * W, dtype=dt)
     final_T = torch.ones(H * W, dtype=dt)
     n_contrib = torch.zeros(H * W, dtype=torch.int32)
     if len(tiles):
@@ -362,12 +363,12 @@ def render_tiles(geom, binning, bg, H, W, tile_subset=None, rows_per_group=8192)
         if emp.any():
             inside = (px_all[emp] < W) & (py_all[emp] < H)
             flat = torch.from_numpy((py_all[emp] * W + px_all[emp])[inside])
-            bgv = torch.zeros(8, flat.numel(), dtype=dt)
+            bgv = torch.zeros(8 + E, flat.numel(), dtype=dt)
             bgv[0:3] = bgc.view(3, 1)
             out = out.index_copy(1, flat, bgv)
         attrs = torch.cat([geom["px"].unsqueeze(1), geom["py"].unsqueeze(1), geom["conic"],
                            geom["opacity"].unsqueeze(1), geom["rgb"], geom["depth"].unsqueeze(1), geom["normal"],
-                           ], dim=1)                                                        # [P, 6 + 7]
+                           ] + ([geom["extra"].to(dt)] if E else []), dim=1)                # [P, 6 + 7 + E]
         attrs = torch.cat([attrs, torch.zeros(1, attrs.shape[1], dtype=dt)], dim=0)        # row P = padding slot
         order = np.argsort(lens, kind="stable")
         order = order[lens[order] > 0]
@@ -394,27 +395,31 @@ def render_tiles(geom, binning, bg, H, W, tile_subset=None, rows_per_group=8192)
             inside = torch.from_numpy((px_all[sel] < W) & (py_all[sel] < H))
             flat = torch.from_numpy(py_all[sel] * W + px_all[sel])[inside]
             pix_idx.append(flat)
-            pix_val.append(v.permute(1, 0, 2)[:, inside])                                  # [8, n_inside]
+            pix_val.append(v.permute(1, 0, 2)[:, inside])                                  # [8 + E, n_inside]
             with torch.no_grad():
                 final_T[flat] = Tf[inside]
                 n_contrib[flat] = nc[inside]
             i = j
         if pix_idx:
             out = out.index_copy(1, torch.cat(pix_idx), torch.cat(pix_val, dim=1))
-    out = out.reshape(8, H, W)
-    return dict(color=out[0:3], depth=out[3:4], normal=out[4:7], alpha=out[7:8], final_T=final_T.reshape(H, W),
-                n_contrib=n_contrib.reshape(H, W))
+    out = out.reshape(8 + E, H, W)
+    return dict(color=out[0:3], depth=out[3:4], normal=out[4:7], extra=out[7:7 + E], alpha=out[7 + E:8 + E],
+                final_T=final_T.reshape(H, W), n_contrib=n_contrib.reshape(H, W))
 
 
 def rasterize(means3D, means2D, opacities, viewmatrix, settings: OracleSettings, shs=None, colors_precomp=None,
-              scales=None, rotations=None, cov3Ds_precomp=None, tile_subset=None):
-    """Full oracle forward.  Returns (color, depth, normal, alpha, radii, aux)."""
+              scales=None, rotations=None, cov3Ds_precomp=None, tile_subset=None, extra_attrs=None):
+    """Full oracle forward.  Returns (color, depth, normal, alpha, radii, aux).  extra_attrs [P,E] (the upstream kwarg no
+    reference caller passes; assumed semantics: composited with the colour's weights, no background term) -> aux["extra"]
+    [E,H,W]."""
     geom = preprocess(means3D, means2D, opacities, viewmatrix, settings, shs=shs, colors_precomp=colors_precomp,
                       scales=scales, rotations=rotations, cov3Ds_precomp=cov3Ds_precomp)
+    if extra_attrs is not None:
+        geom["extra"] = extra_attrs
     binning = bin_and_sort(geom)
     img = render_tiles(geom, binning, settings.bg, int(settings.image_height), int(settings.image_width),
                        tile_subset=tile_subset)
-    aux = dict(geom=geom, binning=binning, final_T=img["final_T"], n_contrib=img["n_contrib"])
+    aux = dict(geom=geom, binning=binning, final_T=img["final_T"], n_contrib=img["n_contrib"], extra=img["extra"])
     return img["color"], img["depth"], img["normal"], img["alpha"], geom["radii"], aux
 
 

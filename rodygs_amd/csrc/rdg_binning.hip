@@ -1,18 +1,12 @@
-// rdg_binning.hip -- tile binning: bucket binning (default, second half of the file) and the
-// duplicateWithKeys + stable LSD radix sort + tile ranges path it replaced (kept: rdg_sort_pairs, K-NN, A/B switch).
+// rdg_binning.hip -- tile binning, two algorithms with the same result bit for bit:
+//   * bucket binning (bin_mode 0, second half of the file): count / scan / scatter into per-tile buckets + per-tile sort;
+//   * radix binning (bin_mode 1, "depth first", end of the file): the Gaussians are sorted by depth once (P keys), their
+//     tile instances emitted in that order and then stably partitioned by tile with the radix sort of
+//     rdg_radix_sort.hip -- two 8-bit passes over (tile id, Gaussian id) pairs instead of six over 64-bit (tile | depth)
+//     keys, and no per-tile work at all, so its time does not depend on how the instances are spread over the tiles.
 //
 // Integer/byte work, HBM-bound.  Nothing here needs the host to know D (= num_rendered): every kernel is
 // launched with a D-independent grid and reads D from device memory, so the forward pass has no D2H stall.
-//
-// Radix sort design (wave64-native, no inter-workgroup communication => nothing to deadlock or go stale):
-//   the key array is cut into n_seg contiguous WAVE SEGMENTS; a wave owns one segment in every kernel.
-//   per 8-bit pass:  (1) hist    : each wave counts its segment's digits in wave-private LDS counters
-//                                  -> table[digit][segment]
-//                    (2) scan    : one 1024-thread block per digit row -> exclusive prefix over segments
-//                    (3) scatter : each wave re-reads its segment in order; ranks within a 64-key chunk come
-//                                  from a ballot "match" (8 ballots -> mask of equal-digit lanes ->
-//                                  popcount below me), so the order inside a segment, and therefore the
-//                                  whole sort, is stable.
 #include "rdg_common.h"
 #include <stdlib.h>
 
@@ -82,186 +76,11 @@ rdg_duplicate_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// radix sort
+// radix sort: the stable LSD radix sort of rdg_radix_sort.hip (one kernel per 8-bit pass + one histogram kernel)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rdg_seg_bounds(long long n, int nseg, int seg, long long& b, long long& e) {
-    long long per = (n + nseg - 1) / nseg;
-    per = (per + 63) / 64 * 64;
-    b = (long long)seg * per;
-    e = b + per;
-    if (b > n) b = n;
-    if (e > n) e = n;
-}
-
-__global__ void __launch_bounds__(RDG_SORT_BLOCK)
-rdg_sort_hist_kernel(const uint64_t* __restrict__ keys, long long capacity, const int32_t* __restrict__ n_dev,
-                     int shift, int nseg, uint32_t* __restrict__ table) {
-    long long n = *n_dev;
-    if (n > capacity) return;
-    __shared__ uint32_t cnt[RDG_SORT_BLOCK / RDG_WAVE][RDG_SORT_RADIX];
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int seg = blockIdx.x * (RDG_SORT_BLOCK / RDG_WAVE) + w;
-#pragma unroll
-    for (int k = 0; k < RDG_SORT_RADIX / RDG_WAVE; ++k) cnt[w][lane + 64 * k] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    long long b, e;
-    rdg_seg_bounds(n, nseg, seg, b, e);
-    // 4 chunks of 64 keys in flight per wave (the kernel is latency-bound otherwise), counted with the same ballot
-    // "match" as the scatter: the lowest lane of every equal-digit group adds the group size with a plain LDS
-    // read-modify-write (LDS atomics measured several times slower than plain LDS traffic on this part).
-    volatile uint32_t* cw = cnt[w];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (long long i0 = b; i0 < e; i0 += 4 * 64) {
-        uint64_t k4[4]; bool a4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const long long i = i0 + 64 * c + lane;
-            a4[c] = i < e;
-            k4[c] = a4[c] ? keys[i] : 0ull;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const uint32_t dgt = (uint32_t)(k4[c] >> shift) & (RDG_SORT_RADIX - 1);
-            unsigned long long m = __ballot(a4[c]);
-            if (m == 0ull) break;
-#pragma unroll
-            for (int bit = 0; bit < RDG_SORT_BITS; ++bit) {
-                const bool bset = (dgt >> bit) & 1u;
-                const unsigned long long bal = __ballot(a4[c] && bset);
-                m &= bset ? bal : ~bal;
-            }
-            if (a4[c] && (m & lt_mask) == 0ull) cw[dgt] = cw[dgt] + (uint32_t)__popcll(m);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int k = 0; k < RDG_SORT_RADIX / RDG_WAVE; ++k) {
-        const int dg = lane + 64 * k;
-        table[(size_t)dg * nseg + seg] = cnt[w][dg];
-    }
-}
-
-// one block per digit row: exclusive scan over segments (in place) + row total
-__global__ void __launch_bounds__(1024)
-rdg_sort_scan_kernel(uint32_t* __restrict__ table, int nseg, uint32_t* __restrict__ totals, long long capacity,
-                     const int32_t* __restrict__ n_dev) {
-    if ((long long)(*n_dev) > capacity) return;
-    __shared__ uint32_t wtot[16];
-    __shared__ uint32_t carry_s;
-    uint32_t* row = table + (size_t)blockIdx.x * nseg;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < nseg; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nseg ? row[i] : 0u;
-        const uint32_t inc = rdg_wave_scan_incl(v);
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
-        const uint32_t carry = carry_s;
-        if (i < nseg) row[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
-}
-
-__global__ void __launch_bounds__(RDG_SORT_BLOCK)
-rdg_sort_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-                        uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, long long capacity,
-                        const int32_t* __restrict__ n_dev, int shift, int nseg,
-                        const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals) {
-    long long n = *n_dev;
-    if (n > capacity) return;
-    __shared__ uint32_t dbase[RDG_SORT_RADIX];
-    __shared__ uint32_t wtot[RDG_SORT_BLOCK / RDG_WAVE];
-    __shared__ uint32_t cursor_s[RDG_SORT_BLOCK / RDG_WAVE][RDG_SORT_RADIX];
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // exclusive scan of the 256 digit totals (thread = digit)
-    {
-        const uint32_t v = totals[threadIdx.x];
-        const uint32_t inc = rdg_wave_scan_incl(v);
-        if (lane == 63) wtot[w] = inc;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (uint32_t k = 0; k < w; ++k) woff += wtot[k];
-        dbase[threadIdx.x] = woff + inc - v;
-        __syncthreads();
-    }
-    const int seg = blockIdx.x * (RDG_SORT_BLOCK / RDG_WAVE) + w;
-    volatile uint32_t* cursor = cursor_s[w];
-#pragma unroll
-    for (int k = 0; k < RDG_SORT_RADIX / RDG_WAVE; ++k) {
-        const int dg = lane + 64 * k;
-        cursor[dg] = dbase[dg] + table[(size_t)dg * nseg + seg];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    long long b, e;
-    rdg_seg_bounds(n, nseg, seg, b, e);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (long long i0 = b; i0 < e; i0 += 4 * 64) {
-        // prefetch 4 chunks (keys + values) before ranking them IN ORDER: the ranking is serial per segment, the
-        // global loads need not be
-        uint64_t k4[4]; uint32_t v4[4]; bool a4[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const long long i = i0 + 64 * c + lane;
-            a4[c] = i < e;
-            k4[c] = 0; v4[c] = 0;
-            if (a4[c]) { k4[c] = keys_in[i]; v4[c] = vals_in[i]; }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool act = a4[c];
-            const uint64_t key = k4[c];
-            const uint32_t val = v4[c];
-            const uint32_t dgt = (uint32_t)(key >> shift) & (RDG_SORT_RADIX - 1);
-            unsigned long long m = __ballot(act);
-            if (m == 0ull) break;
-#pragma unroll
-            for (int bit = 0; bit < RDG_SORT_BITS; ++bit) {
-                const bool bset = (dgt >> bit) & 1u;
-                const unsigned long long bal = __ballot(act && bset);
-                m &= bset ? bal : ~bal;
-            }
-            const uint32_t rank = __popcll(m & lt_mask);
-            uint32_t pos = 0;
-            if (act) pos = cursor[dgt] + rank;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (act && rank == 0) cursor[dgt] = pos + (uint32_t)__popcll(m);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (act) { keys_out[pos] = key; vals_out[pos] = val; }
-        }
-    }
-}
-
 int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
                     const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s) {
-    const RdgSortLayout L = rdg_sort_layout(capacity);
-    const int nseg = rdg_sort_nseg(capacity);
-    uint32_t* table = (uint32_t*)((char*)sort_tmp + L.table);
-    uint32_t* totals = (uint32_t*)((char*)sort_tmp + L.totals);
-    const int npass = (end_bit + RDG_SORT_BITS - 1) / RDG_SORT_BITS;
-    uint64_t* kin = keys_a; uint64_t* kout = keys_b;
-    uint32_t* vin = vals_a; uint32_t* vout = vals_b;
-    const int nblk = nseg / (RDG_SORT_BLOCK / RDG_WAVE);
-    for (int p = 0; p < npass; ++p) {
-        const int shift = p * RDG_SORT_BITS;
-        hipLaunchKernelGGL(rdg_sort_hist_kernel, dim3(nblk), dim3(RDG_SORT_BLOCK), 0, s, kin, (long long)capacity,
-                           n_dev, shift, nseg, table);
-        hipLaunchKernelGGL(rdg_sort_scan_kernel, dim3(RDG_SORT_RADIX), dim3(1024), 0, s, table, nseg, totals,
-                           (long long)capacity, n_dev);
-        hipLaunchKernelGGL(rdg_sort_scatter_kernel, dim3(nblk), dim3(RDG_SORT_BLOCK), 0, s, kin, vin, kout, vout,
-                           (long long)capacity, n_dev, shift, nseg, table, totals);
-        uint64_t* tk = kin; kin = kout; kout = tk;
-        uint32_t* tv = vin; vin = vout; vout = tv;
-    }
-    if (result_in_b) *result_in_b = (npass & 1);
-    return rdg_check_hip(hipGetLastError(), "sort launch");
+    return rdg_launch_radix_sort<uint64_t>(keys_a, keys_b, vals_a, vals_b, capacity, n_dev, 0, end_bit, sort_tmp, result_in_b, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1094,6 +913,128 @@ rdg_tile_max_kernel(int n_tiles, const uint2* __restrict__ ranges, long long cap
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// radix binning, depth first: helper kernels (see rdg_launch_bin)
+// ---------------------------------------------------------------------------------------------------------
+// depth key of every Gaussian (its view-space depth's bits: positive floats order like their bits; Gaussians that touch no
+// tile go last), value = its index; n_p[0] = P for the sort
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_depth_keys_kernel(int P, const RdgRec* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
+                      uint32_t* __restrict__ dkey, uint32_t* __restrict__ dval, int32_t* __restrict__ n_p) {
+    const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    if (i == 0) n_p[0] = P;
+    if (i >= P) return;
+    dkey[i] = tiles_touched[i] > 0 ? __float_as_uint(rec[i].q1.z) : 0xFFFFFFFFu;
+    dval[i] = (uint32_t)i;
+}
+
+// psum[b] = instances of the 256 Gaussians at depth ranks [256 b, 256 b + 256)
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_perm_block_sums_kernel(int P, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
+                           uint32_t* __restrict__ psum) {
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    const int j = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
+    const uint32_t t = j < P ? tiles_touched[perm[j]] : 0u;
+    const uint32_t inc = rdg_wave_scan_incl(t);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) psum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// exclusive scan of v[0..n) in place by one workgroup, v[n] = total (n <= 16 k block sums: runs of <= 16 per thread)
+__global__ void __launch_bounds__(1024) rdg_scan_u32_kernel(uint32_t* __restrict__ v, int n) {
+    __shared__ uint32_t wtot[16];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (n + 1023) / 1024;
+    const int t0 = min(n, (int)threadIdx.x * per), t1 = min(n, t0 + per);
+    uint32_t mine = 0;
+    for (int c = t0; c < t1; ++c) mine += v[c];
+    const uint32_t inc = rdg_wave_scan_incl(mine);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (uint32_t k = 0; k < w; ++k) run += wtot[k];
+    for (int c = t0; c < t1; ++c) { const uint32_t x = v[c]; v[c] = run; run += x; }
+    if (threadIdx.x == 1023) v[n] = run;
+}
+
+// rdg_duplicate_kernel over the Gaussians in DEPTH order (slot j <-> Gaussian perm[j]): (tile id, Gaussian id) pairs, a
+// Gaussian's tiles row by row; slots dealt round-robin to the threads of a block (coalesced stores however skewed the
+// footprints are)
+__global__ void __launch_bounds__(RDG_PRE_BLOCK)
+rdg_duplicate_sorted_kernel(int P, int gx, int gy, const uint32_t* __restrict__ perm, const RdgRec* __restrict__ rec,
+                            const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
+                            const uint32_t* __restrict__ psum, uint32_t* __restrict__ tkey, uint32_t* __restrict__ vals,
+                            long long capacity, const int32_t* __restrict__ num_rendered) {
+    if ((long long)(*num_rendered) > capacity) return;
+    __shared__ uint32_t sOff[RDG_PRE_BLOCK], sId[RDG_PRE_BLOCK];
+    __shared__ uint16_t sX0[RDG_PRE_BLOCK], sY0[RDG_PRE_BLOCK], sW[RDG_PRE_BLOCK];
+    __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
+    const int tid = threadIdx.x;
+    const int j = blockIdx.x * RDG_PRE_BLOCK + tid;
+    uint32_t t = 0;
+    if (j < P) {
+        const uint32_t i = perm[j];
+        sId[tid] = i;
+        t = tiles_touched[i];
+        if (t > 0) {
+            const float4 q0 = rec[i].q0;
+            int x0, y0, x1, y1;
+            rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
+            sX0[tid] = (uint16_t)x0; sY0[tid] = (uint16_t)y0; sW[tid] = (uint16_t)(x1 - x0);
+        }
+    }
+    const uint32_t inc = rdg_wave_scan_incl(t);
+    const uint32_t lane = tid & 63, w = tid >> 6;
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t k = 0; k < w; ++k) woff += wsum[k];
+    sOff[tid] = woff + inc - t;
+    __syncthreads();
+    const uint32_t base = psum[blockIdx.x];
+    const uint32_t total = psum[blockIdx.x + 1] - base;
+    for (uint32_t k = tid; k < total; k += RDG_PRE_BLOCK) {
+        int lo = 0, hi = RDG_PRE_BLOCK - 1;        // last slot owner with sOff <= k
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sOff[mid] <= k) lo = mid; else hi = mid - 1;
+        }
+        const uint32_t r = k - sOff[lo];
+        const uint32_t wd = sW[lo];
+        const uint32_t ry = r / wd, rx = r - ry * wd;
+        tkey[base + k] = (uint32_t)(sY0[lo] + ry) * (uint32_t)gx + (uint32_t)(sX0[lo] + rx);
+        vals[base + k] = sId[lo];
+    }
+}
+
+// identifyTileRanges on sorted 32-bit tile ids
+__global__ void __launch_bounds__(256)
+rdg_tile_ranges32_kernel(const uint32_t* __restrict__ tk, long long capacity, const int32_t* __restrict__ n_dev,
+                         uint2* __restrict__ ranges) {
+    const long long n = *n_dev;
+    if (n > capacity) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t tile = tk[i];
+        if (i == 0) ranges[tile].x = 0;
+        else {
+            const uint32_t prev = tk[i - 1];
+            if (prev != tile) { ranges[prev].y = (uint32_t)i; ranges[tile].x = (uint32_t)i; }
+        }
+        if (i == n - 1) ranges[tile].y = (uint32_t)n;
+    }
+}
+
+// tests: the 64-bit (tile | depth) key of every sorted instance
+__global__ void __launch_bounds__(256)
+rdg_rebuild_keys_kernel(const uint32_t* __restrict__ tk, const uint32_t* __restrict__ vals, const RdgRec* __restrict__ rec,
+                        uint64_t* __restrict__ keys, long long capacity, const int32_t* __restrict__ n_dev) {
+    const long long n = *n_dev;
+    if (n > capacity) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        keys[i] = ((uint64_t)tk[i] << 32) | (uint64_t)__float_as_uint(rec[vals[i]].q1.z);
+}
+
 int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, void* bin_ws, int64_t capacity,
                    void* image_ws, int32_t* num_rendered, uint64_t* keys_unsorted_copy,
                    uint32_t* vals_unsorted_copy, hipStream_t s, bool radix_export_keys) {
@@ -1175,35 +1116,81 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         return rdg_check_hip(hipGetLastError(), "bucket bin launch");
     }
 
+    // ---- radix binning, depth first (bin_mode 1) ---------------------------------------------------------------------
+    // (1) sort the Gaussians by depth: P 32-bit keys, four passes;  (2) emit their tile instances IN THAT ORDER as
+    // (tile id, Gaussian id) pairs;  (3) partition the pairs stably by tile: ceil(log2 tiles / 8) passes over 8 B
+    // per pair (two at 1080p and 4K) -- the (tile, depth, Gaussian id) order of the 64-bit (tile | depth) key sort,
+    // reached with a third of its passes on a third of its bytes; equal depths keep the order of their Gaussian
+    // indices (both sorts are stable).
     {
         hipError_t eh = rdg_zero_async(b + B.hit, rdg_hit_bytes(capacity, n_tiles), s);
         if (eh != hipSuccess) return rdg_check_hip(eh, "hit bits memset");
     }
-    rdg_stage_begin(RDG_STAGE_SCAN_DUP, s);
-    if (d.P > 0) {
-        const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
+    const int tile_bits = rdg_key_bits(n_tiles) - 32;
+    const int npass = (tile_bits + RDG_SORT_BITS - 1) / RDG_SORT_BITS;       // same parity as the 64-bit sort's pass count
+    uint32_t* tkey_a = (uint32_t*)keys_a;
+    uint32_t* tkey_b = (uint32_t*)keys_b;
+    if ((keys_unsorted_copy || vals_unsorted_copy) && d.P > 0) {
+        // emission-order (key, value) stream of the reference algorithm, for the parity tests only
         hipLaunchKernelGGL(rdg_duplicate_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
                            (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
-                           (const uint32_t*)(g + G.block_sums), keys_a, vals_a, (long long)capacity, num_rendered);
-    }
-    rdg_stage_end(RDG_STAGE_SCAN_DUP, s);
-    if (keys_unsorted_copy || vals_unsorted_copy) {
-        hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_a, vals_a, keys_unsorted_copy,
+                           (const uint32_t*)(g + G.block_sums), keys_b, vals_b, (long long)capacity, num_rendered);
+        hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_b, vals_b, keys_unsorted_copy,
                            vals_unsorted_copy, (long long)capacity, num_rendered);
     }
-    rdg_stage_begin(RDG_STAGE_SORT, s);
+    {
+        RdgStageScope scope(RDG_STAGE_SCAN_DUP, s);
+        if (d.P > 0) {
+            // scratch for the per-Gaussian sort lives in the second key buffer (8 cap >= 32 P + ...: cap >= 4 P + 4096)
+            const size_t Pp = rdg_align_up((size_t)d.P * 4, 256);
+            char* q = (char*)keys_b;
+            uint32_t* dk_a = (uint32_t*)q;              uint32_t* dk_b = (uint32_t*)(q + Pp);
+            uint32_t* dv_a = (uint32_t*)(q + 2 * Pp);   uint32_t* dv_b = (uint32_t*)(q + 3 * Pp);
+            uint32_t* psum = (uint32_t*)(q + 4 * Pp);                               // nblk + 1 block sums, sorted order
+            int32_t* n_p = (int32_t*)(q + 4 * Pp + rdg_align_up((size_t)(nblk + 1) * 4, 256));   // [0] = P, [1] = scratch
+            if ((size_t)((char*)(n_p + 2) - q) > (size_t)capacity * 8)
+                return rdg_set_error("radix binning: capacity %lld too small for %d Gaussians", (long long)capacity, d.P);
+            hipLaunchKernelGGL(rdg_depth_keys_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, (const RdgRec*)(g + G.rec),
+                               (const uint32_t*)(g + G.tiles_touched), dk_a, dv_a, n_p);
+            int in_b = 0;
+            int rc = rdg_launch_radix_sort<uint32_t>(dk_a, dk_b, dv_a, dv_b, (int64_t)d.P, n_p, 0, 32, b + B.sort_tmp, &in_b, s);
+            if (rc) return rc;
+            const uint32_t* perm = in_b ? dv_b : dv_a;
+            hipLaunchKernelGGL(rdg_perm_block_sums_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, perm,
+                               (const uint32_t*)(g + G.tiles_touched), psum);
+            hipLaunchKernelGGL(rdg_scan_u32_kernel, dim3(1), dim3(1024), 0, s, psum, nblk);
+            hipLaunchKernelGGL(rdg_duplicate_sorted_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, perm,
+                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii, psum, tkey_a,
+                               vals_a, (long long)capacity, num_rendered);
+        }
+    }
     int in_b = 0;
-    int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, capacity, num_rendered, rdg_key_bits(n_tiles),
-                             b + B.sort_tmp, &in_b, s);
-    rdg_stage_end(RDG_STAGE_SORT, s);
-    if (rc) return rc;
+    {
+        RdgStageScope scope(RDG_STAGE_SORT, s);
+        int rc = rdg_launch_radix_sort<uint32_t>(tkey_a, tkey_b, vals_a, vals_b, capacity, num_rendered, 0, tile_bits,
+                                               b + B.sort_tmp, &in_b, s);
+        if (rc) return rc;
+    }
     RdgStageScope scope(RDG_STAGE_RANGES, s);
     hipError_t e = rdg_zero_async(ranges, (size_t)n_tiles * sizeof(uint2), s);
     if (e != hipSuccess) return rdg_check_hip(e, "ranges memset");
-    hipLaunchKernelGGL(rdg_tile_ranges_kernel, dim3(2048), dim3(256), 0, s, in_b ? keys_b : keys_a,
-                       (long long)capacity, num_rendered, ranges);
+    const uint32_t* tk_sorted = in_b ? tkey_b : tkey_a;
+    hipLaunchKernelGGL(rdg_tile_ranges32_kernel, dim3(2048), dim3(256), 0, s, tk_sorted, (long long)capacity, num_rendered,
+                       ranges);
     if (d.nren_stats)
         hipLaunchKernelGGL(rdg_tile_max_kernel, dim3(1), dim3(1024), 0, s, n_tiles, ranges, (long long)capacity,
                            num_rendered, d.nren_host);
+    if (radix_export_keys) {
+        // tests only: the sorted 64-bit (tile | depth) keys, where rdg_bin_forward looks for them (the buffer the sorted
+        // tile ids are in: built in the other one, then copied over)
+        uint64_t* kx = in_b ? keys_b : keys_a;
+        uint64_t* ky = in_b ? keys_a : keys_b;
+        hipLaunchKernelGGL(rdg_rebuild_keys_kernel, dim3(2048), dim3(256), 0, s, tk_sorted, in_b ? vals_b : vals_a,
+                           (const RdgRec*)(g + G.rec), ky, (long long)capacity, num_rendered);
+        hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, ky, (const uint32_t*)nullptr, kx,
+                           (uint32_t*)nullptr, (long long)capacity, num_rendered);
+    }
+    (void)npass;
     return rdg_check_hip(hipGetLastError(), "bin launch");
 }

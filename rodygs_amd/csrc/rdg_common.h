@@ -57,28 +57,12 @@ static inline RdgGeomLayout rdg_geom_layout(int32_t P) {
 
 // ---- sort geometry ---------------------------------------------------------------------------------------
 #define RDG_SORT_BITS 8
-#define RDG_SORT_RADIX 256
-#define RDG_SORT_BLOCK 256                    // 4 independent waves per block
-#define RDG_SORT_MAX_WAVES 4096               // columns of the (digit, wave-segment) table
-
-struct RdgSortLayout {
-    size_t table;   // uint32[RADIX][n_seg]
-    size_t totals;  // uint32[RADIX]
-    size_t total;
-};
-static inline int32_t rdg_sort_nseg(int64_t capacity) {
-    int64_t n = (capacity + 1023) / 1024;  // >= 1024 keys per wave segment
-    if (n < 4) n = 4;
-    if (n > RDG_SORT_MAX_WAVES) n = RDG_SORT_MAX_WAVES;
-    n = (n + 3) / 4 * 4;
-    return (int32_t)n;
-}
+// workspace of the radix sort (rdg_radix_sort.hip): the (digit, segment) count table and the digit totals
+size_t rdg_radix_sort_tmp_bytes(int64_t capacity);
+struct RdgSortLayout { size_t total; };
 static inline RdgSortLayout rdg_sort_layout(int64_t capacity) {
     RdgSortLayout L;
-    size_t o = 0;
-    L.table = o;   o = rdg_align_up(o + (size_t)RDG_SORT_RADIX * rdg_sort_nseg(capacity) * 4, 256);
-    L.totals = o;  o = rdg_align_up(o + RDG_SORT_RADIX * 4, 256);
-    L.total = o;
+    L.total = rdg_radix_sort_tmp_bytes(capacity);
     return L;
 }
 
@@ -293,6 +277,10 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                    uint32_t* vals_unsorted_copy, hipStream_t s, bool export_sorted_keys = false);
 int rdg_launch_sort(uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
                     const int32_t* n_dev, int end_bit, void* sort_tmp, int* result_in_b, hipStream_t s);
+// stable LSD sort on key bits [begin_bit, end_bit) of uint32 / uint64 keys with uint32 values (rdg_radix_sort.hip)
+template <typename KeyT>
+int rdg_launch_radix_sort(KeyT* keys_a, KeyT* keys_b, uint32_t* vals_a, uint32_t* vals_b, int64_t capacity,
+                        const int32_t* n_dev, int begin_bit, int end_bit, void* tmp, int* result_in_b, hipStream_t s);
 int rdg_launch_render_fwd(const RdgDev& d, const float* bg, const void* geom_ws, void* bin_ws,
                           int64_t capacity, void* image_ws, const int32_t* num_rendered, float* out_color,
                           float* out_depth, float* out_normal, float* out_alpha, hipStream_t s);

@@ -30,11 +30,16 @@ RENDER_NORMAL = True          # composite the (unused-by-RoDyGS) normal channels
 PREZERO_GRAD_ROWS = os.environ.get("RDG_PREZERO_GRAD_ROWS", "1") != "0"   # the forward clears the backward's gradient rows
 NREN_HOST_MIRROR = os.environ.get("RDG_NREN_MIRROR", "1") != "0"           # deferred check: the device writes D to pinned memory
 # Bucket binning (count / scan / scatter + per-tile sort) is the fast path on ordinary frames, but its cost grows with
-# the longest tile list (same-address atomics in the count pass, a merge tree in the sort); the LSD radix path does not
-# care how instances are spread.  Same result bit for bit, so the choice is made per frame from the PREVIOUS frame's
-# largest tile list (it arrives with num_rendered: no extra read-back), with hysteresis.
+# the tile lists' lengths (same-address atomics in the count pass; the per-tile sort leaves its one-wave register form
+# above 1024 instances and needs merges above that); the radix path (Gaussians sorted by depth once, their instances
+# partitioned by tile in two 8-bit passes) does not care how instances are spread.  Same result bit for bit, so the choice
+# is made per frame from the PREVIOUS frame's largest tile list and instance count (they arrive together: no extra
+# read-back), with hysteresis.  Measured at 1080p (profiles/r04_binning_modes.txt): 3.6 M instances (440 per tile) bucket
+# 0.14 ms / radix 0.26; 9.4 M (1 150 per tile) 0.36 / 0.35; 17 M (2 100 per tile) 0.71 / 0.45.
 BIN_RADIX_ABOVE = 32768
 BIN_BUCKET_BELOW = 16384
+BIN_RADIX_MEAN_LIST_ABOVE = 1200        # instances per tile, averaged over the tile grid
+BIN_BUCKET_MEAN_LIST_BELOW = 900
 # Compositing of long tile lists: one workgroup walks a tile's list front to back, which is serial in the list length (a
 # 200 k-instance tile: 15 ms).  Lists above 4096 instances can be cut into segments composited by a workgroup each
 # (csrc/rdg_render.hip "split path"; the backward follows the forward's choice) -- three extra launches in the forward and
@@ -92,10 +97,13 @@ class RasterState:
     def pinned_slot(self) -> torch.Tensor:
         return self.pinned_free.pop() if self.pinned_free else torch.empty(2, dtype=torch.int32).pin_memory()
 
-    def note_largest_tile(self, key, largest: int) -> None:
-        if largest > BIN_RADIX_ABOVE:
+    def note_largest_tile(self, key, largest: int, n: int = 0) -> None:
+        """What a frame's largest tile list and instance count say about the next frame of that (P, H, W)."""
+        tiles = ((key[2] + 15) // 16) * ((key[1] + 15) // 16)
+        mean = n / max(tiles, 1)
+        if largest > BIN_RADIX_ABOVE or mean > BIN_RADIX_MEAN_LIST_ABOVE:
             self.bin_hint[key] = 1
-        elif largest < BIN_BUCKET_BELOW:
+        elif largest < BIN_BUCKET_BELOW and mean < BIN_BUCKET_MEAN_LIST_BELOW:
             self.bin_hint.pop(key, None)
         if largest > SPLIT_ABOVE:
             self.split_hint[key] = 1
@@ -119,7 +127,7 @@ class RasterState:
                 if n >= _INSTANCE_LIMIT:
                     raise RuntimeError(_too_many(key))
                 self.capacity_hint[key] = max(n, int(self.capacity_hint.get(key, 0) * 0.9))
-                self.note_largest_tile(key, int(host[1]))
+                self.note_largest_tile(key, int(host[1]), n)
                 if n > cap:
                     self.capacity_hint[key] = n
                     raise RasterizerCapacityOverflow(
@@ -135,8 +143,8 @@ _SPLIT_HINT = DEFAULT_STATE.split_hint
 _PENDING = DEFAULT_STATE.pending
 
 
-def _note_largest_tile(key, largest: int) -> None:
-    DEFAULT_STATE.note_largest_tile(key, largest)
+def _note_largest_tile(key, largest: int, n: int = 0) -> None:
+    DEFAULT_STATE.note_largest_tile(key, largest, n)
 
 
 _INSTANCE_LIMIT = 2 ** 31 - 1      # the device saturates its (tile, Gaussian) instance count here (rdg_scan_block_sums_kernel)
@@ -379,7 +387,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise RuntimeError(_too_many(key))
                 with state.lock:
                     state.capacity_hint[key] = n
-                    state.note_largest_tile(key, largest)
+                    state.note_largest_tile(key, largest, n)
                 if n <= cap:
                     break
                 cap = int(n * 1.25) + 4096
@@ -555,14 +563,12 @@ class GaussianRasterizer(nn.Module):
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3Ds_precomp=None, viewmatrix=None, extra_attrs=None, grad_sinks=None):
         """Reference call signature (renderer.py:87-101).  ``grad_sinks`` is an extension outside the reference
-        surface: {"shs": tensor} makes backward write dL/dshs into that tensor instead of returning it;
+        surface (``extra_attrs``: see ``_composite_extra``): {"shs": tensor} makes backward write dL/dshs into that tensor instead of returning it;
         {"shs_adam": {param, exp_avg, exp_avg_sq, head_len, lr_head, lr_tail, betas, eps, step}} makes backward apply
         the Adam step of the SH features itself (``rdg_preprocess_backward_adam``) -- the parameters change DURING
         backward, so use it only where backward runs exactly once per optimiser step and nothing else needs dL/dshs
         (rodygs_amd/trainstep.py does, for the single-GPU photometric step); {"densify": {...}} makes backward update
         the densification statistics of the train loop (see ``_bind_densify_stats``)."""
-        if extra_attrs is not None:
-            raise NotImplementedError("extra_attrs is not used by RoDyGS and is not implemented")
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3Ds_precomp is None) or (
@@ -570,5 +576,34 @@ class GaussianRasterizer(nn.Module):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         if viewmatrix is None:
             raise Exception("viewmatrix must be given (it is a differentiable forward argument in the pose branch)")
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                   viewmatrix, self.raster_settings, grad_sinks, self.state)
+        out = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                  viewmatrix, self.raster_settings, grad_sinks, self.state)
+        if extra_attrs is None:
+            return out
+        return (*out[:5], self._composite_extra(extra_attrs, means3D, means2D, opacities, scales, rotations,
+                                                cov3Ds_precomp, viewmatrix))
+
+    def _composite_extra(self, extra_attrs, means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, viewmatrix):
+        """``extra_attrs`` [P,E] (an upstream kwarg no RoDyGS caller passes; semantics assumed, SURVEY.md section 7 open
+        question 3): per-Gaussian attributes composited with the colour's own blending weights, no background term ->
+        ``extra`` [E,H,W].  The compositing kernels carry three colour channels, so the attributes go through them three
+        at a time as precomputed colours over a black background -- E / 3 more passes of the same forward, each a node of
+        the autograd graph, so their gradients reach the attributes and, through the weights, every geometric input
+        (they accumulate on ``means2D`` and ``viewmatrix`` with the main pass's).  Not a fast path: it exists so that a
+        caller of the upstream surface finds the argument honoured."""
+        P = means3D.shape[0]
+        if extra_attrs.dim() != 2 or extra_attrs.shape[0] != P:
+            raise RuntimeError("extra_attrs must be [P,E]")
+        E = extra_attrs.shape[1]
+        rs = self.raster_settings._replace(bg=torch.zeros_like(self.raster_settings.bg))
+        planes = []
+        for c0 in range(0, E, 3):
+            chunk = extra_attrs[:, c0:c0 + 3].to(torch.float32)
+            if chunk.shape[1] < 3:
+                chunk = torch.cat([chunk, chunk.new_zeros(P, 3 - chunk.shape[1])], dim=1)
+            img = rasterize_gaussians(means3D, means2D, None, chunk.contiguous(), opacities, scales, rotations,
+                                      cov3Ds_precomp, viewmatrix, rs, None, self.state)[0]
+            planes.append(img[:min(3, E - c0)])
+        if not planes:
+            return torch.empty(0, int(rs.image_height), int(rs.image_width), dtype=torch.float32, device=means3D.device)
+        return torch.cat(planes, dim=0)

@@ -382,7 +382,7 @@ class ShardedDynamicScene:
                 break
             D, largest = (int(v) for v in self.nren.tolist())
             hint[self.key] = D
-            rasterizer._note_largest_tile(self.key, largest)
+            rasterizer._note_largest_tile(self.key, largest, D)
             if D <= cap:
                 break
             cap = int(D * 1.5) + 4096

@@ -426,7 +426,7 @@ def test_bin_mode_hint_has_hysteresis():
     """rasterizer._note_largest_tile: above BIN_RADIX_ABOVE the next frame of that (P, H, W) takes the radix path, and it
     stays there until the largest list falls below BIN_BUCKET_BELOW (no flapping around one threshold)."""
     from rodygs_amd import rasterizer as R
-    key = ("test", 1, 2)
+    key = ("test", 1080, 1920)                                   # (P, H, W): 8160 tiles
     R._BIN_HINT.pop(key, None)
     R._note_largest_tile(key, R.BIN_RADIX_ABOVE)
     assert key not in R._BIN_HINT
@@ -437,6 +437,14 @@ def test_bin_mode_hint_has_hysteresis():
     R._note_largest_tile(key, R.BIN_BUCKET_BELOW - 1)
     assert key not in R._BIN_HINT
     R._note_largest_tile(key, R.BIN_BUCKET_BELOW + 5)           # between the thresholds from below: still bucket
+    assert key not in R._BIN_HINT
+    # the same for the MEAN list length (dense frames: the per-tile sorts of bucket binning leave their fast form)
+    tiles = 8160
+    R._note_largest_tile(key, 3000, int(R.BIN_RADIX_MEAN_LIST_ABOVE * tiles) + tiles)
+    assert R._BIN_HINT[key] == 1
+    R._note_largest_tile(key, 3000, int(0.5 * (R.BIN_RADIX_MEAN_LIST_ABOVE + R.BIN_BUCKET_MEAN_LIST_BELOW) * tiles))
+    assert R._BIN_HINT[key] == 1
+    R._note_largest_tile(key, 3000, int(R.BIN_BUCKET_MEAN_LIST_BELOW * tiles) - tiles)
     assert key not in R._BIN_HINT
 
 

@@ -368,3 +368,42 @@ def test_pose_gradient_of_the_two_deep_list_sweep_cases(seed0, case):
     from sweep_cases import sweep_case
     sc, deg, bg, kw = sweep_case(seed0, case)
     check_pair(run_pair(sc, deg, bg, **kw), NAMES)
+
+
+# ---- extra_attrs (upstream kwarg, no RoDyGS caller) --------------------------------------------------------------------
+
+@pytest.mark.parametrize("E", [1, 3, 5])
+def test_extra_attrs_are_composited_with_the_colour_weights(E):
+    """``GaussianRasterizer(...)(..., extra_attrs=[P,E])`` -> ``extra`` [E,H,W] against the oracle compositing the same
+    attributes natively (one pass, E more feature columns), with gradients to the attributes and -- through the blending
+    weights -- to every other input, summed with the colour loss's (viewmatrix and means2D included)."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    P, W, H = 3000, 200, 152
+    sc = O.synthetic_scene(P, W, H, 3, seed=17)
+    sc["viewmatrix"] = orbit_view(5.0, 3.0, (0.2, 0.1, 0.5))
+    bg = torch.tensor([0.2, 0.1, 0.3])
+    gen = torch.Generator().manual_seed(3)
+    attrs = torch.randn(P, E, generator=gen)
+    wc, we = torch.rand(3, H, W, generator=gen), torch.randn(E, H, W, generator=gen)
+    hi = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+    ha = attrs.clone().to(DEV).requires_grad_(True)
+    hm2 = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    out = GaussianRasterizer(HS.make_settings(sc, 3, bg=bg))(
+        means3D=hi["means3D"], means2D=hm2, shs=hi["shs"], opacities=hi["opacities"], scales=hi["scales"],
+        rotations=hi["rotations"], viewmatrix=hi["viewmatrix"], extra_attrs=ha)
+    assert out[5].shape == (E, H, W)
+    ((out[0] * wc.to(DEV)).sum() + (out[5] * we.to(DEV)).sum()).backward()
+    oi = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+    oa = attrs.clone().requires_grad_(True)
+    om2 = torch.zeros(P, 3, requires_grad=True)
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], bg, 1.0, sc["projmatrix"], 3)
+    oo = O.rasterize(oi["means3D"], om2, oi["opacities"], oi["viewmatrix"], st, shs=oi["shs"], scales=oi["scales"],
+                     rotations=oi["rotations"], extra_attrs=oa)
+    ((oo[0] * wc).sum() + (oo[5]["extra"] * we).sum()).backward()
+    rel_ok(out[0], oo[0], outliers=2e-5, what="color")
+    rel_ok(out[5], oo[5]["extra"], outliers=2e-5, what="extra")
+    rel_ok(ha.grad, oa.grad, outliers=2e-5, what="d_extra_attrs")
+    for k in NAMES:
+        rel_ok(hi[k].grad, oi[k].grad, outliers=2e-5, what="d_" + k)
+    rel_ok(hm2.grad, om2.grad, outliers=2e-5, what="d_means2D")

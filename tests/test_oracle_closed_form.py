@@ -140,3 +140,22 @@ def test_oracle_gradients_against_float64_finite_differences():
                 a[idx] = old
             fd = (lp - lm) / (2 * eps)
             assert abs(fd - g[idx].item()) <= 2e-4 * max(1.0, abs(fd)), (a.shape, idx, fd, g[idx].item())
+
+
+def test_oracle_extra_attributes_follow_the_colour_weights():
+    """The oracle's ``extra_attrs`` extension: attributes equal to the precomputed colours composite to the colour image
+    minus its background term, and a constant attribute of 1 composites to the alpha image."""
+    import torch
+    from oracle import rasterizer_oracle as O
+    sc = O.synthetic_scene(400, 64, 48, 3, seed=3)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    st = O.OracleSettings(48, 64, sc["tanfovx"], sc["tanfovy"], bg, 1.0, sc["projmatrix"], 0)
+    cols = torch.rand(400, 3, generator=torch.Generator().manual_seed(1))
+    attrs = torch.cat([cols, torch.ones(400, 1)], dim=1)
+    with torch.no_grad():
+        o = O.rasterize(sc["means3D"], torch.zeros(400, 3), sc["opacities"], sc["viewmatrix"], st, colors_precomp=cols,
+                        scales=sc["scales"], rotations=sc["rotations"], extra_attrs=attrs)
+    ex, T = o[5]["extra"], o[5]["final_T"]
+    assert ex.shape == (4, 48, 64)
+    assert torch.allclose(ex[:3] + T.unsqueeze(0) * bg.view(3, 1, 1), o[0], atol=1e-6)
+    assert torch.allclose(ex[3:4], o[3], atol=1e-6)
