@@ -258,6 +258,27 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     # After the warm-up the instance count D of every frame is known to within a few percent: stop reading it back
     # inside the forward (no host wait in the step).  Capacity is 1.25x the last D; an overflow would render that
     # frame empty and raise RasterizerCapacityOverflow at the next forward / at the final poll below.
+    points_after = None
+    if args.densify_first and not sharded:
+        if not densify_stats:
+            raise SystemExit("--densify-first needs the densification statistics (drop --no-densify-stats)")
+        # one densify-and-prune on the statistics of the steps so far (thresholds: the reference's rule at the 80 % quantile of
+        # the mean screen-space gradient, so that about a fifth of the visible cloud is cloned or split): the timed steps
+        # then run on a cloud whose rows were rebuilt, re-sorted along the Z curve and appended to -- not a BASELINE
+        # config, a check that the headline does not depend on a cloud that never densified
+        for _ in range(max(0, 24 - args.warmup)):
+            train_step(step)
+            step += 1
+        with torch.no_grad():
+            g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
+            seen = ds.stats.denom.reshape(-1) > 0
+            thr = float(torch.quantile(g_mean[seen][:2000000], 0.8)) if bool(seen.any()) else 1e9
+        info = ds.densify(max_grad=thr, min_opacity=0.005, percent_dense=0.01)
+        points_after = int(info["P"])
+        rstate = ds.raster_state
+        for _ in range(args.warmup):             # the new (P, H, W) needs its own capacity hint before the deferred check
+            train_step(step)
+            step += 1
     rasterizer.DEFERRED_OVERFLOW_CHECK = True
     # Untimed settling steps in the configuration the timed region runs in (deferred check, its pinned slots and hints in
     # place; clocks and allocator warm): W = 5 warm-up steps are 8 ms of GPU work, and the FIRST bench run on a fresh box
@@ -318,6 +339,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         dt = float(tt.item())
     out = {"mode": mode, "sharded": sharded, "dt": dt, "loss": float(loss.item()), "spatial_order": spatial_order,
            "graph": graphed is not None, "densify_stats": densify_stats, "deferred": deferred_in_timed_region,
+           "points_after_densify": points_after,
            "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
         if sharded:
@@ -334,7 +356,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
                 for f in perm:
                     o, _ = ds.render(f)
                     vsum += int((o[4] > 0).sum().item())
-                    dsum += int(rstate.capacity_hint.get((P, H, W), 0))
+                    dsum += int(rstate.capacity_hint.get((ds.P, H, W), 0))
                     _, n_contrib = rasterizer.last_compositing_state(rstate)
                     ssum += int(n_contrib.sum(dtype=torch.int64).item())
             out["D"], out["V"], out["S"] = dsum // len(perm), vsum // len(perm), ssum // len(perm)
@@ -366,6 +388,9 @@ def main():
                          "launching its ~50 kernels from Python -- what makes the step kernel-bound at the size of the "
                          "reference's real clouds (~100 k points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--densify-first", action="store_true",
+                    help="run ONE densify-and-prune (on the statistics of ~24 untimed steps) before the timed region: the "
+                         "timed steps then train a cloud that went through the row surgery (not the headline)")
     ap.add_argument("--no-densify-stats", action="store_true",
                     help="leave the per-iteration densification statistics (max_radii2D, xyz_gradient_accum, denom) out of "
                          "the step; by default they are part of it, as in every reference iteration below densify_until_iter")
@@ -459,7 +484,8 @@ def main():
         sh_adam_in_backward = bool(world == 1 and not sharded and not args.full_losses
                                    and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")
         radix_binning = bool(rasterizer_mod._FORCE_RADIX)
-        sb = stage_bytes(P, K, V, D, H, W, world=world, sharded=sharded, sh_adam_in_backward=sh_adam_in_backward,
+        P_eff = best["points_after_densify"] or P
+        sb = stage_bytes(P_eff, K, V, D, H, W, world=world, sharded=sharded, sh_adam_in_backward=sh_adam_in_backward,
                          radix_binning=radix_binning, densify_stats=best["densify_stats"])
         sms = dict(per_stage)
         sms["binning"] = per_stage["scan_dup"] + per_stage["sort"] + per_stage["ranges"]
@@ -520,6 +546,8 @@ def main():
                        "graph_replay": graph_replay,
                        # the statistics of /root/reference/src/trainer/rodygs.py:316-341 are kept by every timed step
                        "densify_stats": best["densify_stats"],
+                       # --densify-first: Gaussians after the one densify-and-prune that ran before the timed region
+                       "points_after_densify": best["points_after_densify"],
                        "deterministic_backward": bool(rasterizer_mod.DETERMINISTIC),
                        "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",
@@ -528,7 +556,7 @@ def main():
                        "sh_adam_in_backward": sh_adam_in_backward,
                        "binning": "radix" if radix_binning else "bucket",
                        "row_order": "z-curve of the canonical positions" if spatial_order else "generator (random)"},
-            "gaussians_per_s": fps * P,
+            "gaussians_per_s": fps * (best["points_after_densify"] or P),
             "loss": best["loss"],
             "stage_ms": per_stage,
             "step_roofline": {"algorithmic_bytes_per_step": b_step, "achieved_GBps": b_step * fps / world / 1e9,

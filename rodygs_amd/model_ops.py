@@ -222,6 +222,6 @@ def pose_view_matrix(cam_q: torch.Tensor, cam_t: torch.Tensor, frame: int, grad_
                      step_scalars=None) -> torch.Tensor:
     """W2C^T (glm storage, what the rasterizer takes as ``viewmatrix``) of frame ``frame`` from the learnable
     camera-to-world quaternions cam_q[T,4] (r,i,j,k) and translations cam_t[T,3].  ``step_scalars``: a device
-    ``RdgStepScalars`` (16-byte tensor) whose ``frame`` field replaces the argument -- the form a captured hipGraph can
+    ``RdgStepScalars`` (128-byte tensor) whose ``frame`` field replaces the argument -- the form a captured hipGraph can
     replay for a different frame (rodygs_amd.trainstep.GraphedStep)."""
     return _PoseView.apply(cam_q, cam_t, frame, grad_sinks, step_scalars)

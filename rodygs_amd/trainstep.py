@@ -209,13 +209,6 @@ class DynamicScene:
         self.fp = fp
         self.row_lr = {"features": (K * 3, 3, 0.0025 / 20.0)}
         self.time_ind = torch.randint(0, num_frames, (P,), generator=g).to(dev)
-        if os.environ.get("RDG_ROW_ORDER") == "birth":
-            # experiment: rows sorted by birth index, Z curve inside a birth index (what a one-pass deformation backward wants)
-            p2 = torch.sort(self.time_ind, stable=True).indices
-            with torch.no_grad():
-                for k in fp.names:
-                    fp[k].copy_(fp[k].detach()[p2].clone())
-            self.time_ind = self.time_ind[p2].contiguous()
         # the MLP initialises from the GLOBAL random stream: pin it to the scene seed (without disturbing the caller's
         # stream) so that every rank of a frame-DP job builds the same network
         with torch.random.fork_rng(devices=[]):
