@@ -176,9 +176,11 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
  *   - splat records: the first P*64 bytes of geom_ws, one 64-B row per Gaussian
  *       (px, py, conic_a, conic_b | conic_c, opacity, depth, radius as int bits | r, g, b, - | nx, ny, nz, -);
  *   - gradient rows: the first P*64 bytes of grad_ws, one 16-float row per Gaussian
- *       (m1x, m1y = sum over pixels of G dL/dG (px - x), G dL/dG (py - y): dL/dmean2D = -conic . (m1x, m1y) is formed by
- *        rdg_preprocess_backward; dL/dconic a b c -- these five divided by the Gaussian's opacity, which
- *        rdg_preprocess_backward multiplies back in --, dL/dopacity, dL/drgb, dL/ddepth, pad).
+ *       (moments of t = G dL/dG over the pixels about (w, dy), w = (px - x) + beta (py - y), beta = conic_b / conic_a of the
+ *        record -- the skew coordinate the exponent is evaluated in, so that needle-shaped footprints lose nothing to
+ *        cancellation: sum(t w), sum(t dy), -1/2 sum(t w^2), -sum(t w dy), -1/2 sum(t dy^2); these five divided by the
+ *        Gaussian's opacity, which rdg_preprocess_backward multiplies back in when it turns them into dL/dmean2D and
+ *        dL/dconic --, dL/dopacity, dL/drgb, dL/ddepth, pad).
  * A rank that owns a slice of the Gaussians runs the per-Gaussian halves for every camera of the step; the rank that
  * owns a camera gathers that camera's records into one geom_ws, calls rdg_geom_from_records (tile counts, radii and
  * the instance count D rebuilt from the records alone) and runs the compositing halves over all P records.        */

@@ -26,8 +26,9 @@ struct __attribute__((aligned(64))) RdgRec {
 };
 
 // 64-byte per-Gaussian gradient accumulator row (one 64-B atomic request per (tile, splat)):
-//   [0] [1] first moments sum(G dL/dG dx), sum(G dL/dG dy) of the pixel offsets (dL/dmean2D = -conic . moments,
-//   formed by the per-Gaussian backward)  [2..4] dL/dconic(a,b,c) -- these five DIVIDED BY THE OPACITY  [5] dL/dopacity  [6..8] dL/drgb  [9] dL/ddepth
+//   moments of t = G dL/dG about (w, dy), w = dx + beta dy, beta = conic_b / conic_a (the skew coordinate the exponent is
+//   evaluated in): [0] [1] sum(t w), sum(t dy) (dL/dmean2D = -conic . (dx, dy) moments, formed by the per-Gaussian backward)
+//   [2..4] -1/2 sum(t w^2), -sum(t w dy), -1/2 sum(t dy^2) (-> dL/dconic a, b, c there) -- these five DIVIDED BY THE OPACITY  [5] dL/dopacity  [6..8] dL/drgb  [9] dL/ddepth
 #define RDG_GROW 16
 
 static inline size_t rdg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -26,7 +26,8 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                           const float* __restrict__ colors, const float* __restrict__ opac,
                           const float* __restrict__ scales, const float* __restrict__ rots_b,
                           const float* __restrict__ cov3Dp, const int32_t* __restrict__ radii_b,
-                          const uint8_t* __restrict__ clampedm_b, const float* __restrict__ grow_b,
+                          const uint8_t* __restrict__ clampedm_b, const RdgRec* __restrict__ rec_b,
+                          const float* __restrict__ grow_b,
                           float* __restrict__ posebuf_b, float* __restrict__ dmeans3D_b, float* __restrict__ dmeans2D_b,
                           float* __restrict__ dshs, float* __restrict__ dcolors, float* __restrict__ dopac_b,
                           float* __restrict__ dscales_b, float* __restrict__ drots_b, float* __restrict__ dcov3D,
@@ -65,6 +66,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
     const float* __restrict__ rots = rots_b ? rots_b + vo * 4 : nullptr;
     const int32_t* __restrict__ radii = radii_b + vo;
     const uint8_t* __restrict__ clampedm = clampedm_b + vo;
+    const RdgRec* __restrict__ rec = rec_b + vo;
     const float* __restrict__ grow = grow_b + vo * RDG_GROW;
     float* __restrict__ posebuf = posebuf_b + (vo / BT) * RDG_POSE_N;
     float* __restrict__ dmeans3D = dmeans3D_b + vo * 3;
@@ -95,10 +97,20 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
             const float4* gr = reinterpret_cast<const float4*>(grow + (size_t)i * RDG_GROW);
             const float4 ga = gr[0], gb = gr[1], gc = gr[2];
             // the five geometric sums arrive divided by the opacity (a per-splat constant the compositing backward does
-            // not multiply every pixel-splat pair with): first moments sum(G dL/dG dx), sum(G dL/dG dy), conic gradients
+            // not multiply every pixel-splat pair with), as moments about (w, dy), w = dx + beta dy the conic's skew
+            // coordinate (beta = conic_b / conic_a as the compositing stage staged it, rdg_stage_conic; see rdg_bwd_walk for
+            // why): S_w, S_y, -1/2 S_ww, -S_wy, -1/2 S_yy.  With dx = w - beta dy:
+            //   -1/2 S_xx = (-1/2 S_ww) - beta (-S_wy) + beta^2 (-1/2 S_yy),   -S_xy = (-S_wy) - 2 beta (-1/2 S_yy)
             const float o_ = opac[i];
-            const float m1x = o_ * ga.x, m1y = o_ * ga.y;
-            const float gca = o_ * ga.z, gcb = o_ * ga.w, gcc = o_ * gb.x;
+            const float m1u = o_ * ga.x, m1y = o_ * ga.y;
+            // the conic the compositing kernels used, bit for bit (the record), and their beta from it
+            const float4 rq0 = rec[i].q0;
+            const float rka = rq0.z, rkb = rq0.w, rkc = rec[i].q1.x;
+            const float rA2 = -1.4426950408889634f * rka, rB = -1.4426950408889634f * rkb;
+            const float beta_s = (rA2 < 0.0f) ? rB / rA2 : 0.0f;
+            const float gcc = o_ * gb.x;
+            const float gcb = fmaf(-2.0f * beta_s, gcc, o_ * ga.w);
+            const float gca = fmaf(beta_s, fmaf(beta_s, gcc, -(o_ * ga.w)), o_ * ga.z);
             gop = gb.y;
             grgb[0] = gb.z; grgb[1] = gb.w; grgb[2] = gc.x;
             const float gdepth = gc.y;
@@ -159,9 +171,11 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
             // dL/dmean2D = -(conic . moments), and the pixel -> ndc factors 0.5 W, 0.5 H are applied here, once per
             // Gaussian, instead of per pixel-splat pair there (conic = Sigma2D^-1 = (c, -b, a) / det)
             if (det != 0.0f) {
-                const float idet = 1.0f / det;
-                gnx = -0.5f * (float)d.W * ((c * idet) * m1x - (b * idet) * m1y);
-                gny = -0.5f * (float)d.H * ((a * idet) * m1y - (b * idet) * m1x);
+                // conic . (m1x, m1y) with m1x = M_u - beta m1y:  ka M_u + (kb - ka beta) m1y,  kb M_u + (kc - kb beta) m1y --
+                // the first bracket is the rounding residue of beta (an FMA gives it exactly), the second det(conic) / ka:
+                // no term of the size of |conic| |m| is left to cancel
+                gnx = -0.5f * (float)d.W * fmaf(rka, m1u, __fmaf_rn(-rka, beta_s, rkb) * m1y);
+                gny = -0.5f * (float)d.H * fmaf(rkb, m1u, __fmaf_rn(-rkb, beta_s, rkc) * m1y);
             }
             {
                 const float hx = Pm[0] * vx + Pm[4] * vy + Pm[8] * vz + Pm[12];
@@ -488,7 +502,7 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
     if (d.P > 0) {
         hipLaunchKernelGGL(rdg_preprocess_bwd_kernel<false>, dim3(nblk), dim3(256), 0, s, d, view, proj, means3D, shs, colors,
                            opac, scales, rots, cov3D, radii, (const uint8_t*)((const char*)geom_ws + G.clamped),
-                           grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D, 1, 0,
+                           (const RdgRec*)((const char*)geom_ws + G.rec), grow, posebuf, dmeans3D, dmeans2D, dshs, dcolors, dopac, dscales, drots, dcov3D, 1, 0,
                            sh_adam ? *sh_adam : RdgShAdam{});
     }
     // second-level rows live behind the per-workgroup rows (rdg_grad_bytes reserves them)
@@ -509,7 +523,8 @@ int rdg_launch_preprocess_bwd_views(const RdgDev& d, int32_t nviews, int32_t str
     if (d.P > 0)
         hipLaunchKernelGGL(rdg_preprocess_bwd_kernel<true>, dim3(nblk), dim3(128), 0, s, d, views, proj, means3D, shs,
                            (const float*)nullptr, opac, scales, rots, (const float*)nullptr, radii,
-                           (const uint8_t*)((const char*)geom_ws + G.clamped), grow, posebuf, dmeans3D, dmeans2D, dshs,
+                           (const uint8_t*)((const char*)geom_ws + G.clamped),
+                           (const RdgRec*)((const char*)geom_ws + G.rec), grow, posebuf, dmeans3D, dmeans2D, dshs,
                            (float*)nullptr, dopac, dscales, drots, (float*)nullptr, nviews, stride, RdgShAdam{});
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd views launch");
 }

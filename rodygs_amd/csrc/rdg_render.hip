@@ -106,6 +106,11 @@ __device__ __forceinline__ float rdg_log2_gauss(float hA, float beta, float gam,
     const float w = fmaf(beta, dy, dx);
     return fmaf(hA * w, w, (gam * dy) * dy);
 }
+// the same, handing out the skew coordinate w = dx + beta dy (the backward takes its x-moments along it)
+__device__ __forceinline__ float rdg_log2_gauss_w(float hA, float beta, float gam, float dx, float dy, float& w) {
+    w = fmaf(beta, dy, dx);
+    return fmaf(hA * w, w, (gam * dy) * dy);
+}
 
 // wave votes straight from the ballot (hip's __any/__all go through an int compare per lane)
 __device__ __forceinline__ bool rdg_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -667,7 +672,8 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
         const float4 q0 = *(const float4*)(sQ0 + aj);
         const float4 q1 = *(const float4*)(sQ1 + aj);
         const float dx = q0.x - pixx, dy = q0.y - pixy;
-        const float power = rdg_log2_gauss(q0.z, q0.w, q1.x, dx, dy);
+        float wsk;                                                  // dx + beta dy
+        const float power = rdg_log2_gauss_w(q0.z, q0.w, q1.x, dx, dy, wsk);
         const float G = __builtin_amdgcn_exp2f(power);
         float alpha = q1.y * G;
         const bool capped = CAPPED && ((cap >> jb) & 1ull);
@@ -709,15 +715,21 @@ __device__ __forceinline__ void rdg_bwd_walk(unsigned long long mask, const unsi
         behind = fmaf(aeff, e_, behind);
         const float dL_dalpha = e_ * T;
         // What leaves the lane: the weight t0 = G dL/dalpha (= dL/dopacity; G dL/dG = opacity * t0, the opacity
-        // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 dx and
-        // t2 = t0 dx^2, and the colour terms.  The y-moments are NOT formed per pixel: the eight lanes of a
+        // being a per-splat constant applied by the per-Gaussian backward), its x-moments t1 = t0 w and
+        // t2 = t0 w^2 ALONG THE CONIC'S SKEW AXIS, w = dx + beta dy (beta = conic_b / conic_a: the coordinate the
+        // exponent was evaluated in, so it costs nothing here), and the colour terms.  Moments about (w, dy) instead of
+        // (dx, dy): for a needle-shaped footprint sum(t0 dx) and beta sum(t0 dy) are large and cancel in
+        // dL/dmean = -conic . moments; accumulated separately over pixels, waves and tiles, their rounding would come out
+        // amplified by the footprint's condition number (1.5e-4 of the column's largest entry of dL/dmean on a
+        // det / (a c) = 0.04 splat, sweep case 90000 / 159), where sum(t0 w) has nothing to cancel.  The per-Gaussian
+        // backward turns the (w, dy) moments back into the (dx, dy) ones it needs (rdg_preprocess_bwd.hip).  The y-moments are NOT formed per pixel: the eight lanes of a
         // pixel row share dy, so sum(t0 dy) = dy sum(t0), sum(t0 dx dy) = dy sum(t1), sum(t0 dy^2) = dy^2 sum(t0)
         // are formed from the row totals (two multiplies per visit instead of three, and six values to reduce
         // instead of nine).  The constant factors of the conic derivatives (-0.5, -1, -0.5) are applied once per
         // flushed row total (rdg_ring_flush).
         const float t0 = Gm * dL_dalpha;
-        const float t1 = t0 * dx;
-        const float t2 = t1 * dx;
+        const float t1 = t0 * wsk;
+        const float t2 = t1 * wsk;
         const float c0 = dch * dLp0, c1 = dch * dLp1, c2 = dch * dLp2, cd = HAS_DEPTH ? dch * dLd : 0.0f;
         // Transposed reduction over the 8 lanes of a pixel row: DPP write masks work on quads (bank_mask), so the
         // step across the row's two quads comes first and folds two values into one register (quad A = lanes

@@ -113,10 +113,15 @@ gpy = geom["py"].grad if geom["py"].grad is not None else z
 cov2 = geom["cov2D"].detach()
 m1x = -(cov2[:, 0] * gpx + cov2[:, 1] * gpy)
 m1y = -(cov2[:, 1] * gpx + cov2[:, 2] * gpy)
+# the rows hold moments about (w, dy), w = dx + beta dy, beta = conic_b / conic_a (rdg_bwd_walk)
+kon = geom["conic"].detach()
+beta = torch.where(kon[:, 0] != 0, kon[:, 1] / kon[:, 0], z)
 orow = torch.zeros(P, 16, dtype=torch.float64)
 inv_o = torch.where(op != 0, 1.0 / op, z)
-orow[:, 0], orow[:, 1] = m1x * inv_o, m1y * inv_o
-orow[:, 2:5] = gcon * inv_o.unsqueeze(1)
+orow[:, 0], orow[:, 1] = (m1x + beta * m1y) * inv_o, m1y * inv_o
+# conic-gradient columns in the (w, dy) moment basis of the rows: -1/2 S_ww = gca + beta gcb + beta^2 gcc, -S_wy = gcb + 2 beta gcc
+gw = torch.stack([gcon[:, 0] + beta * gcon[:, 1] + beta * beta * gcon[:, 2], gcon[:, 1] + 2 * beta * gcon[:, 2], gcon[:, 2]], 1)
+orow[:, 2:5] = gw * inv_o.unsqueeze(1)
 orow[:, 6:9] = geom["rgb"].grad if geom["rgb"].grad is not None else 0.0
 orow = torch.where(vis.unsqueeze(1), orow, torch.zeros_like(orow))
 # the float32 oracle's own rows: what float32 autograd (every T_i kept from the forward) reaches
@@ -130,7 +135,9 @@ for k in ("conic", "rgb"):
     g32[k].retain_grad()
 ((o32[0] * wc).sum() + (o32[3] * wa).sum() + (o32[1] * wd).sum() * kw["depth_loss"]).backward()
 r32 = torch.zeros(P, 16, dtype=torch.float64)
-r32[:, 2:5] = g32["conic"].grad.double() * inv_o.unsqueeze(1)
+g32c = g32["conic"].grad.double()
+r32[:, 2:5] = torch.stack([g32c[:, 0] + beta * g32c[:, 1] + beta * beta * g32c[:, 2], g32c[:, 1] + 2 * beta * g32c[:, 2],
+                           g32c[:, 2]], 1) * inv_o.unsqueeze(1)
 r32[:, 6:9] = g32["rgb"].grad.double()
 print("(0) float32-oracle rows vs float64 oracle:")
 for name, sl in (("conic", slice(2, 5)), ("rgb", slice(6, 9))):
