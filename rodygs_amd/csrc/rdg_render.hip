@@ -932,6 +932,11 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
     __shared__ unsigned long long sMask[4][4];
     __shared__ unsigned long long sCap[4];   // per staging wave: splats whose opacity exceeds the alpha cap
     __shared__ int sMax[4];
+#ifdef RDG_ABL_BWD_LDSPAD   // ablation build: extra LDS per workgroup = fewer workgroups per CU (what a matrix-core row
+                            // reduction with its per-wave transpose buffers would leave: profiles/r04_render_bwd_mfma_bound.txt)
+    __shared__ float sPad[RDG_ABL_BWD_LDSPAD / 4];
+    if (W == -12345) sPad[threadIdx.x] = 1.0f;
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const size_t hw = (size_t)H * W;
