@@ -7,7 +7,7 @@ set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=$PWD
-T=${1:-r03}
+T=${1:-r04}
 O=$R/gpurun_out/prof_$T
 mkdir -p $O
 python3 bench.py > $O/${T}_bench.json 2> $O/bench.err
@@ -30,6 +30,13 @@ done
 python3 bench.py --points 100000 --no-cpu-baseline > $O/${T}_photometric_100k_bench.json 2>/dev/null
 python3 bench.py --points 100000 --no-cpu-baseline --graph > $O/${T}_photometric_100k_graph_bench.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --graph > $O/${T}_graph_bench.json 2>/dev/null
+# the config-5 loss set under the graph (four replayed steps between two eager rigidity steps), at the reference's real cloud size
+python3 bench.py --points 100000 --full-losses --no-cpu-baseline > $O/${T}_full_losses_100k_bench.json 2>/dev/null
+python3 bench.py --points 100000 --full-losses --no-cpu-baseline --graph > $O/${T}_full_losses_100k_graph_bench.json 2>/dev/null
+# the step on a cloud that went through one densify-and-prune (not a BASELINE config)
+python3 bench.py --no-cpu-baseline --densify-first > $O/${T}_densified_bench.json 2>/dev/null
+# the radix binning forced on the headline frame (the default picks bucket binning there)
+RDG_BIN_MODE=radix python3 bench.py --no-cpu-baseline > $O/${T}_radix_binning_bench.json 2>/dev/null
 python3 bench.py --points 4000000 --width 3840 --height 2160 --steps 10 --warmup 5 --gt-frames 4 --no-cpu-baseline > $O/${T}_photometric_4m_4k_bench.json 2>/dev/null
 python3 bench.py --full-losses --no-cpu-baseline > $O/${T}_full_losses_bench.json 2>/dev/null
 python3 bench.py --full-losses --points 4000000 --width 3840 --height 2160 --steps 10 --warmup 5 --gt-frames 4 --no-cpu-baseline > $O/${T}_full_losses_4m_4k_bench.json 2>/dev/null
