@@ -17,7 +17,9 @@
 // A chained-scan ("onesweep") form of the pass -- one launch, the tile's place in the output taken from its predecessors
 // through a decoupled look-back -- was built first and measured (round 4): bit-exact, and 2.3 TB/s, because with 8 XCDs
 // the agent-scope status loads of the look-back cost a microsecond apiece and a tile of the first dispatch wave has
-// hundreds of predecessors to walk: 120 us per pass at 17 M pairs against 75 us for the three launches here.
+// hundreds of predecessors to walk: 120 us per pass + a 50 us histogram launch per sort at 17 M pairs against 37 + 11 + 78 us
+// (count, scan, scatter) for the three launches here; 18 against 22 us at 1 M keys (profiles/r04_experiments.txt).  No gain
+// worth a kernel that relies on the forward progress of its predecessors; the three-launch form is kept.
 #include "rdg_common.h"
 
 #define RDG_RS_THREADS 256
