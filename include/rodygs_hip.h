@@ -397,24 +397,34 @@ int rdg_reset_opacity(int64_t n, float max_opacity, float* opacity_logit, float*
                       void* stream);
 
 /* Distance-preserving term of RigidityLoss (/root/reference/src/trainer/losses.py:293-358) without the [t,n,K,3]
- * intermediates: pos_t4 [nt,n,4] = position (canonical + translation, w unused) of every sampled Gaussian at the
- * drawn times, nn_idx [n,K] (indices into the sample), d2 [n,K] squared neighbour distances, and the reverse
- * adjacency of nn_idx (rev_off [n+1], rev_edge [n*K] = edge ids i*K+k sorted by destination) so that every gradient
- * row is written once instead of through scattered atomics.  rev_dst (optional, [n*K]): the destination of every entry
- * of rev_edge (the sorted keys themselves); with it a wave shares out the edges arriving at its 64 Gaussians evenly
- * among its lanes instead of each lane walking its own in-degree.  orig (optional, [n]): when the caller stores the sample
- * in another (cache-friendly) order, orig[s] = position of stored element s in the reference's sample order, which
- * defines the pairing f / nt; d2 / d_d2 stay in that original order.  Writes loss_sum[0] (f64) = sum over
- * (tau, i, k) of sqrt((gap - d2_flat[f / nt])^2 + eps^2), its unscaled gradient w.r.t. the positions -- G_t4 [nt,n,4]
- * in stored order, or, when G3_orig is given (needs orig), G3_orig [nt,n,3] in the ORIGINAL sample order, i.e. already in
- * the layout of the caller's position tensor (G_t4 may then be NULL) -- and d_d2 [n,K].                                                                                          */
-int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const float* pos_t4, const int64_t* nn_idx,
-                            const float* d2, const int64_t* rev_off, const int64_t* rev_edge, const int64_t* rev_dst,
-                            const int64_t* orig, float eps, double* loss_sum, float* G_t4, float* d_d2, float* G3_orig,
-                            void* stream);
-/* pos4 [nt,n,4] = (pos3 [nt,n,3] rows taken in `order` [n], 0): the stored-order, 16-B-row copy of the sample's positions
- * that rdg_rigidity_dp_forward gathers from, in one launch.                                                           */
-int rdg_rigidity_pack(int64_t n, int32_t nt, const float* pos3, const int64_t* order, float* pos4, void* stream);
+ * intermediates, on the layout of the reference's own translation tensor (`own` [n, nt, 3], losses.py:305-306): positions
+ * Gaussian-major, a group of lanes per Gaussian with lane = drawn time, every edge end one coalesced row read.
+ * rdg_rigidity_pack_rows: P3 [n][nt][3] = own[order[s]] + canon[order[s]] (canon [n,3]; order NULL = identity): the sample
+ * re-laid along a cache-friendly stored order.
+ * rdg_rigidity_dp_rows: P3 as above; nn_idx [n,K] neighbour lists and the reverse adjacency (rev_off [n+1], rev_edge [n*K] =
+ * edge ids s*K+k sorted by destination) in stored ids; orig = order (stored position -> row of the reference's sample order,
+ * which defines the pairing f / nt), rank = its inverse; d2 / d_d2 [n,K] in that original order; IG: workspace of n*K*nt floats;
+ * RA (optional): workspace of n*nt*2 floats -- with it (and nt >= K) d_d2 is added up in a fixed order by a third launch
+ * instead of through float atomics.  Writes loss_sum[0] (f64) = sum over (tau, i, k) of sqrt((gap - d2_flat[f / nt])^2 + eps^2),
+ * d_d2, and the unscaled gradient in the CALLER's layout and row order: G_own [n,nt,3] (w.r.t. own) and G_canon [n,3] (its sum
+ * over the times; may be NULL).                                                                                         */
+int rdg_rigidity_pack_rows(int64_t n, int32_t nt, const float* own, const float* canon, const int64_t* order, float* P3,
+                           void* stream);
+int rdg_rigidity_dp_rows(int64_t n, int32_t K, int32_t nt, const float* P3, const int64_t* nn_idx, const float* d2,
+                         const int64_t* rev_off, const int64_t* rev_edge, const int64_t* orig, const int64_t* rank, float eps,
+                         double* loss_sum, float* IG, float* RA, float* d_d2, float* G_own, float* G_canon, void* stream);
+
+/* The other two scatters of a RigidityLoss step through the same stored-order K-NN graph (X [n,3] = the sample's positions,
+ * nbr [n,K] neighbour lists, rev_off [n+1] / rev_edge [n*K] reverse adjacency -- all in the stored (curve) order; orig [n] =
+ * row of stored element s in the caller's order).  Every gradient row is written once, no float atomics.
+ * rdg_graph_points_backward: the backward of knn_points(p, p, K) (pytorch3d; call site /root/reference/src/trainer/losses.py:235):
+ *   g_dists [n,K] and d_pts [n,3] in the caller's order; same sum as rdg_knn_points_backward with queries == targets.
+ * rdg_graph_surface: the "surface" term (/root/reference/src/trainer/losses.py:241-250): loss_sum[0] (f64) = sum_i
+ *   || x_i - mean_k x_nn(i,k) + 1e-6 || and d_pts [n,3] (caller's order) = its gradient; U: workspace of n*3 floats.     */
+int rdg_graph_points_backward(int64_t n, int32_t K, const float* X, const int64_t* nbr, const int64_t* rev_off,
+                              const int64_t* rev_edge, const int64_t* orig, const float* g_dists, float* d_pts, void* stream);
+int rdg_graph_surface(int64_t n, int32_t K, const float* X, const int64_t* nbr, const int64_t* rev_off,
+                      const int64_t* rev_edge, const int64_t* orig, float* U, double* loss_sum, float* d_pts, void* stream);
 
 /* ---- Pearson depth losses (GlobalPearsonDepthLoss / LocalPearsonDepthLoss, /root/reference/src/trainer/losses.py:108-182;
  *      pearson_depth_loss, /root/reference/src/utils/loss_utils.py:100-117) -------------------------------------------

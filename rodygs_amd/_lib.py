@@ -102,8 +102,10 @@ _SIGS = {
     "rdg_split_children": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
     "rdg_densify_stats": (C.c_int, [C.c_int64, C.c_int64] + [_vp] * 6),
     "rdg_reset_opacity": (C.c_int, [C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
-    "rdg_rigidity_dp_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32] + [_vp] * 7 + [C.c_float] + [_vp] * 5),
-    "rdg_rigidity_pack": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp]),
+    "rdg_graph_points_backward": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
+    "rdg_graph_surface": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 9),
+    "rdg_rigidity_pack_rows": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "rdg_rigidity_dp_rows": (C.c_int, [C.c_int64, C.c_int32, C.c_int32] + [_vp] * 7 + [C.c_float] + [_vp] * 7),
     "rdg_motion_reg_forward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp]),
     "rdg_motion_reg_backward": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, C.c_float, C.c_float, _vp, C.c_int32, _vp]),
     "rdg_basis_reg_ws_bytes": (C.c_size_t, [C.c_int32]),

@@ -493,20 +493,8 @@ int rdg_knn_gather_backward(int64_t n_rows, int32_t U, int64_t n_src_rows, const
 
 }  // extern "C"
 
-// ---------------------------------------------------------------------------------------------------------
-// Distance-preserving term of RigidityLoss (/root/reference/src/trainer/losses.py:293-358), the part that the
-// reference materialises as several [t, n, K, 3] tensors (1.2 GB each at n = 500 k, t = 25): for every sampled
-// Gaussian i, neighbour k and drawn time tau,
-//     gap = || (canon_nn + own_nn(tau)) - (canon_i + own_i(tau)) ||,
-//     term = sqrt((gap - y)^2 + eps^2),   y = d2_flat[f / nt],  f = (tau * n + i) * K + k
-// (the reference views the [t, n, K] block of gaps as rows of nt consecutive entries and compares row r with the
-// r-th squared neighbour distance; kept).  One thread per (tau, i) walks the K neighbours; the positions
-// pos_t = canon + own(tau) and the gradient G_t are laid out [nt][n] float4, one 16-B gather per edge end.
-// Outputs are the SUM of the terms and its unscaled gradients: G_t (w.r.t. pos_t) and d_d2 [n*K].
-// ---------------------------------------------------------------------------------------------------------
-// f / d for f < 2^52 through one double multiply and a correction step: the 64-bit integer division the compiler emits is
-// ~100 instructions, and the kernel below needs one per edge end (the reference's f / nt row pairing) -- a third of its
-// run time before (2.2 -> 1.4 ms at n = 500 k, nt = 25)
+// f / d for 0 <= f < 2^52 through one double multiply and a correction step: the 64-bit integer division the compiler emits is
+// ~100 instructions, and the kernels below need one per (Gaussian, time) pair (the reference's f / nt row pairing)
 __device__ __forceinline__ long long rdg_div_pos(long long f, long long d, double inv_d) {
     long long q = (long long)((double)f * inv_d);
     const long long r = f - q * d;
@@ -514,173 +502,119 @@ __device__ __forceinline__ long long rdg_div_pos(long long f, long long d, doubl
     return q;
 }
 
-// Time slabs a workgroup carries its 256 Gaussians through: the index data (neighbour lists, arriving edges) is read once
-// per group instead of once per slab.  Measured at n = 2 M, nt = 25 (scripts/rig_probe.py): 1 / 2 / 3 / 5 slabs per group
-// 9.4 / 9.1 / 9.0 / 9.2 ms -- the kernel is bound by the latency of its ~33 gathers per (time, Gaussian), not by the index
-// traffic; 2 keeps the LDS small.
-#ifndef RDG_RIG_TG
-#define RDG_RIG_TG 2
+
+// ---------------------------------------------------------------------------------------------------------
+// Distance-preserving term of RigidityLoss (/root/reference/src/trainer/losses.py:293-358), the part that the
+// reference materialises as several [t, n, K, 3] tensors (1.2 GB each at n = 500 k, t = 25): for every sampled
+// Gaussian i, neighbour k and drawn time tau,
+//     gap = || (canon_nn + own_nn(tau)) - (canon_i + own_i(tau)) ||,
+//     term = sqrt((gap - y)^2 + eps^2),   y = d2_flat[f / nt],  f = (tau * n + i) * K + k
+// (the reference views the [t, n, K] block of gaps as rows of nt consecutive entries and compares row r with the
+// r-th squared neighbour distance; kept).  Outputs are the SUM of the terms and its unscaled gradients.
+//
+// The positions are stored GAUSSIAN-major: P3 [n][nt][3], the nt positions of a sampled Gaussian in one contiguous row
+// (300 B at nt = 25) -- which is how the caller's translation tensor [n, nt, 3] is laid out anyway.
+// A group of LPG lanes (LPG = 8 ... 64, the power of two >= nt) owns one Gaussian, lane = drawn time: an edge end is then ONE
+// coalesced row read for the group.  (Rounds 1-4 kept time-major slabs [nt][n] float4 with a thread per (time, Gaussian):
+// one 16-B gather per (time, edge end), 0.8 G gathers at n = 2 M, nt = 25, served at the rate the L2 hands out 64-B
+// sectors: 9.0 ms against 4.7 ms for the three launches below on the same cloud.)  Launches:
+//   out : the K edges leaving every Gaussian: the terms, the d2 gradient, -u on this end; the factor ig = s / gap of every
+//         (edge, time) is kept (IG [n*K][nt], one coalesced row per edge);
+//   in  : the edges arriving at every Gaussian (reverse adjacency): +ig (p - q) with the stored factor: one row of the
+//         source's positions and one row of IG per edge -- no d2 gather, no division, no square root, and nothing to
+//         balance: a group's trip count is its Gaussian's in-degree, groups are independent.
+// The gradient leaves in the caller's layout and row order (G_own [n][nt][3], written by `out`, completed by `in`), with its
+// sum over the times (the canonical position's gradient, G_canon [n][3]).
+// ---------------------------------------------------------------------------------------------------------
+#ifndef RDG_RIGR_ITERS
+#define RDG_RIGR_ITERS 4       // Gaussians a lane group handles one after the other
 #endif
-template <int KT>      // KT > 0: K known at compile time -- the K neighbour loads of a thread are issued together
+
+// RA (optional, needs nt >= K): the K terms of a (Gaussian, time) pair fall into at most two consecutive rows of d2; their two
+// partial d2 gradients are then STORED (RA [n][nt][2], coalesced) and rdg_rigidity_d2grad_kernel adds up every row's handful
+// of contributions in a fixed order -- instead of 1.3 scattered float atomics per pair (66 M at n = 2 M, nt = 25: 1.5 of
+// the 3.6 ms of this kernel, measured with them removed).
+template <int LPG, int KT>
 __global__ void __launch_bounds__(256)
-rdg_rigidity_dp_kernel(long long n, int K_rt, int nt, const float4* __restrict__ pos_t, const long long* __restrict__ nn_idx,
-                       const float* __restrict__ d2, const long long* __restrict__ rev_off,
-                       const long long* __restrict__ rev_edge, const long long* __restrict__ rev_dst,
-                       const long long* __restrict__ orig, float eps2,
-                       double* __restrict__ loss_sum, float4* __restrict__ G_t, float* __restrict__ d_d2,
-                       float* __restrict__ G3_orig) {
-    // grid: (blocks over i, groups of RDG_RIG_TG time slabs) -- the 64 lanes of a wave are 64 consecutive sampled Gaussians
-    const int tau0 = blockIdx.y * RDG_RIG_TG;
-    const int ntg = min(RDG_RIG_TG, nt - tau0);
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+rdg_rigidity_rows_out_kernel(long long n, int K_rt, int nt, const float* __restrict__ P3, const long long* __restrict__ nn_idx,
+                             const float* __restrict__ d2, const long long* __restrict__ orig, float eps2,
+                             double* __restrict__ loss_sum, float* __restrict__ IG, float2* __restrict__ RA,
+                             float* __restrict__ G_own, float* __restrict__ d_d2) {
+    constexpr int GPB = 256 / LPG;                 // lane groups per workgroup
+    const int tl = threadIdx.x % LPG;
     const int K = KT > 0 ? KT : K_rt;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const double inv_nt = 1.0 / (double)nt;
-    __shared__ float4 sP[4][RDG_RIG_TG][64];       // the wave's own positions per slab, for the edges that arrive at them
-    __shared__ float4 sC[4][64];                   // one chunk of 64 arriving edges: their gradient contributions
-    double local = 0.0;
-    const bool act = i < n;
-    float gx[RDG_RIG_TG], gy[RDG_RIG_TG], gz[RDG_RIG_TG];    // d/d(pos_i(tau)) for the slabs of the group
-    // `orig` (optional): the sample is stored in a cache-friendly order (neighbours close in memory); the
-    // reference's pairing of gaps with d2 entries is defined on the ORIGINAL sample order, so rows use orig[]
-    const long long i_row = act ? (orig ? orig[i] : i) : 0;
-    long long nbr[KT > 0 ? KT : 1];
-    if (KT > 0 && act) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k) nbr[k] = nn_idx[i * K + k];           // all K index loads in flight together
-    }
     const long long n_rows = n * K;
+    const bool two_rows = nt >= K;                 // K consecutive flat entries touch at most two rows of d2
+    double local = 0.0;
+    for (int it = 0; it < RDG_RIGR_ITERS; ++it) {
+        const long long s = ((long long)blockIdx.x * RDG_RIGR_ITERS + it) * GPB + threadIdx.x / LPG;
+        if (s >= n) break;
+        const long long i_row = orig ? orig[s] : s;
+        long long nbr[KT > 0 ? KT : 1];
+        if (KT > 0) {
 #pragma unroll
-    for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
-        gx[tg] = gy[tg] = gz[tg] = 0.f;
-        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act && tg < ntg) {
-            const long long tau = tau0 + tg;
-            const float4* slab = pos_t + tau * n;      // positions of all sampled Gaussians at this time, 16 B each
-            p = slab[i];
-            // (1) edges leaving i: the loss terms themselves, -u on this end, the d2 gradient.  Their rows are
-            // (f0 + k) / nt for consecutive k: one division, then a running remainder
-            const long long f0 = (tau * n + i_row) * K;
+            for (int k = 0; k < KT; ++k) nbr[k] = nn_idx[s * K + k];
+        }
+        for (int tau = tl; tau < nt; tau += LPG) {
+            const float* pp = P3 + (s * nt + tau) * 3;
+            const float px = pp[0], py = pp[1], pz = pp[2];
+            const long long f0 = ((long long)tau * n + i_row) * K;
             long long row = rdg_div_pos(f0, nt, inv_nt);
             int rem = (int)(f0 - row * nt);
-            // K consecutive flat entries touch at most two rows when nt >= K: two loads instead of K gathers
-            const bool two_rows = nt >= K;
-            const float y0 = d2[row], y1 = two_rows ? d2[row + 1 < n_rows ? row + 1 : row] : 0.f;
-            const long long row0 = row;
-            long long row_prev = -1;
-            float row_acc = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            float* ig_row = IG + (s * K) * nt + tau;
+            if (two_rows) {
+                const float y0 = d2[row], y1 = d2[row + 1 < n_rows ? row + 1 : row];
+                const int k1 = nt - rem;                          // entries k >= k1 belong to the next row
+                float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
-                const float4 q = slab[KT > 0 ? nbr[k] : nn_idx[i * K + k]];
-                const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-                const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-                const float y = two_rows ? (row == row0 ? y0 : y1) : d2[row];
-                const float diff = gap - y;
-                const float term = sqrtf(diff * diff + eps2);
-                local += (double)term;
-                const float s = diff / term;                 // d term / d gap ;  d term / d y = -s
-                if (row != row_prev) {
-                    if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
-                    row_prev = row; row_acc = 0.f;
+                for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
+                    const float* qp = P3 + ((KT > 0 ? nbr[k] : nn_idx[s * K + k]) * nt + tau) * 3;
+                    const float dx = qp[0] - px, dy = qp[1] - py, dz = qp[2] - pz;
+                    const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+                    const bool nx = k >= k1;
+                    const float diff = gap - (nx ? y1 : y0);
+                    const float term = sqrtf(diff * diff + eps2);
+                    local += (double)term;
+                    const float sg = diff / term;                 // d term / d gap ;  d term / d y = -sg
+                    acc0 -= nx ? 0.f : sg; acc1 -= nx ? sg : 0.f;
+                    const float ig = gap > 0.f ? sg / gap : 0.f;  // torch.norm backward is 0 at the origin
+                    ig_row[(long long)k * nt] = ig;
+                    ax -= ig * dx; ay -= ig * dy; az -= ig * dz;
                 }
-                row_acc -= s;
-                const float ig = gap > 0.f ? s / gap : 0.f;  // torch.norm backward is 0 at the origin
-                ax -= ig * dx; ay -= ig * dy; az -= ig * dz;
-                if (++rem == nt) { rem = 0; ++row; }
-            }
-            if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
-            gx[tg] = ax; gy[tg] = ay; gz[tg] = az;
-        }
-        sP[wv][tg][lane] = p;
-    }
-    // (2) edges ARRIVING at i (reverse adjacency): the same terms recomputed, +u on this end -- instead of three
-    // scattered float atomics per (tau, edge), which ran at the 4-byte-atomic rate (13 ms at n = 500 k).
-    if (rev_dst) {
-        // Balanced form: the edges that arrive at the wave's 64 Gaussians are ONE contiguous stretch of the
-        // destination-sorted edge list; the lanes take them 64 at a time, one edge per lane whatever its destination (a
-        // lane walking its OWN arrivals made the wave wait for its largest in-degree: ~25 trips for an average of 8),
-        // park the edge's contribution in LDS, and every destination lane then adds its own run of the chunk (three
-        // LDS reads per edge: the heavy part -- two gathers, a division, two square roots -- is what got balanced).
-        const long long i_first = (long long)blockIdx.x * 256 + (wv << 6);
-        if (i_first < n) {
-            const long long i_end = i_first + 64 < n ? i_first + 64 : n;
-            const long long E0 = rev_off[i_first], E1 = rev_off[i_end];
-            const long long my0 = act ? rev_off[i] : 0, my1 = act ? rev_off[i + 1] : 0;
-            rdg_wave_lds_sync();
-            for (long long base = E0; base < E1; base += 64) {
-                const long long e = base + lane;
-                const bool ev = e < E1;
-                long long src = 0, fk = 0;
-                int dl = 0;
-                if (ev) {
-                    const long long edge = rev_edge[e];
-                    src = KT > 0 ? edge / KT : edge / K;
-                    fk = (orig ? orig[src] : src) * K + (edge - src * K);      // flat index of the edge inside a slab
-                    dl = (int)(rev_dst[e] - i_first);
+                if (RA) RA[s * nt + tau] = make_float2(acc0, acc1);
+                else {
+                    atomicAdd(&d_d2[row], acc0);
+                    if (k1 < K) atomicAdd(&d_d2[row + 1], acc1);
                 }
-                const int a0 = (int)((my0 > base ? my0 : base) - base), a1 = (int)((my1 < base + 64 ? my1 : base + 64) - base);
-#pragma unroll
-                for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
-                    if (tg >= ntg) break;
-                    const long long tau = tau0 + tg;
-                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ev) {
-                        const float4 q = pos_t[tau * n + src];
-                        const float4 pd = sP[wv][tg][dl];
-                        const float dx = pd.x - q.x, dy = pd.y - q.y, dz = pd.z - q.z;
-                        const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-                        const long long rrow = rdg_div_pos(tau * n * K + fk, nt, inv_nt);
-                        const float diff = gap - d2[rrow];
-                        const float s = diff / sqrtf(diff * diff + eps2);
-                        const float ig = gap > 0.f ? s / gap : 0.f;
-                        c = make_float4(ig * dx, ig * dy, ig * dz, 0.f);
-                    }
-                    sC[wv][lane] = c;
-                    rdg_wave_lds_sync();
-                    float ax = 0.f, ay = 0.f, az = 0.f;
-                    for (int t = a0; t < a1; ++t) {
-                        const float4 v = sC[wv][t];
-                        ax += v.x; ay += v.y; az += v.z;
-                    }
-                    gx[tg] += ax; gy[tg] += ay; gz[tg] += az;
-                    rdg_wave_lds_sync();
-                }
-            }
-        }
-    } else if (act) {
-        for (long long e = rev_off[i]; e < rev_off[i + 1]; ++e) {
-            const long long edge = rev_edge[e];
-            const long long src = KT > 0 ? edge / KT : edge / K;
-            const long long fk = (orig ? orig[src] : src) * K + (edge - src * K);
-#pragma unroll
-            for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
-                if (tg >= ntg) break;
-                const long long tau = tau0 + tg;
-                const float4 q = pos_t[tau * n + src], p = sP[wv][tg][lane];
-                const float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-                const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
-                const long long rrow = rdg_div_pos(tau * n * K + fk, nt, inv_nt);
-                const float diff = gap - d2[rrow];
-                const float s = diff / sqrtf(diff * diff + eps2);
-                const float ig = gap > 0.f ? s / gap : 0.f;
-                gx[tg] += ig * dx; gy[tg] += ig * dy; gz[tg] += ig * dz;
-            }
-        }
-    }
-    if (act) {
-#pragma unroll
-        for (int tg = 0; tg < RDG_RIG_TG; ++tg) {
-            if (tg >= ntg) break;
-            const long long tau = tau0 + tg;
-            if (G3_orig) {            // the caller's own layout: [nt][n][3] in the ORIGINAL sample order
-                float* g3 = G3_orig + (tau * n + i_row) * 3;
-                g3[0] = gx[tg]; g3[1] = gy[tg]; g3[2] = gz[tg];
             } else {
-                G_t[tau * n + i] = make_float4(gx[tg], gy[tg], gz[tg], 0.f);
+                long long row_prev = -1;
+                float row_acc = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    const float* qp = P3 + ((KT > 0 ? nbr[k] : nn_idx[s * K + k]) * nt + tau) * 3;
+                    const float dx = qp[0] - px, dy = qp[1] - py, dz = qp[2] - pz;
+                    const float gap = sqrtf(dx * dx + dy * dy + dz * dz);
+                    const float diff = gap - d2[row];
+                    const float term = sqrtf(diff * diff + eps2);
+                    local += (double)term;
+                    const float sg = diff / term;
+                    if (row != row_prev) {
+                        if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
+                        row_prev = row; row_acc = 0.f;
+                    }
+                    row_acc -= sg;
+                    const float ig = gap > 0.f ? sg / gap : 0.f;
+                    ig_row[(long long)k * nt] = ig;
+                    ax -= ig * dx; ay -= ig * dy; az -= ig * dz;
+                    if (++rem == nt) { rem = 0; ++row; }
+                }
+                if (row_prev >= 0) atomicAdd(&d_d2[row_prev], row_acc);
             }
+            float* go = G_own + (i_row * nt + tau) * 3;
+            go[0] = ax; go[1] = ay; go[2] = az;
         }
     }
-    // block sum of the terms (f64)
     __shared__ double sh[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
@@ -689,50 +623,285 @@ rdg_rigidity_dp_kernel(long long n, int K_rt, int nt, const float4* __restrict__
     if (threadIdx.x == 0) atomicAdd(loss_sum, (sh[0] + sh[1]) + (sh[2] + sh[3]));
 }
 
-// pos4[tau][s] = (pos3[tau][order[s]], 0): the sample re-laid along the curve order, padded to 16-B rows (what the
-// framework did as a zero fill + an advanced-indexing copy: 1.1 ms at n = 2 M, nt = 25)
+// d_d2[r] = the stored partial gradients of the (time, Gaussian) pairs whose K flat entries [m K, (m + 1) K) meet row r =
+// [r nt, (r + 1) nt): nt / K + 1 pairs at most, consecutive in the ORIGINAL sample order (m = tau n + i_row); a pair's first
+// partial belongs to the row its first entry falls into, the second to the next row.  One thread per row, fixed order.
 __global__ void __launch_bounds__(256)
-rdg_rigidity_pack_kernel(long long n, const float* __restrict__ pos3, const long long* __restrict__ order,
-                         float4* __restrict__ pos4) {
+rdg_rigidity_d2grad_kernel(long long n, int K, int nt, const long long* __restrict__ rank, const float2* __restrict__ RA,
+                           float* __restrict__ d_d2) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n * K) return;
+    const long long f_lo = r * nt;
+    const long long m_lo = rdg_div_pos(f_lo, K, 1.0 / (double)K);
+    const int cnt = (int)((f_lo + nt - 1 - m_lo * K) / K) + 1;          // pairs that meet the row (small numbers: 32-bit division)
+    // the first pair's time, Gaussian and first row; the following pairs by increments
+    long long tau = rdg_div_pos(m_lo, n, 1.0 / (double)n);
+    long long i_row = m_lo - tau * n;
+    // pair m's first entry lies in row (m K) / nt: r - 1 or r for the first pair (it meets row r), r for all the others
+    bool first_in_prev = m_lo * K < f_lo;
+    float acc = 0.f;
+    for (int c0 = 0; c0 < cnt; c0 += 4) {
+        long long sidx[4]; long long tt[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            tt[u] = tau;
+            sidx[u] = c0 + u < cnt ? (rank ? rank[i_row] : i_row) : 0;
+            if (++i_row == n) { i_row = 0; ++tau; }
+        }
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = c0 + u < cnt ? RA[sidx[u] * nt + tt[u]] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc += (c0 + u == 0 && first_in_prev) ? v[u].y : v[u].x;
+        }
+    }
+    d_d2[r] = acc;
+}
+
+template <int LPG, int KT>
+__global__ void __launch_bounds__(256)
+rdg_rigidity_rows_in_kernel(long long n, int K_rt, int nt, const float* __restrict__ P3, const long long* __restrict__ rev_off,
+                            const long long* __restrict__ rev_edge, const long long* __restrict__ orig,
+                            const float* __restrict__ IG, float* __restrict__ G_own, float* __restrict__ G_canon) {
+    constexpr int GPB = 256 / LPG;
+    const int tl = threadIdx.x % LPG;
+    const int K = KT > 0 ? KT : K_rt;
+    for (int it = 0; it < RDG_RIGR_ITERS; ++it) {
+        const long long s = ((long long)blockIdx.x * RDG_RIGR_ITERS + it) * GPB + threadIdx.x / LPG;
+        if (s >= n) break;
+        const long long i_row = orig ? orig[s] : s;
+        const long long e0 = rev_off[s], e1 = rev_off[s + 1];
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        for (int tau = tl; tau < nt; tau += LPG) {
+            const float* pp = P3 + (s * nt + tau) * 3;
+            const float px = pp[0], py = pp[1], pz = pp[2];
+            float* go = G_own + (i_row * nt + tau) * 3;
+            float gx = go[0], gy = go[1], gz = go[2];
+            for (long long e = e0; e < e1; e += 4) {
+                long long edge[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) edge[u] = rev_edge[e + u < e1 ? e + u : e1 - 1];
+                float q[4][3], ig[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long src = KT > 0 ? edge[u] / KT : edge[u] / K;
+                    const float* qp = P3 + (src * nt + tau) * 3;
+                    q[u][0] = qp[0]; q[u][1] = qp[1]; q[u][2] = qp[2];
+                    ig[u] = e + u < e1 ? IG[edge[u] * nt + tau] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gx += ig[u] * (px - q[u][0]); gy += ig[u] * (py - q[u][1]); gz += ig[u] * (pz - q[u][2]);
+                }
+            }
+            go[0] = gx; go[1] = gy; go[2] = gz;
+            cx += gx; cy += gy; cz += gz;
+        }
+        if (G_canon) {
+#pragma unroll
+            for (int o = LPG >> 1; o > 0; o >>= 1) {
+                cx += __shfl_xor(cx, o); cy += __shfl_xor(cy, o); cz += __shfl_xor(cz, o);
+            }
+            if (tl == 0) { float* gc = G_canon + i_row * 3; gc[0] = cx; gc[1] = cy; gc[2] = cz; }
+        }
+    }
+}
+
+// P3[s][tau] = own[order[s]][tau] + canon[order[s]]: the sample's positions at the drawn times, rows re-laid along the
+// curve order.  One thread per output float (whole rows move: coalesced on both sides, no idle lanes whatever nt is)
+__global__ void __launch_bounds__(256)
+rdg_rigidity_pack_rows_kernel(long long n, int nt, const float* __restrict__ own, const float* __restrict__ canon,
+                              const long long* __restrict__ order, float* __restrict__ P3) {
+    const int len = nt * 3;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * len) return;
+    const long long s = rdg_div_pos(e, len, 1.0 / (double)len);
+    const int j = (int)(e - s * len);
+    const long long r = order ? order[s] : s;
+    P3[e] = own[r * len + j] + canon[r * 3 + j % 3];
+}
+
+template <int LPG>
+static int rdg_rigidity_rows_launch(int64_t n, int32_t K, int32_t nt, const float* P3, const int64_t* nn_idx, const float* d2,
+                                    const int64_t* rev_off, const int64_t* rev_edge, const int64_t* orig, float eps,
+                                    double* loss_sum, float* IG, float2* RA, float* d_d2, float* G_own, float* G_canon,
+                                    hipStream_t st) {
+    const long long per_wg = (256 / LPG) * RDG_RIGR_ITERS;
+    const dim3 grid((unsigned)((n + per_wg - 1) / per_wg));
+    if (K == 8) {
+        hipLaunchKernelGGL((rdg_rigidity_rows_out_kernel<LPG, 8>), grid, dim3(256), 0, st, (long long)n, K, nt, P3,
+                           (const long long*)nn_idx, d2, (const long long*)orig, eps * eps, loss_sum, IG, RA, G_own, d_d2);
+        hipLaunchKernelGGL((rdg_rigidity_rows_in_kernel<LPG, 8>), grid, dim3(256), 0, st, (long long)n, K, nt, P3,
+                           (const long long*)rev_off, (const long long*)rev_edge, (const long long*)orig, IG, G_own, G_canon);
+    } else {
+        hipLaunchKernelGGL((rdg_rigidity_rows_out_kernel<LPG, 0>), grid, dim3(256), 0, st, (long long)n, K, nt, P3,
+                           (const long long*)nn_idx, d2, (const long long*)orig, eps * eps, loss_sum, IG, RA, G_own, d_d2);
+        hipLaunchKernelGGL((rdg_rigidity_rows_in_kernel<LPG, 0>), grid, dim3(256), 0, st, (long long)n, K, nt, P3,
+                           (const long long*)rev_off, (const long long*)rev_edge, (const long long*)orig, IG, G_own, G_canon);
+    }
+    return rdg_check_hip(hipGetLastError(), "rigidity_rows launch");
+}
+
+static inline int rdg_rig_lpg(int nt) { return nt <= 8 ? 8 : nt <= 16 ? 16 : nt <= 32 ? 32 : 64; }
+
+extern "C" int rdg_rigidity_pack_rows(int64_t n, int32_t nt, const float* own, const float* canon, const int64_t* order,
+                                      float* P3, void* stream) {
+    if (n <= 0 || nt <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)n * nt * 3;
+    hipLaunchKernelGGL(rdg_rigidity_pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (long long)n, nt,
+                       own, canon, (const long long*)order, P3);
+    return rdg_check_hip(hipGetLastError(), "rigidity_pack_rows launch");
+}
+
+extern "C" int rdg_rigidity_dp_rows(int64_t n, int32_t K, int32_t nt, const float* P3, const int64_t* nn_idx, const float* d2,
+                                    const int64_t* rev_off, const int64_t* rev_edge, const int64_t* orig, const int64_t* rank,
+                                    float eps, double* loss_sum, float* IG, float* RA, float* d_d2, float* G_own,
+                                    float* G_canon, void* stream) {
+    if (n <= 0 || K <= 0 || nt <= 0) return rdg_set_error("rigidity_dp_rows: bad sizes");
+    if (!IG || !G_own || !d_d2 || !loss_sum) return rdg_set_error("rigidity_dp_rows: IG, G_own, d_d2 and loss_sum are required");
+    if (orig && RA && !rank) return rdg_set_error("rigidity_dp_rows: RA with a stored order needs rank (the inverse of orig)");
+    if (((uintptr_t)RA) & 7) return rdg_set_error("rigidity_dp_rows: RA must be 8-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    float2* ra = nt >= K ? (float2*)RA : nullptr;      // the two-row form of the d2 gradient needs nt >= K
+    hipError_t e = rdg_zero_async(loss_sum, 8, st);
+    if (e == hipSuccess && !ra) e = rdg_zero_async(d_d2, (size_t)n * K * 4, st);
+    if (e != hipSuccess) return rdg_check_hip(e, "rigidity_dp_rows memset");
+    int rc;
+    switch (rdg_rig_lpg(nt)) {
+        case 8:  rc = rdg_rigidity_rows_launch<8>(n, K, nt, P3, nn_idx, d2, rev_off, rev_edge, orig, eps, loss_sum, IG, ra, d_d2, G_own, G_canon, st); break;
+        case 16: rc = rdg_rigidity_rows_launch<16>(n, K, nt, P3, nn_idx, d2, rev_off, rev_edge, orig, eps, loss_sum, IG, ra, d_d2, G_own, G_canon, st); break;
+        case 32: rc = rdg_rigidity_rows_launch<32>(n, K, nt, P3, nn_idx, d2, rev_off, rev_edge, orig, eps, loss_sum, IG, ra, d_d2, G_own, G_canon, st); break;
+        default: rc = rdg_rigidity_rows_launch<64>(n, K, nt, P3, nn_idx, d2, rev_off, rev_edge, orig, eps, loss_sum, IG, ra, d_d2, G_own, G_canon, st); break;
+    }
+    if (rc || !ra) return rc;
+    const long long rows = (long long)n * K;
+    hipLaunchKernelGGL(rdg_rigidity_d2grad_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (long long)n, K, nt,
+                       (const long long*)rank, (const float2*)ra, d_d2);
+    return rdg_check_hip(hipGetLastError(), "rigidity_d2grad launch");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The other two scatters of a rigidity step, through the same stored-order graph (nbr [n][K] neighbour lists, rev_off / rev_edge
+// reverse adjacency, X [n][3] the sample's positions, all along the curve order; orig[s] = row of stored element s in the
+// caller's order): every gradient row is written once by the thread that owns it, its arriving edges read from rows that are
+// close in memory.
+//   rdg_graph_points_backward : knn_points' backward for p1 is p2 (rdg_knn_points_backward: 27 float atomics per query)
+//   rdg_graph_surface_*       : RigidityLoss "surface" (/root/reference/src/trainer/losses.py:241-250): mean_i || x_i - mean_k x_nn(i,k) + 1e-6 ||
+//                               (F.pairwise_distance adds its eps to the difference), forward + the unit vectors its backward needs
+// ---------------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ void __launch_bounds__(256)
+rdg_graph_points_bwd_kernel(long long n, int K_rt, const float* __restrict__ X, const long long* __restrict__ nbr,
+                            const long long* __restrict__ rev_off, const long long* __restrict__ rev_edge,
+                            const long long* __restrict__ orig, const float* __restrict__ g, float* __restrict__ d_pts) {
     const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
-    const long long tau = blockIdx.y;
-    const float* src = pos3 + (tau * n + order[s]) * 3;
-    pos4[tau * n + s] = make_float4(src[0], src[1], src[2], 0.f);
+    const int K = KT > 0 ? KT : K_rt;
+    const long long i_row = orig[s];
+    const float x = X[3 * s], y = X[3 * s + 1], z = X[3 * s + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
+        const long long t = nbr[s * K + k];
+        const float w = 2.0f * g[i_row * K + k];
+        ax += w * (x - X[3 * t]); ay += w * (y - X[3 * t + 1]); az += w * (z - X[3 * t + 2]);
+    }
+    const long long e1 = rev_off[s + 1];
+    for (long long e = rev_off[s]; e < e1; ++e) {
+        const long long edge = rev_edge[e];
+        const long long src = KT > 0 ? edge / KT : edge / K;
+        const float w = 2.0f * g[orig[src] * K + (edge - src * K)];
+        ax -= w * (X[3 * src] - x); ay -= w * (X[3 * src + 1] - y); az -= w * (X[3 * src + 2] - z);
+    }
+    d_pts[3 * i_row] = ax; d_pts[3 * i_row + 1] = ay; d_pts[3 * i_row + 2] = az;
 }
 
-extern "C" int rdg_rigidity_pack(int64_t n, int32_t nt, const float* pos3, const int64_t* order, float* pos4,
+template <int KT>
+__global__ void __launch_bounds__(256)
+rdg_graph_surface_fwd_kernel(long long n, int K_rt, const float* __restrict__ X, const long long* __restrict__ nbr,
+                             float* __restrict__ U, double* __restrict__ loss_sum) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int K = KT > 0 ? KT : K_rt;
+    double local = 0.0;
+    if (s < n) {
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+        for (int k = 0; k < (KT > 0 ? KT : K); ++k) {
+            const long long t = nbr[s * K + k];
+            cx += X[3 * t]; cy += X[3 * t + 1]; cz += X[3 * t + 2];
+        }
+        const float fk = (float)K;
+        const float dx = X[3 * s] - cx / fk + 1e-6f, dy = X[3 * s + 1] - cy / fk + 1e-6f, dz = X[3 * s + 2] - cz / fk + 1e-6f;
+        const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+        local = (double)r;
+        const float ir = r > 0.f ? 1.0f / r : 0.f;
+        U[3 * s] = dx * ir; U[3 * s + 1] = dy * ir; U[3 * s + 2] = dz * ir;
+    }
+    __shared__ double sh[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+}
+
+// d(sum_i r_i) / d x_s = u_s - (1 / K) sum over the edges arriving at s of u_src
+template <int KT>
+__global__ void __launch_bounds__(256)
+rdg_graph_surface_bwd_kernel(long long n, int K_rt, const float* __restrict__ U, const long long* __restrict__ rev_off,
+                             const long long* __restrict__ rev_edge, const long long* __restrict__ orig,
+                             float* __restrict__ d_pts) {
+    const long long s = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int K = KT > 0 ? KT : K_rt;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const long long e1 = rev_off[s + 1];
+    for (long long e = rev_off[s]; e < e1; ++e) {
+        const long long edge = rev_edge[e];
+        const long long src = KT > 0 ? edge / KT : edge / K;
+        ax += U[3 * src]; ay += U[3 * src + 1]; az += U[3 * src + 2];
+    }
+    const float fk = (float)K;
+    const long long i_row = orig[s];
+    d_pts[3 * i_row] = U[3 * s] - ax / fk; d_pts[3 * i_row + 1] = U[3 * s + 1] - ay / fk; d_pts[3 * i_row + 2] = U[3 * s + 2] - az / fk;
+}
+
+extern "C" int rdg_graph_points_backward(int64_t n, int32_t K, const float* X, const int64_t* nbr, const int64_t* rev_off,
+                                         const int64_t* rev_edge, const int64_t* orig, const float* g_dists, float* d_pts,
+                                         void* stream) {
+    if (n <= 0 || K <= 0) return 0;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (K == 8)
+        hipLaunchKernelGGL(rdg_graph_points_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, (long long)n, K, X,
+                           (const long long*)nbr, (const long long*)rev_off, (const long long*)rev_edge, (const long long*)orig,
+                           g_dists, d_pts);
+    else
+        hipLaunchKernelGGL(rdg_graph_points_bwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (long long)n, K, X,
+                           (const long long*)nbr, (const long long*)rev_off, (const long long*)rev_edge, (const long long*)orig,
+                           g_dists, d_pts);
+    return rdg_check_hip(hipGetLastError(), "graph_points_backward launch");
+}
+
+extern "C" int rdg_graph_surface(int64_t n, int32_t K, const float* X, const int64_t* nbr, const int64_t* rev_off,
+                                 const int64_t* rev_edge, const int64_t* orig, float* U, double* loss_sum, float* d_pts,
                                  void* stream) {
-    if (n <= 0 || nt <= 0) return 0;
-    if (nt > 65535) return rdg_set_error("rigidity_pack: at most 65535 time samples");
-    if (((uintptr_t)pos4) & 15) return rdg_set_error("rigidity_pack: pos4 must be 16-B aligned");
-    hipLaunchKernelGGL(rdg_rigidity_pack_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nt), dim3(256), 0,
-                       (hipStream_t)stream, (long long)n, pos3, (const long long*)order, (float4*)pos4);
-    return rdg_check_hip(hipGetLastError(), "rigidity_pack launch");
-}
-
-extern "C" int rdg_rigidity_dp_forward(int64_t n, int32_t K, int32_t nt, const float* pos_t4, const int64_t* nn_idx,
-                                       const float* d2, const int64_t* rev_off, const int64_t* rev_edge,
-                                       const int64_t* rev_dst, const int64_t* orig, float eps, double* loss_sum,
-                                       float* G_t4, float* d_d2, float* G3_orig, void* stream) {
-    if (n <= 0 || K <= 0 || nt <= 0) return rdg_set_error("rigidity_dp: bad sizes");
-    if (nt > 65535 * RDG_RIG_TG) return rdg_set_error("rigidity_dp: too many time samples");
-    if (!G_t4 && !G3_orig) return rdg_set_error("rigidity_dp: one of G_t4 / G3_orig is required");
-    if ((((uintptr_t)pos_t4) | ((uintptr_t)G_t4)) & 15) return rdg_set_error("rigidity_dp: buffers must be 16-B aligned");
+    if (n <= 0 || K <= 0) return rdg_set_error("graph_surface: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = rdg_zero_async(loss_sum, 8, st);
-    if (e == hipSuccess) e = rdg_zero_async(d_d2, (size_t)n * K * 4, st);
-    if (e != hipSuccess) return rdg_check_hip(e, "rigidity_dp memset");
-    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((nt + RDG_RIG_TG - 1) / RDG_RIG_TG));
-    if (K == 8)
-        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<8>, grid, dim3(256), 0, st, (long long)n, K,
-                           nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
-                           (const long long*)rev_edge, (const long long*)rev_dst, (const long long*)orig, eps * eps,
-                           loss_sum, (float4*)G_t4, d_d2, G3_orig);
-    else
-        hipLaunchKernelGGL(rdg_rigidity_dp_kernel<0>, grid, dim3(256), 0, st, (long long)n, K,
-                           nt, (const float4*)pos_t4, (const long long*)nn_idx, d2, (const long long*)rev_off,
-                           (const long long*)rev_edge, (const long long*)rev_dst, (const long long*)orig, eps * eps,
-                           loss_sum, (float4*)G_t4, d_d2, G3_orig);
-    return rdg_check_hip(hipGetLastError(), "rigidity_dp launch");
+    if (e != hipSuccess) return rdg_check_hip(e, "graph_surface memset");
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (K == 8) {
+        hipLaunchKernelGGL(rdg_graph_surface_fwd_kernel<8>, grid, dim3(256), 0, st, (long long)n, K, X, (const long long*)nbr, U,
+                           loss_sum);
+        hipLaunchKernelGGL(rdg_graph_surface_bwd_kernel<8>, grid, dim3(256), 0, st, (long long)n, K, U, (const long long*)rev_off,
+                           (const long long*)rev_edge, (const long long*)orig, d_pts);
+    } else {
+        hipLaunchKernelGGL(rdg_graph_surface_fwd_kernel<0>, grid, dim3(256), 0, st, (long long)n, K, X, (const long long*)nbr, U,
+                           loss_sum);
+        hipLaunchKernelGGL(rdg_graph_surface_bwd_kernel<0>, grid, dim3(256), 0, st, (long long)n, K, U, (const long long*)rev_off,
+                           (const long long*)rev_edge, (const long long*)orig, d_pts);
+    }
+    return rdg_check_hip(hipGetLastError(), "graph_surface launch");
 }

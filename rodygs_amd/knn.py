@@ -35,19 +35,25 @@ from collections import namedtuple
 _KNN = namedtuple("KNN", "dists idx knn")
 
 
+def _knn_forward(q: torch.Tensor, t: torch.Tensor, K: int):
+    """dists [Pq,K] (squared, ascending), idx [Pq,K] of the K nearest rows of t for every row of q (float32, contiguous)."""
+    L = _lib.lib()
+    Pq, Pt = q.shape[0], t.shape[0]
+    dists = torch.empty(Pq, K, dtype=torch.float32, device=q.device)
+    idx = torch.empty(Pq, K, dtype=torch.int64, device=q.device)
+    with torch.cuda.device(q.device):
+        tmp = torch.empty(L.rdg_knn_tmp_bytes(Pt), dtype=torch.uint8, device=q.device)
+        _lib.check(L.rdg_knn_points_forward(Pq, Pt, K, _lib.ptr(q), _lib.ptr(t), _lib.ptr(dists), _lib.ptr(idx),
+                                            _lib.ptr(tmp), _lib.stream_ptr()), "rdg_knn_points_forward")
+    return dists, idx
+
+
 class _KnnPoints(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p1, p2, K, same):
-        L = _lib.lib()
         q = p1.detach().to(torch.float32).contiguous()
         t = q if same else p2.detach().to(torch.float32).contiguous()
-        Pq, Pt = q.shape[0], t.shape[0]
-        dists = torch.empty(Pq, K, dtype=torch.float32, device=q.device)
-        idx = torch.empty(Pq, K, dtype=torch.int64, device=q.device)
-        with torch.cuda.device(q.device):
-            tmp = torch.empty(L.rdg_knn_tmp_bytes(Pt), dtype=torch.uint8, device=q.device)
-            _lib.check(L.rdg_knn_points_forward(Pq, Pt, K, _lib.ptr(q), _lib.ptr(t), _lib.ptr(dists), _lib.ptr(idx),
-                                                _lib.ptr(tmp), _lib.stream_ptr()), "rdg_knn_points_forward")
+        dists, idx = _knn_forward(q, t, K)
         ctx.save_for_backward(q, t, idx)
         ctx.same = same
         ctx.K = K

@@ -77,50 +77,128 @@ def _sort_by_key(keys: torch.Tensor, end_bit: int):
     return k, v.to(torch.int64)
 
 
-class _FusedDistancePreserving(torch.autograd.Function):
-    """sum over (tau, i, k) of Charbonnier(gap, d2_flat[f // nt]) and its gradients in one HIP kernel
-    (rdg_rigidity_dp_forward): no [t,n,K,3] intermediates.  pos_t [nt,n,3] = canonical position + translation."""
+class _NeighbourGraph:
+    """The K-NN graph of one rigidity step in the form the fused kernels read it: the sample stored along a space-filling curve
+    (a Gaussian's neighbours, and the threads next to it, touch rows that are close in memory and mostly still in the L2),
+    neighbour lists in stored ids, and the reverse adjacency (edge ids s*K + k grouped by destination) that lets every
+    gradient row be written once by its owner instead of through scattered float atomics.  Built once per step and shared by
+    the distance-preserving term, the surface term and the backward of the neighbour search."""
+
+    def __init__(self, pts: torch.Tensor, nn_idx: torch.Tensor):
+        n, dev = pts.shape[0], pts.device
+        self.n, self.K = n, nn_idx.shape[-1]
+        with torch.cuda.device(dev):
+            p = pts.detach().to(torch.float32).contiguous()
+            self.order = _curve_order(p)                                   # stored position -> row of the sample
+            self.rank = torch.empty_like(self.order)                       # row of the sample -> stored position
+            self.rank[self.order] = torch.arange(n, device=dev)
+            self.nbr = self.rank[nn_idx.detach().to(torch.int64)[self.order]].contiguous()
+            self.X = p.index_select(0, self.order).contiguous()
+            srt, self.rev_edge = _sort_by_key(self.nbr.reshape(-1), max(1, (n - 1).bit_length()))
+            # offsets of every destination in the sorted edge list (searchsorted instead of bincount + cumsum: bincount reads
+            # its output size back to the host and stalls the stream of launches)
+            self.rev_off = torch.searchsorted(srt, torch.arange(n + 1, device=dev)).contiguous()
+
+
+class _GraphSlot:
+    """Filled with the step's graph once the neighbour search has run; read by that search's backward."""
+    graph = None
+
+
+class _KnnPointsGraph(torch.autograd.Function):
+    """knn_points(pts, pts, K) whose backward goes through the step's graph (rdg_graph_points_backward) instead of 27 float
+    atomics per query (rdg_knn_points_backward: 2.2 ms at n = 2 M)."""
 
     @staticmethod
-    def forward(ctx, pos_t, nn_idx, d2, eps):
+    def forward(ctx, pts, K, slot):
+        q = pts.detach().to(torch.float32).contiguous()
+        dists, idx = _knn._knn_forward(q, q, K)
+        ctx.save_for_backward(q, idx)
+        ctx.slot, ctx.K = slot, K
+        ctx.mark_non_differentiable(idx)
+        return dists, idx
+
+    @staticmethod
+    def backward(ctx, g_dists, _g_idx):
         from . import _lib
         L = _lib.lib()
-        nt, n = pos_t.shape[0], pos_t.shape[1]
-        dev = pos_t.device
-        ii = nn_idx.detach().to(torch.int64).contiguous()
-        dd = d2.detach().to(torch.float32).contiguous()
-        K = ii.shape[-1]
+        q, idx = ctx.saved_tensors
+        G = ctx.slot.graph
+        g = g_dists.to(torch.float32).contiguous()
+        d_q = torch.empty_like(q)
+        with torch.cuda.device(q.device):
+            if G is None:
+                _lib.check(L.rdg_knn_points_backward(q.shape[0], q.shape[0], ctx.K, _lib.ptr(q), _lib.ptr(q), _lib.ptr(idx),
+                                                     _lib.ptr(g), _lib.ptr(d_q), _lib.ptr(d_q), _lib.stream_ptr()),
+                           "rdg_knn_points_backward")
+            else:
+                _lib.check(L.rdg_graph_points_backward(G.n, G.K, _lib.ptr(G.X), _lib.ptr(G.nbr), _lib.ptr(G.rev_off),
+                                                       _lib.ptr(G.rev_edge), _lib.ptr(G.order), _lib.ptr(g), _lib.ptr(d_q),
+                                                       _lib.stream_ptr()), "rdg_graph_points_backward")
+        return d_q, None, None
+
+
+class _FusedSurface(torch.autograd.Function):
+    """sum_i || x_i - mean_k x_nn(i,k) + 1e-6 || and its gradient in two launches (rdg_graph_surface); `pts` only carries the
+    gradient, the positions are the graph's."""
+
+    @staticmethod
+    def forward(ctx, pts, G):
+        from . import _lib
+        L = _lib.lib()
+        dev = pts.device
         with torch.cuda.device(dev):
-            # the sample is a random subset: store it along a space-filling curve so that a Gaussian's neighbours
-            # (and the threads next to it) gather from nearby addresses (4.6 -> ~1.5 ms at n = 500 k, t = 25)
-            order = _curve_order(pos_t[0].detach())
-            rank = torch.empty_like(order)
-            rank[order] = torch.arange(n, device=dev)
-            ii = rank[ii[order]].contiguous()                       # neighbour lists in stored order
-            p3 = pos_t.detach().to(torch.float32).contiguous()
-            p4 = torch.empty(nt, n, 4, dtype=torch.float32, device=dev)
-            _lib.check(L.rdg_rigidity_pack(n, nt, _lib.ptr(p3), _lib.ptr(order), _lib.ptr(p4), _lib.stream_ptr()),
-                       "rdg_rigidity_pack")
-            # reverse adjacency of the K-NN graph: edge ids (i*K + k) grouped by their destination
-            flat = ii.reshape(-1)
-            srt, rev_edge = _sort_by_key(flat, max(1, (n - 1).bit_length()))     # destinations (sorted), edge ids
-            # offsets of every destination in the sorted edge list (searchsorted instead of bincount + cumsum:
-            # bincount reads its output size back to the host and stalls the stream of launches)
-            rev_off = torch.searchsorted(srt, torch.arange(n + 1, device=dev)).contiguous()
+            U = torch.empty(G.n, 3, dtype=torch.float32, device=dev)
+            d_pts = torch.empty(G.n, 3, dtype=torch.float32, device=dev)
             loss = torch.empty(1, dtype=torch.float64, device=dev)
-            G3 = torch.empty(nt, n, 3, dtype=torch.float32, device=dev)      # gradient in the caller's own row order
-            d_d2 = torch.empty_like(dd)
-            _lib.check(L.rdg_rigidity_dp_forward(n, K, nt, _lib.ptr(p4), _lib.ptr(ii), _lib.ptr(dd), _lib.ptr(rev_off),
-                                                 _lib.ptr(rev_edge), _lib.ptr(srt), _lib.ptr(order), float(eps), _lib.ptr(loss),
-                                                 None, _lib.ptr(d_d2), _lib.ptr(G3), _lib.stream_ptr()),
-                       "rdg_rigidity_dp_forward")
-        ctx.save_for_backward(G3, d_d2)
+            _lib.check(L.rdg_graph_surface(G.n, G.K, _lib.ptr(G.X), _lib.ptr(G.nbr), _lib.ptr(G.rev_off), _lib.ptr(G.rev_edge),
+                                           _lib.ptr(G.order), _lib.ptr(U), _lib.ptr(loss), _lib.ptr(d_pts), _lib.stream_ptr()),
+                       "rdg_graph_surface")
+        ctx.save_for_backward(d_pts)
         return loss[0].to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
-        G3, d_d2 = ctx.saved_tensors
-        return G3 * g, None, d_d2 * g, None
+        (d_pts,) = ctx.saved_tensors
+        return d_pts * g, None
+
+
+class _FusedDistancePreservingRows(torch.autograd.Function):
+    """The distance-preserving sum on the reference's own layout: own [n,nt,3] (translation of every sampled Gaussian at the
+    drawn times) and canon [n,3]; positions = canon + own.  rdg_rigidity_pack_rows + rdg_rigidity_dp_rows: a lane group per
+    Gaussian, lane = time, every edge end one coalesced row; gradients come back in the caller's layout (no permute, no sum
+    over times).  G: the step's graph."""
+
+    @staticmethod
+    def forward(ctx, own, canon, d2, G, eps):
+        from . import _lib
+        L = _lib.lib()
+        n, nt, K = own.shape[0], own.shape[1], G.K
+        dev = own.device
+        dd = d2.detach().to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            o3 = own.detach().to(torch.float32).contiguous()
+            c3 = canon.detach().to(torch.float32).contiguous()
+            P3 = torch.empty(n, nt, 3, dtype=torch.float32, device=dev)
+            _lib.check(L.rdg_rigidity_pack_rows(n, nt, _lib.ptr(o3), _lib.ptr(c3), _lib.ptr(G.order), _lib.ptr(P3),
+                                                _lib.stream_ptr()), "rdg_rigidity_pack_rows")
+            loss = torch.empty(1, dtype=torch.float64, device=dev)
+            IG = torch.empty(n * K * nt, dtype=torch.float32, device=dev)
+            RA = torch.empty(n * nt * 2, dtype=torch.float32, device=dev)
+            G_own = torch.empty(n, nt, 3, dtype=torch.float32, device=dev)
+            G_canon = torch.empty(n, 3, dtype=torch.float32, device=dev)
+            d_d2 = torch.empty_like(dd)
+            _lib.check(L.rdg_rigidity_dp_rows(n, K, nt, _lib.ptr(P3), _lib.ptr(G.nbr), _lib.ptr(dd), _lib.ptr(G.rev_off),
+                                              _lib.ptr(G.rev_edge), _lib.ptr(G.order), _lib.ptr(G.rank), float(eps),
+                                              _lib.ptr(loss), _lib.ptr(IG), _lib.ptr(RA), _lib.ptr(d_d2), _lib.ptr(G_own),
+                                              _lib.ptr(G_canon), _lib.stream_ptr()), "rdg_rigidity_dp_rows")
+        ctx.save_for_backward(G_own, G_canon, d_d2)
+        return loss[0].to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        G_own, G_canon, d_d2 = ctx.saved_tensors
+        return G_own * g, G_canon * g, d_d2 * g, None, None
 
 
 class RigidityLoss(nn.Module):
@@ -144,7 +222,8 @@ class RigidityLoss(nn.Module):
         # it, but 0.3 s of Python per call at 1 M Gaussians.  True: the same uniform draw without replacement from
         # torch.randperm on the device.
         self.device_sampling = device_sampling
-        # distance_preserving through the fused HIP kernel whenever the native ops are in use (GPU tensors)
+        # neighbour-search backward, surface and distance_preserving through the fused HIP kernels on the step's graph
+        # whenever the native ops are in use (GPU tensors)
         self.fused_dp = knn_points is None and knn_gather is None
 
     def _neighbours(self, rows: torch.Tensor, nn_idx: torch.Tensor) -> torch.Tensor:
@@ -168,13 +247,25 @@ class RigidityLoss(nn.Module):
         pts, coeffs = moved.index_select(0, pick), coeff_all.index_select(0, pick)
         colors = model._features_dc.index_select(0, pick) if "coeff" in self.mode else None
         n = pts.shape[0]
-        res = self._knn_points(pts[None], pts[None], K=self.K)                        # losses.py:235
-        d2, nn_idx = res.dists, res.idx                                               # [1,n,K] squared, [1,n,K]
+        graph = None
+        if self.fused_dp and pts.is_cuda:
+            # the native path: neighbour search, then the step's graph (curve order + reverse adjacency) that its own backward,
+            # the surface term and the distance-preserving term all go through
+            slot = _GraphSlot()
+            d2_, idx_ = _KnnPointsGraph.apply(pts, self.K, slot)
+            slot.graph = graph = _NeighbourGraph(pts, idx_)
+            d2, nn_idx = d2_[None], idx_[None]
+        else:
+            res = self._knn_points(pts[None], pts[None], K=self.K)                    # losses.py:235
+            d2, nn_idx = res.dists, res.idx                                           # [1,n,K] squared, [1,n,K]
         total = torch.tensor(0.0, dtype=torch.float32, device=pts.device)
 
         if "surface" in self.mode:                                                    # losses.py:241-250
-            centre = self._neighbours(pts, nn_idx).mean(dim=1)
-            total = total + F.pairwise_distance(pts, centre, p=2).mean()
+            if graph is not None:
+                total = total + _FusedSurface.apply(pts, graph) / n
+            else:
+                centre = self._neighbours(pts, nn_idx).mean(dim=1)
+                total = total + F.pairwise_distance(pts, centre, p=2).mean()
 
         if "coeff" in self.mode:                                                      # losses.py:252-291
             c_nn = self._neighbours(coeffs, nn_idx)                                   # [n,K,1,B]
@@ -212,9 +303,8 @@ class RigidityLoss(nn.Module):
                 own = own.view(-1, nt * 3)[:n].reshape(n, nt, 3)
             else:
                 own = (c2 @ bmat).reshape(n, nt, 3)
-            if self.fused_dp and own.is_cuda:
-                pos_t = own.permute(1, 0, 2) + canon.index_select(0, pick)[None]        # [t,n,3]: one slab per time
-                dp_sum = _FusedDistancePreserving.apply(pos_t, nn_idx[0], d2[0], 1e-6)
+            if graph is not None:
+                dp_sum = _FusedDistancePreservingRows.apply(own, canon.index_select(0, pick), d2[0], graph, 1e-6)
                 return total + dp_sum / (n * self.K * nt)
             nb = self._knn_gather(own[None].reshape(1, n, -1), nn_idx).reshape(1, n, self.K, own.shape[1], 3)
             nb = nb.squeeze().permute(2, 0, 1, 3)                                     # [t,n,K,3]

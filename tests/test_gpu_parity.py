@@ -1211,31 +1211,62 @@ def test_rigidity_loss_on_hip_knn_matches_reference_golden(name):
         rel_ok(gr, w_, tol=5e-3 if name == "all" else 1e-4, what=f"rigidity {name} d_{k} vs reference golden")
 
 
-def test_fused_distance_preserving_equals_unfused_on_the_same_device():
-    """The fused HIP kernel for the distance-preserving term vs the module's own tensor-by-tensor expression (the
-    reference's formulation) on the same device and the same random draws: value and all gradients."""
+_DP, _SURF, _COEFF = "distance_preserving", "surface", "coeff"
+
+
+@pytest.mark.parametrize("Tu,K,mode", [(16, 8, [_DP]), (100, 8, [_DP]), (140, 5, [_DP]), (300, 8, [_DP]), (100, 8, [_SURF]),
+                                       (100, 5, [_DP, _SURF]), (100, 8, [_COEFF, _SURF, _DP])])
+def test_fused_rigidity_terms_equal_the_unfused_module_on_the_same_device(Tu, K, mode):
+    """The fused HIP path of RigidityLoss (neighbour-search backward, surface term and distance-preserving term through the
+    step's stored-order graph: no float atomics, no [t,n,K,3] tensors) vs the module's own tensor-by-tensor expression (the
+    reference's formulation, on the public knn_points / knn_gather ops) on the same device and the same random draws: value
+    and all gradients.  Drawn times 4 / 25 / 35 / 75: every lane-group width of the kernels, fewer times than neighbours
+    (d2 gradient through atomics), more times than a wave has lanes; K = 5: the run-time neighbour count."""
     import random
     from rodygs_amd.rigidity import RigidityLoss
     from test_oracle_golden import _FakeDynModel
     g = torch.Generator().manual_seed(12)
-    P, Tu, B = 3000, 16, 16
+    P, B = 3000, 16
     base = dict(xyz=torch.rand(P, 3, generator=g) * 4 - 2, transl=0.05 * torch.randn(P, 3, generator=g),
                 coeff=0.3 * torch.randn(P, 1, B, generator=g), fdc=torch.rand(P, 1, 3, generator=g),
                 table=0.2 * torch.randn(Tu, B, 7, generator=g))
+    names = ["xyz", "transl"] + (["coeff"] if _DP in mode or _COEFF in mode else []) + (["table"] if _DP in mode else []) \
+        + (["fdc"] if _COEFF in mode else [])
     outs = []
     for fused in (True, False):
         t = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
         random.seed(5)
         torch.manual_seed(6)
-        mod = RigidityLoss(mode=["distance_preserving"], K=8)
+        mod = RigidityLoss(mode=mode, K=K)
         mod.fused_dp = fused
         loss = mod(_FakeDynModel(t["xyz"], t["coeff"], t["fdc"], t["table"]), t["transl"])
-        grads = torch.autograd.grad(loss, [t["xyz"], t["transl"], t["coeff"], t["table"]])
+        grads = torch.autograd.grad(loss, [t[k] for k in names])
         outs.append((loss, grads))
     (lf, gf), (lu, gu) = outs
     assert abs(float(lf) - float(lu)) <= 2e-6 * abs(float(lu))
-    for a, b, nm in zip(gf, gu, ("xyz", "transl", "coeff", "table")):
-        rel_ok(a, b, tol=2e-5, what="fused dp d_" + nm)
+    for a, b, nm in zip(gf, gu, names):
+        rel_ok(a, b, tol=2e-5, what=f"fused rigidity {mode} d_" + nm)
+
+
+def test_graph_backward_of_the_neighbour_search_equals_the_atomic_one():
+    """rdg_graph_points_backward (every gradient row written once through the stored-order reverse adjacency) vs
+    rdg_knn_points_backward (float atomics) on the same upstream gradient, K = 8 and K = 3."""
+    from rodygs_amd import knn as KN
+    from rodygs_amd.rigidity import _GraphSlot, _KnnPointsGraph, _NeighbourGraph
+    g = torch.Generator().manual_seed(3)
+    for n, K in ((5000, 8), (777, 3)):
+        pts = (torch.rand(n, 3, generator=g) * 3).to(DEV)
+        up = torch.randn(n, K, generator=g).to(DEV)
+        a = pts.clone().requires_grad_(True)
+        res = KN.knn_points(a[None], a[None], K=K)
+        (ga,) = torch.autograd.grad((res.dists[0] * up).sum(), a)
+        b = pts.clone().requires_grad_(True)
+        slot = _GraphSlot()
+        d2, idx = _KnnPointsGraph.apply(b, K, slot)
+        assert torch.equal(idx, res.idx[0]) and torch.equal(d2, res.dists[0])
+        slot.graph = _NeighbourGraph(b, idx)
+        (gb,) = torch.autograd.grad((d2 * up).sum(), b)
+        rel_ok(gb, ga, tol=1e-5, what=f"graph knn backward n={n} K={K}")
 
 
 def test_pytorch3d_shim_resolves_to_hip_ops():
