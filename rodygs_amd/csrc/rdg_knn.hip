@@ -1,17 +1,20 @@
 // rdg_knn.hip -- simple_knn.distCUDA2 replacement: mean squared distance to the 3
 // nearest other points.  Call site: /root/reference/src/model/rodygs_static.py:130-133 (init only).
 //
-// Exact 3-NN: points are ordered along a 30-bit Morton curve with the library's own radix sort and cut into leaf
-// boxes of 32 consecutive points with their AABBs, grouped 16 by 16 into two coarser levels (512 and 8192 points).
+// Exact 3-NN: points are ordered along a 48-bit Morton curve with the library's own radix sort and cut into leaf
+// boxes of 16 consecutive points with their AABBs, grouped 16 by 16 into two coarser levels (256 and 4096 points).
 // A thread (one point, in Morton order, so a wave's 64 points are spatial neighbours and take the same branches)
 // seeds its best-3 from its curve neighbours and then descends only into the boxes whose AABB is closer than its
 // current 3rd-best distance.  The top level is streamed through LDS; lower levels are uniform (broadcast) loads.
 #include "rdg_common.h"
 #include <float.h>
 
-#define RDG_KNN_BOX 32    // points per leaf box (consecutive along the Morton curve)
+#ifndef RDG_KNN_BOX
+#define RDG_KNN_BOX 16    // points per leaf box (consecutive along the Morton curve)
+#endif
 #define RDG_KNN_SUP 16    // children per box of the two upper pruning levels (512 and 8192 points)
 #define RDG_KNN_MMB 256   // workgroups of the bounding-box reduction
+#define RDG_KNN_PBATCH 8  // leaf points fetched ahead of their distance tests
 
 struct RdgKnnLayout {
     size_t minmax;      // float[8]
@@ -99,32 +102,44 @@ __global__ void __launch_bounds__(64) rdg_knn_minmax_final_kernel(int P, int nbl
     }
 }
 
-__device__ __forceinline__ uint32_t rdg_expand10(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+// Curve code: RDG_KNN_BITS bits per axis over the cloud's bounding box.  16 bits (48-bit keys, six 8-bit sort passes): with
+// the 10 bits of rounds 1-3 a cloud whose bounding box is set by a few far points -- or that has a dense core -- put
+// thousands of points into ONE cell of the grid, in arbitrary order, and every leaf of such a cell overlaps every other
+// (2 M points with a dense core: 77 ms against 4.4 ms for a uniform cloud).
+#define RDG_KNN_BITS 16
+__device__ __forceinline__ uint64_t rdg_expand21(uint64_t v) {      // bit k of v (k < 21) -> bit 3 k
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
+}
+__device__ __forceinline__ uint64_t rdg_knn_code(float x, float y, float z, const float* __restrict__ minmax) {
+    const float p[3] = {x, y, z};
+    const float top = (float)((1u << RDG_KNN_BITS) - 1u);
+    uint64_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lo = minmax[c], hi = minmax[4 + c];
+        const float ext = hi - lo;
+        float t = ext > 0.f ? (p[c] - lo) / ext : 0.f;
+        t = fminf(fmaxf(t * top, 0.0f), top);
+        code |= rdg_expand21((uint64_t)(uint32_t)t) << (2 - c);
+    }
+    return code;
 }
 
 __global__ void rdg_knn_morton_kernel(int P, const float* __restrict__ pts, const float* __restrict__ minmax,
                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
-    uint32_t code = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float lo = minmax[c], hi = minmax[4 + c];
-        const float ext = hi - lo;
-        float t = ext > 0.f ? (pts[3 * i + c] - lo) / ext : 0.f;
-        t = fminf(fmaxf(t * 1023.0f, 0.0f), 1023.0f);
-        code |= rdg_expand10((uint32_t)t) << (2 - c);
-    }
-    keys[i] = (uint64_t)code;
+    keys[i] = rdg_knn_code(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], minmax);
     vals[i] = (uint32_t)i;
 }
 
-// sorted[i] = (x, y, z, original index) in curve order; one AABB per 32 consecutive points (half a wave)
+// sorted[i] = (x, y, z, original index) in curve order; one AABB per RDG_KNN_BOX consecutive points
 __global__ void __launch_bounds__(256)
 rdg_knn_gather_box_kernel(int P, const float* __restrict__ pts, const uint32_t* __restrict__ order,
                           float4* __restrict__ sorted, float4* __restrict__ boxes) {
@@ -238,40 +253,33 @@ rdg_knn_search_kernel(int P, int nbox, const float4* __restrict__ sorted, const 
 // ---------------------------------------------------------------------------------------------------------
 // K nearest neighbours + gather: the pytorch3d.ops.knn_points / knn_gather pair RigidityLoss is built on
 // (/root/reference/src/trainer/losses.py:235-331; pytorch3d is the third un-vendored native dependency,
-// .gitmodules:11-13).  Same machinery as above -- targets Morton-sorted into 256-point boxes with AABBs -- with a
+// .gitmodules:11-13).  Same machinery as above -- targets Morton-sorted into leaf boxes with AABBs under two coarser levels -- with a
 // register-resident sorted best-K list per query.  Self mode (queries ARE the targets, the only form the
 // reference uses) walks the queries in Morton order so a wave's 64 queries prune the same boxes; the general
 // mode locates each query on the targets' curve by binary search over the sorted codes and seeds from there.
 // Distances are squared Euclidean, ascending; a self query returns itself first (distance 0), as pytorch3d does.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rdg_knn_code(float x, float y, float z, const float* __restrict__ minmax) {
-    const float p[3] = {x, y, z};
-    uint32_t code = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float lo = minmax[c], hi = minmax[4 + c];
-        const float ext = hi - lo;
-        float t = ext > 0.f ? (p[c] - lo) / ext : 0.f;
-        t = fminf(fmaxf(t * 1023.0f, 0.0f), 1023.0f);
-        code |= rdg_expand10((uint32_t)t) << (2 - c);
-    }
-    return code;
-}
-
+// Inserts (d, id) into the ascending best list (the caller has checked d < bd[KM - 1]): the new element sinks from the front,
+// every slot keeps the smaller of itself and what arrives and hands on the larger; an element equal to a kept one stays behind
+// it (first found, first listed).  One compare and four selects per slot on named registers -- the form "append, then swap
+// upwards" compiled into chains of selects over the WHOLE array per swap (register arrays indexed by a run-time position).
 template <int KM>
 __device__ __forceinline__ void rdg_knn_push(float d, uint32_t id, float (&bd)[KM], uint32_t (&bi)[KM]) {
-    if (d < bd[KM - 1]) {
-        bd[KM - 1] = d; bi[KM - 1] = id;
 #pragma unroll
-        for (int s = KM - 1; s > 0; --s) {
-            const bool sw = bd[s] < bd[s - 1];
-            const float td = sw ? bd[s - 1] : bd[s];
-            const uint32_t ti = sw ? bi[s - 1] : bi[s];
-            bd[s - 1] = sw ? bd[s] : bd[s - 1];
-            bi[s - 1] = sw ? bi[s] : bi[s - 1];
-            bd[s] = td; bi[s] = ti;
-        }
+    for (int s = 0; s < KM; ++s) {
+        const bool lt = d < bd[s];
+        const float td = lt ? bd[s] : d;
+        const uint32_t ti = lt ? bi[s] : id;
+        bd[s] = lt ? d : bd[s];
+        bi[s] = lt ? id : bi[s];
+        d = td; id = ti;
     }
+}
+
+// (dx^2 + dy^2) + dz^2 with every product and sum rounded on its own: the value torch's float32 arithmetic gives, whatever
+// the compiler would like to contract -- neighbours at (nearly) equal distances then come out in the oracle's order
+__device__ __forceinline__ float rdg_knn_d2(float dx, float dy, float dz) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
 template <int KM>
@@ -300,16 +308,40 @@ rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const floa
         } else {
             mx = queries[3 * i]; my = queries[3 * i + 1]; mz = queries[3 * i + 2];
             out_row = i;
-            const uint64_t code = (uint64_t)rdg_knn_code(mx, my, mz, minmax);
+            const uint64_t code = rdg_knn_code(mx, my, mz, minmax);
             int lo = 0, hi = Pt;          // first sorted target whose code is >= the query's
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (tkeys[mid] < code) lo = mid + 1; else hi = mid; }
             pos = min(lo, Pt - 1);
         }
-        s_lo = max(0, pos - KM); s_hi = min(Pt - 1, pos + KM);
-        for (int j = s_lo; j <= s_hi; ++j) {
-            const float4 o = sorted[j];
-            const float dx = mx - o.x, dy = my - o.y, dz = mz - o.z;
-            rdg_knn_push<KM>(dx * dx + dy * dy + dz * dz, __float_as_uint(o.w), bd, bi);
+        if (!self_mode) {
+            s_lo = max(0, pos - KM); s_hi = min(Pt - 1, pos + KM);
+            for (int j = s_lo; j <= s_hi; ++j) {
+                const float4 o = sorted[j];
+                const float d = rdg_knn_d2(mx - o.x, my - o.y, mz - o.z);
+                if (d < bd[KM - 1]) rdg_knn_push<KM>(d, __float_as_uint(o.w), bd, bi);
+            }
+        }
+    }
+    if (self_mode) {
+        // Self mode: the wave's 64 queries ARE 64 consecutive points of the curve.  Their own leaves and 32 points on either
+        // side are scanned first (wave-uniform addresses: scalar loads, fetched in batches), so the walk below starts with a
+        // K-th distance that is already close to final and prunes from its first box on (seeded from 2 K curve neighbours it
+        // descended into everything near the START of the curve with a loose bound); those leaves are then skipped.
+        const int w0 = __builtin_amdgcn_readfirstlane(i & ~63);
+        if (w0 < Pt) {
+            constexpr int PAD = RDG_KNN_BOX >= 32 ? 1 : 32 / RDG_KNN_BOX;      // leaves on either side: 32 points
+            const int l0 = w0 / RDG_KNN_BOX, l1 = min(Pt - 1, w0 + 63) / RDG_KNN_BOX;
+            s_lo = max(0, (l0 - PAD) * RDG_KNN_BOX); s_hi = min(Pt, (l1 + 1 + PAD) * RDG_KNN_BOX) - 1;
+            for (int j0 = s_lo; j0 <= s_hi; j0 += RDG_KNN_PBATCH) {
+                float4 o[RDG_KNN_PBATCH];
+#pragma unroll
+                for (int w = 0; w < RDG_KNN_PBATCH; ++w) o[w] = sorted[min(j0 + w, Pt - 1)];
+#pragma unroll
+                for (int w = 0; w < RDG_KNN_PBATCH; ++w) {
+                    const float d = rdg_knn_d2(mx - o[w].x, my - o[w].y, mz - o[w].z);
+                    if (act && j0 + w <= s_hi && d < bd[KM - 1]) rdg_knn_push<KM>(d, __float_as_uint(o[w].w), bd, bi);
+                }
+            }
         }
     }
     const int nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP, ntb = (nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
@@ -324,21 +356,41 @@ rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const floa
         for (int k = 0; k < nb; ++k) {
             const bool near_top = act && rdg_knn_box_d2(sBox[2 * k], sBox[2 * k + 1], mx, my, mz) <= bd[KM - 1];
             if (__builtin_amdgcn_ballot_w64(near_top) == 0ull) continue;
+            // The AABBs of a node's children and the points of a leaf sit at wave-uniform addresses (scalar loads).  One load,
+            // one wait, one test per child and per point made the walk a chain of scalar-cache round trips (3.9 ms at 2 M
+            // points, K = 8): the next child's AABB is fetched while the current one is tested and scanned, a leaf's points
+            // RDG_KNN_PBATCH at a time.
             const int sx0 = (base + k) * RDG_KNN_SUP, sx1 = min(nsb, sx0 + RDG_KNN_SUP);
+            float4 slo = sboxes[2 * sx0], shi = sboxes[2 * sx0 + 1];
             for (int sx = sx0; sx < sx1; ++sx) {
-                const bool near_sup = act && rdg_knn_box_d2(sboxes[2 * sx], sboxes[2 * sx + 1], mx, my, mz) <= bd[KM - 1];
+                const int sxn = min(sx + 1, nsb - 1);
+                const float4 slo_n = sboxes[2 * sxn], shi_n = sboxes[2 * sxn + 1];
+                const bool near_sup = act && rdg_knn_box_d2(slo, shi, mx, my, mz) <= bd[KM - 1];
+                slo = slo_n; shi = shi_n;
                 if (__builtin_amdgcn_ballot_w64(near_sup) == 0ull) continue;
                 const int bx0 = sx * RDG_KNN_SUP, bx1 = min(nbox, bx0 + RDG_KNN_SUP);
+                float4 blo = boxes[2 * bx0], bhi = boxes[2 * bx0 + 1];
                 for (int bx = bx0; bx < bx1; ++bx) {
-                    const bool visit = act && rdg_knn_box_d2(boxes[2 * bx], boxes[2 * bx + 1], mx, my, mz) <= bd[KM - 1];
+                    const int bxn = min(bx + 1, nbox - 1);
+                    const float4 blo_n = boxes[2 * bxn], bhi_n = boxes[2 * bxn + 1];
+                    const int b0 = bx * RDG_KNN_BOX, b1 = min(Pt, b0 + RDG_KNN_BOX);
+                    const bool done = self_mode && b0 >= s_lo && b1 - 1 <= s_hi;       // scanned before the walk
+                    const bool visit = act && !done && rdg_knn_box_d2(blo, bhi, mx, my, mz) <= bd[KM - 1];
+                    blo = blo_n; bhi = bhi_n;
                     if (__builtin_amdgcn_ballot_w64(visit) == 0ull) continue;
                     if (visit) {
-                        const int b0 = bx * RDG_KNN_BOX, b1 = min(Pt, b0 + RDG_KNN_BOX);
-                        for (int j = b0; j < b1; ++j) {
-                            if (j >= s_lo && j <= s_hi) continue;   // seeds already taken
-                            const float4 o = sorted[j];
-                            const float dx = mx - o.x, dy = my - o.y, dz = mz - o.z;
-                            rdg_knn_push<KM>(dx * dx + dy * dy + dz * dz, __float_as_uint(o.w), bd, bi);
+                        for (int j0 = b0; j0 < b1; j0 += RDG_KNN_PBATCH) {
+                            float4 o[RDG_KNN_PBATCH];
+#pragma unroll
+                            for (int w = 0; w < RDG_KNN_PBATCH; ++w) o[w] = sorted[min(j0 + w, Pt - 1)];
+#pragma unroll
+                            for (int w = 0; w < RDG_KNN_PBATCH; ++w) {
+                                const int j = j0 + w;
+                                const float d = rdg_knn_d2(mx - o[w].x, my - o[w].y, mz - o[w].z);
+                                // not a seed (already taken), inside the leaf, and better than the current K-th
+                                if (j < b1 && (j < s_lo || j > s_hi) && d < bd[KM - 1])
+                                    rdg_knn_push<KM>(d, __float_as_uint(o[w].w), bd, bi);
+                            }
                         }
                     }
                 }
@@ -404,7 +456,7 @@ static int rdg_knn_prepare(int32_t P, const float* points, char* t, const RdgKnn
     hipLaunchKernelGGL(rdg_knn_minmax_final_kernel, dim3(1), dim3(64), 0, st, P, mmb, (const float*)(t + L.mm_part),
                        minmax, n_dev);
     hipLaunchKernelGGL(rdg_knn_morton_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points, minmax, keys_a, vals_a);
-    int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, (int64_t)P, n_dev, 30, t + L.sort_tmp, in_b, st);
+    int rc = rdg_launch_sort(keys_a, keys_b, vals_a, vals_b, (int64_t)P, n_dev, 3 * RDG_KNN_BITS, t + L.sort_tmp, in_b, st);
     if (rc) return rc;
     hipLaunchKernelGGL(rdg_knn_gather_box_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, points,
                        *in_b ? vals_b : vals_a, (float4*)(t + L.sorted), (float4*)(t + L.boxes));

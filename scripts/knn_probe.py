@@ -1,16 +1,14 @@
-"""Timing probe: knn_points (self query, K=8) and distCUDA2 at RigidityLoss / init sizes."""
-import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import torch
-from rodygs_amd.knn import knn_points, distCUDA2
-from oracle import rasterizer_oracle as O
-from rodygs_amd.synthetic import synthetic_scene
-for n in (100_000, 500_000, 1_000_000):
-    sc = synthetic_scene(n, 1920, 1080, 3, seed=1)
-    p = sc["means3D"].cuda()
-    for name, fn in (("knn_points K=8 self", lambda: knn_points(p[None], p[None], K=8)), ("distCUDA2", lambda: distCUDA2(p))):
-        fn(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3): fn()
-        torch.cuda.synchronize()
-        print(f"{name:22s} N={n:8d}  {(time.perf_counter() - t0) / 3 * 1e3:8.2f} ms", flush=True)
+"""Times knn_points(p, p, K = 8) (pytorch3d call of RigidityLoss) on a uniform random cloud and on a clustered one."""
+import sys, torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from rodygs_amd import knn as KN
+n = int(sys.argv[1])
+g = torch.Generator().manual_seed(1)
+clouds = {"uniform": torch.rand(n, 3, generator=g) * torch.tensor([8.0, 5.0, 12.0]),
+          "clustered": torch.randn(n, 3, generator=g) * torch.rand(n, 1, generator=g) ** 3 * 4.0}
+for name, p in clouds.items():
+    p = p.cuda()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(4):
+        ev[0].record(); res = KN.knn_points(p[None], p[None], K=8); ev[1].record(); torch.cuda.synchronize()
+    print(f"n={n} {name}: knn_points {ev[0].elapsed_time(ev[1]):.3f} ms, checksum idx {int(res.idx.sum())} d2 {float(res.dists.double().sum()):.9e}")
