@@ -18,8 +18,8 @@
 // through a decoupled look-back -- was built first and measured (round 4): bit-exact, and 2.3 TB/s, because with 8 XCDs
 // the agent-scope status loads of the look-back cost a microsecond apiece and a tile of the first dispatch wave has
 // hundreds of predecessors to walk: 120 us per pass + a 50 us histogram launch per sort at 17 M pairs against 37 + 11 + 78 us
-// (count, scan, scatter) for the three launches here; 18 against 22 us at 1 M keys (profiles/r04_experiments.txt).  No gain
-// worth a kernel that relies on the forward progress of its predecessors; the three-launch form is kept.
+// (count, scan, scatter) for the three launches here at that time, 13 + 12 + 85 us since the count pass uses plain LDS
+// atomics; 18 against 22 us at 1 M keys (profiles/r04_experiments.txt).  The three-launch form is kept.
 #include "rdg_common.h"
 
 #define RDG_RS_THREADS 256
@@ -79,8 +79,10 @@ rdg_rs_count_kernel(const KeyT* __restrict__ keys, long long capacity, const int
     __syncthreads();
     long long t0, t1;
     rdg_rs_bounds<RDG_RS_ITEMS>(n, nseg, blockIdx.x, t0, t1);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    volatile uint32_t* cw = sCnt[wv];
+    // Plain LDS atomics on the wave's own copy of the counters (no return value: one instruction per key; equal digits in
+    // a wave serialise on their bank, at worst 64 cycles -- a third of what ranking the wave by ballot "match" cost in
+    // instructions: 37 -> 13 us per pass at 17 M 32-bit keys.  The scatter pass needs the match for its stable ranks; a count does not)
+    uint32_t* cw = sCnt[wv];
     for (long long t = t0; t < t1; ++t) {
         const long long base = t * RDG_RS_TILE + wv * (RDG_RS_ITEMS * 64) + lane;
         KeyT key[RDG_RS_ITEMS];
@@ -88,13 +90,7 @@ rdg_rs_count_kernel(const KeyT* __restrict__ keys, long long capacity, const int
         for (int i = 0; i < RDG_RS_ITEMS; ++i) key[i] = (base + i * 64 < n) ? keys[base + i * 64] : (KeyT)0;
 #pragma unroll
         for (int i = 0; i < RDG_RS_ITEMS; ++i) {
-            const bool act = base + i * 64 < n;
-            const uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
-            const unsigned long long m = rdg_rs_match(d, act);
-            // the lowest lane of every group of equal digits adds the group's size: plain LDS read-modify-write, the
-            // counters are the wave's own
-            if (act && (m & lt_mask) == 0ull) cw[d] = cw[d] + (uint32_t)__popcll(m);
-            rdg_wave_lds_sync();
+            if (base + i * 64 < n) atomicAdd(&cw[(uint32_t)(key[i] >> shift) & 255u], 1u);
         }
     }
     __syncthreads();
