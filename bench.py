@@ -92,6 +92,18 @@ def wire_bytes(P, K, world, sharded, frames=100, mlp_params=68656):
             "all_reduce_payload_bytes": small}
 
 
+def _spread_order(n):
+    """0 .. n-1 ordered by the base-2 radical inverse (bit-reversed counting, also for n that is no power of two)."""
+    def rinv(i):
+        r, f = 0.0, 0.5
+        while i:
+            r += f * (i & 1)
+            i >>= 1
+            f *= 0.5
+        return r
+    return sorted(range(n), key=rinv)
+
+
 def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=False, radix_binning=False,
                 densify_stats=False):
     """ALGORITHMIC HBM bytes per stage and step (SURVEY.md §8d formulas, adjusted to the algorithm that actually runs
@@ -220,6 +232,11 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         ds.track_densification()
     n_gt = min(args.gt_frames * world, args.frames)
     perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
+    # Visit order: the reference draws its frames from a random permutation of the video (src/data/dataloader.py:28-71).  Its
+    # deterministic stand-in here: the orbit positions in bit-reversed order (0, 8, 4, 12, 2, ...), so that ANY window of
+    # steps samples the orbit evenly -- walking the orbit in order, a 20-step window was one pass plus the four frames it
+    # happened to start on (the heavy side of the orbit: 1.63 ms per step where 100 steps read 1.53 on the same box).
+    perm = [perm[j] for j in _spread_order(len(perm))]
     ds.make_ground_truth(target, perm)
     sharded = mode == "shard"
     ss = None
@@ -283,6 +300,14 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     # Untimed settling steps in the configuration the timed region runs in (deferred check, its pinned slots and hints in
     # place; clocks and allocator warm): W = 5 warm-up steps are 8 ms of GPU work, and the FIRST bench run on a fresh box
     # has read 1.93 ms per step where every later run of the same binary reads 1.63.  Not part of W, not timed.
+    # The interpreter's cyclic collector runs a full (generation-2) pass once the start-up garbage has piled up -- a 40 ms
+    # host stall that would land somewhere in a 20-step window: collect now and keep the survivors out of later passes.
+    # BEFORE the settling steps, not after them: the GPU idles while the host collects, its clocks fall, and the first
+    # four or five steps after such a pause run 8-15 % slow (kernel durations in a rocprofv3 trace: 1.74, 1.77, 1.69,
+    # 1.66 ms, then 1.55) -- a 20-step window read 1.63-1.65 ms per step where 100 steps read 1.53-1.55.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.settle):
         train_step(step)
         step += 1
@@ -300,12 +325,6 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     # of its kernels: the dominant kernel's time is then taken from the eager steps after the timed region.)
     _lib.timing_enable(not use_graph, stages=["render_bwd"])
     _lib.timing_reset()
-    # the interpreter's cyclic collector runs a full (generation-2) pass once the start-up garbage has piled up -- a
-    # 40 ms host stall that would land somewhere in a 20-step window: collect now, and keep the survivors out of later
-    # passes
-    import gc
-    gc.collect()
-    gc.freeze()
     deferred_in_timed_region = bool(rasterizer.DEFERRED_OVERFLOW_CHECK)
     sync()
     t0 = time.perf_counter()
@@ -540,7 +559,7 @@ def main():
                        # switches that shape the number: no read-back of the instance count inside the timed steps
                        # (capacity from the warm-up; an overflow renders that frame empty and raises afterwards), and
                        # whether every rank shares one device (functional check of the N > 1 flow, not a measurement)
-                       "deferred_overflow_check": best["deferred"], "untimed_settle_steps": args.settle, "one_device": bool(os.environ.get("RDG_ONE_DEVICE")),
+                       "deferred_overflow_check": best["deferred"], "untimed_settle_steps": args.settle, "frame_order": "orbit positions, bit-reversed", "one_device": bool(os.environ.get("RDG_ONE_DEVICE")),
                        # True: the timed steps are replays of ONE captured hipGraph (trainstep.GraphedStep); the
                        # dominant kernel's avg_ms then comes from eager steps after the timed region
                        "graph_replay": graph_replay,
