@@ -38,16 +38,17 @@ NREN_HOST_MIRROR = os.environ.get("RDG_NREN_MIRROR", "1") != "0"           # def
 # 0.14 ms / radix 0.26; 9.4 M (1 150 per tile) 0.36 / 0.35; 17 M (2 100 per tile) 0.71 / 0.45.
 BIN_RADIX_ABOVE = 32768
 BIN_BUCKET_BELOW = 16384
-BIN_RADIX_MEAN_LIST_ABOVE = 1200        # instances per tile, averaged over the tile grid
-BIN_BUCKET_MEAN_LIST_BELOW = 900
+BIN_RADIX_MEAN_LIST_ABOVE = 1000        # instances per tile, averaged over the tile grid
+BIN_BUCKET_MEAN_LIST_BELOW = 800
 # Compositing of long tile lists: one workgroup walks a tile's list front to back, which is serial in the list length (a
 # 200 k-instance tile: 15 ms).  Lists above 4096 instances can be cut into segments composited by a workgroup each
 # (csrc/rdg_render.hip "split path"; the backward follows the forward's choice) -- three extra launches in the forward and
 # one in the backward, so, like the binning algorithm, the choice is made per frame from the previous frame's largest list.
 SPLIT_ABOVE = 4096            # = RDG_SPLIT_MIN of the library: shorter lists are never split
 SPLIT_BELOW = 3072
-# RDG_BIN_MODE=radix in the environment: every forward takes the radix binning (A/B switch; read once, here)
+# RDG_BIN_MODE=radix / bucket in the environment: every forward takes that binning (A/B switch; read once, here)
 _FORCE_RADIX = os.environ.get("RDG_BIN_MODE", "") == "radix"
+_FORCE_BUCKET = os.environ.get("RDG_BIN_MODE", "") == "bucket"
 
 # Deterministic backward (RDG_DETERMINISTIC=1 or set at run time): the compositing backward stores
 # per-(wave, list position) partial rows and reduces them per Gaussian in a fixed order instead of accumulating with float
@@ -101,7 +102,7 @@ class RasterState:
         """What a frame's largest tile list and instance count say about the next frame of that (P, H, W)."""
         tiles = ((key[2] + 15) // 16) * ((key[1] + 15) // 16)
         mean = n / max(tiles, 1)
-        if largest > BIN_RADIX_ABOVE or mean > BIN_RADIX_MEAN_LIST_ABOVE:
+        if (largest > BIN_RADIX_ABOVE or mean > BIN_RADIX_MEAN_LIST_ABOVE) and not _FORCE_BUCKET:
             self.bin_hint[key] = 1
         elif largest < BIN_BUCKET_BELOW and mean < BIN_BUCKET_MEAN_LIST_BELOW:
             self.bin_hint.pop(key, None)

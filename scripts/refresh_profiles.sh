@@ -41,6 +41,26 @@ python3 bench.py --points 4000000 --width 3840 --height 2160 --steps 10 --warmup
 python3 bench.py --full-losses --no-cpu-baseline > $O/${T}_full_losses_bench.json 2>/dev/null
 python3 bench.py --full-losses --points 4000000 --width 3840 --height 2160 --steps 10 --warmup 5 --gt-frames 4 --no-cpu-baseline > $O/${T}_full_losses_4m_4k_bench.json 2>/dev/null
 RDG_DETERMINISTIC=1 python3 bench.py --no-cpu-baseline > $O/${T}_deterministic_bench.json 2>/dev/null
+# kernel tables of the config-5 loss set (every 5th step is a rigidity step)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_fl -- python3 bench.py --full-losses --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/kt_fl.err
+cp $(find $O/kt_fl -name "*kernel_stats.csv" | head -1) $O/${T}_full_losses_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_fl4 -- python3 bench.py --full-losses --points 4000000 --width 3840 --height 2160 --steps 10 --warmup 5 --gt-frames 4 --no-cpu-baseline > /dev/null 2> $O/kt_fl4.err
+cp $(find $O/kt_fl4 -name "*kernel_stats.csv" | head -1) $O/${T}_full_losses_4m_4k_kernel_stats.csv
+rm -rf $O/kt_fl $O/kt_fl4
+# the two binning algorithms on the three scenes (stage timers of the bench line), one box
+{
+  for SC in uniform sheets dense; do
+    for M in bucket radix; do
+      RDG_BIN_MODE=$M python3 bench.py --scene $SC --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=b['stage_ms']; print('$SC', '$M', 'binning %.1f us' % (1e3*(s.get('scan_dup',0)+s.get('sort',0)+s.get('ranges',0))), 'step %.4f ms' % b['ms_per_step'])"
+    done
+  done
+} > $O/${T}_binning_modes_raw.txt
+# probes of the rigidity step's kernels, the neighbour search and the sort (n = 2 M and 500 k: config-5 sample sizes)
+{
+  python3 scripts/rig_rows_probe.py 2000000; python3 scripts/rig_rows_probe.py 500000
+  python3 scripts/knn_probe.py 2000000; python3 scripts/knn_probe.py 500000
+  python3 scripts/sort_probe.py 17000000 16; python3 scripts/sort_probe.py 2000000 48
+} > $O/${T}_rigidity_probes.txt 2>/dev/null
 python3 scripts/heavy_tile_probe.py > $O/${T}_heavy_tile.json 2> $O/heavy.err
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_sq
 ls -la $O
