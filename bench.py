@@ -110,20 +110,23 @@ def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=Fa
     -- DESIGN.md §4 'Roofline accounting'):
       * binning: bucket binning moves, per tile instance, a 4-B rank (written by the count pass, read by the scatter
         pass), an 8-B (depth, id) composite (written by the scatter, read by the per-tile sort) and the 4-B sorted id
-        = 28 B, plus two passes over 40 B of per-Gaussian geometry and the per-tile counters / ranges; the survey's
-        6-pass radix formula applies only under RDG_BIN_MODE=radix;
+        = 28 B, plus two passes over 40 B of per-Gaussian geometry and the per-tile counters / ranges; the radix
+        path (depth first: the Gaussians sorted once, their instances partitioned by tile id) is priced by its own passes;
       * optimizer in backward: the SH features' Adam step happens inside the per-Gaussian backward kernel -- their
         28 B/float leave the Adam launch; the kernel no longer writes dL/dshs (-12K B) and instead reads and writes the
         parameter and both moments (24 B/float) of those 3K floats;
       * densification statistics: the per-Gaussian backward reads and writes max_radii2D, xyz_gradient_accum and denom of
         every visible Gaussian (24 B)."""
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    n_pass = (32 + max(tiles - 1, 1).bit_length() + 7) // 8
+    n_tile_pass = (max(tiles - 1, 1).bit_length() + 7) // 8      # 8-bit passes over the tile-id bits (two at 1080p and 4K)
     n_adam = 59 + 16                                    # floats per Gaussian: 11 geometry + 3K SH (K=16) + 16 coeff
     own = P // world if sharded else P                  # Gaussian-sharded frame-DP: a rank steps its slice only
     sb = {
         "preprocess": P * (44 + 12 * K) + V * 48 + P * 8,
-        "binning": (D * 12 + D * 24 * n_pass + D * 8 + tiles * 8) if radix_binning else (D * 28 + P * 80 + tiles * 16),
+        # radix binning, depth first: P 4-byte keys + ids sorted in four passes (20 B per pair and pass: 4 counted, 8 read,
+        # 8 written), D (tile id, Gaussian id) pairs written once, partitioned in n_tile_pass passes, their ids read once
+        "binning": (P * (8 + 20 * 4) + D * (8 + 20 * n_tile_pass + 4) + tiles * 8) if radix_binning
+                   else (D * 28 + P * 80 + tiles * 16),
         "render_fwd": D * 44 + H * W * 40,
         "render_bwd": D * 44 + H * W * 40 + V * 40,
         "preprocess_bwd": P * (44 + 12 * K) * 2 + V * 48,
@@ -358,6 +361,8 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         dt = float(tt.item())
     out = {"mode": mode, "sharded": sharded, "dt": dt, "loss": float(loss.item()), "spatial_order": spatial_order,
            "graph": graphed is not None, "densify_stats": densify_stats, "deferred": deferred_in_timed_region,
+           # the binning algorithm the timed steps ran: forced by RDG_BIN_MODE, or what the per-frame rule has picked
+           "radix": bool(rasterizer._FORCE_RADIX or any(rstate.bin_hint.values())),
            "points_after_densify": points_after,
            "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
@@ -502,7 +507,7 @@ def main():
         K = 16
         sh_adam_in_backward = bool(world == 1 and not sharded and not args.full_losses
                                    and os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0")
-        radix_binning = bool(rasterizer_mod._FORCE_RADIX)
+        radix_binning = bool(best["radix"])
         P_eff = best["points_after_densify"] or P
         sb = stage_bytes(P_eff, K, V, D, H, W, world=world, sharded=sharded, sh_adam_in_backward=sh_adam_in_backward,
                          radix_binning=radix_binning, densify_stats=best["densify_stats"])
