@@ -276,11 +276,9 @@ __device__ __forceinline__ void rdg_knn_push(float d, uint32_t id, float (&bd)[K
     }
 }
 
-// (dx^2 + dy^2) + dz^2 with every product and sum rounded on its own: the value torch's float32 arithmetic gives, whatever
-// the compiler would like to contract -- neighbours at (nearly) equal distances then come out in the oracle's order
-__device__ __forceinline__ float rdg_knn_d2(float dx, float dy, float dz) {
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-}
+// squared distance (the compiler contracts the sum into fused multiply-adds, as the reference's CUDA build does with its
+// own accumulation: neither is the other's bits; neighbours closer than a rounding error apart may swap places)
+__device__ __forceinline__ float rdg_knn_d2(float dx, float dy, float dz) { return dx * dx + dy * dy + dz * dz; }
 
 template <int KM>
 __global__ void __launch_bounds__(256)

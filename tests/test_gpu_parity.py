@@ -1168,6 +1168,36 @@ def test_knn_points_matches_brute_force(Pq, Pt, K, same):
         rel_ok(h2.grad, o2.grad.float(), tol=1e-5, what="d_p2")
 
 
+@pytest.mark.parametrize("K", [3, 8, 16])
+def test_knn_points_on_a_cloud_with_a_dense_core_outliers_and_duplicates(K):
+    """The neighbour search on the kind of cloud its 48-bit curve codes are for: most points in a core a thousandth of the
+    bounding box wide, a few far outliers that set the box, and blocks of exact duplicates (equal distances: any of the tied
+    indices is a correct answer, so the DISTANCES are compared with a float32 brute force, to rounding: 1e-6 relative -- and
+    every returned index must be at its returned distance and appear once per query)."""
+    from rodygs_amd.knn import knn_points
+    g = torch.Generator().manual_seed(77 + K)
+    n = 20000
+    p = torch.randn(n, 3, generator=g) * (torch.rand(n, 1, generator=g) ** 3) * 4.0
+    p[:40] = torch.randn(40, 3, generator=g) * 500.0            # outliers: the bounding box is 1000x the core
+    p[1000:1300] = p[2000:2300]                                   # exact duplicates
+    p[5000:5064] = p[5000]                                        # 64 copies of one point: more ties than K
+    h = p.to(DEV)
+    res = knn_points(h[None], h[None], K=K)
+    d_h, i_h = res.dists[0], res.idx[0]
+    ref = torch.empty(n, K, device=DEV)
+    for a in range(0, n, 2000):
+        diff = h[a:a + 2000, None, :] - h[None, :, :]
+        ref[a:a + 2000] = torch.topk((diff * diff).sum(-1), K, dim=1, largest=False, sorted=True)[0]
+    assert bool(((d_h - ref).abs() <= 1e-6 * ref).all()), f"distances differ on {int(((d_h - ref).abs() > 1e-6 * ref).any(1).sum())} queries"
+    assert bool((d_h[:, 1:] >= d_h[:, :-1]).all()), "distances not ascending"
+    dd = h[:, None, :] - h[i_h]
+    at = (dd * dd).sum(-1)
+    assert bool(((at - d_h).abs() <= 1e-6 * d_h).all()), "an index is not at its returned distance"
+    srt = torch.sort(i_h, dim=1)[0]
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "a neighbour is listed twice"
+    assert float(d_h[:, 0].max()) == 0.0                          # every query finds itself (or a copy of itself) first
+
+
 def test_knn_gather_forward_backward():
     from rodygs_amd.knn import knn_gather
     g = torch.Generator().manual_seed(5)
