@@ -24,6 +24,7 @@ struct RdgKnnLayout {
     size_t boxes;       // float4[2*nbox]
     size_t sboxes;      // float4[2*nsb]   AABBs of RDG_KNN_SUP consecutive boxes
     size_t tboxes;      // float4[2*ntb]   AABBs of RDG_KNN_SUP consecutive super-boxes
+    size_t qboxes;      // float4[2*nqb]   AABBs of RDG_KNN_SUP consecutive top boxes (65 536 points)
     size_t mm_part;     // float[RDG_KNN_MMB][8]
     size_t total;
 };
@@ -44,6 +45,7 @@ static RdgKnnLayout rdg_knn_layout(int32_t P) {
     const size_t nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
     L.sboxes = o;   o = rdg_align_up(o + nsb * 32, 256);
     L.tboxes = o;   o = rdg_align_up(o + ((nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP) * 32, 256);
+    L.qboxes = o;   o = rdg_align_up(o + ((((nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP) + RDG_KNN_SUP - 1) / RDG_KNN_SUP) * 32, 256);
     L.mm_part = o;  o = rdg_align_up(o + (size_t)RDG_KNN_MMB * 32, 256);
     L.total = o;
     return L;
@@ -285,9 +287,10 @@ __global__ void __launch_bounds__(256)
 rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const float* __restrict__ queries,
                       const float4* __restrict__ sorted, const uint64_t* __restrict__ tkeys,
                       const float* __restrict__ minmax, const float4* __restrict__ boxes,
-                      const float4* __restrict__ sboxes, const float4* __restrict__ tboxes, float* __restrict__ dists,
-                      long long* __restrict__ idx) {
+                      const float4* __restrict__ sboxes, const float4* __restrict__ tboxes,
+                      const float4* __restrict__ qboxes, float* __restrict__ dists, long long* __restrict__ idx) {
     __shared__ float4 sBox[2 * 256];
+    __shared__ float4 sQ[2 * (256 / RDG_KNN_SUP)];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const bool act = i < Pq;
     float mx = 0.f, my = 0.f, mz = 0.f;
@@ -343,6 +346,7 @@ rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const floa
         }
     }
     const int nsb = (nbox + RDG_KNN_SUP - 1) / RDG_KNN_SUP, ntb = (nsb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
+    const int nqb = (ntb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
     for (int base = 0; base < ntb; base += 256) {
         __syncthreads();
         const int nb = min(256, ntb - base);
@@ -350,8 +354,19 @@ rdg_knn_points_kernel(int Pq, int Pt, int nbox, int K, int self_mode, const floa
             sBox[2 * threadIdx.x] = tboxes[2 * (base + threadIdx.x)];
             sBox[2 * threadIdx.x + 1] = tboxes[2 * (base + threadIdx.x) + 1];
         }
+        // a fourth level over the top boxes (16 of them = 65 536 points): at 2 M points a wave tested all 488 top boxes,
+        // a fifth of its instructions
+        if ((int)threadIdx.x < 256 / RDG_KNN_SUP && base / RDG_KNN_SUP + (int)threadIdx.x < nqb) {
+            sQ[2 * threadIdx.x] = qboxes[2 * (base / RDG_KNN_SUP + threadIdx.x)];
+            sQ[2 * threadIdx.x + 1] = qboxes[2 * (base / RDG_KNN_SUP + threadIdx.x) + 1];
+        }
         __syncthreads();
         for (int k = 0; k < nb; ++k) {
+            if ((k & (RDG_KNN_SUP - 1)) == 0) {
+                const int q = k / RDG_KNN_SUP;
+                const bool near_q = act && rdg_knn_box_d2(sQ[2 * q], sQ[2 * q + 1], mx, my, mz) <= bd[KM - 1];
+                if (__builtin_amdgcn_ballot_w64(near_q) == 0ull) { k += RDG_KNN_SUP - 1; continue; }
+            }
             const bool near_top = act && rdg_knn_box_d2(sBox[2 * k], sBox[2 * k + 1], mx, my, mz) <= bd[KM - 1];
             if (__builtin_amdgcn_ballot_w64(near_top) == 0ull) continue;
             // The AABBs of a node's children and the points of a leaf sit at wave-uniform addresses (scalar loads).  One load,
@@ -463,6 +478,9 @@ static int rdg_knn_prepare(int32_t P, const float* points, char* t, const RdgKnn
                        (const float4*)(t + L.boxes), (float4*)(t + L.sboxes));
     hipLaunchKernelGGL(rdg_knn_superbox_kernel, dim3((ntb + 63) / 64), dim3(64), 0, st, nsb,
                        (const float4*)(t + L.sboxes), (float4*)(t + L.tboxes));
+    const int nqb = (ntb + RDG_KNN_SUP - 1) / RDG_KNN_SUP;
+    hipLaunchKernelGGL(rdg_knn_superbox_kernel, dim3((nqb + 63) / 64), dim3(64), 0, st, ntb,
+                       (const float4*)(t + L.tboxes), (float4*)(t + L.qboxes));
     return 0;
 }
 
@@ -498,7 +516,8 @@ int rdg_knn_points_forward(int32_t Pq, int32_t Pt, int32_t K, const float* queri
 #define RDG_KNN_LAUNCH(KM)                                                                                        \
     hipLaunchKernelGGL(rdg_knn_points_kernel<KM>, dim3((Pq + 255) / 256), dim3(256), 0, st, Pq, Pt, nbox, K, self_mode, \
                        queries, (const float4*)(t + L.sorted), tkeys, (const float*)(t + L.minmax),                \
-                       (const float4*)(t + L.boxes), (const float4*)(t + L.sboxes), (const float4*)(t + L.tboxes), dists, \
+                       (const float4*)(t + L.boxes), (const float4*)(t + L.sboxes), (const float4*)(t + L.tboxes),                        \
+                       (const float4*)(t + L.qboxes), dists, \
                        (long long*)idx)
     if (K <= 4) RDG_KNN_LAUNCH(4); else if (K <= 8) RDG_KNN_LAUNCH(8); else if (K <= 16) RDG_KNN_LAUNCH(16);
     else RDG_KNN_LAUNCH(32);

@@ -40,3 +40,5 @@ print("f32 oracle - f64:\n", ov - tv)
 for k in ("means3D", "scales", "rotations", "opacities"):
     a, b = res[0][k].grad.cpu().double(), d[k].grad
     print(k, "HIP vs f64 per-column max rel:", [float(x) for x in ((a - b).abs().amax(0) / b.abs().amax(0).clamp_min(1e-30))])
+    o32 = res[3][k].grad.double()
+    print(k, "f32 oracle vs f64 per-column :", [float(x) for x in ((o32 - b).abs().amax(0) / b.abs().amax(0).clamp_min(1e-30))])

@@ -14,9 +14,49 @@ from oracle import rasterizer_oracle as O  # noqa: E402,F401
 from sweep_cases import sweep_case  # noqa: E402
 
 T.FLIP_ENTRIES = int(os.environ.get("RDG_SWEEP_FLIP_ENTRIES", "4"))     # see tests/test_gpu_parity.py::FLIP_ENTRIES
+
+
+def against_float64(sc, deg, bg, kw, res):
+    """A case outside the bar against the (float32) oracle: the same gradients against the oracle run in float64, HIP and the
+    float32 oracle side by side.  Returns (HIP inside the bar against float64, text)."""
+    P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
+    gen = torch.Generator().manual_seed(kw["seed"])
+    wc, wd, wa = torch.rand(3, H, W, generator=gen), torch.rand(1, H, W, generator=gen), torch.rand(1, H, W, generator=gen)
+    wn = torch.randn(3, H, W, generator=gen) * kw["normal_loss"]
+    d = {k: sc[k].clone().double().requires_grad_(True) for k in T.NAMES}
+    m2 = torch.zeros(P, 3, dtype=torch.float64, requires_grad=True)
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.tensor(bg).double(), kw["scale_modifier"],
+                          sc["projmatrix"].double(), deg, enable_cov_grad=kw["cov_grad"], enable_sh_grad=kw["sh_grad"])
+    o = O.rasterize(d["means3D"], m2, d["opacities"], d["viewmatrix"], st, shs=d["shs"], scales=d["scales"],
+                    rotations=d["rotations"])
+    ls = (o[0] * wc.double()).sum() + (o[3] * wa.double()).sum()
+    if kw["depth_loss"]:
+        ls = ls + (o[1] * wd.double()).sum() * kw["depth_loss"]
+    if kw["normal_loss"]:
+        ls = ls + (o[2] * wn.double()).sum()
+    ls.backward()
+    hi, hm2, _hout, oi, om2, _oout = res
+    ok, lines = True, []
+    for k in list(T.NAMES) + ["means2D"]:
+        h = (hm2 if k == "means2D" else hi[k]).grad.cpu()
+        o32 = (om2 if k == "means2D" else oi[k]).grad
+        r64 = (m2 if k == "means2D" else d[k]).grad
+        r64 = torch.zeros_like(h, dtype=torch.float64) if r64 is None else r64
+        try:
+            T.rel_ok(h, r64.float(), outliers=T.OUTLIER_FRAC, what="d_" + k + " vs float64")
+        except AssertionError as e:                                    # noqa: PERF203
+            ok = False
+            lines.append(str(e)[:300])
+        cols = lambda a: (a.double().reshape(a.shape[0], -1) - r64.reshape(a.shape[0], -1)).abs().amax(0) / \
+            r64.reshape(a.shape[0], -1).abs().amax(0).clamp_min(1e-30)               # noqa: E731
+        ch, co = cols(h), cols(o32)
+        if float(torch.maximum(ch, co).max()) > 5e-5:
+            j = int(torch.maximum(ch, co).argmax())
+            lines.append(f"d_{k} column {j} against the float64 oracle: HIP {float(ch[j]):.2e}, float32 oracle {float(co[j]):.2e}")
+    return ok, "; ".join(lines)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-bad = flips = 0
+bad = flips = o32 = 0
 for c in range(n_cases):
     sc, deg, bg, kw = sweep_case(seed0, c)
     P, W, H, deg_max = sc["means3D"].shape[0], sc["W"], sc["H"], int(round(sc["shs"].shape[1] ** 0.5)) - 1
@@ -40,8 +80,15 @@ for c in range(n_cases):
             flips += 1
             print("flip", tag, f"\n      {n_flip} pixel(s) with another contributor count / transmittance;", str(e)[:300])
         else:
-            bad += 1
-            print("FAIL", tag, "\n     ", str(e)[:400])
-print(f"{n_cases - bad - flips} of {n_cases} cases within the per-column bar, {flips} more differ by a flipped pixel decision "
-      f"(contributor count or final transmittance of a pixel differs), {bad} fail")
+            ok64, txt = (False, "") if res is None else against_float64(sc, deg, bg, kw, res)
+            if ok64:
+                o32 += 1
+                print("or32", tag, "\n      outside the bar against the float32 oracle, inside it against the oracle run in float64:",
+                      str(e)[:300], "\n     ", txt)
+            else:
+                bad += 1
+                print("FAIL", tag, "\n     ", str(e)[:400], "\n     ", txt)
+print(f"{n_cases - bad - flips - o32} of {n_cases} cases within the per-column bar, {flips} more differ by a flipped pixel decision "
+      f"(contributor count or final transmittance of a pixel differs), {o32} more are inside the bar against the oracle run in "
+      f"float64 where the float32 oracle is not, {bad} fail")
 sys.exit(1 if bad else 0)
