@@ -2,7 +2,8 @@
 // nearest other points.  Call site: /root/reference/src/model/rodygs_static.py:130-133 (init only).
 //
 // Exact 3-NN: points are ordered along a 48-bit Morton curve with the library's own radix sort and cut into leaf
-// boxes of 16 consecutive points with their AABBs, grouped 16 by 16 into two coarser levels (256 and 4096 points).
+// boxes of 16 consecutive points with their AABBs, grouped 16 by 16 into coarser levels (256, 4096 and -- for the K-NN walk --
+// 65 536 points).
 // A thread (one point, in Morton order, so a wave's 64 points are spatial neighbours and take the same branches)
 // seeds its best-3 from its curve neighbours and then descends only into the boxes whose AABB is closer than its
 // current 3rd-best distance.  The top level is streamed through LDS; lower levels are uniform (broadcast) loads.
