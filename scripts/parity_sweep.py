@@ -16,9 +16,18 @@ from sweep_cases import sweep_case  # noqa: E402
 T.FLIP_ENTRIES = int(os.environ.get("RDG_SWEEP_FLIP_ENTRIES", "4"))     # see tests/test_gpu_parity.py::FLIP_ENTRIES
 
 
+F32_FACTOR = 4.0
+
+
 def against_float64(sc, deg, bg, kw, res):
-    """A case outside the bar against the (float32) oracle: the same gradients against the oracle run in float64, HIP and the
-    float32 oracle side by side.  Returns (HIP inside the bar against float64, text)."""
+    """A case outside the bar against the (float32) oracle: every gradient column against the oracle run in FLOAT64, HIP and
+    the float32 oracle side by side, no outlier allowance.  Returns (verdict, text):
+      "f64"  -- HIP is inside the bar against the float64 oracle in every column (the float32 oracle was the one that is off);
+      "f32"  -- some column is outside the bar for HIP, but within F32_FACTOR times the float32 ORACLE's own distance from the
+                float64 oracle there: the column is at or below what float32 arithmetic resolves (a gradient that is the small
+                difference of large terms, orders of magnitude below its neighbours), neither implementation can be held to
+                1e-4 of it;
+      "fail" -- anything else."""
     P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
     gen = torch.Generator().manual_seed(kw["seed"])
     wc, wd, wa = torch.rand(3, H, W, generator=gen), torch.rand(1, H, W, generator=gen), torch.rand(1, H, W, generator=gen)
@@ -36,28 +45,32 @@ def against_float64(sc, deg, bg, kw, res):
         ls = ls + (o[2] * wn.double()).sum()
     ls.backward()
     hi, hm2, _hout, oi, om2, _oout = res
-    ok, lines = True, []
+    verdict, lines = "f64", []
     for k in list(T.NAMES) + ["means2D"]:
-        h = (hm2 if k == "means2D" else hi[k]).grad.cpu()
-        o32 = (om2 if k == "means2D" else oi[k]).grad
+        h = (hm2 if k == "means2D" else hi[k]).grad.cpu().double()
+        o32 = (om2 if k == "means2D" else oi[k]).grad.double()
         r64 = (m2 if k == "means2D" else d[k]).grad
-        r64 = torch.zeros_like(h, dtype=torch.float64) if r64 is None else r64
-        try:
-            T.rel_ok(h, r64.float(), outliers=T.OUTLIER_FRAC, what="d_" + k + " vs float64")
-        except AssertionError as e:                                    # noqa: PERF203
-            ok = False
-            lines.append(str(e)[:300])
-        cols = lambda a: (a.double().reshape(a.shape[0], -1) - r64.reshape(a.shape[0], -1)).abs().amax(0) / \
-            r64.reshape(a.shape[0], -1).abs().amax(0).clamp_min(1e-30)               # noqa: E731
-        ch, co = cols(h), cols(o32)
-        if float(torch.maximum(ch, co).max()) > 5e-5:
-            j = int(torch.maximum(ch, co).argmax())
-            lines.append(f"d_{k} column {j} against the float64 oracle: HIP {float(ch[j]):.2e}, float32 oracle {float(co[j]):.2e}")
-    return ok, "; ".join(lines)
+        r64 = torch.zeros_like(h) if r64 is None else r64
+        H_, O_, R_ = T._columns(h), T._columns(o32), T._columns(r64)
+        scale = R_.abs().amax(1).clamp_min(1e-300)
+        eh, eo = (H_ - R_).abs().amax(1) / scale, (O_ - R_).abs().amax(1) / scale
+        for j in torch.nonzero(eh > T.TOL).flatten().tolist():
+            within = float(eh[j]) <= F32_FACTOR * float(eo[j])
+            verdict = "fail" if not within else ("f32" if verdict != "fail" else verdict)
+            lines.append(f"d_{k} column {j} (scale {float(scale[j]):.2e}, the tensor's largest {float(scale.max()):.2e}) against "
+                         f"the float64 oracle: HIP {float(eh[j]):.2e}, float32 oracle {float(eo[j]):.2e}")
+        if verdict == "f64":
+            j = int(eo.argmax())
+            if float(eo[j]) > T.TOL:
+                lines.append(f"d_{k} column {j}: HIP {float(eh[j]):.2e}, float32 oracle {float(eo[j]):.2e} from the float64 oracle")
+    return verdict, "; ".join(lines)
+
+
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-bad = flips = o32 = 0
-for c in range(n_cases):
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0            # first case index (to re-run one case of a sweep)
+bad = flips = o64 = o32 = 0
+for c in range(first, first + n_cases):
     sc, deg, bg, kw = sweep_case(seed0, c)
     P, W, H, deg_max = sc["means3D"].shape[0], sc["W"], sc["H"], int(round(sc["shs"].shape[1] ** 0.5)) - 1
     tag = f"case {c:3d}: P={P:5d} {W}x{H} deg {deg}/{deg_max} {kw}"
@@ -80,15 +93,20 @@ for c in range(n_cases):
             flips += 1
             print("flip", tag, f"\n      {n_flip} pixel(s) with another contributor count / transmittance;", str(e)[:300])
         else:
-            ok64, txt = (False, "") if res is None else against_float64(sc, deg, bg, kw, res)
-            if ok64:
-                o32 += 1
-                print("or32", tag, "\n      outside the bar against the float32 oracle, inside it against the oracle run in float64:",
+            verdict, txt = ("fail", "") if res is None else against_float64(sc, deg, bg, kw, res)
+            if verdict == "f64":
+                o64 += 1
+                print("or64", tag, "\n      outside the bar against the float32 oracle, inside it against the oracle run in float64:",
                       str(e)[:300], "\n     ", txt)
+            elif verdict == "f32":
+                o32 += 1
+                print("or32", tag, "\n      a column at float32 resolution: outside the bar against the float64 oracle, within "
+                      f"{F32_FACTOR:g}x the float32 oracle's own distance from it:", str(e)[:300], "\n     ", txt)
             else:
                 bad += 1
                 print("FAIL", tag, "\n     ", str(e)[:400], "\n     ", txt)
-print(f"{n_cases - bad - flips - o32} of {n_cases} cases within the per-column bar, {flips} more differ by a flipped pixel decision "
-      f"(contributor count or final transmittance of a pixel differs), {o32} more are inside the bar against the oracle run in "
-      f"float64 where the float32 oracle is not, {bad} fail")
+print(f"{n_cases - bad - flips - o64 - o32} of {n_cases} cases within the per-column bar, {flips} more differ by a flipped pixel "
+      f"decision (contributor count or final transmittance of a pixel differs), {o64} more are inside the bar against the oracle "
+      f"run in float64 where the float32 oracle is not, {o32} more have a column at float32 resolution (HIP outside the bar against "
+      f"float64, within {F32_FACTOR:g}x the float32 oracle's own distance from it), {bad} fail")
 sys.exit(1 if bad else 0)
