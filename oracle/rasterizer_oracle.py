@@ -13,6 +13,12 @@ Numerical contract (mirrored 1:1 by ``rodygs_amd/csrc/rdg_preprocess.hip``):
     written below -- torch CPU elementwise ops never contract to FMA, and the HIP preprocess kernel is built
     with ``-ffp-contract=off`` -- so view-space depth bits, radii and tile rectangles (hence tile keys and the
     sorted order) are BIT-EXACT between oracle and HIP;
+  * the two square roots on that bit-exact path (the radius) go through ``_sqrt_rn``: the square root is taken in float64
+    and rounded to float32, i.e. the correctly rounded float32 square root (what ``sqrtf`` is on the GPU and in CUDA's default
+    build).  ``torch.sqrt`` on float32 CPU tensors is NOT that on every host: on the GPU boxes' hosts it returns
+    0x1.2aaaaap+1 for sqrt(0x1.5c71c8p+2) where the correctly rounded value is 0x1.2aaaacp+1 (numpy, libm and the container
+    this file was written in agree), and 3 sqrt(lambda) = 7.0000005 then became 7.0: radius 7 instead of 8, one Gaussian of
+    one scene in 7 000 of scripts/parity_sweep.py (seed 300000, case 713);
   * the compositing stage differs from the HIP kernel only by ``exp`` rounding and summation order
     (tolerance 1e-4 relative, see tests).
 
@@ -28,6 +34,11 @@ from typing import Optional
 
 import numpy as np
 import torch
+
+def _sqrt_rn(x: torch.Tensor) -> torch.Tensor:
+    """Correctly rounded square root in x's own precision (see the numerical contract above)."""
+    return torch.sqrt(x.double()).to(x.dtype) if x.dtype == torch.float32 else torch.sqrt(x)
+
 
 # ---- constants of the algorithm (SURVEY.md §7 "open questions" 6: 3DGS constants kept verbatim) -------------
 NEAR_CULL = 0.2
@@ -216,9 +227,9 @@ def preprocess(means3D, means2D, opacities, viewmatrix, settings: OracleSettings
     conic_c = ca * det_inv
     with torch.no_grad():
         mid = 0.5 * (ca + cc)
-        disc = torch.sqrt(torch.clamp(mid * mid - det, min=LAMBDA_FLOOR))
+        disc = _sqrt_rn(torch.clamp(mid * mid - det, min=LAMBDA_FLOOR))
         lam = torch.maximum(mid + disc, mid - disc)
-        radius_f = torch.ceil(3.0 * torch.sqrt(lam))
+        radius_f = torch.ceil(3.0 * _sqrt_rn(lam))
     px = ((ndc_x + 1.0) * W - 1.0) * 0.5
     py = ((ndc_y + 1.0) * H - 1.0) * 0.5
     gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE

@@ -1,6 +1,7 @@
 """Randomised parity sweep on the GPU box: HIP path vs oracle on N random small scenes (random size, ragged image sizes,
 SH degree, background, pose, scale modifier, gradient gates) with the per-column bar of the test-suite
-(tests/test_gpu_parity.py::check_pair).  Prints one line per case and a summary; exit code 1 on any failure."""
+(tests/test_gpu_parity.py::check_pair).  Prints one line per case and a summary; exit code 1 on any failure.
+  usage: parity_sweep.py <cases> <seed0> [<first case index>]      RDG_SWEEP_PROFILE=aniso: pancakes and needles"""
 import os
 import sys
 
@@ -11,12 +12,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as T  # noqa: E402
 from oracle import rasterizer_oracle as O  # noqa: E402,F401
-from sweep_cases import sweep_case  # noqa: E402
+from sweep_cases import sweep_case, sweep_case_aniso  # noqa: E402
 
 T.FLIP_ENTRIES = int(os.environ.get("RDG_SWEEP_FLIP_ENTRIES", "4"))     # see tests/test_gpu_parity.py::FLIP_ENTRIES
 
 
 F32_FACTOR = 4.0
+PROFILE = os.environ.get("RDG_SWEEP_PROFILE", "")        # "aniso": pancakes and needles (tests/sweep_cases.py::sweep_case_aniso)
 
 
 def against_float64(sc, deg, bg, kw, res):
@@ -71,7 +73,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0            # first case index (to re-run one case of a sweep)
 bad = flips = o64 = o32 = 0
 for c in range(first, first + n_cases):
-    sc, deg, bg, kw = sweep_case(seed0, c)
+    sc, deg, bg, kw = (sweep_case_aniso if PROFILE == "aniso" else sweep_case)(seed0, c)
     P, W, H, deg_max = sc["means3D"].shape[0], sc["W"], sc["H"], int(round(sc["shs"].shape[1] ** 0.5)) - 1
     tag = f"case {c:3d}: P={P:5d} {W}x{H} deg {deg}/{deg_max} {kw}"
     res = None
@@ -93,7 +95,10 @@ for c in range(first, first + n_cases):
             flips += 1
             print("flip", tag, f"\n      {n_flip} pixel(s) with another contributor count / transmittance;", str(e)[:300])
         else:
-            verdict, txt = ("fail", "") if res is None else against_float64(sc, deg, bg, kw, res)
+            # only a miss of the 1e-4 bar can be a matter of float32 resolution; anything that must be exact (radii,
+            # contributor counts beyond the allowance) is a failure whatever the float64 oracle says
+            exact = res is None or not str(e).startswith(("d_", "color", "depth", "normal", "alpha", "final_T"))
+            verdict, txt = ("fail", "") if exact else against_float64(sc, deg, bg, kw, res)
             if verdict == "f64":
                 o64 += 1
                 print("or64", tag, "\n      outside the bar against the float32 oracle, inside it against the oracle run in float64:",
