@@ -188,37 +188,95 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                 dvy += Pm[4] * dhx + Pm[5] * dhy + Pm[7] * dhw;
                 dvz += Pm[8] * dhx + Pm[9] * dhy + Pm[11] * dhw;
             }
-            // (3) conic -> cov2D.  conic = (c, -b, a) / det, differentiated in the association reverse-mode differentiation
-            // of those three quotients produces (through 1 / det, then det = a c - b^2), NOT as the closed forms
-            // da = (-c^2 gca + b c gcb - b^2 gcc) / det^2 ...: for a needle-shaped footprint (b^2 close to a c: det / (a c) = 0.03
-            // on the Gaussian that decided sweep case 40000 / 353) the closed forms add three terms of the size of
-            // c^2 g that cancel to a fraction of it, and what is left of their rounding errors is then amplified again
-            // when the covariance path cancels against the projection path in dL/dmean -- 7.5e-4 of the column's largest
-            // entry on that Gaussian, 2e-4 on the pose gradient; this form: 2.5e-5 / 6e-6, the float32 oracle's own level
-            // (scripts/dbg_pose_rows.py)
+            // (3)-(4) conic -> cov2D -> (Sigma3D, T)
+            // With scale and rotation given (the only form RoDyGS uses) everything below goes through the PROJECTED AXES
+            // u_k = T r_k of the Gaussian (the columns of M = T R S are s_k u_k, so cov2D = sum_k s_k^2 u_k u_k^T + 0.3 I):
+            //   det        = sum_{j<l} s_j^2 s_l^2 (u_j x u_l)^2 + 0.3 sum_k s_k^2 |u_k|^2 + 0.09      (Cauchy-Binet: positive terms;
+            //                a c - b^2 loses log10(a c / det) digits on a needle-shaped footprint: 3 of 7 at det / (a c) = 1.6e-3)
+            //   dL/dcov2D  = G = di adj(Gk) + ddet adj(cov2D),  Gk = dL/dconic,  di = 1 / det,  ddet = -ddi di^2,
+            //   ddi        = sum_k s_k^2 B_k + 0.3 (gca + gcc),   B_k = u_k^T adj(Gk) u_k
+            //   u_k^T adj(cov2D) u_k = sum_{j != k} s_j^2 (u_j x u_k)^2 + 0.3 |u_k|^2 = A_k:  the axis' own rank-one term drops out
+            //                EXACTLY (u_k x u_k = 0) -- formed from the matrix (c u0^2 - 2 b u0 u1 + a u1^2) it is what the other
+            //                terms are the small remainder of, for the long axis of a needle
+            //   dL/ds_k    = 2 s_k (di B_k + ddet A_k),   G u_k = di adj(Gk) u_k + ddet (sum_{j != k} s_j^2 p_j (p_j . u_k) + 0.3 u_k),
+            //                p_j = (u_j1, -u_j0);   dL/dR[:, k] = 2 s_k^2 T^T (G u_k);   dL/dT = 2 sum_k s_k^2 (G u_k) r_k^T.
+            // Strict sweep, anisotropic profile (pancakes and needles 10-300x, tests/sweep_cases.py), case 400000 / 349: the scale
+            // gradient of a 300 x 6 pixel needle was 4.5e-4 off with float64-exact input rows (the float32 oracle 6e-5) while
+            // dL/dcov2D was formed as three numbers and contracted with the axes; finding 3 of DESIGN.md section 2 was the first half
+            // of this (the contraction), this is the second (det and the adjugate).
             float da = 0.f, db = 0.f, dc = 0.f;
-            if (det != 0.0f) {
-                const float di = 1.0f / det;
-                const float ddi = (gca * c - gcb * b) + gcc * a;          // dL/d(1/det)
-                const float ddet = -(ddi * di) * di;
-                da = gcc * di + ddet * c;
-                dc = gca * di + ddet * a;
-                db = -gcb * di - 2.0f * b * ddet;
-            }
-            // (4) cov2D -> Sigma3D (6-vector grads count both off-diagonal entries; only a precomputed covariance asks for
-            // it: scale and rotation take the factored form of step (8)) and T
+            float dT00 = 0.f, dT01 = 0.f, dT02 = 0.f, dT10 = 0.f, dT11 = 0.f, dT12 = 0.f;
+            float dR00 = 0.f, dR01 = 0.f, dR02 = 0.f, dR10 = 0.f, dR11 = 0.f, dR12 = 0.f, dR20 = 0.f, dR21 = 0.f, dR22 = 0.f;
             if (cov3Dp) {
+                // a precomputed covariance has no axes: the matrix form, in the association reverse-mode differentiation of
+                // conic = (c, -b, a) / det produces (through 1 / det, then det = a c - b^2; NOT the closed forms
+                // da = (-c^2 gca + b c gcb - b^2 gcc) / det^2 ..., which add three terms of the size of c^2 g that cancel)
+                if (det != 0.0f) {
+                    const float di = 1.0f / det;
+                    const float ddi = (gca * c - gcb * b) + gcc * a;          // dL/d(1/det)
+                    const float ddet = -(ddi * di) * di;
+                    da = gcc * di + ddet * c;
+                    dc = gca * di + ddet * a;
+                    db = -gcb * di - 2.0f * b * ddet;
+                }
+                // (4) cov2D -> Sigma3D (6-vector grads count both off-diagonal entries) and T
                 dS[0] = T00 * T00 * da + T00 * T10 * db + T10 * T10 * dc;
                 dS[3] = T01 * T01 * da + T01 * T11 * db + T11 * T11 * dc;
                 dS[5] = T02 * T02 * da + T02 * T12 * db + T12 * T12 * dc;
                 dS[1] = 2.0f * T00 * T01 * da + (T00 * T11 + T01 * T10) * db + 2.0f * T10 * T11 * dc;
                 dS[2] = 2.0f * T00 * T02 * da + (T00 * T12 + T02 * T10) * db + 2.0f * T10 * T12 * dc;
                 dS[4] = 2.0f * T01 * T02 * da + (T01 * T12 + T02 * T11) * db + 2.0f * T11 * T12 * dc;
+                dT00 = 2.0f * u00 * da + u10 * db; dT01 = 2.0f * u01 * da + u11 * db; dT02 = 2.0f * u02 * da + u12 * db;
+                dT10 = 2.0f * u10 * dc + u00 * db; dT11 = 2.0f * u11 * dc + u01 * db; dT12 = 2.0f * u12 * dc + u02 * db;
+            } else if (det != 0.0f) {
+                // projected axes
+                const float a0x = T00 * R00 + T01 * R10 + T02 * R20, a0y = T10 * R00 + T11 * R10 + T12 * R20;
+                const float a1x = T00 * R01 + T01 * R11 + T02 * R21, a1y = T10 * R01 + T11 * R11 + T12 * R21;
+                const float a2x = T00 * R02 + T01 * R12 + T02 * R22, a2y = T10 * R02 + T11 * R12 + T12 * R22;
+                const float q0 = s0 * s0, q1 = s1 * s1, q2 = s2 * s2;
+                const float n0 = a0x * a0x + a0y * a0y, n1 = a1x * a1x + a1y * a1y, n2 = a2x * a2x + a2y * a2y;
+                const float x01 = a0x * a1y - a0y * a1x, x02 = a0x * a2y - a0y * a2x, x12 = a1x * a2y - a1y * a2x;
+                const float detp = ((q0 * q1) * (x01 * x01) + (q0 * q2) * (x02 * x02) + (q1 * q2) * (x12 * x12)) +
+                                   RDG_DILATION * (q0 * n0 + q1 * n1 + q2 * n2) + RDG_DILATION * RDG_DILATION;
+                const float di = 1.0f / detp;
+                const float hb = 0.5f * gcb;
+                // adj(Gk) u_k and B_k
+                const float e0x = gcc * a0x - hb * a0y, e0y = gca * a0y - hb * a0x;
+                const float e1x = gcc * a1x - hb * a1y, e1y = gca * a1y - hb * a1x;
+                const float e2x = gcc * a2x - hb * a2y, e2y = gca * a2y - hb * a2x;
+                const float B0 = a0x * e0x + a0y * e0y, B1 = a1x * e1x + a1y * e1y, B2 = a2x * e2x + a2y * e2y;
+                const float ddi = (q0 * B0 + q1 * B1 + q2 * B2) + RDG_DILATION * (gca + gcc);
+                const float ddet = -(ddi * di) * di;
+                // adj(cov2D) u_k without the axis' own term:  sum_{j != k} s_j^2 p_j (p_j . u_k) + 0.3 u_k,  p_j . u_k = -(u_j x u_k)
+                // (p_0 . u_1 = -x01, p_1 . u_0 = x01, p_0 . u_2 = -x02, p_2 . u_0 = x02, p_1 . u_2 = -x12, p_2 . u_1 = x12)
+                const float c0x = (q1 * x01) * a1y + (q2 * x02) * a2y + RDG_DILATION * a0x;
+                const float c0y = -(q1 * x01) * a1x - (q2 * x02) * a2x + RDG_DILATION * a0y;
+                const float c1x = -(q0 * x01) * a0y + (q2 * x12) * a2y + RDG_DILATION * a1x;
+                const float c1y = (q0 * x01) * a0x - (q2 * x12) * a2x + RDG_DILATION * a1y;
+                const float c2x = -(q0 * x02) * a0y - (q1 * x12) * a1y + RDG_DILATION * a2x;
+                const float c2y = (q0 * x02) * a0x + (q1 * x12) * a1x + RDG_DILATION * a2y;
+                const float A0 = (q1 * (x01 * x01) + q2 * (x02 * x02)) + RDG_DILATION * n0;
+                const float A1 = (q0 * (x01 * x01) + q2 * (x12 * x12)) + RDG_DILATION * n1;
+                const float A2 = (q0 * (x02 * x02) + q1 * (x12 * x12)) + RDG_DILATION * n2;
+                // G u_k
+                const float g0x = di * e0x + ddet * c0x, g0y = di * e0y + ddet * c0y;
+                const float g1x = di * e1x + ddet * c1x, g1y = di * e1y + ddet * c1y;
+                const float g2x = di * e2x + ddet * c2x, g2y = di * e2y + ddet * c2y;
+                dsc0 = d.smod * (2.0f * s0) * (di * B0 + ddet * A0);
+                dsc1 = d.smod * (2.0f * s1) * (di * B1 + ddet * A1);
+                dsc2 = d.smod * (2.0f * s2) * (di * B2 + ddet * A2);
+                const float f0 = 2.0f * q0, f1 = 2.0f * q1, f2 = 2.0f * q2;
+                dR00 = f0 * (T00 * g0x + T10 * g0y); dR10 = f0 * (T01 * g0x + T11 * g0y); dR20 = f0 * (T02 * g0x + T12 * g0y);
+                dR01 = f1 * (T00 * g1x + T10 * g1y); dR11 = f1 * (T01 * g1x + T11 * g1y); dR21 = f1 * (T02 * g1x + T12 * g1y);
+                dR02 = f2 * (T00 * g2x + T10 * g2y); dR12 = f2 * (T01 * g2x + T11 * g2y); dR22 = f2 * (T02 * g2x + T12 * g2y);
+                // dL/dT = 2 sum_k s_k^2 (G u_k) r_k^T
+                dT00 = (f0 * g0x) * R00 + (f1 * g1x) * R01 + (f2 * g2x) * R02;
+                dT01 = (f0 * g0x) * R10 + (f1 * g1x) * R11 + (f2 * g2x) * R12;
+                dT02 = (f0 * g0x) * R20 + (f1 * g1x) * R21 + (f2 * g2x) * R22;
+                dT10 = (f0 * g0y) * R00 + (f1 * g1y) * R01 + (f2 * g2y) * R02;
+                dT11 = (f0 * g0y) * R10 + (f1 * g1y) * R11 + (f2 * g2y) * R12;
+                dT12 = (f0 * g0y) * R20 + (f1 * g1y) * R21 + (f2 * g2y) * R22;
             }
-            const float dT00 = 2.0f * u00 * da + u10 * db, dT01 = 2.0f * u01 * da + u11 * db,
-                        dT02 = 2.0f * u02 * da + u12 * db;
-            const float dT10 = 2.0f * u10 * dc + u00 * db, dT11 = 2.0f * u11 * dc + u01 * db,
-                        dT12 = 2.0f * u12 * dc + u02 * db;
             // (5) T = J W
             const float dJ00 = W00 * dT00 + W01 * dT01 + W02 * dT02;
             const float dJ02 = W20 * dT00 + W21 * dT01 + W22 * dT02;
@@ -349,27 +407,8 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
             pose[8] += z * pvx;  pose[9] += z * pvy;  pose[10] += z * pvz;
             pose[12] += pvx;     pose[13] += pvy;     pose[14] += pvz;
 
-            // (8) Sigma3D -> scale, raw quaternion.  dL/dSigma3D = T^T G T with G = dL/dcov2D, so for the k-th axis r_k of the
-            // rotation  dL/ds_k = 2 s_k r_k^T (T^T G T) r_k = 2 s_k u^T G u  and  dL/dR[:, k] = 2 s_k^2 T^T (G u),  u = T r_k the
-            // axis as the camera sees it.  Formed from u: for an axis that points at the camera -- the thin axis of a
-            // surface-aligned Gaussian, the common case -- u is small and the result inherits ITS size.  Formed from the 3x3
-            // matrix T^T G T (rounds 1-4a), r_k^T F r_k was nine products of the size of |F| cancelling to a fraction: a scale
-            // gradient 4e-5 of its neighbours came out 3.9e-4 off (strict sweep case 120000 / 248; the float32 oracle 1.1e-4).
+            // (8) rotation matrix -> raw quaternion (dL/dR and dL/dscale were formed in (3)-(4))
             if (!cov3Dp) {
-                const float hb = 0.5f * db;
-                const float ua0 = T00 * R00 + T01 * R10 + T02 * R20, ua1 = T10 * R00 + T11 * R10 + T12 * R20;
-                const float ub0 = T00 * R01 + T01 * R11 + T02 * R21, ub1 = T10 * R01 + T11 * R11 + T12 * R21;
-                const float uc0 = T00 * R02 + T01 * R12 + T02 * R22, uc1 = T10 * R02 + T11 * R12 + T12 * R22;
-                const float ga0 = da * ua0 + hb * ua1, ga1 = hb * ua0 + dc * ua1;
-                const float gb0 = da * ub0 + hb * ub1, gb1 = hb * ub0 + dc * ub1;
-                const float gc0 = da * uc0 + hb * uc1, gc1 = hb * uc0 + dc * uc1;
-                dsc0 = d.smod * (2.0f * s0) * (ua0 * ga0 + ua1 * ga1);
-                dsc1 = d.smod * (2.0f * s1) * (ub0 * gb0 + ub1 * gb1);
-                dsc2 = d.smod * (2.0f * s2) * (uc0 * gc0 + uc1 * gc1);
-                const float f0 = 2.0f * s0 * s0, f1 = 2.0f * s1 * s1, f2 = 2.0f * s2 * s2;
-                const float dR00 = f0 * (T00 * ga0 + T10 * ga1), dR10 = f0 * (T01 * ga0 + T11 * ga1), dR20 = f0 * (T02 * ga0 + T12 * ga1);
-                const float dR01 = f1 * (T00 * gb0 + T10 * gb1), dR11 = f1 * (T01 * gb0 + T11 * gb1), dR21 = f1 * (T02 * gb0 + T12 * gb1);
-                const float dR02 = f2 * (T00 * gc0 + T10 * gc1), dR12 = f2 * (T01 * gc0 + T11 * gc1), dR22 = f2 * (T02 * gc0 + T12 * gc1);
                 dq0 = 2.0f * (-qz * dR01 + qy * dR02 + qz * dR10 - qx * dR12 - qy * dR20 + qx * dR21);
                 dq1 = 2.0f * (qy * dR01 + qz * dR02 + qy * dR10 - 2.0f * qx * dR11 - qr * dR12 + qz * dR20 + qr * dR21 -
                               2.0f * qx * dR22);

@@ -5,9 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_parity as T
 from oracle import rasterizer_oracle as O
-from sweep_cases import sweep_case
+from sweep_cases import sweep_case, sweep_case_aniso
 seed0, c = int(sys.argv[1]), int(sys.argv[2])
-sc, deg, bg, kw = sweep_case(seed0, c)
+sc, deg, bg, kw = (sweep_case_aniso if os.environ.get("RDG_SWEEP_PROFILE") == "aniso" else sweep_case)(seed0, c)
 P, W, H, deg_max = sc["means3D"].shape[0], sc["W"], sc["H"], int(round(sc["shs"].shape[1] ** 0.5)) - 1
 for a in sys.argv[3:]:                                    # e.g. cov_grad=0 sh_grad=0 normal_loss=0 depth_loss=0
     k_, v_ = a.split("="); kw[k_] = type(kw[k_])(float(v_))

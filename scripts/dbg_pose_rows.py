@@ -19,10 +19,10 @@ import test_gpu_parity as T  # noqa: E402
 from oracle import rasterizer_oracle as O  # noqa: E402
 from rodygs_amd import _lib  # noqa: E402
 from rodygs_amd.rasterizer import _c_settings  # noqa: E402
-from sweep_cases import sweep_case  # noqa: E402
+from sweep_cases import sweep_case, sweep_case_aniso  # noqa: E402
 
 seed0, c = int(sys.argv[1]), int(sys.argv[2])
-sc, deg, bg, kw = sweep_case(seed0, c)
+sc, deg, bg, kw = (sweep_case_aniso if os.environ.get("RDG_SWEEP_PROFILE") == "aniso" else sweep_case)(seed0, c)
 P, H, W = sc["means3D"].shape[0], sc["H"], sc["W"]
 print(P, W, H, deg, kw)
 dev = "cuda"

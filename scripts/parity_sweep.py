@@ -95,9 +95,10 @@ for c in range(first, first + n_cases):
             flips += 1
             print("flip", tag, f"\n      {n_flip} pixel(s) with another contributor count / transmittance;", str(e)[:300])
         else:
-            # only a miss of the 1e-4 bar can be a matter of float32 resolution; anything that must be exact (radii,
+            # only a GRADIENT's miss of the 1e-4 bar can be a matter of float32 resolution; anything that must be exact (radii,
             # contributor counts beyond the allowance) is a failure whatever the float64 oracle says
-            exact = res is None or not str(e).startswith(("d_", "color", "depth", "normal", "alpha", "final_T"))
+            # (images are not re-checked either: only the gradients have a float64 twin here)
+            exact = res is None or not str(e).startswith("d_")
             verdict, txt = ("fail", "") if exact else against_float64(sc, deg, bg, kw, res)
             if verdict == "f64":
                 o64 += 1

@@ -370,15 +370,18 @@ def test_pose_gradient_of_the_two_deep_list_sweep_cases(seed0, case):
     check_pair(run_pair(sc, deg, bg, **kw), NAMES)
 
 
-def test_scale_gradient_of_an_axis_that_points_at_the_camera():
-    """Strict sweep case 120000 / 248 (profiles/r04_parity_sweep.txt): 63 Gaussians whose first scale axis nearly points at the
-    camera; d_scales[:, 0] is 4e-5 of the other two columns and came out 3.9e-4 of its column's scale off while dL/dSigma3D
-    was formed as a 3x3 matrix and contracted with the axis (nine products cancelling).  Held here against the oracle run in
-    FLOAT64 -- the float32 oracle is itself 1.1e-4 off in that column -- with the per-column bar of every other test; the other
-    gradients against the float32 oracle as usual."""
-    from sweep_cases import sweep_case
-    from test_gpu_parity import OUTLIER_FRAC, rel_ok
-    sc, deg, bg, kw = sweep_case(120000, 248)
+@pytest.mark.parametrize("profile,seed0,case", [("", 120000, 248), ("aniso", 400000, 349), ("", 310000, 790)])
+def test_gradients_of_thin_axes_and_needle_footprints_against_the_float64_oracle(profile, seed0, case):
+    """Three cases the strict sweeps of round 4 found (profiles/r04_parity_sweep.txt), where the per-Gaussian backward lost
+    accuracy while dL/dcov2D was three numbers contracted with 3x3 matrices: 120000 / 248 (a scale axis that points at the
+    camera: d_scales[:, 0], 4e-5 of the other columns, 3.9e-4 off), 400000 / 349 of the anisotropic profile (a 300 x 6 pixel
+    needle, det / (a c) = 1.6e-3: d_scales 3e-4 off) and 310000 / 790 (a rotation-gradient column 260x below its neighbours,
+    1.06e-4).  Since the backward goes through the projected axes u_k = T r_k (Cauchy-Binet determinant, adjugate without the
+    axis' own term) they hold the per-column bar -- here against the oracle run in FLOAT64 without any outlier allowance (the
+    float32 oracle is itself outside the bar on the first two)."""
+    from sweep_cases import sweep_case, sweep_case_aniso
+    from test_gpu_parity import _columns
+    sc, deg, bg, kw = (sweep_case_aniso if profile == "aniso" else sweep_case)(seed0, case)
     res = run_pair(sc, deg, bg, **kw)
     hi = res[0]
     P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
@@ -390,13 +393,16 @@ def test_scale_gradient_of_an_axis_that_points_at_the_camera():
                           sc["projmatrix"].double(), deg, enable_cov_grad=kw["cov_grad"], enable_sh_grad=kw["sh_grad"])
     o = O.rasterize(d["means3D"], torch.zeros(P, 3, dtype=torch.float64, requires_grad=True), d["opacities"], d["viewmatrix"], st,
                     shs=d["shs"], scales=d["scales"], rotations=d["rotations"])
-    ls = (o[0] * wc.double()).sum() + (o[3] * wa.double()).sum() + (o[1] * wd.double()).sum() * kw["depth_loss"]
+    ls = (o[0] * wc.double()).sum() + (o[3] * wa.double()).sum()
+    if kw["depth_loss"]:
+        ls = ls + (o[1] * wd.double()).sum() * kw["depth_loss"]
     if kw["normal_loss"]:
         ls = ls + (o[2] * wn.double()).sum()
     ls.backward()
     for k in ("scales", "rotations", "means3D", "opacities"):
-        rel_ok(hi[k].grad, d[k].grad.float(), outliers=OUTLIER_FRAC, what=f"d_{k} vs the float64 oracle")
-    check_pair(res, [k for k in NAMES if k != "scales"])
+        h_, r_ = _columns(hi[k].grad.cpu().double()), _columns(d[k].grad)
+        err = (h_ - r_).abs().amax(1) / r_.abs().amax(1).clamp_min(1e-300)
+        assert float(err.max()) <= 1e-4, f"d_{k} against the float64 oracle, per column: {[f'{float(e):.2e}' for e in err]}"
 
 
 # ---- extra_attrs (upstream kwarg, no RoDyGS caller) --------------------------------------------------------------------
