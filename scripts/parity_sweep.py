@@ -109,8 +109,8 @@ for c in range(first, first + n_cases):
             flips += 1
             print("flip", tag, f"\n      {n_flip} pixel(s) with another contributor count / transmittance;", str(e)[:300])
         else:
-            # only a GRADIENT's miss of the 1e-4 bar can be a matter of float32 resolution; anything that must be exact (radii,
-            # contributor counts beyond the allowance) is a failure whatever the float64 oracle says
+            # only a miss of the 1e-4 bar (an image, a gradient) can be a matter of float32 resolution; anything that must be exact
+            # (radii, contributor counts beyond the allowance, the per-pixel state) is a failure whatever the float64 oracle says
             exact = res is None or not str(e).startswith(("d_", "color", "depth", "normal", "alpha"))
             verdict, txt = ("fail", "") if exact else against_float64(sc, deg, bg, kw, res)
             if verdict == "f64":
