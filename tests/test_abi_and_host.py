@@ -469,3 +469,29 @@ def test_measurement_scripts_and_entry_points_parse_and_stay_off_the_oracle_in_t
             elif isinstance(node, ast.ImportFrom):
                 names = [node.module or ""]
             assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{f} imports the oracle"
+
+
+def test_bench_visits_the_orbit_in_bit_reversed_order():
+    """bench.py's frame order (the deterministic stand-in for the reference's permutation sampler): a permutation, and any
+    window of it samples the orbit evenly -- the first four of sixteen are the four quarter points."""
+    import bench
+    for n in (1, 2, 5, 12, 16, 100):
+        assert sorted(bench._spread_order(n)) == list(range(n))
+    assert bench._spread_order(16)[:4] == [0, 8, 4, 12] and bench._spread_order(16)[4:8] == [2, 10, 6, 14]
+
+
+def test_anisotropic_sweep_profile_keeps_the_regular_draws():
+    """tests/sweep_cases.py: the anisotropic profile changes the scales only (pancakes / needles from its own random stream);
+    every other draw of the case, and the regular profile itself, stay what the named tests and profiles/r04_parity_sweep.txt
+    refer to."""
+    import torch
+    from sweep_cases import sweep_case, sweep_case_aniso
+    a, b = sweep_case(400000, 349), sweep_case_aniso(400000, 349)
+    assert a[1:3] == b[1:3] and a[3] == b[3]
+    for k in a[0]:
+        same = torch.equal(a[0][k], b[0][k]) if torch.is_tensor(a[0][k]) else a[0][k] == b[0][k]
+        assert same == (k != "scales"), k
+    ratio = (b[0]["scales"].amax(1) / b[0]["scales"].amin(1))
+    assert float(ratio.median()) > 10.0 and float((a[0]["scales"].amax(1) / a[0]["scales"].amin(1)).median()) < 5.0
+    c = sweep_case_aniso(400000, 349)
+    assert torch.equal(b[0]["scales"], c[0]["scales"])
