@@ -141,26 +141,52 @@ def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=Fa
     return sb
 
 
-def _cpu_train_step(scene, P, W, H, sh_degree, budget_s):
-    """One CPU train step of the bench workload's shape built from the oracle (kind "port"): activations ->
-    oracle rasterizer forward -> 0.8 L1 + 0.2 D-SSIM (torch) -> backward -> torch.optim.Adam (eps 1e-15) over every
-    Gaussian parameter.  The compositing runs over interleaved eighths of the tile grid until `budget_s` is spent;
-    if tiles remain, their share is extrapolated by splat instances and the returned dict says so."""
+def _host_cpu():
+    """(logical cores, model name) of the box the cpu_baseline leg runs on."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return os.cpu_count(), model
+
+
+FRAME_KEYS = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
+
+
+def _cpu_train_step(frame, gt, sh_degree, budget_s):
+    """One CPU train step built from the oracle (kind "port") on EXACTLY the rasterizer inputs in `frame` (FRAME_KEYS +
+    H, W, tanfovx, tanfovy, projmatrix): raw parameters -> activations -> oracle rasterizer forward -> 0.8 L1 + 0.2 D-SSIM
+    (torch) against `gt` -> backward -> torch.optim.Adam (eps 1e-15) over every Gaussian parameter.  The activations are
+    computed and differentiated, but the rasterizer is fed `frame`'s tensors bit for bit (value = captured + (act - act
+    .detach())): exp(log(s)) is not s to the last bit, and one ulp in a scale can move a radius -- the parity check below
+    needs the two implementations on identical inputs.  The compositing runs over interleaved eighths of the tile grid
+    until `budget_s` is spent; if tiles remain, their share is extrapolated by splat instances and the dict says so.
+    Returns (timing dict, oracle results of the frame for the parity check -- None if tiles were left out)."""
     from oracle import rasterizer_oracle as O   # checker / baseline only -- never on the product path
     from rodygs_amd.losses import photometric_loss     # torch expression (host mirror pinned by golden G6)
-    st = O.OracleSettings(H, W, scene["tanfovx"], scene["tanfovy"], torch.zeros(3), 1.0, scene["projmatrix"], sh_degree)
-    op0 = scene["opacities"].clamp(1e-4, 1 - 1e-4)
-    params = {"xyz": scene["means3D"].clone(), "features": scene["shs"].clone(), "scaling": torch.log(scene["scales"]),
-              "rotation": scene["rotations"].clone(), "opacity": torch.log(op0 / (1 - op0))}
+    H, W = frame["H"], frame["W"]
+    P = frame["means3D"].shape[0]
+    st = O.OracleSettings(H, W, frame["tanfovx"], frame["tanfovy"], torch.zeros(3), 1.0, frame["projmatrix"], sh_degree)
+    op0 = frame["opacities"].clamp(1e-6, 1 - 1e-6)
+    params = {"xyz": frame["means3D"].clone(), "features": frame["shs"].clone(), "scaling": torch.log(frame["scales"]),
+              "rotation": frame["rotations"].clone(), "opacity": torch.log(op0 / (1 - op0))}
     params = {k: v.requires_grad_(True) for k, v in params.items()}
     opt = torch.optim.Adam([{"params": [v], "lr": 1e-3} for v in params.values()], lr=0.0, eps=1e-15)
-    vm = scene["viewmatrix"].clone().requires_grad_(True)
+    vm = frame["viewmatrix"].clone().requires_grad_(True)
     m2 = torch.zeros(P, 3, requires_grad=True)
-    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(1))
     t0 = time.perf_counter()
-    rot = torch.nn.functional.normalize(params["rotation"], dim=1)
-    geom = O.preprocess(params["xyz"], m2, torch.sigmoid(params["opacity"]), vm, st, shs=params["features"],
-                        scales=torch.exp(params["scaling"]), rotations=rot)
+    act = {"means3D": params["xyz"], "shs": params["features"], "opacities": torch.sigmoid(params["opacity"]),
+           "scales": torch.exp(params["scaling"]), "rotations": torch.nn.functional.normalize(params["rotation"], dim=1)}
+    x = {k: (frame[k] + (a - a.detach())) for k, a in act.items()}      # the frame's own bits, the activations' graph
+    for v in x.values():
+        v.retain_grad()
+    geom = O.preprocess(x["means3D"], m2, x["opacities"], vm, st, shs=x["shs"], scales=x["scales"],
+                        rotations=x["rotations"])
     binning = O.bin_and_sort(geom)
     t_pre = time.perf_counter() - t0
     gx, gy = geom["grid"]
@@ -168,11 +194,17 @@ def _cpu_train_step(scene, P, W, H, sh_degree, budget_s):
     ranges = binning["ranges"].astype("int64")
     total_pairs = int(binning["num_rendered"])
     color = torch.zeros(3, H, W)
+    other = {"depth": torch.zeros(1, H, W), "alpha": torch.zeros(1, H, W)}
+    final_T, n_contrib = torch.ones(H, W), torch.zeros(H, W, dtype=torch.int32)
     done_tiles, done_pairs = 0, 0
     t1 = time.perf_counter()
     for c in range(8):
         subset = list(range(c, n_tiles, 8))
-        color = color + O.render_tiles(geom, binning, st.bg, H, W, tile_subset=subset)["color"]
+        img = O.render_tiles(geom, binning, st.bg, H, W, tile_subset=subset)
+        color = color + img["color"]
+        with torch.no_grad():      # tiles outside the subset: zero images, T = 1, no contributor
+            other = {k: v + img[k] for k, v in other.items()}
+            final_T, n_contrib = torch.minimum(final_T, img["final_T"]), torch.maximum(n_contrib, img["n_contrib"])
         done_tiles += len(subset)
         done_pairs += int((ranges[subset, 1] - ranges[subset, 0]).sum())
         if time.perf_counter() - t1 > 0.4 * budget_s:     # backward costs about as much again
@@ -184,37 +216,115 @@ def _cpu_train_step(scene, P, W, H, sh_degree, budget_s):
     opt.step()
     t_adam = time.perf_counter() - t2
     scale = total_pairs / max(done_pairs, 1)
-    return {"seconds": t_pre + t_tiles * scale + t_adam, "t_pre": t_pre, "t_tiles": t_tiles, "t_adam": t_adam,
-            "tiles_done": done_tiles, "n_tiles": n_tiles, "pairs_done": done_pairs, "pairs": total_pairs,
-            "extrapolated": done_tiles < n_tiles}
+    timing = {"seconds": t_pre + t_tiles * scale + t_adam, "t_pre": t_pre, "t_tiles": t_tiles, "t_adam": t_adam,
+              "tiles_done": done_tiles, "n_tiles": n_tiles, "pairs_done": done_pairs, "pairs": total_pairs,
+              "extrapolated": done_tiles < n_tiles}
+    if timing["extrapolated"]:
+        return timing, None
+    orc = {"images": {"color": color.detach(), **other}, "final_T": final_T, "n_contrib": n_contrib, "radii": geom["radii"],
+           "D": total_pairs, "loss": float(loss.detach()), "vals_sorted": binning["vals_sorted"], "ranges": binning["ranges"],
+           "grid_x": gx, "grads": {**{k: x[k].grad for k in x}, "viewmatrix": vm.grad, "means2D": m2.grad}}
+    return timing, orc
 
 
-def cpu_baseline(scene, sh_degree, budget_s=60.0, threads=16):
+def hip_frame(frame, gt, sh_degree, dev):
+    """The product path on the rasterizer inputs of `frame`: GaussianRasterizer forward, the fused 0.8 L1 + 0.2 D-SSIM
+    kernel against `gt`, backward; everything the parity check compares, on the host.  Runs on its own RasterState (no
+    deferred check: D is read back), outside every timed region."""
+    from rodygs_amd.losses import fused_photometric_loss
+    from rodygs_amd.rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, RasterState,
+                                       last_compositing_state)
+    H, W = frame["H"], frame["W"]
+    P = frame["means3D"].shape[0]
+    st = RasterState()
+    ins = {k: frame[k].to(dev).clone().requires_grad_(True) for k in FRAME_KEYS}
+    m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+    rs = GaussianRasterizationSettings(H, W, frame["tanfovx"], frame["tanfovy"], torch.zeros(3, device=dev), 1.0,
+                                       frame["projmatrix"].to(dev).contiguous(), sh_degree, False, False, True, True)
+    out = GaussianRasterizer(rs, state=st)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                           scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+    fT, nc = last_compositing_state(st)
+    loss = fused_photometric_loss(out[0], gt.to(dev), 0.2)
+    loss.backward()
+    torch.cuda.synchronize()
+    return {"images": {"color": out[0].detach().cpu(), "depth": out[1].detach().cpu(), "alpha": out[3].detach().cpu()},
+            "final_T": fT.cpu(), "n_contrib": nc.cpu(), "radii": out[4].cpu(), "D": int(st.capacity_hint[(P, H, W)]),
+            "loss": float(loss), "grads": {**{k: v.grad.cpu() for k, v in ins.items()}, "means2D": m2.grad.cpu()}}
+
+
+def _parity(hip, orc):
+    """parity_check entry: the HIP frame against the oracle frame the cpu_baseline leg just computed (every tile, every
+    gradient entry; oracle.parity.full_frame_report: 1e-4 per column, misses only where a witnessed pixel flip explains
+    them, 2e-2 there)."""
+    if hip is None:
+        return {"skipped": "no HIP frame was captured for this workload"}
+    if orc is None:
+        return {"skipped": "the oracle composited only part of the tile grid within --cpu-budget"}
+    from oracle.parity import full_frame_report
+    rep = full_frame_report(hip, orc, orc["vals_sorted"], orc["ranges"], orc["grid_x"])
+    rep["loss_hip"], rep["loss_oracle"] = hip["loss"], orc["loss"]
+    return rep
+
+
+def cpu_baseline(frame, gt, hip, sh_degree, dev, budget_s=60.0, threads=16):
     """cpu_baseline leg (N = 1, rank 0): the oracle-built CPU train step on this box's host cores.
-      value    : the bench workload itself (the scene the GPU was timed on), one full step; compositing over as many
-                 interleaved eighths of the tile grid as fit in `budget_s` (all of them on a box with enough cores --
-                 then nothing is extrapolated; otherwise by splat instances, and `sample` says so);
+      value    : the bench frame itself -- the rasterizer inputs of the first frame of the timed region's cycle, as they
+                 stand after the timed steps (deformed, activated, that frame's pose), and its ground truth --, one full
+                 step; compositing over as many interleaved eighths of the tile grid as fit in `budget_s` (all of them
+                 on a box with enough cores -- then nothing is extrapolated; otherwise by splat instances, and `sample`
+                 says so);
       c2_full  : BASELINE configs[1] size (100 k Gaussians, 1080p, SH3) timed IN FULL, forward + backward + Adam,
-                 median of 3 -- no extrapolation."""
+                 median of 3 -- no extrapolation.
+    Returns (cpu_baseline dict, parity_check dict): the oracle's image and gradients of both frames are not thrown away
+    but compared with the HIP path's on the same inputs (`hip`: hip_frame() of the bench frame)."""
     from rodygs_amd.synthetic import synthetic_scene
-    P, H, W = scene["means3D"].shape[0], scene["H"], scene["W"]
+    P, H, W = frame["means3D"].shape[0], frame["H"], frame["W"]
     # the oracle's tensors are a few hundred KB each: beyond ~16 threads torch's intra-op fork/join costs more than it
     # buys (measured on the 128-core GPU box); `cores` reports the threads actually used
     cores = max(1, min(torch.get_num_threads(), int(threads)))
     torch.set_num_threads(cores)
-    r = _cpu_train_step(scene, P, W, H, sh_degree, budget_s)
+    r, orc = _cpu_train_step(frame, gt, sh_degree, budget_s)
+    parity = {"bench_frame": _parity(hip, orc)}
+    del orc
     how = ("every tile composited: no extrapolation" if not r["extrapolated"] else
            f"{r['tiles_done']}/{r['n_tiles']} tiles holding {r['pairs_done']}/{r['pairs']} splat instances composited, "
            f"the rest extrapolated by instances")
     c2 = synthetic_scene(100000, 1920, 1080, 3, seed=777)
-    runs = sorted(_cpu_train_step(c2, 100000, 1920, 1080, sh_degree, 1e9)["seconds"] for _ in range(3))
-    return {"value": 1.0 / r["seconds"], "unit": "frames/s", "cores": cores, "kind": "port",
+    gt2 = torch.rand(3, 1080, 1920, generator=torch.Generator().manual_seed(1))
+    hip2 = hip_frame(c2, gt2, sh_degree, dev)
+    runs = []
+    for i in range(3):
+        r2, orc2 = _cpu_train_step(c2, gt2, sh_degree, 1e9)
+        runs.append(r2["seconds"])
+        if i == 0:
+            parity["c2"] = _parity(hip2, orc2)
+        del orc2
+    runs.sort()
+    n_cpu, model = _host_cpu()
+    base = {"value": 1.0 / r["seconds"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "host": {"cpu_count": n_cpu, "cpu_model": model, "torch_threads_used": cores},
             "sample": f"oracle train step (activations + rasterizer fwd/bwd + 0.8 L1 + 0.2 D-SSIM + torch Adam eps 1e-15; "
-                      f"no deformation MLP) of the bench frame, {P} Gaussians {W}x{H}: per-Gaussian stage + binning "
+                      f"no deformation MLP) of the bench frame (the deformed, activated cloud and pose of the timed "
+                      f"region's first frame), {P} Gaussians {W}x{H}: per-Gaussian stage + binning "
                       f"{r['t_pre']:.1f}s, compositing fwd+bwd {r['t_tiles']:.1f}s ({how}), Adam {r['t_adam']:.1f}s",
             "c2_full": {"value": 1.0 / runs[1], "unit": "frames/s", "seconds_median_of_3": runs[1], "runs_s": runs,
                         "workload": "100000 Gaussians, 1920x1080, SH3 (BASELINE configs[1] size), every tile, "
                                     "fwd + bwd + Adam, no extrapolation"}}
+    return base, parity
+
+
+def capture_bench_frame(ds, frame_idx):
+    """The rasterizer inputs the train step hands to the rasterizer for video frame `frame_idx`, as the parameters stand
+    now (deformation MLP + per-Gaussian deformation + activations, that frame's learnable pose), copied to the host: what
+    the cpu_baseline leg times the oracle on and what hip_frame() renders for the parity check."""
+    from rodygs_amd.model_ops import pose_view_matrix
+    with torch.no_grad():
+        xyz, opacity, scaling, rot, feats = ds.gaussians_at(frame_idx)
+        vm = pose_view_matrix(ds.cam_q, ds.cam_t, int(frame_idx))
+        fr = {"means3D": xyz, "shs": feats, "opacities": opacity, "scales": scaling, "rotations": rot, "viewmatrix": vm}
+        fr = {k: v.detach().float().cpu().contiguous().clone() for k, v in fr.items()}
+    fr.update(H=ds.H, W=ds.W, tanfovx=ds.tanfovx, tanfovy=ds.tanfovy, projmatrix=ds.proj_t.detach().cpu().clone())
+    return fr, ds.gt[int(frame_idx)].detach().cpu().clone()
 
 
 def run_mode(args, mode, rank, world, dev, backend, scene, target):
@@ -384,6 +494,9 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
                     _, n_contrib = rasterizer.last_compositing_state(rstate)
                     ssum += int(n_contrib.sum(dtype=torch.int64).item())
             out["D"], out["V"], out["S"] = dsum // len(perm), vsum // len(perm), ssum // len(perm)
+    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
+        # the frame the cpu_baseline leg times the oracle on and the parity check compares: first frame of the cycle
+        out["bench_frame"] = capture_bench_frame(ds, perm[0])
     del ds, ss, train_step
     gc.unfreeze()
     gc.collect()
@@ -612,10 +725,18 @@ def main():
                                     "one_device": bool(os.environ.get("RDG_ONE_DEVICE"))}
         if not args.no_cpu_baseline and world == 1:      # contract: the CPU leg runs at N = 1 only
             try:
-                res["cpu_baseline"] = cpu_baseline(scene, 3, budget_s=args.cpu_budget, threads=args.cpu_threads)
+                if best.get("bench_frame") is not None:
+                    frame, gt = best["bench_frame"]
+                    hip = hip_frame(frame, gt, 3, dev)
+                else:                                    # (RDG_FORCE_SHARD: no replica to capture from) the canonical cloud
+                    frame, gt, hip = scene, torch.rand(3, H, W, generator=torch.Generator().manual_seed(1)), None
+                res["cpu_baseline"], res["parity_check"] = cpu_baseline(frame, gt, hip, 3, dev, budget_s=args.cpu_budget,
+                                                                        threads=args.cpu_threads)
             except Exception as e:  # the baseline must never take the GPU number down with it
+                n_cpu, model = _host_cpu()
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(),
-                                       "kind": "port", "sample": f"failed: {e}"}
+                                       "host": {"cpu_count": n_cpu, "cpu_model": model},
+                                       "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(res))
     if dist.is_initialized():
         dist.barrier()

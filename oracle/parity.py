@@ -1,0 +1,138 @@
+"""How two implementations of the rasterizer are compared.  TEST INFRASTRUCTURE ONLY (tests/, bench.py's cpu_baseline leg).
+
+The bar of BASELINE.json's north_star ("within 1e-4 rel on rendered RGB / depth and gradients") is read COLUMN BY COLUMN:
+every component of a per-Gaussian tensor, every SH band x channel, every image channel is held to its own largest entry.
+The only entries that may miss it are the ones a WITNESSED decision flip explains: a pixel whose blend / stop decision sits
+on the alpha = 1/255 or T = 1e-4 discontinuity of the algorithm itself (an exp() ulp decides it).
+"""
+import torch
+
+
+def columns(t):
+    """[n_columns, n_entries] view of a tensor, a column being what shares ONE scale: a component of a per-Gaussian
+    tensor ([P, ...]: every trailing index is its own column -- each SH band x channel of d_shs, each of x / y / z, each
+    quaternion component), a channel of an image ([C, H, W]); a small matrix (the pose, [4, 4]) or a vector is one
+    column."""
+    if t.dim() == 3 and t.shape[0] <= 4 and t.shape[1] * t.shape[2] > 64:        # image [C, H, W]
+        return t.reshape(t.shape[0], -1)
+    if t.dim() >= 2 and t.shape[0] > 16 and t[0].numel() <= 64:                   # per-Gaussian rows
+        return t.reshape(t.shape[0], -1).t()
+    return t.reshape(1, -1)
+
+
+def flip_mask(fT_h, nc_h, fT_o, nc_o):
+    """bool mask of the pixels whose blend / stop decision differs between the two implementations: a decision flipped on
+    the LAST splat of a pixel changes its contributor count, one in the middle of the list changes the pixel's final
+    transmittance by that splat's (1 - alpha), alpha >= 1/255, and nothing else."""
+    fT_h, fT_o = torch.as_tensor(fT_h).detach().double().cpu(), torch.as_tensor(fT_o).detach().double().cpu()
+    nc_h, nc_o = torch.as_tensor(nc_h).cpu().to(torch.int64), torch.as_tensor(nc_o).cpu().to(torch.int64)
+    return (nc_h != nc_o) | ((fT_h - fT_o).abs() > 1e-3 * fT_o.abs())
+
+
+def flipped_pixels(fT_h, nc_h, fT_o, nc_o) -> int:
+    """Number of pixels with a witnessed decision flip (flip_mask)."""
+    return int(flip_mask(fT_h, nc_h, fT_o, nc_o).sum())
+
+
+def column_stats(a, b, tol=1e-4):
+    """Per-column comparison of ``a`` against the reference ``b``: dict with the worst column's relative error
+    (|a - b| / max|b| of that column), the largest number of entries of any one column above ``tol``, the number of columns
+    and entries.  A column ``b`` has exactly zero counts as 0 where ``a`` is zero too, as inf otherwise."""
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    A, B = columns(a), columns(b)
+    d = (A - B).abs()
+    scale = B.abs().amax(dim=1, keepdim=True)
+    rel = d / scale.clamp_min(1e-300)
+    rel = torch.where((scale == 0) & (d == 0), torch.zeros_like(rel), rel)
+    over = (rel > tol).sum(dim=1)
+    return {"max_rel": float(rel.max()) if rel.numel() else 0.0, "entries_over_bar": int(over.max()) if over.numel() else 0,
+            "columns": int(A.shape[0]), "entries_per_column": int(A.shape[1]), "nan": bool(torch.isnan(a).any())}
+
+
+def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=2e-2):
+    """Every pixel and every gradient entry of a WHOLE frame, HIP against the oracle, with the witness rule taken down to
+    the Gaussian: an entry may miss ``tol`` (and then must stay below ``cap``) only if
+      * it is a pixel with a witnessed decision flip (flip_mask), or
+      * it belongs to a Gaussian that stands in the tile list of such a pixel at or before the pixel's last contributor
+        (max of the two implementations' counts) -- the splats whose blend decision can have flipped there, and the ones
+        whose weight at that pixel changed with it.
+    Everything else -- all other pixels, all other Gaussians' rows, the pose gradient -- is held to ``tol`` of its column's
+    largest oracle entry with no allowance at all.
+
+    hip / orc: {"images": {name: [C,H,W]}, "final_T": [H,W], "n_contrib": [H,W], "radii": [P], "D": int,
+                "grads": {name: tensor}}; vals_sorted / ranges: the oracle's sorted Gaussian indices and tile ranges
+    (bit-exact with the HIP binning: a separate test); grid_x: tiles per row.
+    Returns a dict of plain numbers (JSON-able) with ``ok`` and the list of ``violations``."""
+    import numpy as np
+    viol = []
+    fT_h, fT_o = torch.as_tensor(hip["final_T"]).cpu(), torch.as_tensor(orc["final_T"]).cpu()
+    nc_h, nc_o = torch.as_tensor(hip["n_contrib"]).cpu(), torch.as_tensor(orc["n_contrib"]).cpu()
+    H, W = fT_o.shape
+    fm = flip_mask(fT_h, nc_h, fT_o, nc_o)
+    n_flip = int(fm.sum())
+    radii_equal = bool(torch.equal(torch.as_tensor(hip["radii"]).cpu().to(torch.int64),
+                                   torch.as_tensor(orc["radii"]).cpu().to(torch.int64)))
+    D_equal = int(hip["D"]) == int(orc["D"])
+    if not radii_equal:
+        viol.append("radii differ")
+    if not D_equal:
+        viol.append(f"D differs: {hip['D']} vs {orc['D']}")
+    # the Gaussians a flipped pixel can have moved
+    P = int(torch.as_tensor(orc["radii"]).numel())
+    cand = np.zeros(P, dtype=bool)
+    ys, xs = np.nonzero(fm.numpy())
+    ranges = np.asarray(ranges).astype(np.int64)
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        s, e = ranges[(y // 16) * grid_x + (x // 16)]
+        n = int(max(int(nc_h[y, x]), int(nc_o[y, x])))
+        cand[np.asarray(vals_sorted[s:min(e, s + n)]).astype(np.int64)] = True
+    cand_t = torch.from_numpy(cand)
+    rep = {"tol": tol, "cap": cap, "pixels": H * W, "witnessed_flips": n_flip, "flip_candidate_gaussians": int(cand.sum()),
+           "radii_equal": radii_equal, "D_equal": D_equal, "image_max_rel": {}, "image_max_rel_on_flipped_pixels": {},
+           "grad_max_rel_per_tensor": {}, "grad_max_rel_on_flip_candidates": {}}
+
+    def rel_cols(a, b):
+        A, B = columns(torch.as_tensor(a).detach().double().cpu()), columns(torch.as_tensor(b).detach().double().cpu())
+        d = (A - B).abs()
+        scale = B.abs().amax(dim=1, keepdim=True)
+        rel = d / scale.clamp_min(1e-300)
+        return torch.where((scale == 0) & (d == 0), torch.zeros_like(rel), rel), bool(torch.isnan(A).any())
+
+    fmf = fm.reshape(-1)
+    imgs = dict(hip["images"])
+    imgs["final_T"] = torch.as_tensor(hip["final_T"]).reshape(1, H, W)
+    oimgs = dict(orc["images"])
+    oimgs["final_T"] = torch.as_tensor(orc["final_T"]).reshape(1, H, W)
+    for name, o_img in oimgs.items():
+        rel, nan = rel_cols(imgs[name], o_img)
+        clean = float(rel[:, ~fmf].max()) if bool((~fmf).any()) else 0.0
+        flipped = float(rel[:, fmf].max()) if n_flip else 0.0
+        rep["image_max_rel"][name] = clean
+        rep["image_max_rel_on_flipped_pixels"][name] = flipped
+        if nan or not clean <= tol:
+            viol.append(f"{name}: {clean:.3e} on a pixel without a witnessed flip ({int((rel[:, ~fmf] > tol).sum())} entries)")
+        if not flipped <= cap:
+            viol.append(f"{name}: {flipped:.3e} on a flipped pixel (cap {cap:g})")
+    mism = int(((nc_h.to(torch.int64) != nc_o.to(torch.int64)) & ~fm).sum())     # zero by construction of flip_mask
+    rep["n_contrib_mismatch_off_flips"] = mism
+    for name, go in orc["grads"].items():
+        gh = hip["grads"][name]
+        rel, nan = rel_cols(gh, go)
+        per_gaussian = rel.shape[1] == P and rel.shape[0] < P
+        if per_gaussian:
+            clean = float(rel[:, ~cand_t].max()) if bool((~cand_t).any()) else 0.0
+            onc = float(rel[:, cand_t].max()) if bool(cand_t.any()) else 0.0
+            n_over = int((rel[:, ~cand_t] > tol).sum())
+        else:
+            clean, onc, n_over = float(rel.max()), 0.0, int((rel > tol).sum())
+        rep["grad_max_rel_per_tensor"][name] = clean
+        rep["grad_max_rel_on_flip_candidates"][name] = onc
+        if nan or not clean <= tol:
+            viol.append(f"d_{name}: {clean:.3e} off the flip candidates ({n_over} entries over the bar)")
+        if not onc <= cap:
+            viol.append(f"d_{name}: {onc:.3e} on a flip candidate (cap {cap:g})")
+    rep["violations"] = viol
+    rep["ok"] = not viol
+    return rep
