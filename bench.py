@@ -504,6 +504,31 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks the way the driver's torchrun command does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)
+    as a CHILD process, pass its output through (rank 0's JSON line is the only line on stdout) and return its exit status.
+    This parent never initialises a GPU (torch.cuda.device_count() does not, on this image) and never exec()s: a process
+    that has touched the GPU must not be replaced, and the children need fresh ones anyway.  Fewer visible devices than
+    ranks is an error (exit 2) unless RDG_ONE_DEVICE=1 (functional check of the N > 1 flow on one device, with
+    RDG_DIST_BACKEND=gloo: RCCL refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < n and not os.environ.get("RDG_ONE_DEVICE"):
+        print(f"bench.py: --gpus {n} needs {n} visible devices, this node shows {n_dev} "
+              f"(RDG_ONE_DEVICE=1 RDG_DIST_BACKEND=gloo runs every rank on device 0 as a functional check)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL across processes needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -546,6 +571,13 @@ def main():
                          "each, back to back, reports the faster one as `value` and both under `dp_modes`")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (it never touches a GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE="
+                         f"{os.environ.get('WORLD_SIZE', '1')} ranks; they must agree (n_gpus in the JSON line is the number of "
+                         f"ranks that ran)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

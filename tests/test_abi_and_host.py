@@ -495,3 +495,23 @@ def test_anisotropic_sweep_profile_keeps_the_regular_draws():
     assert float(ratio.median()) > 10.0 and float((a[0]["scales"].amax(1) / a[0]["scales"].amin(1)).median()) < 5.0
     c = sweep_case_aniso(400000, 349)
     assert torch.equal(b[0]["scales"], c[0]["scales"])
+
+
+def test_bench_gpus_flag_is_never_silently_ignored():
+    """bench.py --gpus N (CPU side of the launcher logic): without a launcher and without N visible devices the command
+    refuses (exit 2) instead of running one GPU and printing n_gpus = 1; under a launcher whose WORLD_SIZE disagrees with
+    --gpus it refuses too; with RDG_ONE_DEVICE=1 it really starts N child ranks (which, on this GPU-less box, stop at
+    "needs a GPU" -- the parent hands their failure on)."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RDG_ONE_DEVICE")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    run = lambda a, e: subprocess.run([sys.executable, os.path.join(root, "bench.py"), *a], env=e, cwd=root,   # noqa: E731
+                                      capture_output=True, text=True, timeout=300)
+    r = run(["--gpus", "2", "--steps", "1"], env)
+    assert r.returncode == 2 and "needs 2 visible devices" in r.stderr and not r.stdout.strip()
+    r = run(["--gpus", "4", "--steps", "1"], dict(env, WORLD_SIZE="2", RANK="0"))
+    assert r.returncode != 0 and "they must agree" in r.stderr
+    r = run(["--gpus", "2", "--steps", "1"], dict(env, RDG_ONE_DEVICE="1", RDG_DIST_BACKEND="gloo"))
+    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]

@@ -2846,6 +2846,35 @@ def test_bench_runs_both_dp_formulations_the_way_the_driver_launches_it():
     assert all(v["hbm_frac"] is None or 0 < v["hbm_frac"] <= 1.0 for v in d["stage_roofline"].values())
 
 
+def test_plain_bench_command_with_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --steps 3` with NO launcher around it (how the driver's N = 1 command line looks with a
+    larger N): the process starts the two ranks itself (bench.launch_ranks: a torchrun child, no exec, the parent never
+    touches the GPU), relays rank 0's JSON line -- n_gpus == 2, both formulations under dp_modes -- and returns the
+    children's status.  Without RDG_ONE_DEVICE the same command on this 1-GPU box must refuse (exit 2), not run one GPU
+    and call it two."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--steps", "3", "--warmup", "1", "--points", "20000", "--width", "320", "--height", "240", "--frames", "8",
+             "--gt-frames", "4"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(RDG_ONE_DEVICE="1", RDG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *small], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and set(d["dp_modes"]) == {"allreduce", "shard"}
+    assert d["process_group"]["world_size"] == 2 and d["config"]["one_device"] is True
+    if torch.cuda.device_count() < 2:
+        env.pop("RDG_ONE_DEVICE")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *small], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2 and "needs 2 visible devices" in r.stderr and not r.stdout.strip()
+
+
 def test_psnr_delta_through_the_real_train_step():
     """BASELINE metric "PSNR delta vs ref" (north_star: within 0.05 dB), at 20 k dynamic Gaussians, 320x240, 500
     optimiser steps with one densification (scripts/psnr_delta.py; PSNR per /root/reference/src/utils/eval_utils.py:36-39).
