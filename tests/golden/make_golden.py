@@ -37,6 +37,14 @@ What is pinned: the pieces of the hot path that exist as import
                    append_motion_optim build (src/trainer/rodygs_static.py:106-141, rodygs_dynamic.py:93-116), one Adam
                    step is taken, and DynTrainer.state_dict (rodygs_dynamic.py:217-222) writes the checkpoint the
                    import direction is tested on (``... make_golden.py checkpoint``)
+  G13 densify   : DynTrainer.densify_and_prune -- densify_and_clone / densify_and_split / prune_points /
+                   densification_postfix and the optimizer surgery under them (src/trainer/rodygs_static.py:170-315,
+                   rodygs_dynamic.py:150-197, src/trainer/utils.py:36-95) -- RUN on the model and optimizer the
+                   reference builds from a checkpoint (as G12), with statistics set by hand; every ``device="cuda"``
+                   factory call is redirected to the CPU by a TorchFunctionMode, and torch.normal(mean, std) is
+                   served as mean + std * z with the standard-normal z recorded (the split samples); two cases
+                   (no screen-size limit / max_screen_size 20 with the world-size prune firing)
+                   (``... make_golden.py densify``)
 Nothing from the reference is copied: only inputs and the outputs it produced are stored.
 """
 import os
@@ -469,13 +477,109 @@ def checkpoint_golden():
     np.savez_compressed(os.path.join(OUT, "checkpoint_golden.npz"), **out)
 
 
+def densify_golden():
+    """G13: the reference's own densify-and-prune, run here on the CPU (see the module docstring)."""
+    import tempfile
+    from torch.overrides import TorchFunctionMode
+    from src.model.rodygs_dynamic import DynRoDyGS
+    from src.trainer.rodygs_dynamic import DynTrainer
+    from rodygs_amd import checkpoint as CK
+
+    class OnCpu(TorchFunctionMode):
+        """device="cuda" -> "cpu" on every torch call; torch.normal(mean=, std=) -> mean + std * z, z recorded."""
+
+        def __init__(self, gen):
+            super().__init__()
+            self.gen, self.z = gen, []
+
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            kwargs = dict(kwargs or {})
+            if str(kwargs.get("device", "")).startswith("cuda"):
+                kwargs["device"] = "cpu"
+            if func is torch.normal:
+                mean, std = kwargs["mean"], kwargs["std"]
+                z = torch.randn(std.shape, generator=self.gen)
+                self.z.append(z)
+                return mean + std * z
+            return func(*args, **kwargs)
+
+    out = {}
+    cases = {"a": dict(seed=1313, percent_dense=0.01, max_screen_size=None, min_opacity=0.3, max_grad=0.0002),
+             "b": dict(seed=1414, percent_dense=0.08, max_screen_size=20, min_opacity=0.45, max_grad=0.0003)}
+    for tag, c in cases.items():
+        fp, net, sp, g2t, cams, g = checkpoint_inputs(seed=c["seed"])
+        P = CKPT_P
+        sd = CK.export_state_dict(fp, 5, 3, CKPT_SCALE, net, g2t, cams, feature_lr_rest=CKPT_LR["feature_lr"] / 20.0,
+                                  deform_state=sp, deform_lr=CKPT_DEFORM["deform_lr_init"])
+        with tempfile.TemporaryDirectory() as td:
+            CK.save_checkpoint(os.path.join(td, "dynamic_last.ckpt"), sd)
+            loaded = torch.load(os.path.join(td, "dynamic_last.ckpt"), weights_only=False)[0]
+        t_cuda, m_cuda = torch.Tensor.cuda, torch.nn.Module.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        try:
+            model = DynRoDyGS(3, 128, 26, False, 16, inverse_motion=True)
+            model.create_from_state_dict(loaded, CKPT_SCALE)
+            tr_ = object.__new__(DynTrainer)
+            tr_.model, tr_.spatial_lr_scale, tr_.is_optimizable_cam = model, CKPT_SCALE, False
+            tr_.optim_setup(**CKPT_LR)
+            tr_.append_motion_optim(**CKPT_DEFORM)
+            tr_.optimizer.load_state_dict(loaded["optim"]["optimizer"])
+            tr_.percent_dense = c["percent_dense"]
+            # statistics: a third of the Gaussians never seen (denom 0 -> NaN average -> 0), gradients around the threshold
+            denom = torch.randint(0, 4, (P, 1), generator=g).float()
+            accum = torch.rand(P, 1, generator=g) * 3.0 * c["max_grad"] * denom
+            radii = torch.rand(P, generator=g) * 40
+            tr_.xyz_gradient_accum, tr_.denom, tr_.max_radii2D = accum.clone(), denom.clone(), radii.clone()
+            max_s = model.get_scaling.max(dim=1).values.detach()
+            extent = float(max_s.median()) / c["percent_dense"]          # half clone candidates, half split candidates
+            names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "motion_coeff")
+            single = {g_["name"]: g_["params"][0] for g_ in tr_.optimizer.param_groups if len(g_["params"]) == 1}
+            assert tuple(single) == names
+            for k in names:
+                st_ = tr_.optimizer.state[single[k]]
+                out[f"{tag}.in.{k}"] = single[k].detach().numpy().copy()
+                out[f"{tag}.in.exp_avg.{k}"] = st_["exp_avg"].numpy().copy()
+                out[f"{tag}.in.exp_avg_sq.{k}"] = st_["exp_avg_sq"].numpy().copy()
+            out[f"{tag}.in.accum"], out[f"{tag}.in.denom"], out[f"{tag}.in.max_radii"] = accum.numpy(), denom.numpy(), radii.numpy()
+            out[f"{tag}.in.gaussian_to_time"] = model.gaussian_to_time.numpy().copy()
+            out[f"{tag}.in.gaussian_to_time_ind"] = model.gaussian_to_time_ind.numpy().astype(np.int64)
+            mode = OnCpu(g)
+            with mode:
+                tr_.densify_and_prune(c["max_grad"], c["min_opacity"], extent, c["max_screen_size"])
+            assert len(mode.z) == 1                                       # one torch.normal call: the split samples
+        finally:
+            torch.Tensor.cuda, torch.nn.Module.cuda = t_cuda, m_cuda
+        out[f"{tag}.z"] = mode.z[0].numpy()
+        out[f"{tag}.args"] = np.array([c["max_grad"], c["min_opacity"], extent, c["max_screen_size"] or 0,
+                                       c["percent_dense"], 2], dtype=np.float64)
+        single = {g_["name"]: g_["params"][0] for g_ in tr_.optimizer.param_groups if len(g_["params"]) == 1}
+        attr = {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                "scaling": "_scaling", "rotation": "_rotation", "motion_coeff": "_motion_coeff"}
+        for k in names:
+            assert getattr(model, attr[k]) is single[k]                  # the model's attributes ARE the optimizer's params
+            st_ = tr_.optimizer.state[single[k]]
+            out[f"{tag}.out.{k}"] = single[k].detach().numpy().copy()
+            out[f"{tag}.out.exp_avg.{k}"] = st_["exp_avg"].numpy().copy()
+            out[f"{tag}.out.exp_avg_sq.{k}"] = st_["exp_avg_sq"].numpy().copy()
+            out[f"{tag}.out.step.{k}"] = np.float64(float(st_["step"]))
+        out[f"{tag}.out.accum"], out[f"{tag}.out.denom"] = tr_.xyz_gradient_accum.numpy().copy(), tr_.denom.numpy().copy()
+        out[f"{tag}.out.max_radii"] = tr_.max_radii2D.numpy().copy()
+        out[f"{tag}.out.gaussian_to_time"] = model.gaussian_to_time.numpy().copy()
+        out[f"{tag}.out.gaussian_to_time_ind"] = model.gaussian_to_time_ind.numpy().astype(np.int64)
+        Pn = out[f"{tag}.out.xyz"].shape[0]
+        print(f"G13 case {tag}: P {P} -> {Pn}, split samples {tuple(mode.z[0].shape)}, extent {extent:.3f}")
+    np.savez_compressed(os.path.join(OUT, "densify_golden.npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose", "optimizer", "checkpoint"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("rigidity", "depth", "motion", "pose", "optimizer", "checkpoint", "densify"):
         sys.dont_write_bytecode = True
         _stub_modules()
         sys.path.insert(0, REF)
         {"rigidity": rigidity_golden, "depth": depth_loss_golden, "motion": motion_reg_golden,
-         "pose": eval_pose_golden, "optimizer": optimizer_golden, "checkpoint": checkpoint_golden}[sys.argv[1]]()
+         "pose": eval_pose_golden, "optimizer": optimizer_golden, "checkpoint": checkpoint_golden,
+         "densify": densify_golden}[sys.argv[1]]()
         print(sys.argv[1], "golden written to", OUT)
     else:
         main()

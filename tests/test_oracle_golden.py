@@ -279,3 +279,57 @@ def test_xyz_lr_schedule_matches_reference_get_expon_lr_func():
         got = [expon_lr(int(s), lr_init, lr_final, int(delay_steps), delay_mult, int(max_steps)) for s in g["lr_steps"]]
         np.testing.assert_allclose(got, g["lr_" + tag], rtol=1e-12)
     assert expon_lr(-1, 1e-3, 1e-5) == 0.0 and expon_lr(5, 0.0, 0.0) == 0.0
+
+
+def densify_case(tag):
+    """G13 (tests/golden/densify_golden.npz: DynTrainer.densify_and_prune RUN by make_golden.py on the CPU): inputs in the
+    flat-bucket layout (features = cat(f_dc, f_rest)), the call's arguments, the recorded split draws, and the reference's
+    outputs in the same layout."""
+    g = load("densify_golden.npz")
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation", "motion_coeff")
+
+    def bucket(prefix):
+        d = {k: torch.from_numpy(g[f"{tag}.{prefix}{k}"]) for k in names}
+        d["features"] = torch.cat([d.pop("f_dc"), d.pop("f_rest")], dim=1)
+        return d
+    ins = dict(params=bucket("in."), exp_avg=bucket("in.exp_avg."), exp_avg_sq=bucket("in.exp_avg_sq."))
+    outs = dict(params=bucket("out."), exp_avg=bucket("out.exp_avg."), exp_avg_sq=bucket("out.exp_avg_sq."))
+    for d, pre in ((ins, "in."), (outs, "out.")):
+        d.update(accum=torch.from_numpy(g[f"{tag}.{pre}accum"]), denom=torch.from_numpy(g[f"{tag}.{pre}denom"]),
+                 max_radii=torch.from_numpy(g[f"{tag}.{pre}max_radii"]),
+                 per_point={k: torch.from_numpy(g[f"{tag}.{pre}{k}"]) for k in ("gaussian_to_time", "gaussian_to_time_ind")})
+    max_grad, min_opacity, extent, mss, percent_dense, N = (float(v) for v in g[f"{tag}.args"])
+    args = dict(max_grad=max_grad, min_opacity=min_opacity, extent=extent, max_screen_size=(mss or None),
+                percent_dense=percent_dense, N=int(N))
+    steps = {k: float(g[f"{tag}.out.step.{k}"]) for k in names}
+    return ins, outs, args, torch.from_numpy(g[f"{tag}.z"]), steps
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_densify_oracle_matches_the_reference_trainers_own_densify_and_prune(tag):
+    """G13 pins oracle/densify_oracle.py with the reference itself: DynTrainer.densify_and_prune
+    (/root/reference/src/trainer/rodygs_static.py:280-315 with densify_and_clone / densify_and_split / prune_points /
+    densification_postfix, rodygs_dynamic.py:150-197, utils.py:36-95) was RUN on a model and optimizer the reference built
+    from a checkpoint; the oracle must reproduce every parameter row, both Adam moments, the statistics and the per-Gaussian
+    time arrays BIT FOR BIT (same torch CPU operations in the same order; the split draws are the recorded ones)."""
+    from oracle import densify_oracle as DZ
+    ins, outs, a, z, steps = densify_case(tag)
+    st = DZ.State({k: v.clone() for k, v in ins["params"].items()}, {k: v.clone() for k, v in ins["exp_avg"].items()},
+                  {k: v.clone() for k, v in ins["exp_avg_sq"].items()}, ins["accum"].clone(), ins["denom"].clone(),
+                  ins["max_radii"].clone(), {k: v.clone() for k, v in ins["per_point"].items()})
+    P0 = st.P
+    n_clone, n_sel = DZ.densify_and_prune(st, a["max_grad"], a["min_opacity"], a["extent"], a["max_screen_size"],
+                                          a["percent_dense"], a["N"], z)
+    assert n_clone > 20 and n_sel > 20 and z.shape[0] == a["N"] * n_sel
+    assert st.P == outs["params"]["xyz"].shape[0] != P0
+    for k, v in outs["params"].items():
+        assert torch.equal(st.params[k], v), k
+        assert torch.equal(st.exp_avg[k], outs["exp_avg"][k]) and torch.equal(st.exp_avg_sq[k], outs["exp_avg_sq"][k]), k
+    assert torch.equal(st.accum, outs["accum"]) and torch.equal(st.denom, outs["denom"])
+    assert torch.equal(st.max_radii, outs["max_radii"]) and float(st.max_radii.abs().sum()) == 0.0
+    for k, v in outs["per_point"].items():
+        assert torch.equal(st.per_point[k], v), k
+    assert set(steps.values()) == {5.0}          # the surgery keeps the step counter of every group
+    if tag == "b":                               # the world-size prune (0.1 * extent) fired on top of the opacity prune
+        big = torch.exp(ins["params"]["scaling"]).max(dim=1).values > 0.1 * a["extent"]
+        assert int(big.sum()) > 5
