@@ -252,7 +252,7 @@ def hip_frame(frame, gt, sh_degree, dev):
             "loss": float(loss), "grads": {**{k: v.grad.cpu() for k, v in ins.items()}, "means2D": m2.grad.cpu()}}
 
 
-def _parity(hip, orc):
+def _parity(hip, orc, gt):
     """parity_check entry: the HIP frame against the oracle frame the cpu_baseline leg just computed (every tile, every
     gradient entry; oracle.parity.full_frame_report: 1e-4 per column, misses only where a witnessed pixel flip explains
     them, 2e-2 there)."""
@@ -261,7 +261,11 @@ def _parity(hip, orc):
     if orc is None:
         return {"skipped": "the oracle composited only part of the tile grid within --cpu-budget"}
     from oracle.parity import full_frame_report
-    rep = full_frame_report(hip, orc, orc["vals_sorted"], orc["ranges"], orc["grid_x"])
+    # the loss is 0.8 L1 + 0.2 D-SSIM: a pixel whose two renderings (equal to 1e-6) lie on different sides of the ground
+    # truth has dL/dpixel of opposite sign in the L1 term -- witnessed here, passed on as the loss's own kink
+    hc, oc = hip["images"]["color"].double(), orc["images"]["color"].double()
+    kink = (torch.sign(hc - gt.double()) != torch.sign(oc - gt.double())).any(dim=0)
+    rep = full_frame_report(hip, orc, orc["vals_sorted"], orc["ranges"], orc["grid_x"], loss_kink=kink)
     rep["loss_hip"], rep["loss_oracle"] = hip["loss"], orc["loss"]
     return rep
 
@@ -284,7 +288,7 @@ def cpu_baseline(frame, gt, hip, sh_degree, dev, budget_s=60.0, threads=16):
     cores = max(1, min(torch.get_num_threads(), int(threads)))
     torch.set_num_threads(cores)
     r, orc = _cpu_train_step(frame, gt, sh_degree, budget_s)
-    parity = {"bench_frame": _parity(hip, orc)}
+    parity = {"bench_frame": _parity(hip, orc, gt)}
     del orc
     how = ("every tile composited: no extrapolation" if not r["extrapolated"] else
            f"{r['tiles_done']}/{r['n_tiles']} tiles holding {r['pairs_done']}/{r['pairs']} splat instances composited, "
@@ -297,7 +301,7 @@ def cpu_baseline(frame, gt, hip, sh_degree, dev, budget_s=60.0, threads=16):
         r2, orc2 = _cpu_train_step(c2, gt2, sh_degree, 1e9)
         runs.append(r2["seconds"])
         if i == 0:
-            parity["c2"] = _parity(hip2, orc2)
+            parity["c2"] = _parity(hip2, orc2, gt2)
         del orc2
     runs.sort()
     n_cpu, model = _host_cpu()

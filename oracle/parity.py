@@ -51,7 +51,7 @@ def column_stats(a, b, tol=1e-4):
             "columns": int(A.shape[0]), "entries_per_column": int(A.shape[1]), "nan": bool(torch.isnan(a).any())}
 
 
-def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=2e-2):
+def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=2e-2, loss_kink=None):
     """Every pixel and every gradient entry of a WHOLE frame, HIP against the oracle, with the witness rule taken down to
     the Gaussian: an entry may miss ``tol`` (and then must stay below ``cap``) only if
       * it is a pixel with a witnessed decision flip (flip_mask), or
@@ -60,6 +60,10 @@ def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=2e-2)
         whose weight at that pixel changed with it.
     Everything else -- all other pixels, all other Gaussians' rows, the pose gradient -- is held to ``tol`` of its column's
     largest oracle entry with no allowance at all.
+    loss_kink: optional bool [H,W] -- pixels where the LOSS the gradients come from is witnessed on two sides of a kink of its
+    own (an L1 term: sign(hip - gt) != sign(oracle - gt) in some channel, i.e. the two images, equal to 1e-6, straddle the
+    ground truth): dL/dpixel differs there by the whole L1 weight although the images agree.  The Gaussians in such a
+    pixel's list join the flip candidates; the pixel itself is still held to ``tol``.
 
     hip / orc: {"images": {name: [C,H,W]}, "final_T": [H,W], "n_contrib": [H,W], "radii": [P], "D": int,
                 "grads": {name: tensor}}; vals_sorted / ranges: the oracle's sorted Gaussian indices and tile ranges
@@ -82,14 +86,21 @@ def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=2e-2)
     # the Gaussians a flipped pixel can have moved
     P = int(torch.as_tensor(orc["radii"]).numel())
     cand = np.zeros(P, dtype=bool)
-    ys, xs = np.nonzero(fm.numpy())
+    n_kink = 0
+    moved = fm
+    if loss_kink is not None:
+        loss_kink = torch.as_tensor(loss_kink).cpu().bool().reshape(H, W)
+        n_kink = int(loss_kink.sum())
+        moved = fm | loss_kink
+    ys, xs = np.nonzero(moved.numpy())
     ranges = np.asarray(ranges).astype(np.int64)
     for y, x in zip(ys.tolist(), xs.tolist()):
         s, e = ranges[(y // 16) * grid_x + (x // 16)]
         n = int(max(int(nc_h[y, x]), int(nc_o[y, x])))
         cand[np.asarray(vals_sorted[s:min(e, s + n)]).astype(np.int64)] = True
     cand_t = torch.from_numpy(cand)
-    rep = {"tol": tol, "cap": cap, "pixels": H * W, "witnessed_flips": n_flip, "flip_candidate_gaussians": int(cand.sum()),
+    rep = {"tol": tol, "cap": cap, "pixels": H * W, "witnessed_flips": n_flip, "loss_kink_pixels": n_kink,
+           "flip_candidate_gaussians": int(cand.sum()),
            "radii_equal": radii_equal, "D_equal": D_equal, "image_max_rel": {}, "image_max_rel_on_flipped_pixels": {},
            "grad_max_rel_per_tensor": {}, "grad_max_rel_on_flip_candidates": {}}
 

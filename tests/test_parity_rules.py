@@ -57,6 +57,16 @@ def test_full_frame_report_rules():
     # ... but not beyond the cap, and not for another Gaussian
     bad["grads"]["opacities"][gid] += 0.5 * fr["grads"]["opacities"].abs().max()
     assert not full_frame_report(bad, fr, binning["vals_sorted"], binning["ranges"], gx)["ok"]
+    # the loss's own kink: the same error is allowed for the Gaussians of a pixel named in loss_kink -- the pixel is not
+    bad = _copy(fr)
+    bad["grads"]["opacities"][gid] += 5e-4 * fr["grads"]["opacities"].abs().max()
+    kink = torch.zeros(fr["final_T"].shape, dtype=torch.bool)
+    assert not full_frame_report(bad, fr, binning["vals_sorted"], binning["ranges"], gx, loss_kink=kink)["ok"]
+    kink[y, x] = True
+    rep = full_frame_report(bad, fr, binning["vals_sorted"], binning["ranges"], gx, loss_kink=kink)
+    assert rep["ok"] and rep["loss_kink_pixels"] == 1 and rep["witnessed_flips"] == 0
+    bad["images"]["color"][0, y, x] += 1e-3
+    assert not full_frame_report(bad, fr, binning["vals_sorted"], binning["ranges"], gx, loss_kink=kink)["ok"]
     # a pixel off the bar without a flip
     bad = _copy(fr)
     bad["images"]["color"][1, 5, 7] += 1e-3
@@ -110,8 +120,8 @@ def test_bench_cpu_leg_feeds_the_oracle_the_frames_own_bits_and_its_result_passe
     assert torch.equal(ref[5]["final_T"], o1["final_T"]) and torch.equal(ref[5]["n_contrib"], o1["n_contrib"])
     o1h = {k: o1[k] for k in ("images", "final_T", "n_contrib", "radii", "D", "grads")}
     o1h["loss"] = o1["loss"]
-    rep = bench._parity(o1h, o2)
+    rep = bench._parity(o1h, o2, gt)
     assert rep["ok"] and rep["witnessed_flips"] == 0 and set(rep["grad_max_rel_per_tensor"]) == set(NAMES) | {"means2D"}
-    assert "skipped" in bench._parity(None, o2) and "skipped" in bench._parity(o1h, None)
+    assert "skipped" in bench._parity(None, o2, gt) and "skipped" in bench._parity(o1h, None, gt)
     n, model = bench._host_cpu()
     assert n == os.cpu_count()
