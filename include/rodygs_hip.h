@@ -174,7 +174,8 @@ int rdg_rasterize_backward(const RdgRasterSettings* s_host, const float* bg, con
  * rdg_rasterize_forward == rdg_preprocess_forward + rdg_composite_forward, rdg_rasterize_backward ==
  * rdg_composite_backward + rdg_preprocess_backward.  The halves meet in two row formats that can cross the wire:
  *   - splat records: the first P*64 bytes of geom_ws, one 64-B row per Gaussian
- *       (px, py, conic_a, conic_b | conic_c, opacity, depth, radius as int bits | r, g, b, - | nx, ny, nz, -);
+ *       (px, py, conic_a, conic_b | conic_c, opacity, depth, radius as int bits | r, g, b, 1 / cov2D_yy | nx, ny, nz, -)
+ *       -- 1 / cov2D_yy = conic_c - conic_b^2 / conic_a, carried because that difference cancels on needle-shaped footprints;
  *   - gradient rows: the first P*64 bytes of grad_ws, one 16-float row per Gaussian
  *       (moments of t = G dL/dG over the pixels about (w, dy), w = (px - x) + beta (py - y), beta = conic_b / conic_a of the
  *        record -- the skew coordinate the exponent is evaluated in, so that needle-shaped footprints lose nothing to

@@ -19,8 +19,10 @@
 #define RDG_LAMBDA_FLOOR 0.1f
 
 // 64-byte per-Gaussian splat record: everything the compositing kernels gather, one L2 line-half per splat.
-//   q0 = (px, py, conic_a, conic_b)   q1 = (conic_c, opacity, depth, _)
-//   q2 = (r, g, b, _)                 q3 = (nx, ny, nz, _)
+//   q0 = (px, py, conic_a, conic_b)   q1 = (conic_c, opacity, depth, radius as int bits)
+//   q2 = (r, g, b, 1 / cov2D_yy)      q3 = (nx, ny, nz, _)
+// (1 / cov2D_yy = conic_c - conic_b^2 / conic_a, the second coefficient of the completed square the compositing kernels
+//  evaluate, carried because that difference cancels on needle-shaped footprints: rdg_stage_conic)
 struct __attribute__((aligned(64))) RdgRec {
     float4 q0, q1, q2, q3;
 };

@@ -105,7 +105,7 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
             const float m1u = o_ * ga.x, m1y = o_ * ga.y;
             // the conic the compositing kernels used, bit for bit (the record), and their beta from it
             const float4 rq0 = rec[i].q0;
-            const float rka = rq0.z, rkb = rq0.w, rkc = rec[i].q1.x;
+            const float rka = rq0.z, rkb = rq0.w;
             const float rA2 = -1.4426950408889634f * rka, rB = -1.4426950408889634f * rkb;
             const float beta_s = (rA2 < 0.0f) ? rB / rA2 : 0.0f;
             const float gcc = o_ * gb.x;
@@ -175,7 +175,8 @@ rdg_preprocess_bwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                 // the first bracket is the rounding residue of beta (an FMA gives it exactly), the second det(conic) / ka:
                 // no term of the size of |conic| |m| is left to cancel
                 gnx = -0.5f * (float)d.W * fmaf(rka, m1u, __fmaf_rn(-rka, beta_s, rkb) * m1y);
-                gny = -0.5f * (float)d.H * fmaf(rkb, m1u, __fmaf_rn(-rkb, beta_s, rkc) * m1y);
+                // (kc - kb beta = det(conic) / ka = 1 / cov2D_yy: the record carries it, formed without the cancellation)
+                gny = -0.5f * (float)d.H * fmaf(rkb, m1u, rec[i].q2.w * m1y);
             }
             {
                 const float hx = Pm[0] * vx + Pm[4] * vy + Pm[8] * vz + Pm[12];

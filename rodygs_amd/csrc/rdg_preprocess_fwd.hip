@@ -212,7 +212,9 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                     R.q0 = make_float4(px, py, cc * det_inv, -cb * det_inv);
                     // q1.w carries the pixel radius: a record is then self-contained (another rank can bin it, rdg_geom_from_records)
                     R.q1 = make_float4(ca * det_inv, opac[i], vz, __int_as_float(radius));
-                    R.q2 = make_float4(cr, cg, cbl, 0.f);
+                    // q2.w = 1 / cov2D_yy = conic_c - conic_b^2 / conic_a without that difference's cancellation: the second
+                    // coefficient of the completed square the compositing kernels evaluate (rdg_stage_conic)
+                    R.q2 = make_float4(cr, cg, cbl, 1.0f / cc);
                     R.q3 = make_float4(nx, ny, nz, 0.f);
                 }
             }

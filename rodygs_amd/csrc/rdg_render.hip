@@ -93,13 +93,18 @@ __device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const flo
 // Forward and backward evaluate exactly this expression on the same staged values, so they take identical blend / skip
 // decisions.
 #define RDG_NEG_LOG2E (-1.4426950408889634f)
+// gam: c - b^2 / a = det(conic) / a is the small remainder of its two terms on a needle-shaped footprint (det / (a c) =
+// 3e-3: 2e-5 of relative error from float32 conic entries -- a SYSTEMATIC stretch of the footprint along its long axis, which
+// the signed pixel sums of the backward do not average out: strict sweep 410000 / 223, dL/dmean of a 300-pixel needle 1.05e-4
+// off where the float32 oracle's per-pixel noise leaves 1.1e-5).  It equals 1 / cov2D_yy exactly, and the per-Gaussian forward
+// has that number without any cancellation: the record carries it (RdgRec.q2.w, `inv_cyy`).
 struct RdgConicS { float hA, beta, gam; };
-__device__ __forceinline__ RdgConicS rdg_stage_conic(float a, float b, float c) {
-    const float A2 = RDG_NEG_LOG2E * a, B = RDG_NEG_LOG2E * b, C2 = RDG_NEG_LOG2E * c;
+__device__ __forceinline__ RdgConicS rdg_stage_conic(float a, float b, float inv_cyy) {
+    const float A2 = RDG_NEG_LOG2E * a, B = RDG_NEG_LOG2E * b;
     RdgConicS s;
     s.hA = 0.5f * A2;
     s.beta = (A2 < 0.0f) ? B / A2 : 0.0f;
-    s.gam = 0.5f * (C2 - s.beta * B);
+    s.gam = (0.5f * RDG_NEG_LOG2E) * inv_cyy;
     return s;
 }
 __device__ __forceinline__ float rdg_log2_gauss(float hA, float beta, float gam, float dx, float dy) {
@@ -227,7 +232,7 @@ rdg_fwd_composite(const int k_begin, const int k_end, const uint2 range, const f
             const uint32_t id = point_list[range.x + k];
             const RdgRec* p = rec + id;
             const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
-            const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
+            const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q2.w);
             sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
             *(float2*)&sQ1[tid] = make_float2(cs.gam, q1.y);
             sQ2[tid] = make_float4(q2.x, q2.y, q2.z, q1.z);
@@ -387,7 +392,7 @@ rdg_render_seg_T_kernel(int W, int H, int gx, const uint2* __restrict__ ranges, 
             if (k < k_end) {
                 const RdgRec* p = rec + point_list[range.x + k];
                 const float4 q0 = p->q0, q1 = p->q1;
-                const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
+                const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, p->q2.w);
                 sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
                 sQ1[tid] = make_float2(cs.gam, q1.y);
             }
@@ -857,7 +862,7 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                     const uint32_t id = point_list[range.x + k];
                     const RdgRec* p = rec + id;
                     const float4 q0 = p->q0, q1 = p->q1, q2 = p->q2;
-                    const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q1.x);
+                    const RdgConicS cs = rdg_stage_conic(q0.z, q0.w, q2.w);
                     sQ0[tid] = make_float4(q0.x, q0.y, cs.hA, cs.beta);
                     sQ1[tid] = make_float4(cs.gam, q1.y, q1.z, 0.0f);
                     uint32_t row = id;
@@ -1049,16 +1054,31 @@ rdg_det_reduce_kernel(int P, const uint32_t* __restrict__ tiles_touched, const u
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int g = (int)(t >> 4), c = (int)(t & 15);
     if (g >= P) return;
-    float acc = 0.0f;
+    // Compensated (two-sum) accumulation: a footprint hundreds of pixels long spans dozens of tiles, and its first moments
+    // are signed sums that cancel to a fraction of their terms (strict sweep 410000 / 223: dL/dmean 1.05e-4 off).  This kernel
+    // waits for gathers, not for its adds, so the exact rounding error of every addition is carried along for free -- the
+    // hot kernel cannot afford the registers; here the order is fixed and the extra adds hide behind the loads.
+    float acc = 0.0f, comp = 0.0f;
     const uint32_t n = tiles_touched[g], first = det_off[g];
     // (an overflowed frame has empty tile lists and meaningless offsets: nothing beyond the workspace is read)
     if ((long long)first + n <= n_instances) {
         for (uint32_t j = 0; j < n; ++j) {
             const float* row = det + (size_t)(first + j) * (4 * RDG_GROW) + c;
-            acc += (row[0] + row[RDG_GROW]) + (row[2 * RDG_GROW] + row[3 * RDG_GROW]);
+            const float a0 = row[0], a1 = row[RDG_GROW], a2 = row[2 * RDG_GROW], a3 = row[3 * RDG_GROW];
+            // the four wave partials of the tile, then the tile's total into the running sum: Knuth's two-sum each time
+            float s01 = a0 + a1, bb = s01 - a0;
+            float e = (a0 - (s01 - bb)) + (a1 - bb);
+            float s23 = a2 + a3; bb = s23 - a2;
+            e += (a2 - (s23 - bb)) + (a3 - bb);
+            float st = s01 + s23; bb = st - s01;
+            e += (s01 - (st - bb)) + (s23 - bb);
+            const float nw = acc + st; bb = nw - acc;
+            e += (acc - (nw - bb)) + (st - bb);
+            acc = nw;
+            comp += e;
         }
     }
-    grow[(size_t)g * RDG_GROW + c] = acc;
+    grow[(size_t)g * RDG_GROW + c] = acc + comp;
 }
 
 // det != nullptr: deterministic mode -- `det` holds 4 * RDG_GROW floats per list position (zeroed by the caller)

@@ -28,6 +28,7 @@ print(P, W, H, deg, kw)
 dev = "cuda"
 gen = torch.Generator().manual_seed(kw["seed"])
 wc, wd, wa = torch.rand(3, H, W, generator=gen), torch.rand(1, H, W, generator=gen), torch.rand(1, H, W, generator=gen)
+wn = torch.randn(3, H, W, generator=gen) * kw["normal_loss"]
 
 # ---- float64 oracle, with the per-Gaussian intermediates kept --------------------------------------------------------
 d = {k: sc[k].clone().double().requires_grad_(True) for k in T.NAMES}
@@ -39,6 +40,8 @@ geom = o[5]["geom"]
 for k in ("conic", "rgb", "px", "py"):
     geom[k].retain_grad()
 ls = (o[0] * wc.double()).sum() + (o[3] * wa.double()).sum() + (o[1] * wd.double()).sum() * kw["depth_loss"]
+if kw["normal_loss"]:
+    ls = ls + (o[2] * wn.double()).sum()
 ls.backward()
 tv = d["viewmatrix"].grad
 scale = float(tv.abs().max())
@@ -75,8 +78,10 @@ while True:
 print("D", D, "largest list", int(nren[1]))
 gws = torch.empty(L.rdg_grad_bytes(P), **u8)
 gc, gd, ga = wc.to(dev).contiguous(), (wd * kw["depth_loss"]).to(dev).contiguous(), wa.to(dev).contiguous()
+gn = wn.to(dev).contiguous() if kw["normal_loss"] else None
 _lib.check(L.rdg_composite_backward(C.byref(cs), bgd.data_ptr(), geom_ws.data_ptr(), bin_ws.data_ptr(), cap,
-                                    image_ws.data_ptr(), gc.data_ptr(), gd.data_ptr(), ga.data_ptr(), None, gws.data_ptr(), s_),
+                                    image_ws.data_ptr(), gc.data_ptr(), gd.data_ptr(), ga.data_ptr(),
+                                    gn.data_ptr() if gn is not None else None, gws.data_ptr(), s_),
            "composite_backward")
 rows = gws[:P * 64].view(torch.float32).view(P, 16)
 rows_hip = rows.clone()
@@ -133,7 +138,8 @@ o32 = O.rasterize(d32["means3D"], torch.zeros(P, 3, requires_grad=True), d32["op
 g32 = o32[5]["geom"]
 for k in ("conic", "rgb"):
     g32[k].retain_grad()
-((o32[0] * wc).sum() + (o32[3] * wa).sum() + (o32[1] * wd).sum() * kw["depth_loss"]).backward()
+((o32[0] * wc).sum() + (o32[3] * wa).sum() + (o32[1] * wd).sum() * kw["depth_loss"]
+ + ((o32[2] * wn).sum() if kw["normal_loss"] else 0.0)).backward()
 r32 = torch.zeros(P, 16, dtype=torch.float64)
 g32c = g32["conic"].grad.double()
 r32[:, 2:5] = torch.stack([g32c[:, 0] + beta * g32c[:, 1] + beta * beta * g32c[:, 2], g32c[:, 1] + 2 * beta * g32c[:, 2],
@@ -173,3 +179,10 @@ for name, hipg, org in (("means3D", dm3, d["means3D"].grad), ("scales", dsc, d["
         print(f"    #{i}: err {float(e[i]):.2e}  |grad|/colmax {float((org[i].abs() / colmax).max()):.2e}  depth {float(geom['depth'][i]):.3f} "
               f"radius {int(geom['radii'][i])} opacity {float(op[i]):.3f} cov2D ({a_:.3e}, {b_:.3e}, {c_:.3e}) det/(ac) {det / (a_ * c_):.2e} "
               f"tiles {int(geom['tiles_touched'][i])}")
+
+# the rows as files: scripts/dbg_scale_grad.py replays the per-Gaussian backward on them on the CPU
+import numpy as np  # noqa: E402
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+pre_bwd()
+np.savez(os.path.join(ROOT, "gpurun_out", f"rows_{seed0}_{c}.npz"), rows_hip=rows_hip.cpu().numpy(), rows_f64=orow.numpy(),
+         dsc_hip=pre_bwd.last[1].numpy(), dm3_hip=pre_bwd.last[0].numpy(), opac=op.numpy())
