@@ -53,3 +53,38 @@ def test_hip_densify_and_prune_matches_the_reference_trainers_own_run(tag):
         assert torch.equal(res.per_point[k].cpu(), v), k
     assert torch.equal(res.stats.xyz_gradient_accum.cpu(), outs["accum"]) and torch.equal(res.stats.denom.cpu(), outs["denom"])
     assert torch.equal(res.stats.max_radii2D.cpu(), outs["max_radii"])
+
+
+# ---- the residue of round 4's strict anisotropic sweeps, named (profiles/r04_parity_sweep.txt: the 3 FAIL of 400) ----------------
+
+@pytest.mark.parametrize("mode", ["radix+deterministic", "bucket+atomic"])
+@pytest.mark.parametrize("case,expect", [(58, {"d_scales": "geom"}), (223, {"d_means3D": "geom", "d_means2D": "geom"}),
+                                         (153, {})])
+def test_the_three_sweep_misses_of_round_4_against_their_arbiters(case, expect, mode):
+    """410000 / 58, 153, 223 of the anisotropic profile (pancakes and needles, tests/sweep_cases.py), radix binning +
+    deterministic backward -- round 4's sweep listed them as misses of the 1e-4 bar against the float64 oracle.  What they are
+    (tests/resolution.py, scripts/dbg_scale_grad.py):
+      * 58 (a scale-gradient column 400x below its neighbours, HIP 5e-4) and 223 (ONE Gaussian, a needle hundreds of pixels long,
+        dL/dmean 1.05e-4): the exact derivative AT THE FLOAT32 GEOMETRY -- the per-Gaussian forward both implementations share bit
+        for bit -- is itself 4.4e-4 / 1.1e-4 from the all-float64 one (conic = adj / det with det = a c - b^2 in float32), and HIP
+        is within 1e-4 of THAT: class "geom", asserted here explicitly;
+      * 153 (ONE Gaussian, a 400-pixel needle): every image and gradient of BOTH float32 implementations is 2-5e-4 from the
+        float64 oracle; HIP must stay within 4x the float32 oracle's own distance (class "f32") or the float32 geometry.
+    No column may be a plain "fail", in either binning / backward mode."""
+    import resolution
+    from rodygs_amd import rasterizer as R
+    from sweep_cases import sweep_case_aniso
+    from test_gpu_parity import run_pair
+    sc, deg, bg, kw = sweep_case_aniso(410000, case)
+    keep = (R._FORCE_RADIX, R.DETERMINISTIC)
+    R._FORCE_RADIX, R.DETERMINISTIC = (mode == "radix+deterministic"), (mode == "radix+deterministic")
+    try:
+        res = run_pair(sc, deg, bg, **kw)
+    finally:
+        R._FORCE_RADIX, R.DETERMINISTIC = keep
+    assert torch.equal(res[2][4].cpu(), res[5][4]), "radii"
+    verdict, txt = resolution.classify(sc, deg, bg, kw, res)
+    assert verdict != "fail", txt
+    for col, cls in expect.items():
+        hit = [ln for ln in txt.split("; [") if col + " column" in ln]
+        assert all(ln.startswith(cls) or ln.startswith("[" + cls) for ln in hit), (col, cls, txt)
