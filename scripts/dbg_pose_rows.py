@@ -186,3 +186,37 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 pre_bwd()
 np.savez(os.path.join(ROOT, "gpurun_out", f"rows_{seed0}_{c}.npz"), rows_hip=rows_hip.cpu().numpy(), rows_f64=orow.numpy(),
          dsc_hip=pre_bwd.last[1].numpy(), dm3_hip=pre_bwd.last[0].numpy(), opac=op.numpy())
+
+# ---- the same split against the float64 oracle AT THE FLOAT32 GEOMETRY (tests/resolution.py class "geom"): rows rebuilt from its
+# dL/d(px, py, conic, rgb) and fed to the per-Gaussian backward -- isolates the float32 per-Gaussian backward from the rows --------
+import resolution  # noqa: E402
+gg, ggeom, g32_ = resolution.float32_geometry_run(sc, deg, bg, kw, return_geom=True)
+kon32 = g32_["conic"].double()
+beta32 = torch.where(kon32[:, 0] != 0, (kon32[:, 1].float() / kon32[:, 0].float()).double(), z)       # the record's float32 beta
+cov32 = g32_["cov2D"].double()
+gpx_, gpy_ = ggeom["px"], ggeom["py"]
+m1x_ = -(cov32[:, 0] * gpx_ + cov32[:, 1] * gpy_)
+m1y_ = -(cov32[:, 1] * gpx_ + cov32[:, 2] * gpy_)
+grow = torch.zeros(P, 16, dtype=torch.float64)
+grow[:, 0], grow[:, 1] = (m1x_ + beta32 * m1y_) * inv_o, m1y_ * inv_o
+gcn = ggeom["conic"]
+grow[:, 2:5] = torch.stack([gcn[:, 0] + beta32 * gcn[:, 1] + beta32 * beta32 * gcn[:, 2], gcn[:, 1] + 2 * beta32 * gcn[:, 2],
+                            gcn[:, 2]], 1) * inv_o.unsqueeze(1)
+grow[:, 5] = ggeom["opacity"]
+grow[:, 6:9] = ggeom["rgb"]
+grow[:, 9] = ggeom["depth"]
+grow = torch.where(vis.unsqueeze(1), grow, torch.zeros_like(grow))
+print("(4) HIP rows vs the float32-geometry arbiter's rows, per column:")
+a_, b_ = hr[vis][:, :10], grow[vis][:, :10]
+print("   ", [f"{float(x):.2e}" for x in ((a_ - b_).abs().amax(0) / b_.abs().amax(0).clamp_min(1e-300))])
+for label, use in (("HIP rows", None), ("arbiter rows", grow)):
+    rows.copy_(rows_hip)
+    if use is not None:
+        rows[:, :10] = use[:, :10].to(torch.float32).to(dev)
+    pre_bwd()
+    dm3_, dsc_, dro_ = pre_bwd.last
+    for name, hipg, ref_ in (("means3D", dm3_, gg["means3D"]), ("scales", dsc_, gg["scales"]), ("rotations", dro_, gg["rotations"])):
+        colmax = d[name].grad.abs().amax(0)
+        print(f"(5) per-Gaussian backward on {label:12s}: d_{name} vs the float32-geometry arbiter, per column",
+              [f"{float(x):.2e}" for x in ((hipg - ref_).abs().amax(0) / colmax)])
+rows.copy_(rows_hip)

@@ -25,7 +25,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0            # first case index (to re-run one case of a sweep)
 bad = flips = 0
-counts = {"f64": 0, "geom": 0, "f32": 0, "cond": 0}
+counts = {"f64": 0, "geom": 0, "f32": 0, "f32s": 0, "cond": 0}
 for c in range(first, first + n_cases):
     sc, deg, bg, kw = (sweep_case_aniso if PROFILE == "aniso" else sweep_case)(seed0, c)
     P, W, H, deg_max = sc["means3D"].shape[0], sc["W"], sc["H"], int(round(sc["shs"].shape[1] ** 0.5)) - 1
@@ -58,6 +58,8 @@ for c in range(first, first + n_cases):
                             "forward both implementations share):",
                     "f32": "a column at float32 resolution: outside the bar against the float64 oracle, within "
                            f"{resolution.F32_FACTOR:g}x the float32 oracle's own distance from it:",
+                    "f32s": "a scene no float32 evaluation resolves: outside the bar against the float64 oracle, within "
+                            f"{resolution.F32_FACTOR:g}x the float32 oracle's LARGEST distance over the scene's gradient columns:",
                     "cond": "a column float32 INPUTS do not determine: the float64 oracle's own gradient moves by more than HIP's "
                             "distance when the inputs are perturbed by 2^-22:"}
             if verdict == "fail":
@@ -65,12 +67,13 @@ for c in range(first, first + n_cases):
                 print("FAIL", tag, "\n     ", str(e)[:400], "\n     ", txt)
             else:
                 counts[verdict] += 1
-                print({"f64": "or64", "geom": "geom", "f32": "or32", "cond": "cond"}[verdict], tag, "\n     ", what[verdict],
+                print({"f64": "or64", "geom": "geom", "f32": "or32", "f32s": "o32s", "cond": "cond"}[verdict], tag, "\n     ", what[verdict],
                       str(e)[:300], "\n     ", txt)
 inside = n_cases - bad - flips - sum(counts.values())
 print(f"{inside} of {n_cases} cases within the per-column bar, {flips} more differ by a flipped pixel decision (contributor count or "
       f"final transmittance of a pixel differs), {counts['f64']} more are inside the bar against the oracle run in float64 where the "
       f"float32 oracle is not, {counts['geom']} more are inside it against the float64 oracle at the float32 geometry, {counts['f32']} "
       f"more have a column at float32 resolution (HIP outside the bar against float64, within {resolution.F32_FACTOR:g}x the float32 "
-      f"oracle's own distance from it), {counts['cond']} more a column float32 inputs do not determine, {bad} fail")
+      f"oracle's own distance from it), {counts['f32s']} more are scenes no float32 evaluation resolves (within "
+      f"{resolution.F32_FACTOR:g}x the float32 oracle's largest distance), {counts['cond']} more a column float32 inputs do not determine, {bad} fail")
 sys.exit(1 if bad else 0)

@@ -12,6 +12,11 @@ tests/test_gpu_round5.py).  HIP's distance from the oracle run in FLOAT64 decide
              former to 1e-6, the float32 oracle lands 1e-5 from the latter because the per-pixel rounding of its naive exponent
              happens to shift the sum back);
   "f32"   -- within 4x the float32 ORACLE's own distance from the float64 oracle: neither float32 implementation resolves it;
+  "f32s"  -- within 4x the float32 oracle's LARGEST distance over all gradient columns of the scene, where that is itself outside
+             the bar: a scene of one or a few extreme needles (410000 / 153: ONE Gaussian, cov2D (5103, -5800, 6594), det / (a c) =
+             1.6e-4, 156 tiles) whose exponent no float32 evaluation resolves -- w = dx + beta dy carries 2^-24 |beta dy| / |w| ~
+             1e-5 per pixel, 1e-4 in G --, so every row sum of BOTH implementations is 1e-4 ... 1e-3 off and which column of the
+             float32 oracle happens to land close is luck (its rotation gradient 1.4e-4, its scale gradient 8.4e-4, from the same rows);
   "cond"  -- within the change of the float64 oracle's OWN gradient under a relative perturbation of 2^-22 (two float32 ulps) of
              the inputs: the column is not determined to 1e-4 by float32 inputs at all (a scale gradient that is the
              null direction of an indefinite dL/dcov2D -- 410000 / 58: half an ulp on the inputs moves it by 2.6e-3);
@@ -75,7 +80,7 @@ def float64_run(sc, deg, bg, kw, perturb_seed=None):
     return [o[i].detach() for i in range(4)], grads
 
 
-def float32_geometry_run(sc, deg, bg, kw):
+def float32_geometry_run(sc, deg, bg, kw, return_geom=False):
     """The float64 oracle AT THE FLOAT32 GEOMETRY (class "geom" above): {name: gradient}."""
     P, H, W = sc["means3D"].shape[0], sc["H"], sc["W"]
     keys = ("px", "py", "conic", "opacity", "rgb", "depth")
@@ -101,7 +106,10 @@ def float32_geometry_run(sc, deg, bg, kw):
     gouts = [gm[k].grad for k in keys if gm[k].grad is not None and g64[k].requires_grad]
     leaves = [d[k] for k in NAMES] + [m2]
     got = torch.autograd.grad(outs, leaves, grad_outputs=gouts, allow_unused=True)
-    return {k: (g if g is not None else zero[k]) for k, g in zip(list(NAMES) + ["means2D"], got)}
+    grads = {k: (g if g is not None else zero[k]) for k, g in zip(list(NAMES) + ["means2D"], got)}
+    if return_geom:       # + dL/d(px, py, conic, opacity, rgb, depth) at the float32 geometry, and that geometry (debug scripts)
+        return grads, {k: gm[k].grad for k in keys}, g32
+    return grads
 
 
 def _col_err(a, ref):
@@ -112,10 +120,10 @@ def _col_err(a, ref):
 
 def classify(sc, deg, bg, kw, res, cond_draws=3):
     """res = test_gpu_parity.run_pair(sc, deg, bg, **kw).  Returns (verdict, text): the WORST class any column fell into
-    (order f64 < geom < f32 < cond < fail) and one line per column outside the bar against the float64 oracle."""
+    (order f64 < geom < f32 < f32s < cond < fail) and one line per column outside the bar against the float64 oracle."""
     hi, hm2, hout, oi, om2, oout = res
     imgs64, g64 = float64_run(sc, deg, bg, kw)
-    rank = {"f64": 0, "geom": 1, "f32": 2, "cond": 3, "fail": 4}
+    rank = {"f64": 0, "geom": 1, "f32": 2, "f32s": 3, "cond": 4, "fail": 5}
     verdict, lines = "f64", []
 
     def worse(v):
@@ -131,6 +139,10 @@ def classify(sc, deg, bg, kw, res, cond_draws=3):
             worse(v)
             lines.append(f"{name} channel {j} [{v}]: HIP {float(eh[j]):.2e}, float32 oracle {float(eo[j]):.2e} from the float64 oracle")
     geom, cond = None, None
+    eo_scene = 0.0
+    for k in list(NAMES) + ["means2D"]:
+        eo, _ = _col_err((om2 if k == "means2D" else oi[k]).grad, g64[k])
+        eo_scene = max(eo_scene, float(eo.max()))
     for k in list(NAMES) + ["means2D"]:
         h = (hm2 if k == "means2D" else hi[k]).grad
         o32 = (om2 if k == "means2D" else oi[k]).grad
@@ -148,6 +160,8 @@ def classify(sc, deg, bg, kw, res, cond_draws=3):
                 v, txt = "geom", txt + f"; {eg:.2e} from the float64 oracle at the float32 geometry"
             elif float(eh[j]) <= F32_FACTOR * float(eo[j]):
                 v = "f32"
+            elif eo_scene > TOL and float(eh[j]) <= F32_FACTOR * eo_scene:
+                v, txt = "f32s", txt + f"; {eg:.2e} at the float32 geometry; the float32 oracle's largest distance in this scene {eo_scene:.2e}"
             else:
                 if cond is None:
                     cond = {}
