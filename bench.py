@@ -508,6 +508,128 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     return out
 
 
+def run_loop(args, dev, scene, target):
+    """--loop K: the train LOOP, not the step -- K steps with densify_and_prune every --densify-interval steps, the reference's
+    cadence (/root/reference/src/trainer/rodygs.py:343-356, src/trainer/rodygs_static.py:285-301: every 100 iterations, minimum
+    opacity 0.005, extent = spatial_lr_scale, no screen-size limit below opacity_reset_interval).  The gradient threshold is the
+    --densify-quantile quantile of the mean screen-space gradient (taken on the device: no read-back), so that a fixed share of
+    the cloud is cloned / split whatever the synthetic data's gradient scale is (--densify-grad-threshold: the reference's
+    absolute 0.0002 instead).  Everything between the first and the last step is inside the clock: the densifications, the first
+    steps on the new buffers (allocator, Adam segment table, birth-order sort, new workspaces), the graph re-captures.
+    Reported: sustained fps; per segment P and ms / step (first 20 steps / the rest); per densification its wall time (with
+    --loop-profile: per phase, synchronising) and the P trajectory; the steady-state fps of the same window (the segments' settled
+    step times) and sustained / steady."""
+    import gc
+    from rodygs_amd import rasterizer
+    from rodygs_amd.trainstep import DynamicScene, GraphedStep
+    P, W, H = args.points, args.width, args.height
+    spatial_order = os.environ.get("RDG_SPATIAL_ORDER", "1") != "0"
+    ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, spatial_order=spatial_order)
+    ds.track_densification()
+    n_gt = min(args.gt_frames, args.frames)
+    perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
+    perm = [perm[j] for j in _spread_order(len(perm))]
+    ds.make_ground_truth(target, perm)
+    rasterizer.DEFERRED_OVERFLOW_CHECK = False
+    step = 0
+    for _ in range(args.warmup):
+        ds.train_step(step, 0, 1, perm)
+        step += 1
+    rasterizer.DEFERRED_OVERFLOW_CHECK = True
+    gc.collect()
+    gc.freeze()
+    for _ in range(args.settle):
+        ds.train_step(step, 0, 1, perm)
+        step += 1
+    ds.stats.xyz_gradient_accum.zero_(); ds.stats.denom.zero_(); ds.stats.max_radii2D.zero_()
+
+    def sync():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    K, interval, head = args.loop, args.densify_interval, 20
+    segments, densifies = [], []
+    done = 0
+    graphed = None
+    t_begin = sync()
+    while done < K:
+        n = min(interval, K - done)
+        t_cap = 0.0
+        if args.graph:
+            t0 = sync()
+            rasterizer.DEFERRED_OVERFLOW_CHECK = False
+            ds.raster_state.poll_overflow(block=True)
+            graphed = GraphedStep(ds, perm, warmup=1, first_step=step)     # (its eager warm-up step is one of the segment's n)
+            eager_done = graphed.next_step - step
+            step = graphed.next_step
+            t_cap = (sync() - t0) * 1e3
+        else:
+            eager_done = 0
+        t0 = sync()
+        t_head = None
+        for i in range(eager_done, n):
+            if i == head:
+                t_head = sync()
+            if graphed is not None:
+                graphed.step()
+            else:
+                ds.train_step(step, 0, 1, perm)
+            step += 1
+        t1 = sync()
+        if graphed is not None:
+            graphed.check()
+            step = graphed.next_step
+            graphed.close()
+            graphed = None
+            rasterizer.DEFERRED_OVERFLOW_CHECK = True
+        ds.raster_state.poll_overflow(block=True)
+        n_head = min(head, n) - eager_done
+        segments.append({"P": ds.P, "steps": n, "graph_capture_ms": t_cap,
+                         "ms_per_step_first_20": ((t_head or t1) - t0) * 1e3 / max(n_head, 1),
+                         "ms_per_step_settled": ((t1 - t_head) * 1e3 / (n - head)) if (t_head is not None and n > head) else None})
+        done += n
+        if done < K:
+            t0 = sync()
+            tm = {} if args.loop_profile else None
+            with torch.no_grad():
+                if args.densify_grad_threshold > 0:
+                    thr = args.densify_grad_threshold
+                else:
+                    g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
+                    thr = torch.quantile(g_mean, args.densify_quantile)
+            p0 = ds.P
+            info = ds.densify(max_grad=thr, min_opacity=0.005, percent_dense=0.01, want_decisions=False, timings=tm)
+            t1 = sync()
+            densifies.append({"after_step": done, "ms": (t1 - t0) * 1e3, "P_before": p0, "P_after": info["P"],
+                              "cloned": info["cloned"], "split": info["split"], "pruned": info["pruned"], "phases_ms": tm})
+    t_end = sync()
+    rasterizer.DEFERRED_OVERFLOW_CHECK = False
+    gc.unfreeze()
+    total = t_end - t_begin
+    settled = [(sg["steps"], sg["ms_per_step_settled"]) for sg in segments if sg["ms_per_step_settled"]]
+    steady_ms = sum(n * ms for n, ms in settled) / max(sum(n for n, _ in settled), 1)
+    sustained = K / total
+    mean_P = sum(sg["P"] * sg["steps"] for sg in segments) / K
+    return {"metric": f"sustained train-LOOP fps at {P} initial dynamic Gaussians / {W}x{H} (fwd+bwd+Adam+statistics, "
+                      f"densify_and_prune every {interval} steps)",
+            "value": sustained, "unit": "frames/s", "n_gpus": 1, "steps": K, "warmup": args.warmup,
+            "ms_per_step": total / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": workload_label(P, W, H, args.frames, False, 1, args.scene) + f", train loop with "
+                       f"densification every {interval} steps", "points": P, "width": W, "height": H, "scene": args.scene,
+                       "graph_replay": bool(args.graph), "densify_interval": interval,
+                       "densify_threshold": (args.densify_grad_threshold if args.densify_grad_threshold > 0 else
+                                             f"{args.densify_quantile} quantile of the mean screen-space gradient"),
+                       "row_order": "z-curve of the canonical positions, kept through every densification" if spatial_order
+                       else "generator (random)", "deferred_overflow_check": True},
+            "gaussians_per_s": sustained * mean_P,
+            "loop": {"sustained_fps": sustained, "steady_state_fps_of_the_window": 1e3 / steady_ms if steady_ms else None,
+                     "sustained_over_steady": (sustained * steady_ms / 1e3) if steady_ms else None,
+                     "mean_P": mean_P, "P_trajectory": [sg["P"] for sg in segments], "segments": segments,
+                     "densifications": densifies,
+                     "densify_ms_mean": (sum(d_["ms"] for d_ in densifies) / len(densifies)) if densifies else None}}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks the way the driver's torchrun command does
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)
@@ -567,6 +689,15 @@ def main():
     ap.add_argument("--full-losses", action="store_true",
                     help="config-5 loss set (depth, motion regularisers, rigidity every 5th step) instead of the "
                          "photometric-only step the headline metric is quoted on")
+    ap.add_argument("--loop", type=int, default=0,
+                    help="N = 1: time K steps of the train LOOP with a densify_and_prune every --densify-interval steps "
+                         "(run_loop) instead of the steady-state step; prints one JSON line with the `loop` table")
+    ap.add_argument("--densify-interval", type=int, default=100)
+    ap.add_argument("--densify-quantile", type=float, default=0.97)
+    ap.add_argument("--densify-grad-threshold", type=float, default=0.0,
+                    help="> 0: the reference's absolute threshold on the mean screen-space gradient (its configs: 0.0002) "
+                         "instead of the quantile rule")
+    ap.add_argument("--loop-profile", action="store_true", help="--loop: per-phase times of every densification (synchronises)")
     ap.add_argument("--dp-mode", choices=["both", "allreduce", "shard"], default=os.environ.get("RDG_DP_MODE", "both"),
                     help="N > 1 formulation: 'allreduce' = BASELINE north_star: replicated cloud, frames over the GPUs, "
                          "RCCL all-reduce of the Gaussian / pose gradients (bucketed, overlapped with backward and Adam); "
@@ -612,6 +743,11 @@ def main():
     P, W, H = args.points, args.width, args.height
     scene = synthetic_scene(P, W, H, 3, seed=777, variant=args.scene)
     target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234, variant=args.scene)
+    if args.loop > 0:
+        if world != 1:
+            raise SystemExit("--loop is a single-GPU measurement")
+        print(json.dumps(run_loop(args, dev, scene, target)))
+        return
     if force_shard:
         modes = ["shard"]
     elif world == 1:

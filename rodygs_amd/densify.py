@@ -125,20 +125,12 @@ def rebuild_flat_params(fp: FlatParams, src: torch.Tensor, keep_moments: torch.T
     return out
 
 
-def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad: float,
+def _densify_general(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad: float,
                       min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01, N: int = 2,
                       z: Optional[torch.Tensor] = None, decisions: Optional[Dict[str, torch.Tensor]] = None,
                       spatial_order: bool = False) -> DensifyResult:
-    """``fp`` holds at least xyz [P,3], scaling [P,3] (log), rotation [P,4] (raw), opacity [P,1] (logit); every other
-    segment (SH features, motion coefficients, ...) is carried along row-wise.  ``per_point``: further [P,...]
-    tensors that follow the Gaussians (gaussian_to_time, gaussian_to_time_ind).  ``z``: optional standard-normal
-    draws [N * n_split, 3] for the split children (default: torch.randn on the device).  ``decisions``: replay the
-    masks of an earlier call ({"clone": [P], "split": [P], "prune": [rows after clone + split]}, as returned in
-    ``DensifyResult.decisions``) instead of thresholding this run's statistics -- for experiments that must hold the set
-    of Gaussians fixed across runs (scripts/psnr_delta.py: a borderline Gaussian crossing the gradient threshold in one
-    run and not in the other changes P and, from there, the whole trajectory).  ``spatial_order``: re-sort the surviving
-    rows along the Z curve of their new positions (rodygs_amd/layout.py) -- clones and split children are appended at the
-    end, so without it the memory coherence the kernels profit from decays with every densification."""
+    """The composed-source-row form with the three masks taken from ``decisions`` when given (the replay path of
+    ``densify_and_prune``; several host read-backs: sizes of boolean selections)."""
     if not fp.flat.is_cuda:
         raise RuntimeError("rodygs_amd.densify_and_prune: buffers must be on the GPU (no CPU fallback exists)")
     if fp.shapes["scaling"][1:] != (3,):
@@ -204,6 +196,149 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         n_new = int(src.numel())
         return DensifyResult(out, DensifyStats.zeros(n_new, dev), new_pp, n_clone, n_sel,
                              int(prune.sum()) + n_sel, used)
+
+
+
+class _Phase:
+    """Optional per-phase wall times of a densification (``timings`` dict): a device synchronisation at every phase boundary,
+    so only for diagnosis (bench.py --loop-profile); without a dict nothing is synchronised."""
+
+    def __init__(self, timings, dev):
+        self.t, self.dev, self.last = timings, dev, None
+        if timings is not None:
+            import time
+            self.clock = time.perf_counter
+            torch.cuda.synchronize(dev)
+            self.last = self.clock()
+
+    def mark(self, name: str) -> None:
+        if self.t is None:
+            return
+        torch.cuda.synchronize(self.dev)
+        now = self.clock()
+        self.t[name] = self.t.get(name, 0.0) + (now - self.last) * 1e3
+        self.last = now
+
+
+def _compact(mask: torch.Tensor, n: int) -> torch.Tensor:
+    """Indices of the True entries of ``mask`` in ascending order, their number ``n`` already known on the host: no read-back
+    (a boolean-mask index or ``nonzero`` waits for the count it has to size its result with)."""
+    P = mask.numel()
+    pos = torch.cumsum(mask, 0) - 1
+    out = torch.empty(n + 1, dtype=torch.int64, device=mask.device)
+    out.scatter_(0, torch.where(mask, pos, torch.full_like(pos, n)), torch.arange(P, device=mask.device))
+    return out[:n]
+
+
+def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad,
+                      min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01, N: int = 2,
+                      z: Optional[torch.Tensor] = None, decisions: Optional[Dict[str, torch.Tensor]] = None,
+                      spatial_order: bool = False, want_decisions: bool = True, timings: Optional[dict] = None) -> DensifyResult:
+    """``fp`` holds at least xyz [P,3], scaling [P,3] (log), rotation [P,4] (raw), opacity [P,1] (logit); every other
+    segment (SH features, motion coefficients, ...) is carried along row-wise.  ``per_point``: further [P,...]
+    tensors that follow the Gaussians (gaussian_to_time, gaussian_to_time_ind).  ``z``: optional standard-normal
+    draws [N * n_split, 3] for the split children (default: torch.randn on the device).  ``max_grad``: a float or a 0-dim
+    device tensor (a threshold computed on the device needs no read-back).  ``decisions``: replay the masks of an earlier call
+    ({"clone": [P], "split": [P], "prune": [rows after clone + split]}, as returned in ``DensifyResult.decisions``) instead of
+    thresholding this run's statistics -- for experiments that must hold the set of Gaussians fixed across runs
+    (scripts/psnr_delta.py: a borderline Gaussian crossing the gradient threshold in one run and not in the other changes P
+    and, from there, the whole trajectory).  ``spatial_order``: the surviving rows along the Z curve of their new positions
+    (rodygs_amd/layout.py) -- clones and split children are appended at the end, so without it the memory coherence the kernels
+    profit from decays with every densification.
+
+    What the loop pays for (bench.py --loop): the three masks, the final prune (a per-Gaussian property: both copies of a
+    split Gaussian share opacity and scale) and the five counts the new buffers are sized with are formed on the device and
+    read back ONCE; the source-row list is built from them without further waits (``_compact``); the Z-curve order of the new
+    cloud is composed INTO that list (the children's positions are computed first), so every buffer is gathered once, not
+    twice.  ``want_decisions=False`` skips building the masks of ``DensifyResult.decisions``."""
+    if not fp.flat.is_cuda:
+        raise RuntimeError("rodygs_amd.densify_and_prune: buffers must be on the GPU (no CPU fallback exists)")
+    if fp.shapes["scaling"][1:] != (3,):
+        raise NotImplementedError("isotropic scaling ([P,1]) is not supported")
+    if decisions is not None:
+        return _densify_general(fp, stats, per_point, max_grad, min_opacity, extent, max_screen_size, percent_dense, N, z,
+                                decisions, spatial_order)
+    dev = fp.flat.device
+    P = fp.shapes["xyz"][0]
+    ph = _Phase(timings, dev)
+    with torch.no_grad(), torch.cuda.device(dev):
+        grads = stats.xyz_gradient_accum / stats.denom
+        grads[grads.isnan()] = 0.0
+        max_s = torch.exp(fp["scaling"].detach()).max(dim=1).values
+        small = max_s <= percent_dense * extent
+        clone_mask = (torch.norm(grads, dim=-1) >= max_grad) & small                    # rodygs_static.py:244-251
+        split_mask = (grads.squeeze(-1) >= max_grad) & ~small                            # :185-193 (clones: grad 0)
+        # final prune (rodygs_static.py:286-298) on the rows as they stand after clone + split: originals and clones carry the
+        # Gaussian's own opacity and scale, both children of a split its opacity and max scale / (0.8 N)
+        low = torch.sigmoid(fp["opacity"].detach().reshape(-1)) < min_opacity
+        prune_own, prune_child = low, low
+        if max_screen_size:                                                              # max_radii2D was just zeroed
+            prune_own = low | (max_s > 0.1 * extent)
+            prune_child = low | (max_s / (0.8 * N) > 0.1 * extent)
+        keep0 = ~split_mask & ~prune_own
+        keepc = clone_mask & ~prune_own
+        keeps = split_mask & ~prune_child
+        counts = torch.stack([split_mask.sum(), clone_mask.sum(), keep0.sum(), keepc.sum(), keeps.sum()])
+        ph.mark("decisions")
+        n_sel, n_clone, k0, kc, ks = (int(v) for v in counts.tolist())                  # the ONE read-back
+        ph.mark("readback")
+        n_child = n_sel * N
+        src0, srcc, srcs = _compact(keep0, k0), _compact(keepc, kc), _compact(keeps, ks)
+        src = torch.cat([src0, srcc, srcs.repeat(N)])                                    # repeat(N, 1) order of the children
+        n_new, n_child_kept = k0 + kc + ks * N, ks * N
+        first = n_new - n_child_kept
+        moments = torch.zeros(n_new, dtype=torch.bool, device=dev)
+        moments[:k0] = True                                                              # survivors keep their Adam moments
+        # split children: positions and scales first (small), so that the Z-curve order can be taken on the NEW cloud
+        child_xyz = child_sc = None
+        if n_child_kept:
+            if z is None:
+                z = torch.randn(n_child, 3, device=dev)
+            rank = torch.cumsum(split_mask, 0) - 1                                       # position in the split selection
+            child_no = torch.cat([rank[srcs] + r * n_sel for r in range(N)])
+            zz = z.to(device=dev, dtype=torch.float32)[child_no].contiguous()
+            parents = src[first:].contiguous()
+            child_xyz = torch.empty(n_child_kept, 3, dtype=torch.float32, device=dev)
+            child_sc = torch.empty(n_child_kept, 3, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().rdg_split_children(n_child_kept, N, _lib.ptr(parents), _lib.ptr(fp["xyz"].detach()),
+                                                     _lib.ptr(fp["scaling"].detach()), _lib.ptr(fp["rotation"].detach()),
+                                                     _lib.ptr(zz), _lib.ptr(child_xyz), _lib.ptr(child_sc),
+                                                     _lib.stream_ptr()), "rdg_split_children")
+        ph.mark("row_list")
+        child_dst = None
+        if spatial_order:
+            from .layout import morton_order
+            xyz_new = fp["xyz"].detach()[src]
+            if n_child_kept:
+                xyz_new[first:] = child_xyz
+            perm = morton_order(xyz_new)
+            src, moments = src[perm].contiguous(), moments[perm].contiguous()
+            if n_child_kept:
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(n_new, device=dev)
+                child_dst = inv[first:]
+        ph.mark("re_sort")
+        out = rebuild_flat_params(fp, src, moments)
+        if n_child_kept:
+            if child_dst is None:
+                out["xyz"].detach()[first:] = child_xyz
+                out["scaling"].detach()[first:] = child_sc
+            else:
+                out["xyz"].detach().index_copy_(0, child_dst, child_xyz)
+                out["scaling"].detach().index_copy_(0, child_dst, child_sc)
+        new_pp = {k: v[src] for k, v in per_point.items()}
+        ph.mark("gather")
+        used = None
+        if want_decisions:
+            # the composite-row prune mask of the general form (rows after clone + split: originals not split, clones, children)
+            a0, ac, as_ = _compact(~split_mask, P - n_sel), _compact(clone_mask, n_clone), _compact(split_mask, n_sel)
+            used = {"clone": clone_mask.clone(), "split": split_mask.clone(),
+                    "prune": torch.cat([prune_own[a0], prune_own[ac], prune_child[as_].repeat(N)])}
+        from .deform import invalidate_birth_order_cache
+        invalidate_birth_order_cache()       # the per-point tensors (birth indices) are new objects from here on
+        res = DensifyResult(out, DensifyStats.zeros(n_new, dev), new_pp, n_clone, n_sel, P + n_clone + n_child - n_new, used)
+        ph.mark("finish")
+        return res
 
 
 def reset_opacity_(fp: FlatParams, name: str = "opacity", max_opacity: float = 0.01) -> None:

@@ -338,22 +338,42 @@ class DynamicScene:
         from .densify import DensifyStats
         self.stats = DensifyStats.zeros(self.P, self.device)
 
-    def densify(self, max_grad: float = 0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
+    def densify(self, max_grad=0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
                 max_screen_size=None, percent_dense: float = 0.01, z: Optional[torch.Tensor] = None,
-                decisions=None) -> dict:
+                decisions=None, want_decisions: bool = True, timings: Optional[dict] = None) -> dict:
         """densify_and_prune over the flat bucket, then re-point everything that referred to the old buffers
-        (gradient sinks live in the new bucket, birth indices follow the Gaussians, exchange object rebuilt)."""
-        from .densify import allreduce_stats_, densify_and_prune
+        (gradient sinks live in the new bucket, birth indices follow the Gaussians, exchange object rebuilt).
+        The rasterizer's frame-to-frame memory is carried across the row surgery: the capacity of the binning workspace
+        scaled by P' / P (+ 10 %), the binning / split-compositing hints as they stand -- the first forward of the new cloud
+        then needs no read-back of its instance count (a capacity that turns out too small is found by the usual overflow
+        check).  ``timings``: per-phase wall times (ms) of this call, synchronising at every phase boundary (diagnosis)."""
+        from .densify import _Phase, allreduce_stats_, densify_and_prune
         if self.stats is None:
             raise RuntimeError("call track_densification() first")
         allreduce_stats_(self.stats)
+        P_old = self.P
         res = densify_and_prune(self.fp, self.stats, {"time_ind": self.time_ind}, max_grad, min_opacity,
                                 extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense,
-                                z=z, decisions=decisions, spatial_order=self.spatial_order)
+                                z=z, decisions=decisions, spatial_order=self.spatial_order, want_decisions=want_decisions,
+                                timings=timings)
+        ph = _Phase(timings, self.device)
         self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
         self.P = self.fp.shapes["xyz"][0]
         self.m2 = torch.zeros(self.P, 3, device=self.device, requires_grad=True)
         self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
+        st = self.raster_state
+        old, new = (P_old, self.H, self.W), (self.P, self.H, self.W)
+        with st.lock:
+            if old in st.capacity_hint and new != old:
+                st.capacity_hint[new] = max(int(st.capacity_hint.get(new, 0)),
+                                            int(st.capacity_hint[old] * (self.P / max(P_old, 1)) * 1.1) + 4096)
+                for table in (st.bin_hint, st.split_hint):
+                    if old in table:
+                        table[new] = table[old]
+                # the old cloud's entries are dead weight from here on
+                for table in (st.capacity_hint, st.bin_hint, st.split_hint):
+                    table.pop(old, None)
+        ph.mark("re_hint")
         return {"P": self.P, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned,
                 "decisions": res.decisions}
 

@@ -88,3 +88,108 @@ def test_the_three_sweep_misses_of_round_4_against_their_arbiters(case, expect, 
     for col, cls in expect.items():
         hit = [ln for ln in txt.split("; [") if col + " column" in ln]
         assert all(ln.startswith(cls) or ln.startswith("[" + cls) for ln in hit), (col, cls, txt)
+
+
+# ---- the train loop with periodic densification (bench.py --loop) -----------------------------------------------------------------
+
+def _densify_inputs(P=6000, seed=91):
+    from rodygs_amd.densify import DensifyStats
+    from rodygs_amd.dp import FlatParams
+    g = torch.Generator().manual_seed(seed)
+    spec = {"xyz": ((P, 3), 1e-3), "features": ((P, 16, 3), 1e-3), "scaling": ((P, 3), 1e-3), "rotation": ((P, 4), 1e-3),
+            "opacity": ((P, 1), 1e-3), "motion_coeff": ((P, 1, 16), 1e-3)}
+    fp = FlatParams(spec, DEV)
+    with torch.no_grad():
+        fp.flat.copy_(torch.randn(fp.numel, generator=g))
+        fp["scaling"].copy_(torch.log(torch.rand(P, 3, generator=g) * 0.08 + 0.005 + (torch.rand(P, 1, generator=g) > 0.97) * 1.0))
+        fp["opacity"].copy_(torch.randn(P, 1, generator=g) * 2.5)
+        fp.exp_avg.copy_(torch.randn(fp.numel, generator=g))
+        fp.exp_avg_sq.copy_(torch.rand(fp.numel, generator=g))
+    fp.step_count = 7
+    denom = torch.randint(0, 4, (P, 1), generator=g).float()
+    stats = DensifyStats((torch.rand(P, 1, generator=g) * 0.0006 * denom).to(DEV), denom.to(DEV), (torch.rand(P, generator=g) * 40).to(DEV))
+    pp = {"time_ind": torch.randint(0, 30, (P,), generator=g).to(DEV)}
+    return fp, stats, pp, torch.randn(2 * P, 3, generator=g).to(DEV)
+
+
+@pytest.mark.parametrize("max_screen_size", [None, 20])
+@pytest.mark.parametrize("spatial_order", [False, True])
+def test_one_readback_densify_equals_the_general_form(max_screen_size, spatial_order):
+    """densify_and_prune as the loop pays for it -- masks, final prune and the five counts formed on the device and read back
+    ONCE, the source-row list built without further waits, the Z-curve order composed into the ONE gather per buffer -- against
+    the general (decision-replay) form fed the decisions the fast form reports: the same rows, moments, statistics, birth indices
+    and counts, bit for bit; a device-tensor threshold equals the float."""
+    from rodygs_amd.densify import DensifyStats, densify_and_prune
+    fp, stats, pp, z = _densify_inputs()
+    args = (0.0002, 0.05, 5.0, max_screen_size, 0.01, 2)
+    a = densify_and_prune(fp, stats, pp, *args, z=z, spatial_order=spatial_order)
+    st2 = DensifyStats(stats.xyz_gradient_accum.clone(), stats.denom.clone(), stats.max_radii2D.clone())
+    b = densify_and_prune(fp, st2, pp, *args, z=z, spatial_order=spatial_order, decisions=a.decisions)       # general path
+    c = densify_and_prune(fp, st2, pp, torch.tensor(0.0002, device=DEV), *args[1:], z=z, spatial_order=spatial_order,
+                          want_decisions=False)
+    assert a.n_clone > 100 and a.n_split > 100 and a.n_pruned > a.n_split and c.decisions is None
+    for r in (b, c):
+        assert (r.n_clone, r.n_split, r.n_pruned) == (a.n_clone, a.n_split, a.n_pruned) and r.fp.step_count == 7
+        assert torch.equal(r.fp.flat, a.fp.flat) and torch.equal(r.fp.exp_avg, a.fp.exp_avg)
+        assert torch.equal(r.fp.exp_avg_sq, a.fp.exp_avg_sq) and torch.equal(r.per_point["time_ind"], a.per_point["time_ind"])
+        assert float(r.stats.denom.sum()) == 0.0 and r.stats.max_radii2D.shape[0] == a.fp.shapes["xyz"][0]
+    if spatial_order:
+        from rodygs_amd.layout import morton_codes
+        codes = morton_codes(a.fp["xyz"].detach())
+        assert bool((codes[1:] >= codes[:-1]).all())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_loop_with_periodic_densification(graph):
+    """The loop bench.py --loop times: steps with the statistics in the backward kernel, densify_and_prune every 12 steps with a
+    device-side quantile threshold (no read-back), the rasterizer's hints carried across the row surgery (the first forward of
+    the new cloud runs in deferred mode: no wait for its instance count), and -- graph=True -- a GraphedStep re-captured on
+    every new cloud.  The cloud grows, the loss falls, nothing overflows."""
+    from rodygs_amd import rasterizer
+    from rodygs_amd.trainstep import DynamicScene, GraphedStep
+    sc = O.synthetic_scene(20000, 320, 240, 3, seed=5)
+    tgt = O.synthetic_scene(5000, 320, 240, 3, seed=6)
+    frames = list(range(8))
+    ds = DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True)
+    ds.make_ground_truth(tgt, frames)
+    ds.track_densification()
+    step, losses, traj = 0, [], [ds.P]
+    for _ in range(3):
+        losses.append(float(ds.train_step(step, perm=frames)))
+        step += 1
+    keep = rasterizer.DEFERRED_OVERFLOW_CHECK
+    rasterizer.DEFERRED_OVERFLOW_CHECK = True
+    try:
+        for seg in range(4):
+            if graph:
+                rasterizer.DEFERRED_OVERFLOW_CHECK = False
+                ds.raster_state.poll_overflow(block=True)
+                gs = GraphedStep(ds, frames, warmup=1, first_step=step)
+                step = gs.next_step
+                for _ in range(11):
+                    losses.append(gs.step())
+                gs.check()
+                step = gs.next_step
+                gs.close()
+                losses[-11:] = [float(v) for v in losses[-11:]]
+                rasterizer.DEFERRED_OVERFLOW_CHECK = True
+            else:
+                for _ in range(12):
+                    losses.append(float(ds.train_step(step, perm=frames)))
+                    step += 1
+            assert float(ds.stats.denom.sum()) > 0
+            g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
+            key_old = (ds.P, ds.H, ds.W)
+            info = ds.densify(max_grad=torch.quantile(g_mean, 0.9), min_opacity=0.01, want_decisions=False)
+            traj.append(info["P"])
+            assert info["decisions"] is None and info["cloned"] + info["split"] > 0
+            assert (ds.P, ds.H, ds.W) in ds.raster_state.capacity_hint and key_old not in ds.raster_state.capacity_hint
+            assert ds.time_ind.shape[0] == ds.P == ds.fp.shapes["xyz"][0] and float(ds.stats.denom.sum()) == 0.0
+        for _ in range(6):
+            losses.append(float(ds.train_step(step, perm=frames)))
+            step += 1
+        ds.raster_state.poll_overflow(block=True)          # raises if any deferred frame outgrew its carried capacity
+    finally:
+        rasterizer.DEFERRED_OVERFLOW_CHECK = keep
+    assert traj[-1] > traj[0] and len(set(traj)) == len(traj)
+    assert all(np.isfinite(losses)) and np.mean(losses[-8:]) < np.mean(losses[:8])
