@@ -384,7 +384,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
             dist.barrier()
         torch.cuda.synchronize()
 
-    rasterizer.DEFERRED_OVERFLOW_CHECK = False
+    rstate.deferred_overflow_check = False
     step = 0
     for _ in range(args.warmup):
         train_step(step)
@@ -413,7 +413,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
         for _ in range(args.warmup):             # the new (P, H, W) needs its own capacity hint before the deferred check
             train_step(step)
             step += 1
-    rasterizer.DEFERRED_OVERFLOW_CHECK = True
+    rstate.deferred_overflow_check = True
     # Untimed settling steps in the configuration the timed region runs in (deferred check, its pinned slots and hints in
     # place; clocks and allocator warm): W = 5 warm-up steps are 8 ms of GPU work, and the FIRST bench run on a fresh box
     # has read 1.93 ms per step where every later run of the same binary reads 1.63.  Not part of W, not timed.
@@ -431,7 +431,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     if use_graph:
         # capture after the warm-up (capacity and binning hints are known); the timed region replays the graph
         from rodygs_amd.trainstep import GraphedStep
-        rasterizer.DEFERRED_OVERFLOW_CHECK = False
+        rstate.deferred_overflow_check = False
         rstate.poll_overflow(block=True)
         graphed = GraphedStep(ds, perm, warmup=2, first_step=step)
         step = graphed.next_step
@@ -442,7 +442,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     # of its kernels: the dominant kernel's time is then taken from the eager steps after the timed region.)
     _lib.timing_enable(not use_graph, stages=["render_bwd"])
     _lib.timing_reset()
-    deferred_in_timed_region = bool(rasterizer.DEFERRED_OVERFLOW_CHECK)
+    deferred_in_timed_region = rstate.mode("deferred_overflow_check")
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -468,7 +468,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     if graphed is None:
         stages["render_bwd"] = dom
     _lib.timing_enable(False)
-    rasterizer.DEFERRED_OVERFLOW_CHECK = False
+    rstate.deferred_overflow_check = None
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -476,7 +476,8 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     out = {"mode": mode, "sharded": sharded, "dt": dt, "loss": float(loss.item()), "spatial_order": spatial_order,
            "graph": graphed is not None, "densify_stats": densify_stats, "deferred": deferred_in_timed_region,
            # the binning algorithm the timed steps ran: forced by RDG_BIN_MODE, or what the per-frame rule has picked
-           "radix": bool(rasterizer._FORCE_RADIX or any(rstate.bin_hint.values())),
+           "radix": bool(rstate.mode("force_radix") or any(rstate.bin_hint.values())),
+           "deterministic": rstate.mode("deterministic"),
            "points_after_densify": points_after,
            "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
@@ -530,12 +531,12 @@ def run_loop(args, dev, scene, target):
     perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
     perm = [perm[j] for j in _spread_order(len(perm))]
     ds.make_ground_truth(target, perm)
-    rasterizer.DEFERRED_OVERFLOW_CHECK = False
+    ds.raster_state.deferred_overflow_check = False
     step = 0
     for _ in range(args.warmup):
         ds.train_step(step, 0, 1, perm)
         step += 1
-    rasterizer.DEFERRED_OVERFLOW_CHECK = True
+    ds.raster_state.deferred_overflow_check = True
     gc.collect()
     gc.freeze()
     for _ in range(args.settle):
@@ -557,7 +558,7 @@ def run_loop(args, dev, scene, target):
         t_cap = 0.0
         if args.graph:
             t0 = sync()
-            rasterizer.DEFERRED_OVERFLOW_CHECK = False
+            ds.raster_state.deferred_overflow_check = False
             ds.raster_state.poll_overflow(block=True)
             graphed = GraphedStep(ds, perm, warmup=1, first_step=step)     # (its eager warm-up step is one of the segment's n)
             eager_done = graphed.next_step - step
@@ -581,7 +582,7 @@ def run_loop(args, dev, scene, target):
             step = graphed.next_step
             graphed.close()
             graphed = None
-            rasterizer.DEFERRED_OVERFLOW_CHECK = True
+            ds.raster_state.deferred_overflow_check = True
         ds.raster_state.poll_overflow(block=True)
         n_head = min(head, n) - eager_done
         segments.append({"P": ds.P, "steps": n, "graph_capture_ms": t_cap,
@@ -603,7 +604,7 @@ def run_loop(args, dev, scene, target):
             densifies.append({"after_step": done, "ms": (t1 - t0) * 1e3, "P_before": p0, "P_after": info["P"],
                               "cloned": info["cloned"], "split": info["split"], "pruned": info["pruned"], "phases_ms": tm})
     t_end = sync()
-    rasterizer.DEFERRED_OVERFLOW_CHECK = False
+    ds.raster_state.deferred_overflow_check = False
     gc.unfreeze()
     total = t_end - t_begin
     settled = [(sg["steps"], sg["ms_per_step_settled"]) for sg in segments if sg["ms_per_step_settled"]]
@@ -737,7 +738,6 @@ def main():
 
     from rodygs_amd.synthetic import synthetic_scene
     from rodygs_amd import _lib
-    from rodygs_amd import rasterizer as rasterizer_mod
     _lib.lib()
 
     P, W, H = args.points, args.width, args.height
@@ -857,7 +857,7 @@ def main():
                        "densify_stats": best["densify_stats"],
                        # --densify-first: Gaussians after the one densify-and-prune that ran before the timed region
                        "points_after_densify": best["points_after_densify"],
-                       "deterministic_backward": bool(rasterizer_mod.DETERMINISTIC),
+                       "deterministic_backward": best["deterministic"],
                        "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",
                        # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH

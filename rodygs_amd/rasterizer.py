@@ -82,7 +82,16 @@ class RasterState:
     (/root/reference/src/trainer/renderer.py:65), gets ``DEFAULT_STATE``.  Safe to use from several threads: the host
     bookkeeping of a forward runs under the state's lock (the launches themselves do not)."""
 
-    def __init__(self):
+    def __init__(self, deterministic: Optional[bool] = None, force_radix: Optional[bool] = None,
+                 force_bucket: Optional[bool] = None, deferred_overflow_check: Optional[bool] = None,
+                 render_normal: Optional[bool] = None):
+        """The four mode switches ride on the state (two trainers in one process can differ in them): ``deterministic``
+        (compositing backward without float atomics), ``force_radix`` / ``force_bucket`` (binning algorithm on every frame),
+        ``deferred_overflow_check`` (no host wait for the instance count), ``render_normal`` (composite the normal channels).
+        None = follow the module attribute of that name (DETERMINISTIC, _FORCE_RADIX, _FORCE_BUCKET, DEFERRED_OVERFLOW_CHECK,
+        RENDER_NORMAL) as it stands when a forward runs -- the process-wide default, initialised from the environment."""
+        self.deterministic, self.force_radix, self.force_bucket = deterministic, force_radix, force_bucket
+        self.deferred_overflow_check, self.render_normal = deferred_overflow_check, render_normal
         self.capacity_hint = {}       # (P, H, W) -> last num_rendered
         self.bin_hint = {}            # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
         self.split_hint = {}          # (P, H, W) -> 1 while it calls for the split compositing path
@@ -95,6 +104,14 @@ class RasterState:
         self.det_ws = None            # deterministic mode: the per-instance row workspace, kept across steps
         self.lock = threading.RLock()
 
+    def mode(self, name: str) -> bool:
+        """Effective value of a mode switch for this state (its own setting, else the module default)."""
+        v = getattr(self, name)
+        if v is not None:
+            return bool(v)
+        return bool({"deterministic": DETERMINISTIC, "force_radix": _FORCE_RADIX, "force_bucket": _FORCE_BUCKET,
+                     "deferred_overflow_check": DEFERRED_OVERFLOW_CHECK, "render_normal": RENDER_NORMAL}[name])
+
     def pinned_slot(self) -> torch.Tensor:
         return self.pinned_free.pop() if self.pinned_free else torch.empty(2, dtype=torch.int32).pin_memory()
 
@@ -102,7 +119,7 @@ class RasterState:
         """What a frame's largest tile list and instance count say about the next frame of that (P, H, W)."""
         tiles = ((key[2] + 15) // 16) * ((key[1] + 15) // 16)
         mean = n / max(tiles, 1)
-        if (largest > BIN_RADIX_ABOVE or mean > BIN_RADIX_MEAN_LIST_ABOVE) and not _FORCE_BUCKET:
+        if (largest > BIN_RADIX_ABOVE or mean > BIN_RADIX_MEAN_LIST_ABOVE) and not self.mode("force_bucket"):
             self.bin_hint[key] = 1
         elif largest < BIN_BUCKET_BELOW and mean < BIN_BUCKET_MEAN_LIST_BELOW:
             self.bin_hint.pop(key, None)
@@ -175,7 +192,8 @@ class GaussianRasterizationSettings(NamedTuple):
     enable_sh_grad: bool = True
 
 
-def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int) -> _lib.RdgRasterSettings:
+def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int, state: Optional["RasterState"] = None) -> _lib.RdgRasterSettings:
+    state = state if state is not None else DEFAULT_STATE
     s = _lib.RdgRasterSettings()
     s.P = P
     s.M = M
@@ -189,8 +207,8 @@ def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int) -> _lib.RdgRa
     s.debug = int(bool(rs.debug))
     s.enable_cov_grad = int(bool(rs.enable_cov_grad))
     s.enable_sh_grad = int(bool(rs.enable_sh_grad))
-    s.render_normal = int(bool(RENDER_NORMAL))
-    s.bin_mode = 1 if _FORCE_RADIX else 0
+    s.render_normal = int(state.mode("render_normal"))
+    s.bin_mode = 1 if state.mode("force_radix") else 0
     s.num_rendered_stats = 0
     s.list_hints = 0
     return s
@@ -214,7 +232,7 @@ def _empty(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 def _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws, g_normal=None):
     """The compositing half of backward: float-atomic accumulation, or the deterministic two-pass form."""
-    if not DETERMINISTIC:
+    if not ctx.deterministic:
         _lib.check(L.rdg_composite_backward(C.byref(ctx.cs), _lib.ptr(bg), _lib.ptr(geom), _lib.ptr(binning),
                                             ctx.capacity, _lib.ptr(image), _lib.ptr(g_color), _lib.ptr(g_depth),
                                             _lib.ptr(g_alpha), _lib.ptr(g_normal), _lib.ptr(gws), _lib.stream_ptr()),
@@ -313,8 +331,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             op = ph if op.numel() == 0 else op
             m3 = ph
         H, W = int(raster_settings.image_height), int(raster_settings.image_width)
-        cs = _c_settings(raster_settings, P, M)
+        cs = _c_settings(raster_settings, P, M, state)
         n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        # the backward follows the mode the forward ran in (the state may be switched between the two)
+        ctx.deterministic = det_mode = state.mode("deterministic")
 
         with torch.cuda.device(dev):
             u8 = dict(dtype=torch.uint8, device=dev)
@@ -328,7 +348,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             # a backward will follow: its gradient rows are cleared by the compositing forward (RdgRasterSettings
             # .zero_grad_ws: free there, a 12 us launch at the head of the backward otherwise)
             gws = None
-            if PREZERO_GRAD_ROWS and P > 0 and not DETERMINISTIC and any(ctx.needs_input_grad):
+            if PREZERO_GRAD_ROWS and P > 0 and not det_mode and any(ctx.needs_input_grad):
                 gws = torch.empty(L.rdg_grad_bytes(P), **u8)
                 cs.zero_grad_ws = gws.data_ptr()
             # [0] = D (instances), [1] = largest tile list: both written by the forward on every path (the block-sum scan
@@ -343,11 +363,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 cs.bin_mode = max(int(cs.bin_mode), int(state.bin_hint.get(key, 0)))
                 # deterministic mode: the choice must not depend on what the previous frame looked like (the split path
                 # associates the transmittance product differently: same result to the last bits only)
-                cs.list_hints = 1 if DETERMINISTIC else int(state.split_hint.get(key, 0))
+                cs.list_hints = 1 if det_mode else int(state.split_hint.get(key, 0))
                 cap = max(int(state.capacity_hint.get(key, 0) * 1.25) + 4096, 4 * P + 4096)
                 if capture and key not in state.capacity_hint:
                     raise RuntimeError("graph capture needs a warm-up forward of this (P, H, W) on the same RasterState first")
-                deferred = DEFERRED_OVERFLOW_CHECK and key in state.capacity_hint and not capture
+                deferred = state.mode("deferred_overflow_check") and key in state.capacity_hint and not capture
                 if deferred:
                     state.poll_overflow(block=False)
                 host = None
@@ -430,7 +450,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         with torch.cuda.device(dev):
             gws, ctx.gws = ctx.gws, None          # the rows the forward cleared serve one backward
             _bind_densify_stats(ctx, P)
-            ctx.cs.grad_rows_zeroed = 1 if (gws is not None and not DETERMINISTIC) else 0
+            ctx.cs.grad_rows_zeroed = 1 if (gws is not None and not ctx.deterministic) else 0
             if gws is None:
                 gws = torch.empty(L.rdg_grad_bytes(P), dtype=torch.uint8, device=dev)
             d_m3 = torch.empty(P, 3, **f32)
@@ -488,7 +508,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     float(fused["lr_tail"]), float(fused["betas"][0]), float(fused["betas"][1]), float(fused["eps"]),
                     step, _lib.stream_ptr()), "rdg_preprocess_backward_adam")
                 return d_m3, d_m2, None, None, d_op, d_sc, d_ro, None, d_vm, None, None, None
-            if DETERMINISTIC:
+            if ctx.deterministic:
                 _composite_backward(L, ctx, bg, geom, binning, image, g_color, g_depth, g_alpha, gws, g_normal)
                 rc = L.rdg_preprocess_backward(C.byref(ctx.cs), _lib.ptr(m3), _lib.ptr(shs), _lib.ptr(col), _lib.ptr(op),
                                                _lib.ptr(sc), _lib.ptr(ro), _lib.ptr(cov), _lib.ptr(vm), _lib.ptr(pm),

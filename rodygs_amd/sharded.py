@@ -357,7 +357,7 @@ class ShardedDynamicScene:
         hint = rasterizer._CAPACITY_HINT
         # every step is another camera: 1.5x the last instance count, and the workspace only ever grows
         cap = max(int(hint.get(self.key, 0) * 1.5) + 4096, 4 * self.P_total + 4096, self._capacity)
-        deferred = rasterizer.DEFERRED_OVERFLOW_CHECK and self.key in hint
+        deferred = rasterizer.DEFAULT_STATE.mode("deferred_overflow_check") and self.key in hint
         if deferred:
             rasterizer.poll_overflow(block=False)
         st = _lib.stream_ptr()
@@ -371,7 +371,8 @@ class ShardedDynamicScene:
                 self._binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), dtype=torch.uint8, device=dev)
                 self._capacity = cap
             self.cs_cam.num_rendered_stats = 1
-            self.cs_cam.bin_mode = int(rasterizer._BIN_HINT.get(self.key, 0))
+            # RDG_BIN_MODE=radix / bucket decides here as on the single-GPU path (note_largest_tile honours "bucket")
+            self.cs_cam.bin_mode = 1 if rasterizer.DEFAULT_STATE.mode("force_radix") else int(rasterizer._BIN_HINT.get(self.key, 0))
             _lib.check(L.rdg_composite_forward(C.byref(self.cs_cam), _lib.ptr(self.bg), _lib.ptr(self.geom_cam),
                                                _lib.ptr(self.radii_cam), _lib.ptr(self._binning), cap,
                                                _lib.ptr(self.image_ws), _lib.ptr(self.nren), _lib.ptr(self.color),

@@ -515,3 +515,29 @@ def test_bench_gpus_flag_is_never_silently_ignored():
     assert r.returncode != 0 and "they must agree" in r.stderr
     r = run(["--gpus", "2", "--steps", "1"], dict(env, RDG_ONE_DEVICE="1", RDG_DIST_BACKEND="gloo"))
     assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+
+
+def test_mode_switches_ride_on_the_raster_state():
+    """DETERMINISTIC / _FORCE_RADIX / _FORCE_BUCKET / DEFERRED_OVERFLOW_CHECK / RENDER_NORMAL: module attributes are the
+    process-wide defaults, a RasterState's own setting overrides them -- two trainers in one process can differ."""
+    from rodygs_amd import rasterizer as R
+    a, b = R.RasterState(), R.RasterState(deterministic=True, force_radix=True, render_normal=False)
+    keep = (R.DETERMINISTIC, R._FORCE_RADIX, R.DEFERRED_OVERFLOW_CHECK, R.RENDER_NORMAL)
+    try:
+        R.DETERMINISTIC, R._FORCE_RADIX, R.DEFERRED_OVERFLOW_CHECK, R.RENDER_NORMAL = False, False, True, True
+        assert not a.mode("deterministic") and b.mode("deterministic")
+        assert a.mode("deferred_overflow_check") and b.mode("deferred_overflow_check")
+        b.deferred_overflow_check = False
+        assert not b.mode("deferred_overflow_check") and a.mode("deferred_overflow_check")
+        rs = R.GaussianRasterizationSettings(16, 16, 1.0, 1.0, None, 1.0, None, 0, False, False, True, True)
+        ca, cb = R._c_settings(rs, 10, 1, a), R._c_settings(rs, 10, 1, b)
+        assert (ca.bin_mode, ca.render_normal) == (0, 1) and (cb.bin_mode, cb.render_normal) == (1, 0)
+        R._FORCE_RADIX = True
+        assert R._c_settings(rs, 10, 1, a).bin_mode == 1 and R._c_settings(rs, 10, 1).bin_mode == 1      # default state follows
+        # a frame with a huge tile list flips the binning hint -- unless the state is pinned to bucket binning
+        c = R.RasterState(force_bucket=True)
+        for st in (a, c):
+            st.note_largest_tile((10, 64, 64), 10 ** 6, 10 ** 6)
+        assert a.bin_hint and not c.bin_hint
+    finally:
+        R.DETERMINISTIC, R._FORCE_RADIX, R.DEFERRED_OVERFLOW_CHECK, R.RENDER_NORMAL = keep

@@ -193,3 +193,36 @@ def test_train_loop_with_periodic_densification(graph):
         rasterizer.DEFERRED_OVERFLOW_CHECK = keep
     assert traj[-1] > traj[0] and len(set(traj)) == len(traj)
     assert all(np.isfinite(losses)) and np.mean(losses[-8:]) < np.mean(losses[:8])
+
+
+def test_two_raster_states_in_one_process_differ_in_their_modes():
+    """The mode switches ride on the RasterState: one state renders through radix binning with the deterministic backward
+    (two backward passes: the same bits), another through the defaults, in the same process with the module attributes
+    untouched -- same image bit for bit, gradients to float-atomic noise."""
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    from rodygs_amd import rasterizer as R
+    from test_gpu_parity import NAMES
+    sc = O.synthetic_scene(6000, 320, 200, 2, seed=12)
+    rs = HS.make_settings(sc, 2, bg=torch.tensor([0.1, 0.2, 0.3]))
+    gw = torch.rand(3, 200, 320, device=DEV)
+
+    def run(state):
+        ins = {k: sc[k].clone().to(DEV).requires_grad_(True) for k in NAMES}
+        m2 = torch.zeros(6000, 3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(rs, state=state)(means3D=ins["means3D"], means2D=m2, shs=ins["shs"], opacities=ins["opacities"],
+                                                  scales=ins["scales"], rotations=ins["rotations"], viewmatrix=ins["viewmatrix"])
+        (out[0] * gw).sum().backward()
+        return out[0].detach(), {k: v.grad.clone() for k, v in ins.items()}
+
+    det = R.RasterState(deterministic=True, force_radix=True)
+    plain = R.RasterState()
+    assert (R.DETERMINISTIC, R._FORCE_RADIX) == (False, False) or pytest.skip("module defaults overridden by the environment")
+    i1, g1 = run(det)
+    i0, g0 = run(plain)
+    i2, g2 = run(det)
+    assert det.det_ws is not None and plain.det_ws is None
+    assert torch.equal(i1, i2) and torch.equal(i1, i0)
+    for k in NAMES:
+        assert torch.equal(g1[k], g2[k]), k                       # deterministic state: bit-reproducible
+        rel_ok(g0[k], g1[k], tol=2e-5, outliers=1e-4, cap=2e-3, what="atomic vs deterministic d_" + k)
