@@ -59,11 +59,17 @@ typedef struct RdgRasterSettings {
     int32_t enable_cov_grad; /* pose-gradient gates (SURVEY.md §7 open question 4)           */
     int32_t enable_sh_grad;
     int32_t render_normal;   /* 1: composite the normal channels (default); 0: leave them zero */
-    int32_t bin_mode;        /* tile binning algorithm of THIS forward: 0 = bucket binning (default),
-                              * 1 = stable LSD radix sort of (tile | depth) keys.  Same result bit
-                              * for bit; bucket binning is faster on ordinary frames, the radix sort has no atomics and no
-                              * per-tile work, so its time does not depend on how the instances are spread over the tiles
-                              * (a tile holding 200 k instances).  Callers pick it from num_rendered[1] of the previous frame. */
+    int32_t bin_mode;        /* tile binning algorithm of THIS forward: 0 = bucket binning (default: count / scan / scatter
+                              * into per-tile buckets + a per-tile sort), 1 = radix binning, depth first: the P Gaussians are
+                              * sorted by depth ONCE (32-bit keys), their tile instances emitted in that order as (tile id,
+                              * Gaussian id) pairs and partitioned stably by tile id (ceil(log2 tiles / 8) passes over 8 B per
+                              * pair).  Same result bit for bit; bucket binning is faster on ordinary frames, the radix path has
+                              * no atomics and no per-tile work, so its time does not depend on how the instances are spread
+                              * over the tiles (a tile holding 200 k instances).  Callers pick it from num_rendered[1] of the
+                              * previous frame.  bin_mode 1 keeps its per-Gaussian sort scratch (4 arrays of P uint32 + block
+                              * sums) inside the second key buffer of the binning workspace: `capacity` must be at least
+                              * 2 P + (P / 256 + 320) / 2 (the hosts of this package pass >= 4 P + 4096); a smaller capacity
+                              * fails with "radix binning: capacity too small".                                            */
     int32_t num_rendered_stats; /* 1: num_rendered points to int32[2] and the binning stage also writes
                               * [1] = largest number of instances in one tile                                    */
     int32_t list_hints;      /* what the previous frame of this shape says about tile-list lengths (num_rendered[1]); speed

@@ -37,10 +37,14 @@ static inline int rdg_rs_nseg(int64_t capacity) {
 }
 
 size_t rdg_radix_sort_tmp_bytes(int64_t capacity) {
-    // table[n_seg][256] + totals[256]; sized for the largest segment count, so that one workspace serves sorts of any
-    // smaller capacity too (the binning stage sorts P depth keys and D tile ids in the same one)
-    (void)capacity;
-    return rdg_align_up((size_t)256 * RDG_RS_MAXSEG * 4, 256) + 1024;
+    // table[n_seg][256] + totals[256], for a sort of `capacity` pairs OR ANY SMALLER NUMBER in the same workspace (the
+    // binning stage sorts P depth keys and D tile ids in one; a K-NN workspace serves every sample size up to its own):
+    // the segment count is not monotone in the capacity -- below 4 M pairs the tiles are 1024 pairs, above 4096 -- so the
+    // table is sized for the larger of the two counts a capacity <= this one can produce
+    const int64_t small_cap = capacity < RDG_RS_SMALL_BELOW ? capacity : RDG_RS_SMALL_BELOW - 1;
+    int nseg = rdg_rs_nseg(capacity);
+    if (rdg_rs_nseg(small_cap) > nseg) nseg = rdg_rs_nseg(small_cap);
+    return rdg_align_up((size_t)256 * (size_t)nseg * 4, 256) + 1024;
 }
 
 // tiles [t0, t1) of segment `seg` when n pairs are cut into nseg segments of whole tiles
@@ -237,7 +241,7 @@ int rdg_launch_radix_sort(KeyT* keys_a, KeyT* keys_b, uint32_t* vals_a, uint32_t
     const int nseg = rdg_rs_nseg(capacity);
     const bool small = rdg_rs_items(capacity) == 4;
     uint32_t* table = (uint32_t*)tmp;
-    uint32_t* totals = (uint32_t*)((char*)tmp + rdg_align_up((size_t)256 * RDG_RS_MAXSEG * 4, 256));
+    uint32_t* totals = (uint32_t*)((char*)tmp + rdg_align_up((size_t)256 * (size_t)nseg * 4, 256));   // right behind THIS sort's table
     KeyT* kin = keys_a; KeyT* kout = keys_b;
     uint32_t* vin = vals_a; uint32_t* vout = vals_b;
     for (int p = 0; p < npass; ++p) {

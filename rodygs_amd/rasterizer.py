@@ -101,6 +101,7 @@ class RasterState:
         self.last_image = None        # (image workspace, H, W) of the most recent forward
         self.graph_capture = False
         self.nren_max = None          # optional device int32[1]: sticky maximum of D (RdgRasterSettings.num_rendered_max)
+        self.nren_max_key = None      # ... folded into by forwards of THIS (P, H, W) only (None: by every forward)
         self.det_ws = None            # deterministic mode: the per-instance row workspace, kept across steps
         self.lock = threading.RLock()
 
@@ -378,7 +379,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     host[0], host[1] = -1, -1
                     if NREN_HOST_MIRROR:
                         cs.num_rendered_host = host.data_ptr()
-                if state.nren_max is not None:
+                if state.nren_max is not None and state.nren_max_key in (None, key):
                     cs.num_rendered_max = state.nren_max.data_ptr()     # sticky maximum of D (graph replay)
             while True:
                 binning = torch.empty(L.rdg_binning_bytes(cap, n_tiles), **u8)

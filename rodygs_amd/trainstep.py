@@ -546,6 +546,10 @@ class GraphedStep:
         ds._graph_inputs = (self.emb_in, self.gt_in, self.scal, self.gt_depth_in)
         st = ds.raster_state
         st.nren_max = torch.zeros(1, dtype=torch.int32, device=dev)       # sticky maximum of D over the replays
+        # forwards of another (P, H, W) through the same state (an evaluation render, the eager rigidity step of another
+        # size) must not fold their instance count into this graph's record: the rasterizer binds it for this key only
+        st.nren_max_key = (ds.P, ds.H, ds.W)
+        ds.fp.__dict__.pop("_adam_graph_layout", None)       # a layout left by an earlier GraphedStep on this bucket is stale
         step = first_step
         if ds.full_losses and step % ds.rigidity[1] == 0:
             step += 1                            # a rigidity step is not part of the graph (see step())
@@ -663,3 +667,5 @@ class GraphedStep:
     def close(self) -> None:
         self.ds._graph_inputs = None
         self.ds.raster_state.nren_max = None
+        self.ds.raster_state.nren_max_key = None
+        self.ds.fp.__dict__.pop("_adam_graph_layout", None)

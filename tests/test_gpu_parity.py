@@ -199,7 +199,8 @@ def test_preprocess_and_binning_bit_exact(P, W, H, deg):
 
 
 @pytest.mark.parametrize("n,bits", [(0, 40), (1, 40), (63, 33), (64, 45), (1000, 40), (100000, 45), (3000000, 47),
-                                    (77, 64), (5000, 8)])
+                                    (77, 64), (5000, 8),
+                                    (5000000, 40), (5000000, 16)])     # >= 2^22 pairs: the 4096-pair-tile kernels
 def test_sort_pairs_stable_and_exact(n, bits):
     from rodygs_amd import _lib
     L = _lib.lib()

@@ -226,3 +226,25 @@ def test_two_raster_states_in_one_process_differ_in_their_modes():
     for k in NAMES:
         assert torch.equal(g1[k], g2[k]), k                       # deterministic state: bit-reproducible
         rel_ok(g0[k], g1[k], tol=2e-5, outliers=1e-4, cap=2e-3, what="atomic vs deterministic d_" + k)
+
+
+def test_radix_binning_with_a_production_sized_workspace_is_bit_exact():
+    """Radix binning with a capacity of 2^22 pairs or more -- what the hosts pass at 1 M Gaussians (4 P + 4096) -- runs the
+    4096-pair-tile instantiations of the sort on uint32 keys (below that the 1024-pair ones; tests that size their workspace
+    to D + 17 only reach them at 4 M / 4K): keys, order, ranges and D against the oracle at 100 k / 1080p with a 5 M-pair
+    workspace; and bucket binning in the same workspace."""
+    import hip_stages as HS
+    from test_gpu_parity import NAMES, orbit_view
+    P, W, H = 100000, 1920, 1080
+    sc = O.synthetic_scene(P, W, H, 3, seed=777)
+    sc["viewmatrix"] = orbit_view(4.0, -2.0, (0.3, -0.2, 0.5))
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], torch.zeros(3), 1.0, sc["projmatrix"], 3)
+    with torch.no_grad():
+        geom = O.preprocess(sc["means3D"], torch.zeros(P, 3), sc["opacities"], sc["viewmatrix"], st, shs=sc["shs"],
+                            scales=sc["scales"], rotations=sc["rotations"])
+    ref = O.bin_and_sort(geom)
+    for bin_mode in (1, 0):
+        hs = HS.run_stages(sc, 3, capacity=5000000, bin_mode=bin_mode)
+        assert hs["D"] == ref["num_rendered"] < 5000000
+        assert np.array_equal(hs["keys_sorted"], ref["keys_sorted"]) and np.array_equal(hs["vals_sorted"], ref["vals_sorted"])
+        assert np.array_equal(hs["ranges"], ref["ranges"]), bin_mode
