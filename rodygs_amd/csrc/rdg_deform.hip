@@ -291,7 +291,7 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
                           const float* __restrict__ g_opac, float* __restrict__ d_xyz, float* __restrict__ d_scaling,
                           float* __restrict__ d_rotation, float* __restrict__ d_opacity, float* __restrict__ d_coeff,
                           const int* __restrict__ inv_order, float4* __restrict__ gs, uint32_t* __restrict__ zero_out,
-                          int n_zero) {
+                          int n_zero, const float* __restrict__ coeff_abl = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem_dg[];
     // the finished-workgroup counter of the dB reduction's last stage is cleared here (one memset launch less)
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_zero; k += gridDim.x * blockDim.x) zero_out[k] = 0u;
@@ -356,9 +356,19 @@ rdg_dyn_getter_bwd_kernel(int P, int Tu, const long long* __restrict__ time_ind,
             }
             reinterpret_cast<float4*>(d_rotation)[p] = dq;
             d_opacity[p] = has_o ? gop * sg * (1.0f - sg) : 0.0f;
+#ifdef RDG_ABL_FUSE_DB
+            // ablation build (results wrong, timing only; profiles/r05_experiments.txt): what a dB reduction fused into this
+            // kernel would move at the least -- no birth-sorted copy written, the coefficient row read here instead
+            {
+                const float4* cr = reinterpret_cast<const float4*>(coeff_abl) + 4 * (size_t)p;
+                float4 c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3];
+                asm volatile("" :: "v"(c0.x), "v"(c1.y), "v"(c2.z), "v"(c3.w), "v"(c0.w), "v"(c1.x), "v"(c2.x), "v"(c3.x));
+            }
+#else
             // sorted compact copy (scaled gradient, birth index) for the dB reduction
             gs[2 * sidx] = make_float4(g[0], g[1], g[2], g[3]);
             gs[2 * sidx + 1] = make_float4(g[4], g[5], g[6], __int_as_float(u));
+#endif
         }
         // ---- deformation backward: dL/dcoeff ----
         const float4* r4 = reinterpret_cast<const float4*>(smem_dg + u * RDG_DC_STRIDE);
@@ -1114,11 +1124,13 @@ int rdg_dyn_getter_backward(int32_t P, int32_t Tu, const float* coeff, const int
         hipLaunchKernelGGL(rdg_dyn_getter_bwd_kernel, dim3(nb), dim3(1024), rdg_getter_lds(Tu), st, P, Tu,
                            (const long long*)time_ind, bases, spatial_scale, scaling, rotation, opacity, g_means3D,
                            g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity, d_coeff,
-                           (const int*)inv_order, (float4*)sorted_ws, counter, 2);
+                           (const int*)inv_order, (float4*)sorted_ws, counter, 2, coeff);
         float* part = (float*)((char*)counter + 256);
+#ifndef RDG_ABL_FUSE_DB
         hipLaunchKernelGGL(rdg_deform_bwd_acc_mfma_kernel, dim3(RDG_DEF_ACC_BLOCKS), dim3(256), 0, st, P, coeff,
                            (const long long*)time_ind, (const int*)order, (const float*)nullptr, (const float*)nullptr,
                            spatial_scale, 1, d_basis_t, d_table, (const float*)sorted_ws, part);
+#endif
         hipLaunchKernelGGL(rdg_deform_part_finalize_kernel, dim3(Tu), dim3(128 * RDG_DEF_FIN_GROUPS), 0, st, P, Tu,
                            rdg_deform_rows_per_wave(P, RDG_DEF_ACC_BLOCKS * 4), (const int*)seg_start,
                            (const float*)sorted_ws, (const long long*)time_ind, (const int*)order, (const float*)part,
