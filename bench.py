@@ -25,6 +25,13 @@ import os
 import sys
 import time
 
+# --loop: the cloud grows by a few percent at every densification and with it every per-Gaussian tensor of the step; with the
+# allocator's sizes rounded up to sixteenths of a power of two the blocks of the old cloud serve the new one (otherwise the first
+# step after every densification allocates ~30 new blocks from the driver: 6 ms).  Read when the allocator initialises.
+if "--loop" in sys.argv:
+    os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "roundup_power2_divisions:16")
+    os.environ.setdefault("PYTORCH_CUDA_ALLOC_CONF", os.environ["PYTORCH_HIP_ALLOC_CONF"])
+
 import torch
 import torch.distributed as dist
 
@@ -591,7 +598,8 @@ def run_loop(args, dev, scene, target):
         done += n
         if done < K:
             t0 = sync()
-            tm = {} if args.loop_profile else None
+            tm = ({"_nosync": True} if args.loop_profile == "host" else {}) if args.loop_profile else None
+            t_q = time.perf_counter()
             with torch.no_grad():
                 if args.densify_grad_threshold > 0:
                     thr = args.densify_grad_threshold
@@ -599,6 +607,8 @@ def run_loop(args, dev, scene, target):
                     g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
                     thr = torch.quantile(g_mean, args.densify_quantile)
             p0 = ds.P
+            if tm is not None:
+                tm["threshold_host"] = (time.perf_counter() - t_q) * 1e3
             info = ds.densify(max_grad=thr, min_opacity=0.005, percent_dense=0.01, want_decisions=False, timings=tm)
             t1 = sync()
             densifies.append({"after_step": done, "ms": (t1 - t0) * 1e3, "P_before": p0, "P_after": info["P"],
@@ -622,7 +632,8 @@ def run_loop(args, dev, scene, target):
                        "densify_threshold": (args.densify_grad_threshold if args.densify_grad_threshold > 0 else
                                              f"{args.densify_quantile} quantile of the mean screen-space gradient"),
                        "row_order": "z-curve of the canonical positions, kept through every densification" if spatial_order
-                       else "generator (random)", "deferred_overflow_check": True},
+                       else "generator (random)", "deferred_overflow_check": True,
+                       "allocator": os.environ.get("PYTORCH_HIP_ALLOC_CONF", "default")},
             "gaussians_per_s": sustained * mean_P,
             "loop": {"sustained_fps": sustained, "steady_state_fps_of_the_window": 1e3 / steady_ms if steady_ms else None,
                      "sustained_over_steady": (sustained * steady_ms / 1e3) if steady_ms else None,
@@ -698,7 +709,9 @@ def main():
     ap.add_argument("--densify-grad-threshold", type=float, default=0.0,
                     help="> 0: the reference's absolute threshold on the mean screen-space gradient (its configs: 0.0002) "
                          "instead of the quantile rule")
-    ap.add_argument("--loop-profile", action="store_true", help="--loop: per-phase times of every densification (synchronises)")
+    ap.add_argument("--loop-profile", nargs="?", const="sync", default=None, choices=["sync", "host"],
+                    help="--loop: per-phase times of every densification; 'sync' (default) synchronises the device at every "
+                         "phase boundary, 'host' records host time only (where the host blocks)")
     ap.add_argument("--dp-mode", choices=["both", "allreduce", "shard"], default=os.environ.get("RDG_DP_MODE", "both"),
                     help="N > 1 formulation: 'allreduce' = BASELINE north_star: replicated cloud, frames over the GPUs, "
                          "RCCL all-reduce of the Gaussian / pose gradients (bucketed, overlapped with backward and Adam); "

@@ -102,13 +102,37 @@ def _gather_rows(src_flat: torch.Tensor, row_len: int, idx: torch.Tensor, dst_fl
                                           _lib.stream_ptr()), "rdg_gather_rows")
 
 
-def rebuild_flat_params(fp: FlatParams, src: torch.Tensor, keep_moments: torch.Tensor) -> FlatParams:
+class FlatPool:
+    """Two sets of flat buffers used in turn by successive densifications: the rows are gathered from the set the cloud
+    lives in into the spare one, which then becomes the cloud's -- no allocation per densification (a new gigabyte-sized
+    block every 100 steps stalled the host for 36 ms at 1 M Gaussians: bench.py --loop-profile host).  A set that has become
+    too small is replaced by one with ``headroom`` (x the needed size), so that the next few densifications fit."""
+
+    def __init__(self, headroom: float = 1.3):
+        self.headroom, self.spare = float(headroom), None
+
+    def take(self, numel: int, device):
+        from .dp import FlatStorage
+        st, self.spare = self.spare, None
+        if st is None or st.capacity < numel or st.buffers[0].device != torch.device(device):
+            st = FlatStorage(int(numel * self.headroom) + 4096, device)
+        return st
+
+    def give_back(self, fp: FlatParams) -> None:
+        """The storage ``fp`` lived in (if it has one of its own) is the next spare; ``fp`` must not be used any more."""
+        if fp.storage is not None and (self.spare is None or fp.storage.capacity > self.spare.capacity):
+            self.spare = fp.storage
+
+
+def rebuild_flat_params(fp: FlatParams, src: torch.Tensor, keep_moments: torch.Tensor, pool: Optional[FlatPool] = None) -> FlatParams:
     """New FlatParams whose row i of every segment is row src[i] of ``fp``; Adam moments are carried over where
-    ``keep_moments[i]`` and start at zero elsewhere.  Every segment's first dimension is the Gaussian count."""
+    ``keep_moments[i]`` and start at zero elsewhere.  Every segment's first dimension is the Gaussian count.
+    ``pool``: take the new buffers from it instead of allocating (the caller hands ``fp``'s storage back afterwards)."""
+    from .dp import flat_numel
     dev = fp.flat.device
     n_new = int(src.numel())
     spec = {k: ((n_new, *fp.shapes[k][1:]), fp.lr[k]) for k in fp.names}
-    out = FlatParams(spec, dev)
+    out = FlatParams(spec, dev, storage=None if pool is None else pool.take(flat_numel(spec), dev))
     out.step_count = fp.step_count
     src = src.to(torch.int64).contiguous()
     src_m = torch.where(keep_moments, src, torch.full_like(src, -1)).contiguous()
@@ -205,16 +229,20 @@ class _Phase:
 
     def __init__(self, timings, dev):
         self.t, self.dev, self.last = timings, dev, None
+        # timings["_nosync"]: HOST time per phase only (where does the host block?), no device synchronisation
+        self.sync = timings is not None and not timings.get("_nosync")
         if timings is not None:
             import time
             self.clock = time.perf_counter
-            torch.cuda.synchronize(dev)
+            if self.sync:
+                torch.cuda.synchronize(dev)
             self.last = self.clock()
 
     def mark(self, name: str) -> None:
         if self.t is None:
             return
-        torch.cuda.synchronize(self.dev)
+        if self.sync:
+            torch.cuda.synchronize(self.dev)
         now = self.clock()
         self.t[name] = self.t.get(name, 0.0) + (now - self.last) * 1e3
         self.last = now
@@ -233,7 +261,8 @@ def _compact(mask: torch.Tensor, n: int) -> torch.Tensor:
 def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], max_grad,
                       min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01, N: int = 2,
                       z: Optional[torch.Tensor] = None, decisions: Optional[Dict[str, torch.Tensor]] = None,
-                      spatial_order: bool = False, want_decisions: bool = True, timings: Optional[dict] = None) -> DensifyResult:
+                      spatial_order: bool = False, want_decisions: bool = True, timings: Optional[dict] = None,
+                      pool: Optional[FlatPool] = None) -> DensifyResult:
     """``fp`` holds at least xyz [P,3], scaling [P,3] (log), rotation [P,4] (raw), opacity [P,1] (logit); every other
     segment (SH features, motion coefficients, ...) is carried along row-wise.  ``per_point``: further [P,...]
     tensors that follow the Gaussians (gaussian_to_time, gaussian_to_time_ind).  ``z``: optional standard-normal
@@ -250,7 +279,8 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
     split Gaussian share opacity and scale) and the five counts the new buffers are sized with are formed on the device and
     read back ONCE; the source-row list is built from them without further waits (``_compact``); the Z-curve order of the new
     cloud is composed INTO that list (the children's positions are computed first), so every buffer is gathered once, not
-    twice.  ``want_decisions=False`` skips building the masks of ``DensifyResult.decisions``."""
+    twice.  ``want_decisions=False`` skips building the masks of ``DensifyResult.decisions``.  ``pool``: a ``FlatPool`` the new
+    buffers come from (no allocation); the caller gives ``fp``'s storage back to it once nothing refers to ``fp`` any more."""
     if not fp.flat.is_cuda:
         raise RuntimeError("rodygs_amd.densify_and_prune: buffers must be on the GPU (no CPU fallback exists)")
     if fp.shapes["scaling"][1:] != (3,):
@@ -318,7 +348,7 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
                 inv[perm] = torch.arange(n_new, device=dev)
                 child_dst = inv[first:]
         ph.mark("re_sort")
-        out = rebuild_flat_params(fp, src, moments)
+        out = rebuild_flat_params(fp, src, moments, pool)
         if n_child_kept:
             if child_dst is None:
                 out["xyz"].detach()[first:] = child_xyz

@@ -20,7 +20,12 @@ class FlatParams:
     ``spec``: ordered {name: (shape, lr)}.  Tensors are views into the flat buffers; ``.grad`` of every parameter
     is a view into ``flat_grad`` (autograd accumulates in place into an existing .grad)."""
 
-    def __init__(self, spec: Dict[str, Tuple[Sequence[int], float]], device, align: int = 64):
+    def __init__(self, spec: Dict[str, Tuple[Sequence[int], float]], device, align: int = 64, storage=None):
+        """``storage``: optional (flat, flat_grad, exp_avg, exp_avg_sq) float32 buffers of at least this layout's size to lay
+        the segments out in, instead of allocating (``FlatStorage``: a trainer that densifies every 100 steps re-uses two
+        such sets in turn -- a fresh gigabyte-sized allocation per densification stalls the host for tens of milliseconds).
+        Whoever passes them is responsible for their contents; this constructor only clears the gradient buffer and the
+        alignment padding of the other three."""
         self.names: List[str] = list(spec)
         self.lr: Dict[str, float] = {k: float(v[1]) for k, v in spec.items()}
         self.shapes = {k: tuple(v[0]) for k, v in spec.items()}
@@ -33,10 +38,24 @@ class FlatParams:
             self.offsets[k] = (off, n)
             off += (n + align - 1) // align * align
         self.numel = off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
-        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
-        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+        self.storage = storage
+        if storage is None:
+            self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+            self.flat_grad = torch.zeros(off, dtype=torch.float32, device=device)
+            self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
+            self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+        else:
+            if any(b.numel() < off or b.dtype != torch.float32 or not b.is_contiguous() for b in storage.buffers):
+                raise ValueError("FlatParams: the storage is smaller than the layout (or not contiguous float32)")
+            self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq = (b[:off] for b in storage.buffers)
+            with torch.no_grad():
+                self.flat_grad.zero_()
+                for k in self.names:             # alignment padding: Adam steps merged neighbours across it
+                    o, n = self.offsets[k]
+                    end = (o + n + align - 1) // align * align
+                    if end > o + n:
+                        for b in (self.flat, self.exp_avg, self.exp_avg_sq):
+                            b[o + n:end].zero_()
         self.params: Dict[str, torch.Tensor] = {}
         for k in self.names:
             o, n = self.offsets[k]
@@ -55,6 +74,25 @@ class FlatParams:
     def segment(self, buf: torch.Tensor, k: str) -> torch.Tensor:
         o, n = self.offsets[k]
         return buf[o:o + n]
+
+
+class FlatStorage:
+    """Four float32 buffers of ``capacity`` elements a ``FlatParams`` layout can be placed in (``FlatParams(storage=)``)."""
+
+    def __init__(self, capacity: int, device):
+        self.capacity = int(capacity)
+        self.buffers = tuple(torch.empty(self.capacity, dtype=torch.float32, device=device) for _ in range(4))
+
+
+def flat_numel(spec: Dict[str, Tuple[Sequence[int], float]], align: int = 64) -> int:
+    """Elements a FlatParams of this spec occupies (the layout rule of ``FlatParams.__init__``)."""
+    off = 0
+    for shape, _ in spec.values():
+        n = 1
+        for s_ in shape:
+            n *= int(s_)
+        off += (n + align - 1) // align * align
+    return off
 
 
 def allreduce_sum_(flat_grad: torch.Tensor, extra: Sequence[torch.Tensor] = ()) -> None:

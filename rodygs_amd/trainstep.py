@@ -334,9 +334,21 @@ class DynamicScene:
         return out, m2
 
     # ---- densification in the loop (rodygs.py:319-362) ----------------------------------------------------------
-    def track_densification(self) -> None:
-        from .densify import DensifyStats
+    def track_densification(self, headroom: float = 1.3) -> None:
+        """Start keeping the densification statistics.  The cloud is moved into flat buffers with ``headroom`` (x its size) and
+        a spare set of the same size is allocated NOW: every densification from here on gathers the rows from one set into the
+        other and allocates nothing while the cloud stays below the headroom (``densify.FlatPool``)."""
+        from .densify import DensifyStats, FlatPool, rebuild_flat_params
+        from .dp import FlatStorage
         self.stats = DensifyStats.zeros(self.P, self.device)
+        if self.fp.flat.is_cuda and self.fp.storage is None and headroom > 1.0:
+            self._fp_pool = FlatPool(headroom)
+            with torch.no_grad():
+                every = torch.arange(self.P, device=self.device)
+                self.fp = rebuild_flat_params(self.fp, every, torch.ones(self.P, dtype=torch.bool, device=self.device),
+                                              self._fp_pool)
+            self._fp_pool.spare = FlatStorage(self.fp.storage.capacity, self.device)
+            self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
 
     def densify(self, max_grad=0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
                 max_screen_size=None, percent_dense: float = 0.01, z: Optional[torch.Tensor] = None,
@@ -347,17 +359,22 @@ class DynamicScene:
         scaled by P' / P (+ 10 %), the binning / split-compositing hints as they stand -- the first forward of the new cloud
         then needs no read-back of its instance count (a capacity that turns out too small is found by the usual overflow
         check).  ``timings``: per-phase wall times (ms) of this call, synchronising at every phase boundary (diagnosis)."""
-        from .densify import _Phase, allreduce_stats_, densify_and_prune
+        from .densify import FlatPool, _Phase, allreduce_stats_, densify_and_prune
         if self.stats is None:
             raise RuntimeError("call track_densification() first")
         allreduce_stats_(self.stats)
         P_old = self.P
+        if getattr(self, "_fp_pool", None) is None:
+            self._fp_pool = FlatPool()
+        old_fp = self.fp
         res = densify_and_prune(self.fp, self.stats, {"time_ind": self.time_ind}, max_grad, min_opacity,
                                 extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense,
                                 z=z, decisions=decisions, spatial_order=self.spatial_order, want_decisions=want_decisions,
-                                timings=timings)
+                                timings=timings, pool=self._fp_pool)
         ph = _Phase(timings, self.device)
         self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
+        self._fp_pool.give_back(old_fp)          # (stream-ordered: the gathers that read it are queued before any re-use)
+        del old_fp
         self.P = self.fp.shapes["xyz"][0]
         self.m2 = torch.zeros(self.P, 3, device=self.device, requires_grad=True)
         self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
