@@ -549,6 +549,21 @@ def run_loop(args, dev, scene, target):
     for _ in range(args.settle):
         ds.train_step(step, 0, 1, perm)
         step += 1
+
+    def threshold():
+        with torch.no_grad():
+            if args.densify_grad_threshold > 0:
+                return args.densify_grad_threshold
+            g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
+            return torch.quantile(g_mean, args.densify_quantile)
+
+    # The first densification of a process pays for the lazy initialisation of ~40 framework kernels (180 ms): like the first
+    # train steps it belongs to the warm-up.  One real densification on the statistics of the steps so far, untimed, then the
+    # statistics start afresh and a few more untimed steps settle the new cloud; the P trajectory below starts from its result.
+    warm = ds.densify(max_grad=threshold(), min_opacity=0.005, percent_dense=0.01, want_decisions=False)
+    for _ in range(min(args.settle, 20)):
+        ds.train_step(step, 0, 1, perm)
+        step += 1
     ds.stats.xyz_gradient_accum.zero_(); ds.stats.denom.zero_(); ds.stats.max_radii2D.zero_()
 
     def sync():
@@ -600,12 +615,7 @@ def run_loop(args, dev, scene, target):
             t0 = sync()
             tm = ({"_nosync": True} if args.loop_profile == "host" else {}) if args.loop_profile else None
             t_q = time.perf_counter()
-            with torch.no_grad():
-                if args.densify_grad_threshold > 0:
-                    thr = args.densify_grad_threshold
-                else:
-                    g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
-                    thr = torch.quantile(g_mean, args.densify_quantile)
+            thr = threshold()
             p0 = ds.P
             if tm is not None:
                 tm["threshold_host"] = (time.perf_counter() - t_q) * 1e3
@@ -629,6 +639,7 @@ def run_loop(args, dev, scene, target):
             "config": {"workload": workload_label(P, W, H, args.frames, False, 1, args.scene) + f", train loop with "
                        f"densification every {interval} steps", "points": P, "width": W, "height": H, "scene": args.scene,
                        "graph_replay": bool(args.graph), "densify_interval": interval,
+                       "points_after_warmup_densification": int(warm["P"]),
                        "densify_threshold": (args.densify_grad_threshold if args.densify_grad_threshold > 0 else
                                              f"{args.densify_quantile} quantile of the mean screen-space gradient"),
                        "row_order": "z-curve of the canonical positions, kept through every densification" if spatial_order
