@@ -574,6 +574,7 @@ def run_loop(args, dev, scene, target):
     segments, densifies = [], []
     done = 0
     graphed = None
+    graph_pool = cap_tm = None
     t_begin = sync()
     while done < K:
         n = min(interval, K - done)
@@ -582,7 +583,10 @@ def run_loop(args, dev, scene, target):
             t0 = sync()
             ds.raster_state.deferred_overflow_check = False
             ds.raster_state.poll_overflow(block=True)
-            graphed = GraphedStep(ds, perm, warmup=1, first_step=step)     # (its eager warm-up step is one of the segment's n)
+            cap_tm = {} if args.loop_profile else None
+            graphed = GraphedStep(ds, perm, warmup=1, first_step=step, timings=cap_tm,      # (its eager warm-up step is one
+                                  pool=graph_pool)                                            #  of the segment's n)
+            graph_pool = graphed.pool()
             eager_done = graphed.next_step - step
             step = graphed.next_step
             t_cap = (sync() - t0) * 1e3
@@ -607,7 +611,7 @@ def run_loop(args, dev, scene, target):
             ds.raster_state.deferred_overflow_check = True
         ds.raster_state.poll_overflow(block=True)
         n_head = min(head, n) - eager_done
-        segments.append({"P": ds.P, "steps": n, "graph_capture_ms": t_cap,
+        segments.append({"P": ds.P, "steps": n, "graph_capture_ms": t_cap, "graph_capture_phases_ms": cap_tm,
                          "ms_per_step_first_20": ((t_head or t1) - t0) * 1e3 / max(n_head, 1),
                          "ms_per_step_settled": ((t1 - t_head) * 1e3 / (n - head)) if (t_head is not None and n > head) else None})
         done += n

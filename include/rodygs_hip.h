@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RDG_ABI_VERSION 5
+#define RDG_ABI_VERSION 6
 #define RDG_MAX_VIEWS 16   /* cameras per step in the *_views entry points */
 #define RDG_ADAM_MAX_SEGS 12 /* parameter groups per rdg_adam_step_multi launch */
 
@@ -395,6 +395,12 @@ int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float*
  * same update rides along in rdg_preprocess_backward* for free (RdgRasterSettings.densify_*).                          */
 int rdg_densify_stats(int64_t n, int64_t row0, const float* dL_dmeans2D, const int32_t* radii, float* grad_accum,
                       float* denom, float* max_radii, void* stream);
+
+/* Z-curve (Morton) index of every row of xyz [n,3] inside the box lo_hi = (lo_x, lo_y, lo_z, hi_x, hi_y, hi_z) (device
+ * floats): `bits` (<= 21) bits per axis, x / y / z interleaved from bit 0 -- the row order a trainer built on this package
+ * keeps its cloud in (rodygs_amd/layout.py; the reference keeps whatever order its point cloud and densification appends
+ * produce, /root/reference/src/trainer/rodygs_static.py:218-299).  One launch where the framework expression takes ~35.   */
+int rdg_morton_codes(int64_t n, const float* xyz, const float* lo_hi, int32_t bits, int64_t* codes, void* stream);
 
 /* ThreeDGSTrainer.reset_opacity (/root/reference/src/trainer/rodygs_static.py:151-160) with the optimizer surgery of
  * replace_tensor_to_optimizer (/root/reference/src/trainer/utils.py:15-32), in place on a flat-bucket segment:

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RDG_LIB_PATH: load another build of the same ABI (A/B runs of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("RDG_LIB_PATH") or os.path.join(_HERE, "csrc", "librodygs_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 _lock = threading.Lock()
@@ -102,6 +102,7 @@ _SIGS = {
     "rdg_split_children": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
     "rdg_densify_stats": (C.c_int, [C.c_int64, C.c_int64] + [_vp] * 6),
     "rdg_reset_opacity": (C.c_int, [C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
+    "rdg_morton_codes": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]),
     "rdg_graph_points_backward": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
     "rdg_graph_surface": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 9),
     "rdg_rigidity_pack_rows": (C.c_int, [C.c_int64, C.c_int32, _vp, _vp, _vp, _vp, _vp]),

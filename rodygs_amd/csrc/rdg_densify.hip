@@ -71,6 +71,33 @@ rdg_densify_stats_kernel(long long n, long long row0, const float* __restrict__ 
     if (denom) denom[j] += 1.0f;
 }
 
+// Z-curve index of a row inside the cloud's bounding box (rodygs_amd/layout.py::morton_codes, same arithmetic in double):
+// q = round((x - lo) / max(hi - lo, 1e-30) * (2^bits - 1)) per axis, bits of x / y / z interleaved from bit 0.
+__device__ __forceinline__ unsigned long long rdg_spread3(unsigned long long v) {
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__global__ void __launch_bounds__(256)
+rdg_morton_codes_kernel(long long n, const float* __restrict__ xyz, const float* __restrict__ lo_hi, int bits,
+                        long long* __restrict__ codes) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double top = (double)((1ll << bits) - 1);
+    unsigned long long q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double lo = (double)lo_hi[k], hi = (double)lo_hi[3 + k];
+        const double ext = fmax(hi - lo, 1e-30);
+        q[k] = (unsigned long long)(long long)rint(((double)xyz[3 * i + k] - lo) / ext * top);
+    }
+    codes[i] = (long long)(rdg_spread3(q[0]) | (rdg_spread3(q[1]) << 1) | (rdg_spread3(q[2]) << 2));
+}
+
 int rdg_launch_densify_stats(long long n, long long row0, const float* dmeans2D, const int32_t* radii, float* accum,
                              float* denom, float* maxr, hipStream_t s) {
     hipLaunchKernelGGL(rdg_densify_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, row0, dmeans2D,
@@ -88,6 +115,15 @@ int rdg_reset_opacity(int64_t n, float max_opacity, float* opacity_logit, float*
     hipLaunchKernelGGL(rdg_reset_opacity_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (long long)n, max_opacity, opacity_logit, exp_avg, exp_avg_sq);
     return rdg_check_hip(hipGetLastError(), "reset_opacity launch");
+}
+
+int rdg_morton_codes(int64_t n, const float* xyz, const float* lo_hi, int32_t bits, int64_t* codes, void* stream) {
+    if (n <= 0) return 0;
+    if (bits < 1 || bits > 21) return rdg_set_error("morton_codes: bits must be in [1, 21]");
+    if (!xyz || !lo_hi || !codes) return rdg_set_error("morton_codes: NULL buffer");
+    hipLaunchKernelGGL(rdg_morton_codes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (long long)n, xyz, lo_hi, (int)bits, (long long*)codes);
+    return rdg_check_hip(hipGetLastError(), "morton_codes launch");
 }
 
 int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const float* src, float* dst, void* stream) {

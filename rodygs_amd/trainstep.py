@@ -547,14 +547,33 @@ class GraphedStep:
 
     RING = 256
 
-    def __init__(self, ds: "DynamicScene", perm, warmup: int = 2, first_step: int = 0):
+    # pinned staging rings are expensive to allocate (a page-locked allocation: ~1 ms) and carry nothing across graphs: a
+    # trainer that re-captures after every densification gets the previous one back (keyed by device)
+    _RING_CACHE: dict = {}
+
+    def __init__(self, ds: "DynamicScene", perm, warmup: int = 2, first_step: int = 0, timings: Optional[dict] = None,
+                 pool=None):
+        """``pool``: a graph memory-pool handle (``GraphedStep.pool()`` of an earlier, closed graph of this scene) the capture
+        allocates from instead of a fresh private pool -- a re-capture after a densification then re-uses the blocks of the
+        graph it replaces instead of asking the driver for a new gigabyte.  ``timings``: phase wall times (ms) of this
+        constructor (bench.py --loop --graph)."""
+        import time as _time
+        t_last = [_time.perf_counter()]
+
+        def mark(name):
+            if timings is not None:
+                torch.cuda.synchronize(ds.device)
+                now = _time.perf_counter()
+                timings[name] = timings.get(name, 0.0) + (now - t_last[0]) * 1e3
+                t_last[0] = now
         if ds.full_losses and not _PLAIN_FULL_FAST:
             raise NotImplementedError("GraphedStep needs the fused plain full-loss step (RDG_PLAIN_FULL_FAST=1)")
         self.ds, self.perm = ds, list(perm)
         dev = ds.device
         W = _lib.STEP_SCALARS_FLOATS
         self.scal = torch.zeros(W, dtype=torch.float32, device=dev)                    # RdgStepScalars
-        self.ring = torch.zeros(self.RING, W, dtype=torch.float32).pin_memory()
+        ring = GraphedStep._RING_CACHE.pop(str(dev), None)
+        self.ring = ring if ring is not None else torch.zeros(self.RING, W, dtype=torch.float32).pin_memory()
         self.ring_i32 = self.ring.view(torch.int32)
         self.emb_in = torch.empty_like(ds.emb_rows[0])
         self.gt_in = torch.empty_like(ds.gt[self.perm[0]])
@@ -580,16 +599,18 @@ class GraphedStep:
             step += 1
         self.next_step = step
         torch.cuda.synchronize(dev)
+        mark("setup_and_eager_warmup")
         counts = (ds.fp.step_count, ds.sp.step_count)
         self.graph = torch.cuda.CUDAGraph()
         st.graph_capture = True
         try:
             self._stage(step)
             torch.cuda.synchronize(dev)
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, pool=pool):
                 self.loss = ds.train_step(step, 0, 1, self.perm)       # recorded, not executed
         finally:
             st.graph_capture = False
+        mark("capture_and_instantiate")
         ds.fp.step_count, ds.sp.step_count = counts                    # capture advanced the host counters only
         self._nren, self._key, self._cap = st.last_nren
         st.nren_max.zero_()
@@ -681,7 +702,14 @@ class GraphedStep:
                 f"hint is now {n})")
         return n
 
+    def pool(self):
+        """The memory pool this graph's capture allocated from (hand it to the next GraphedStep of the scene)."""
+        return self.graph.pool()
+
     def close(self) -> None:
+        # wait for the staging copies still reading the ring, then leave it to the next graph
+        torch.cuda.current_stream(self.ds.device).synchronize()
+        GraphedStep._RING_CACHE[str(self.ds.device)] = self.ring
         self.ds._graph_inputs = None
         self.ds.raster_state.nren_max = None
         self.ds.raster_state.nren_max_key = None

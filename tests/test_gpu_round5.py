@@ -248,3 +248,17 @@ def test_radix_binning_with_a_production_sized_workspace_is_bit_exact():
         assert hs["D"] == ref["num_rendered"] < 5000000
         assert np.array_equal(hs["keys_sorted"], ref["keys_sorted"]) and np.array_equal(hs["vals_sorted"], ref["vals_sorted"])
         assert np.array_equal(hs["ranges"], ref["ranges"]), bin_mode
+
+
+def test_morton_codes_kernel_equals_the_framework_expression():
+    """rdg_morton_codes (one launch inside every densification) against layout.morton_codes' float64 torch expression on the
+    host: the same codes, so the row order of a cloud does not depend on where it was computed."""
+    from rodygs_amd.layout import morton_codes, morton_order
+    g = torch.Generator().manual_seed(4)
+    for n in (1, 7, 100003):
+        x = torch.randn(n, 3, generator=g) * torch.tensor([3.0, 0.2, 40.0]) + torch.tensor([1.0, -5.0, 11.0])
+        if n > 7:
+            x[::13] = x[0]                                  # equal cells: the order must stay stable
+        for bits in (10, 16, 21):
+            assert torch.equal(morton_codes(x.to(DEV), bits).cpu(), morton_codes(x, bits)), (n, bits)
+        assert torch.equal(morton_order(x.to(DEV)).cpu(), morton_order(x))
