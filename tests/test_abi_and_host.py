@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
         assert hasattr(raw, n), f"{n} declared in include/rodygs_hip.h but not exported"
     # and the ctypes binding table covers the whole header
     assert set(names) == set(_lib.EXPORTED_SYMBOLS)
-    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 5
+    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_workspace_sizes(hip_lib):
