@@ -123,7 +123,9 @@ def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=Fa
         28 B/float leave the Adam launch; the kernel no longer writes dL/dshs (-12K B) and instead reads and writes the
         parameter and both moments (24 B/float) of those 3K floats;
       * densification statistics: the per-Gaussian backward reads and writes max_radii2D, xyz_gradient_accum and denom of
-        every visible Gaussian (24 B)."""
+        every visible Gaussian (24 B);
+      * deformation: priced as the fused getter that runs (deformation + activations), 160 B forward / 256 B backward per
+        Gaussian (round 5; VERDICT r03 / r04: the survey's 96 B understated what the stage has to move)."""
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     n_tile_pass = (max(tiles - 1, 1).bit_length() + 7) // 8      # 8-bit passes over the tile-id bits (two at 1080p and 4K)
     n_adam = 59 + 16                                    # floats per Gaussian: 11 geometry + 3K SH (K=16) + 16 coeff
@@ -137,7 +139,12 @@ def stage_bytes(P, K, V, D, H, W, world=1, sharded=False, sh_adam_in_backward=Fa
         "render_fwd": D * 44 + H * W * 40,
         "render_bwd": D * 44 + H * W * 40 + V * 40,
         "preprocess_bwd": P * (44 + 12 * K) * 2 + V * 48,
-        "deform_fwd": P * 96, "deform_bwd": P * 96,
+        # the fused getter (deformation + activations in one kernel each way, what the step runs): forward reads xyz 12 +
+        # scaling 12 + rotation 16 + opacity 4 + coefficients 64 + birth index 8 and writes the four activated tensors (44);
+        # backward reads their gradients (44), scaling / rotation / opacity (32), the birth index (8) and the coefficients
+        # (64, for the basis gradient) and writes five parameter gradients (12 + 12 + 16 + 4 + 64).  (SURVEY 8d's 96 B each
+        # way is the bare deformation without the activations; the birth-sorted copy the reduction reads is overhead.)
+        "deform_fwd": P * 160, "deform_bwd": P * 256,
         "adam": 28 * n_adam * own,
     }
     if sh_adam_in_backward:
