@@ -714,3 +714,149 @@ class GraphedStep:
         self.ds.raster_state.nren_max = None
         self.ds.raster_state.nren_max_key = None
         self.ds.fp.__dict__.pop("_adam_graph_layout", None)
+
+
+class ReferenceIteration:
+    """The iteration a RoDyGS user runs (``RoDyGSTrainer.train``, /root/reference/src/trainer/rodygs.py:157-179): a STATIC
+    sub-step, then a DYNAMIC sub-step, each of them ``train_iteration`` (:198-369) on the CONCATENATED cloud --
+
+        MLP basis -> deformation of the dynamic Gaussians -> getters of both clouds written into the two row segments of one
+        set of rasterizer inputs (``gs_properties``: the reference's five ``torch.cat`` copies are not made) -> rasterize
+        (static ‖ dynamic) -> 0.8 L1 + 0.2 D-SSIM -> backward through BOTH clouds -> densification statistics of the
+        sub-step's own slice (rows [0, Ps) / [Ps, Ps + Pd)) -> Adam step and zero_grad of the sub-step's OWN trainer only.
+
+    **Stale-gradient semantics, kept** (SURVEY.md section 3.1): a sub-step's backward deposits gradients in the other cloud's
+    parameters too, and only the cloud that steps clears its gradients afterwards -- so the dynamic step applies
+    (gradient of the static sub-step's frame) + (gradient of its own frame), and the next static step the same with the roles
+    swapped.  Here every parameter's ``.grad`` is a view of its flat bucket's gradient buffer and autograd ACCUMULATES into it
+    (no overwriting sinks on this path); ``fp.zero_grad()`` after a trainer's Adam launch is its ``zero_grad(set_to_none)``.
+    The static trainer owns the camera poses (``is_optimizable_cam``: pose gradients through the rasterizer's view matrix in the
+    static sub-step only; the dynamic sub-step renders with the refined poses, gates off -- rodygs.py:170-178, 268-269).
+    bench.py --iteration reference times it; it is not a trainer (no data module, schedules or densification calls)."""
+
+    def __init__(self, static_scene: dict, dynamic_scene: dict, num_frames: int = 100, sh_degree: int = 3, device="cuda",
+                 seed: int = 777, spatial_lr_scale: float = 5.0, orbit_deg: float = 15.0, spatial_order: bool = True):
+        from .densify import DensifyStats
+        from .layout import morton_order
+        dev = torch.device(device)
+        g = torch.Generator().manual_seed(seed + 1)
+        self.device, self.T, self.sh_degree, self.spatial_lr_scale = dev, num_frames, sh_degree, spatial_lr_scale
+        self.W, self.H = dynamic_scene["W"], dynamic_scene["H"]
+        self.tanfovx, self.tanfovy = dynamic_scene["tanfovx"], dynamic_scene["tanfovy"]
+        self.proj_t = dynamic_scene["projmatrix"].to(dev).contiguous()
+        self.bg = torch.zeros(3, device=dev)
+
+        def bucket(sc, dynamic):
+            if spatial_order:
+                perm = morton_order(sc["means3D"])
+                sc = {k: (v[perm].contiguous() if k in ("means3D", "shs", "scales", "rotations", "opacities") else v)
+                      for k, v in sc.items()}
+            P, K = sc["means3D"].shape[0], sc["shs"].shape[1]
+            spec = {"xyz": ((P, 3), 0.00016 * spatial_lr_scale), "f_dc": ((P, 1, 3), 0.0025),
+                    "f_rest": ((P, K - 1, 3), 0.0025 / 20.0), "scaling": ((P, 3), 0.001), "rotation": ((P, 4), 0.001),
+                    "opacity": ((P, 1), 0.05)}
+            if dynamic:
+                spec["motion_coeff"] = ((P, 1, 16), 0.00016)
+            fp = FlatParams(spec, dev)
+            with torch.no_grad():
+                fp["xyz"].copy_(sc["means3D"])
+                fp["f_dc"].copy_(sc["shs"][:, :1])
+                fp["f_rest"].copy_(sc["shs"][:, 1:])
+                fp["scaling"].copy_(torch.log(sc["scales"]))
+                fp["rotation"].copy_(sc["rotations"])
+                op = sc["opacities"].clamp(1e-4, 1 - 1e-4)
+                fp["opacity"].copy_(torch.log(op / (1 - op)))
+                if dynamic:
+                    fp["motion_coeff"].copy_(0.1 * torch.randn(P, 1, 16, generator=g))
+            return fp
+
+        self.fp_s, self.fp_d = bucket(static_scene, False), bucket(dynamic_scene, True)
+        self.Ps, self.Pd = self.fp_s.shapes["xyz"][0], self.fp_d.shapes["xyz"][0]
+        self.time_ind = torch.randint(0, num_frames, (self.Pd,), generator=g).to(dev)
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed + 2)
+            self.net = MLPBasisNetwork(128, 16, 26, False)
+        self.net = self.net.to(dev)
+        emb = self.net.batch_embedding((torch.arange(num_frames, dtype=torch.float32) / num_frames).to(dev))
+        self.emb_rows = torch.cat([emb.unsqueeze(0).expand(num_frames, -1, -1), emb.unsqueeze(1)], dim=1).contiguous()
+        self.sp_mlp = bind_module_to_flat(self.net, 0.0016, dev)          # the dynamic trainer's deform_network group
+        self.net.grad_sinks = None                                         # gradients ACCUMULATE here (stale-gradient semantics)
+        cz = 11.0
+        qs, ts = [], []
+        for i in range(num_frames):
+            a = math.radians(orbit_deg) * math.sin(2 * math.pi * i / num_frames)
+            qs.append(torch.tensor([math.cos(a / 2), 0.0, math.sin(a / 2), 0.0]))
+            ts.append(torch.tensor([-cz * math.sin(a), 0.0, cz - cz * math.cos(a)]))
+        self.sp_cam = FlatParams({"cam_q": ((num_frames, 4), 1e-5), "cam_t": ((num_frames, 3), 1e-6)}, dev)
+        with torch.no_grad():
+            self.sp_cam["cam_q"].copy_(torch.stack(qs))
+            self.sp_cam["cam_t"].copy_(torch.stack(ts))
+        self.m2 = torch.zeros(self.Ps + self.Pd, 3, device=dev, requires_grad=True)
+        self.stats = {"static": DensifyStats.zeros(self.Ps, dev), "dynamic": DensifyStats.zeros(self.Pd, dev)}
+        self.raster_state = RasterState()
+        self.gt = {}
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
+
+    def settings(self, pose_grads: bool) -> GaussianRasterizationSettings:
+        return GaussianRasterizationSettings(self.H, self.W, self.tanfovx, self.tanfovy, self.bg, 1.0, self.proj_t,
+                                             self.sh_degree, False, False, pose_grads, pose_grads)
+
+    def properties(self, frame: int):
+        """get_GS_properties (rodygs.py:68-113) of the frame: (xyz, opacity, scaling, rotation, features) of static ‖ dynamic."""
+        from .model_ops import gs_properties
+        allb = self.net.motion_basis(self.emb_rows[frame])                 # [T + 1, 16, 7]: birth-time table, then B(t)
+        dxyz, drot = gaussian_deformation_packed(self.fp_d["motion_coeff"], self.time_ind, allb, self.spatial_lr_scale)
+        names = ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")
+        return gs_properties({k: self.fp_s[k] for k in names}, {k: self.fp_d[k] for k in names}, dxyz, drot)
+
+    def make_ground_truth(self, target_scene: dict, frames) -> None:
+        dev = self.device
+        with torch.no_grad():
+            for f in frames:
+                vm = pose_view_matrix(self.sp_cam["cam_q"], self.sp_cam["cam_t"], int(f))
+                out = GaussianRasterizer(self.settings(False), state=self.raster_state)(
+                    means3D=target_scene["means3D"].to(dev), means2D=torch.zeros_like(target_scene["means3D"]).to(dev),
+                    shs=target_scene["shs"].to(dev), opacities=target_scene["opacities"].to(dev),
+                    scales=target_scene["scales"].to(dev), rotations=target_scene["rotations"].to(dev), viewmatrix=vm)
+                self.gt[int(f)] = out[0].clamp(0, 1).clone()
+
+    def forward_backward(self, frame: int, which: str) -> torch.Tensor:
+        """Everything of ``train_iteration`` (rodygs.py:198-341) up to the optimiser: render the concatenated cloud, loss,
+        backward (gradients ACCUMULATE in both clouds' buckets), statistics of the sub-step's own slice."""
+        static = which == "static"
+        xyz, opacity, scaling, rot, feats = self.properties(frame)
+        vm = pose_view_matrix(self.sp_cam["cam_q"], self.sp_cam["cam_t"], frame)
+        if not static:
+            vm = vm.detach()
+        self.m2.grad = None
+        row0, stats = (0, self.stats["static"]) if static else (self.Ps, self.stats["dynamic"])
+        out = GaussianRasterizer(self.settings(static), state=self.raster_state)(
+            means3D=xyz, means2D=self.m2, shs=feats, opacities=opacity, scales=scaling, rotations=rot, viewmatrix=vm,
+            grad_sinks={"densify": stats.sink(row0)})
+        loss = fused_photometric_loss(out[0], self.gt[frame], 0.2)
+        loss.backward(self._one)
+        return loss.detach()
+
+    def step(self, which: str) -> None:
+        """``current_gs.optimizer.step(); zero_grad()`` (+ the camera optimiser for the static trainer, rodygs.py:364-369): the
+        other trainer's gradients stay where they are."""
+        if which == "static":
+            fused_adam_(self.fp_s, extra=(self.sp_cam,))
+            self.fp_s.zero_grad()
+            self.sp_cam.zero_grad()
+        else:
+            fused_adam_(self.fp_d, extra=(self.sp_mlp,))
+            self.fp_d.zero_grad()
+            self.sp_mlp.zero_grad()
+
+    def sub_step(self, frame: int, which: str) -> torch.Tensor:
+        """One ``train_iteration`` (rodygs.py:198-369) with ``learn_static`` (which == "static") or ``learn_dynamic``."""
+        loss = self.forward_backward(frame, which)
+        self.step(which)
+        return loss
+
+    def iteration(self, it: int, perm) -> tuple:
+        """Static sub-step, then dynamic sub-step (each draws its own frame, as the two data loaders of the reference do)."""
+        fs = perm[(2 * it) % len(perm)]
+        fd = perm[(2 * it + 1) % len(perm)]
+        return self.sub_step(fs, "static"), self.sub_step(fd, "dynamic")

@@ -262,3 +262,90 @@ def test_morton_codes_kernel_equals_the_framework_expression():
         for bits in (10, 16, 21):
             assert torch.equal(morton_codes(x.to(DEV), bits).cpu(), morton_codes(x, bits)), (n, bits)
         assert torch.equal(morton_order(x.to(DEV)).cpu(), morton_order(x))
+
+
+def test_reference_iteration_keeps_the_stale_gradient_semantics():
+    """trainstep.ReferenceIteration -- static sub-step, then dynamic sub-step, each on the concatenated cloud
+    (/root/reference/src/trainer/rodygs.py:157-179, 198-369) -- against the reference's own flow written with framework ops:
+    torch.cat of the two clouds' getters (rodygs.py:68-113), the deformation as `coeff @ (B(t) - table[birth])`, the pose as
+    FixedCameraTorch.world_view_transform, the same rasterizer and loss, gradients accumulating in plain leaf tensors.  After
+    the static sub-step both clouds carry its gradient; the static trainer steps and clears ITS gradients only; after the
+    dynamic sub-step the dynamic cloud (and the MLP, and the coefficients) carry the SUM of both frames' gradients, the
+    static cloud the second frame's alone.  Densification statistics: each sub-step updates its own slice."""
+    import copy
+    import torch.nn.functional as F
+    from rodygs_amd import GaussianRasterizer
+    from rodygs_amd.losses import photometric_loss
+    from rodygs_amd.trainstep import ReferenceIteration, world_view_transform
+    W, H, T = 208, 144, 6
+    ri = ReferenceIteration(O.synthetic_scene(3000, W, H, 3, seed=3), O.synthetic_scene(4000, W, H, 3, seed=4), num_frames=T,
+                            device=DEV, spatial_order=True)
+    ri.make_ground_truth(O.synthetic_scene(2000, W, H, 3, seed=5), range(T))
+    names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")
+    leaf = lambda t: t.detach().clone().requires_grad_(True)                                   # noqa: E731
+    s = {k: leaf(ri.fp_s[k]) for k in names}
+    d = {k: leaf(ri.fp_d[k]) for k in names + ("motion_coeff",)}
+    cam = {k: leaf(ri.sp_cam[k]) for k in ("cam_q", "cam_t")}
+    net = copy.deepcopy(ri.net)
+    for p_ in net.parameters():
+        p_.grad = None
+
+    def flow(frame, static):
+        allb = net.motion_basis(ri.emb_rows[frame])
+        table, bt = allb[:-1], allb[-1]
+        delta = (d["motion_coeff"].reshape(-1, 1, 16) @ (bt.unsqueeze(0) - table[ri.time_ind])).squeeze(1)
+        dxyz, drot = delta[:, :3] * ri.spatial_lr_scale, delta[:, 3:]
+        xyz = torch.cat([s["xyz"], d["xyz"] + dxyz])
+        opacity = torch.cat([torch.sigmoid(s["opacity"]), torch.sigmoid(d["opacity"])])
+        scaling = torch.cat([torch.exp(s["scaling"]), torch.exp(d["scaling"])])
+        rot = torch.cat([F.normalize(s["rotation"]), F.normalize(d["rotation"]) + drot])
+        feats = torch.cat([torch.cat([s["f_dc"], s["f_rest"]], 1), torch.cat([d["f_dc"], d["f_rest"]], 1)])
+        vm = world_view_transform(cam["cam_q"][frame], cam["cam_t"][frame]).t().contiguous()
+        if not static:
+            vm = vm.detach()
+        m2 = torch.zeros(xyz.shape[0], 3, device=DEV, requires_grad=True)
+        out = GaussianRasterizer(ri.settings(static))(means3D=xyz, means2D=m2, shs=feats, opacities=opacity, scales=scaling,
+                                                      rotations=rot, viewmatrix=vm)
+        photometric_loss(out[0], ri.gt[frame], 0.2).backward()
+
+    def compare(tag):
+        for k in names:
+            rel_ok(ri.fp_s[k].grad, s[k].grad, tol=2e-4, outliers=1e-4, cap=5e-3, what=f"{tag} static d_{k}")
+        for k in names + ("motion_coeff",):
+            rel_ok(ri.fp_d[k].grad, d[k].grad, tol=2e-4, outliers=1e-4, cap=5e-3, what=f"{tag} dynamic d_{k}")
+        for (n1, p1), (n2, p2) in zip(ri.net.named_parameters(), net.named_parameters()):
+            rel_ok(p1.grad, p2.grad, tol=5e-4, what=f"{tag} MLP d_{n1}")
+        for k in ("cam_q", "cam_t"):
+            g2 = cam[k].grad if cam[k].grad is not None else torch.zeros_like(cam[k])
+            rel_ok(ri.sp_cam[k].grad, g2, tol=5e-4, what=f"{tag} d_{k}")
+
+    ri.forward_backward(1, "static")
+    flow(1, True)
+    assert float(ri.fp_d["xyz"].grad.abs().sum()) > 0 and float(ri.sp_cam["cam_q"].grad[1].abs().sum()) > 0
+    compare("after the static sub-step:")
+    assert float(ri.stats["static"].denom.sum()) > 0 and float(ri.stats["dynamic"].denom.sum()) == 0
+    stale = ri.fp_d["xyz"].grad.clone()
+    ri.step("static")
+    assert float(ri.fp_s.flat_grad.abs().sum()) == 0 and torch.equal(ri.fp_d["xyz"].grad, stale)   # the dynamic gradients stay
+    with torch.no_grad():                                        # the flow's static trainer: same step, own gradients cleared
+        for k in names:
+            s[k].copy_(ri.fp_s[k])
+            s[k].grad = None
+        for k in cam:
+            cam[k].copy_(ri.sp_cam[k])
+            cam[k].grad = None
+    ri.forward_backward(4, "dynamic")
+    flow(4, False)
+    for k in names:
+        s[k].grad = s[k].grad if s[k].grad is not None else torch.zeros_like(s[k])
+    compare("after the dynamic sub-step (stale + fresh):")
+    assert float((ri.fp_d["xyz"].grad - stale).abs().sum()) > 0 and float(ri.sp_cam["cam_q"].grad.abs().sum()) == 0
+    assert float(ri.stats["dynamic"].denom.sum()) > 0
+    before = ri.fp_d["xyz"].detach().clone()
+    ri.step("dynamic")
+    assert float(ri.fp_d.flat_grad.abs().sum()) == 0 and float(ri.fp_s["xyz"].grad.abs().sum()) > 0    # now the static ones stay
+    assert not torch.equal(before, ri.fp_d["xyz"].detach())
+    l0 = [float(x) for x in ri.iteration(0, list(range(T)))]
+    for it in range(1, 12):
+        l1 = [float(x) for x in ri.iteration(it, list(range(T)))]
+    assert all(np.isfinite(l0 + l1))
