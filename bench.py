@@ -664,6 +664,58 @@ def run_loop(args, dev, scene, target):
                      "densify_ms_mean": (sum(d_["ms"] for d_ in densifies) / len(densifies)) if densifies else None}}
 
 
+def run_reference_iteration(args, dev):
+    """--iteration reference: the iteration a RoDyGS user runs (/root/reference/src/trainer/rodygs.py:157-179) -- a static
+    sub-step and a dynamic sub-step, each rendering the CONCATENATED cloud (static ‖ dynamic + deformation), with the
+    reference's stale-gradient semantics (trainstep.ReferenceIteration) -- next to the per-step headline, which BASELINE quotes
+    on the dynamic cloud alone.  --points Gaussians are split evenly between the two clouds, so every sub-step renders --points
+    Gaussians.  value = iterations / s (one iteration = two optimiser steps, two renders)."""
+    import gc
+    from rodygs_amd.synthetic import synthetic_scene
+    from rodygs_amd.trainstep import ReferenceIteration
+    P, W, H = args.points, args.width, args.height
+    ps = P // 2
+    ri = ReferenceIteration(synthetic_scene(ps, W, H, 3, seed=777, variant=args.scene),
+                            synthetic_scene(P - ps, W, H, 3, seed=778, variant=args.scene), num_frames=args.frames, device=dev)
+    n_gt = min(args.gt_frames, args.frames)
+    perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
+    perm = [perm[j] for j in _spread_order(len(perm))]
+    ri.make_ground_truth(synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234, variant=args.scene), perm)
+    it = 0
+    for _ in range(args.warmup):
+        ri.iteration(it, perm)
+        it += 1
+    ri.raster_state.deferred_overflow_check = True
+    gc.collect()
+    gc.freeze()
+    for _ in range(args.settle // 2):
+        ri.iteration(it, perm)
+        it += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = ri.iteration(it, perm)
+        it += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ri.raster_state.poll_overflow(block=True)
+    ri.raster_state.deferred_overflow_check = None
+    gc.unfreeze()
+    return {"metric": f"reference-iteration rate at {ps} static + {P - ps} dynamic Gaussians / {W}x{H} (static sub-step + dynamic "
+                      f"sub-step, each fwd+bwd over the concatenated cloud + its own Adam)",
+            "value": args.steps / dt, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{ps} static + {P - ps} dynamic Gaussians + deformation MLP, {W}x{H}, SH3, {args.frames}-frame "
+                                   f"synthetic video: the reference's iteration (not a BASELINE config: its metric is per step on "
+                                   f"the dynamic cloud)", "points": P, "width": W, "height": H, "scene": args.scene,
+                       "sub_steps_per_iteration": 2, "gaussians_rendered_per_sub_step": P,
+                       "stale_gradient_semantics": "kept (a sub-step's backward accumulates in both clouds; only its own "
+                                                   "trainer steps and clears)", "densify_stats": True,
+                       "deferred_overflow_check": True},
+            "ms_per_sub_step": dt / args.steps * 1e3 / 2, "losses": [float(v) for v in loss]}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks the way the driver's torchrun command does
     (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`)
@@ -734,6 +786,9 @@ def main():
     ap.add_argument("--loop-profile", nargs="?", const="sync", default=None, choices=["sync", "host"],
                     help="--loop: per-phase times of every densification; 'sync' (default) synchronises the device at every "
                          "phase boundary, 'host' records host time only (where the host blocks)")
+    ap.add_argument("--iteration", choices=["step", "reference"], default="step",
+                    help="'reference': time the reference's ITERATION -- static sub-step + dynamic sub-step over the "
+                         "two-segment cloud with its stale-gradient semantics (run_reference_iteration) -- instead of the step")
     ap.add_argument("--dp-mode", choices=["both", "allreduce", "shard"], default=os.environ.get("RDG_DP_MODE", "both"),
                     help="N > 1 formulation: 'allreduce' = BASELINE north_star: replicated cloud, frames over the GPUs, "
                          "RCCL all-reduce of the Gaussian / pose gradients (bucketed, overlapped with backward and Adam); "
@@ -778,6 +833,11 @@ def main():
     P, W, H = args.points, args.width, args.height
     scene = synthetic_scene(P, W, H, 3, seed=777, variant=args.scene)
     target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234, variant=args.scene)
+    if args.iteration == "reference":
+        if world != 1:
+            raise SystemExit("--iteration reference is a single-GPU measurement")
+        print(json.dumps(run_reference_iteration(args, dev)))
+        return
     if args.loop > 0:
         if world != 1:
             raise SystemExit("--loop is a single-GPU measurement")
