@@ -805,6 +805,7 @@ class ReferenceIteration:
         """get_GS_properties (rodygs.py:68-113) of the frame: (xyz, opacity, scaling, rotation, features) of static ‖ dynamic."""
         from .model_ops import gs_properties
         allb = self.net.motion_basis(self.emb_rows[frame])                 # [T + 1, 16, 7]: birth-time table, then B(t)
+        self._last_allb = allb                                             # (tests look at its gradient)
         dxyz, drot = gaussian_deformation_packed(self.fp_d["motion_coeff"], self.time_ind, allb, self.spatial_lr_scale)
         names = ("xyz", "scaling", "rotation", "opacity", "f_dc", "f_rest")
         return gs_properties({k: self.fp_s[k] for k in names}, {k: self.fp_d[k] for k in names}, dxyz, drot)
