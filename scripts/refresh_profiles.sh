@@ -7,18 +7,30 @@ set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=$PWD
-T=${1:-r04}
+T=${1:-r05}
 O=$R/gpurun_out/prof_$T
 mkdir -p $O
-python3 bench.py > $O/${T}_bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${T}_bench_under_rocprof.json 2> $O/kt.err
-cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${T}_bench_kernel_stats.csv
-python3 scripts/trace_one_step.py $O/kt > $O/${T}_one_step.txt 2>&1
+# the PMC passes first: bench.py reads profiles/${T}_pmc_*.json (stamped with the hash of the kernel sources) for `roofline.traffic`
+# and the VALU-issue figures, so they have to exist (in the box's copy of profiles/) before the headline line is printed
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
 python3 scripts/pmc_hbm_traffic.py $O/pmc_fetch $O/pmc_write $O/${T}_pmc_hbm_traffic.json 1000000 1920 1080 > $O/pmc_traffic.txt 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pmc_sq.err
 python3 scripts/pmc_summary.py $O/pmc_sq $O/${T}_pmc_sq_counters.json 1000000 1920 1080 > /dev/null 2>&1
+cp $O/${T}_pmc_hbm_traffic.json $O/${T}_pmc_sq_counters.json $R/profiles/ 2>/dev/null
+python3 bench.py > $O/${T}_bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${T}_bench_under_rocprof.json 2> $O/kt.err
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${T}_bench_kernel_stats.csv
+python3 scripts/trace_one_step.py $O/kt > $O/${T}_one_step.txt 2>&1
+# the train LOOP (densify_and_prune every 100 steps), eager / per-phase profile / graph re-captured per densification, and the
+# reference's iteration (static + dynamic sub-steps over the two-segment cloud)
+python3 bench.py --loop 600 > $O/${T}_loop_bench.json 2>/dev/null
+python3 bench.py --loop 600 --loop-profile > $O/${T}_loop_profile.json 2>/dev/null
+python3 bench.py --loop 600 --graph > $O/${T}_loop_graph_bench.json 2>/dev/null
+python3 bench.py --loop 600 --points 100000 > $O/${T}_loop_100k_bench.json 2>/dev/null
+python3 bench.py --loop 600 --points 100000 --graph > $O/${T}_loop_100k_graph_bench.json 2>/dev/null
+python3 bench.py --iteration reference > $O/${T}_reference_iteration_bench.json 2>/dev/null
+python3 bench.py --iteration reference --points 200000 > $O/${T}_reference_iteration_200k_bench.json 2>/dev/null
 # the two scenes the survey's generator never enters (not the headline): bench line + kernel table each
 for SC in sheets dense; do
   python3 bench.py --scene $SC --no-cpu-baseline > $O/${T}_scene_${SC}_bench.json 2>/dev/null
