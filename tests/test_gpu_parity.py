@@ -890,7 +890,14 @@ def _full_frame_pair(P, W, H, seed=5):
     from rodygs_amd import rasterizer
     sc = O.synthetic_scene(P, W, H, 3, seed=777)
     sc["viewmatrix"] = orbit_view(4.0, -2.0, (0.3, -0.2, 0.5))
-    hi, hm2, hout, oi, om2, oout = run_pair(sc, 3, [0.2, 0.1, 0.3], seed=seed)
+    # the oracle's tensors are a few hundred KB each: beyond ~16 threads torch's intra-op fork / join costs more than it buys
+    # (bench.py's CPU leg: 1 M / 1080p in 15 s on 16 threads of the 256-core box, 100 s on all of them)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))
+    try:
+        hi, hm2, hout, oi, om2, oout = run_pair(sc, 3, [0.2, 0.1, 0.3], seed=seed)
+    finally:
+        torch.set_num_threads(threads)
     aux = oout[5]
     fT, nc = hout[6]
     hip = {"images": {"color": hout[0], "depth": hout[1], "normal": hout[2], "alpha": hout[3]}, "final_T": fT, "n_contrib": nc,
@@ -903,7 +910,8 @@ def _full_frame_pair(P, W, H, seed=5):
 
 
 @pytest.mark.parametrize("P,W,H", [(100000, 1920, 1080),        # BASELINE configs[1]: "bit/tol parity" at 100 k / 1080p / SH 3
-                                   (1000000, 1920, 1080)])      # configs[2..3]: the frame the headline is quoted on
+                                   (1000000, 1920, 1080),       # configs[2..3]: the frame the headline is quoted on
+                                   (4000000, 3840, 2160)])      # configs[4]: the largest size, all 32 400 tiles
 def test_full_frame_parity(P, W, H):
     """EVERY tile of the frame: the oracle composites all 8 160 tiles forward and backward (seconds on the host), the loss
     is unrestricted, and every pixel of colour / depth / normal / alpha / final_T, n_contrib, radii, D and every entry of every
