@@ -635,6 +635,10 @@ rdg_tile_sort_lanes_kernel(int n_tiles, const uint2* __restrict__ ranges, uint64
                            const uint2* __restrict__ hv_work) {
     if ((long long)(*num_rendered) > capacity) return;
     __shared__ uint64_t sA[4][RDG_TSORT_SMALL];
+#ifdef RDG_ABL_SORT_PAD       // ablation (timing only; profiles/r05_experiments.txt 3): 32 KB more LDS per workgroup (5 -> 2 per CU)
+    __shared__ uint32_t sPad[8192];
+    if (num_rendered[0] == -12345) sPad[threadIdx.x] = 1u, vals_out[0] = sPad[(threadIdx.x * 7) & 8191];
+#endif
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint64_t* a = sA[wv];
     const int tile = blockIdx.x * 4 + (int)wv;
