@@ -553,3 +553,28 @@ def test_mode_switches_ride_on_the_raster_state():
         assert a.bin_hint and not c.bin_hint
     finally:
         R.DETERMINISTIC, R._FORCE_RADIX, R.DEFERRED_OVERFLOW_CHECK, R.RENDER_NORMAL = keep
+
+
+def test_flat_params_laid_out_in_given_storage():
+    """FlatParams(storage=): the segments are views of caller-owned buffers (what densify.FlatPool hands out), the gradient
+    buffer and the alignment padding are cleared, the layout equals the allocating constructor's; too small a storage raises."""
+    from rodygs_amd.dp import FlatParams, FlatStorage, flat_numel
+    spec = {"xyz": ((37, 3), 1e-3), "features": ((37, 16, 3), 2e-3), "opacity": ((37, 1), 5e-2)}
+    n = flat_numel(spec)
+    ref = FlatParams(spec, "cpu")
+    assert n == ref.numel and n % 64 == 0
+    st = FlatStorage(n + 1000, "cpu")
+    for b in st.buffers:
+        b.fill_(7.0)
+    fp = FlatParams(spec, "cpu", storage=st)
+    assert fp.offsets == ref.offsets and fp.numel == n and fp.storage is st
+    assert fp.flat.data_ptr() == st.buffers[0].data_ptr() and fp["xyz"].grad.data_ptr() == st.buffers[1].data_ptr()
+    assert float(fp.flat_grad.abs().sum()) == 0.0
+    o, m = fp.offsets["xyz"]
+    assert float(fp.flat[o:o + m].min()) == 7.0                     # the rows themselves are the caller's business ...
+    assert float(fp.flat[o + m:fp.offsets["features"][0]].abs().sum()) == 0.0      # ... the padding behind them is cleared
+    assert float(fp.exp_avg[o + m:fp.offsets["features"][0]].abs().sum()) == 0.0
+    assert float(st.buffers[0][n:].min()) == 7.0                    # nothing beyond the layout is touched
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        FlatParams(spec, "cpu", storage=FlatStorage(n - 1, "cpu"))
