@@ -51,7 +51,7 @@ for c in range(first, first + n_cases):
         else:
             # only a miss of the 1e-4 bar (an image, a gradient) can be a matter of float32 resolution; anything that must be exact
             # (radii, contributor counts beyond the allowance, the per-pixel state) is a failure whatever the float64 oracle says
-            exact = res is None or not str(e).startswith(("d_", "color", "depth", "normal", "alpha"))
+            exact = res is None or not str(e).startswith(("d_", "color", "depth", "normal", "alpha", "final_T"))
             verdict, txt = ("fail", "") if exact else resolution.classify(sc, deg, bg, kw, res)
             what = {"f64": "outside the bar against the float32 oracle, inside it against the oracle run in float64:",
                     "geom": "inside the bar against the float64 oracle evaluated at the float32 geometry (the bit-exact per-Gaussian "
@@ -61,7 +61,7 @@ for c in range(first, first + n_cases):
                     "f32s": "a scene no float32 evaluation resolves: outside the bar against the float64 oracle, within "
                             f"{resolution.F32_FACTOR:g}x the float32 oracle's LARGEST distance over the scene's gradient columns:",
                     "cond": "a column float32 INPUTS do not determine: the float64 oracle's own gradient moves by more than HIP's "
-                            "distance when the inputs are perturbed by 2^-22:"}
+                            "distance when the inputs are perturbed by 2^-21 (four ulps):"}
             if verdict == "fail":
                 bad += 1
                 print("FAIL", tag, "\n     ", str(e)[:400], "\n     ", txt)
