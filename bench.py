@@ -361,6 +361,8 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
     densify_stats = not args.no_densify_stats
     if densify_stats:
         ds.track_densification()
+    if args.no_normal:
+        ds.raster_state.render_normal = False
     n_gt = min(args.gt_frames * world, args.frames)
     perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
     # Visit order: the reference draws its frames from a random permutation of the video (src/data/dataloader.py:28-71).  Its
@@ -491,7 +493,7 @@ def run_mode(args, mode, rank, world, dev, backend, scene, target):
            "graph": graphed is not None, "densify_stats": densify_stats, "deferred": deferred_in_timed_region,
            # the binning algorithm the timed steps ran: forced by RDG_BIN_MODE, or what the per-frame rule has picked
            "radix": bool(rstate.mode("force_radix") or any(rstate.bin_hint.values())),
-           "deterministic": rstate.mode("deterministic"),
+           "deterministic": rstate.mode("deterministic"), "render_normal": rstate.mode("render_normal"),
            "points_after_densify": points_after,
            "per_stage": {k: (ms / n if n else 0.0) for k, (ms, n) in stages.items()}}
     if rank == 0:
@@ -762,6 +764,10 @@ def main():
                          "launching its ~50 kernels from Python -- what makes the step kernel-bound at the size of the "
                          "reference's real clouds (~100 k points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-normal", action="store_true",
+                    help="N = 1: the scene's RasterState leaves the normal channels out (render_normal=False): no RoDyGS loss reads "
+                         "rendered_normal (gt_normal is always None), the upstream rasterizer composites it regardless.  A side line, "
+                         "not the headline: config.render_normal says which one a line is")
     ap.add_argument("--densify-first", action="store_true",
                     help="run ONE densify-and-prune (on the statistics of ~24 untimed steps) before the timed region: the "
                          "timed steps then train a cloud that went through the row surgery (not the headline)")
@@ -952,7 +958,7 @@ def main():
                        "densify_stats": best["densify_stats"],
                        # --densify-first: Gaussians after the one densify-and-prune that ran before the timed region
                        "points_after_densify": best["points_after_densify"],
-                       "deterministic_backward": best["deterministic"],
+                       "deterministic_backward": best["deterministic"], "render_normal": best["render_normal"],
                        "parallelism": parallelism, "num_rendered_D": D, "visible_V": V,
                        "losses": "full (config 5 set)" if args.full_losses else "photometric",
                        # single-GPU photometric step: the per-Gaussian backward kernel applies the Adam update of the SH
