@@ -113,7 +113,18 @@ typedef struct RdgRasterSettings {
                               * num_rendered (a captured hipGraph replays the forward many times into one num_rendered_dev;
                               * a frame in the middle that outgrew the capacity was rendered empty and would go unnoticed).
                               * The caller zeroes it, reads it when it likes and compares with the capacity.  NULL: off. */
+    void* aux_stream;        /* backward calls only, optional (a hipStream_t): the two small launches that finish the pose
+                              * gradient (per-workgroup rows -> dL_dviewmatrix) go to THIS stream, behind an event recorded on
+                              * `stream` after the per-Gaussian kernel, instead of onto `stream` itself.  The caller joins the
+                              * streams before it reads dL_dviewmatrix (and keeps grad_ws / dL_dviewmatrix alive until then).
+                              * Meant for a captured hipGraph, where the fork becomes two independent branches (the pose chain
+                              * next to the deformation / MLP backward); in an eagerly launched step the cross-stream waits
+                              * cost more than the 12 us they hide.  NULL: everything on `stream`.                          */
 } RdgRasterSettings;
+
+/* Creates the (thread-local) event RdgRasterSettings.aux_stream forks through, so that the first backward with an aux_stream can
+ * run under a stream capture without creating one there.  Optional: the backward creates it on first use otherwise.          */
+int rdg_pose_fork_prepare(void);
 
 /* stage ids for rdg_stage_time_ms() */
 enum {

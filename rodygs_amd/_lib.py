@@ -27,7 +27,7 @@ class RdgRasterSettings(C.Structure):
         ("grad_rows_zeroed", C.c_int32), ("densify_row0", C.c_int32), ("zero_grad_ws", C.c_void_p),
         ("num_rendered_host", C.c_void_p), ("densify_grad_accum", C.c_void_p), ("densify_denom", C.c_void_p),
         ("densify_max_radii", C.c_void_p), ("densify_rows", C.c_int32), ("reserved1", C.c_int32),
-        ("num_rendered_max", C.c_void_p),
+        ("num_rendered_max", C.c_void_p), ("aux_stream", C.c_void_p),
     ]
 
 
@@ -54,6 +54,7 @@ STAGES = {
 _vp = C.c_void_p
 _SIGS = {
     "rdg_abi_version": (C.c_int, []),
+    "rdg_pose_fork_prepare": (C.c_int, []),
     "rdg_settings_bytes": (C.c_size_t, []),
     "rdg_last_error": (C.c_char_p, []),
     "rdg_geom_bytes": (C.c_size_t, [C.c_int32]),

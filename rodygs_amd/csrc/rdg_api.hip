@@ -102,6 +102,9 @@ void rdg_stage_end(int stage, hipStream_t s) {
     g_open[stage] = nullptr;
 }
 
+void rdg_set_pose_aux(hipStream_t s);       // rdg_preprocess_bwd.hip: RdgRasterSettings.aux_stream of the call in flight
+int rdg_pose_fork_event_ready();
+
 static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     if (!s) return rdg_set_error("settings pointer is NULL");
     if (s->P < 0 || s->image_height <= 0 || s->image_width <= 0) return rdg_set_error("bad sizes");
@@ -177,6 +180,7 @@ __global__ void __launch_bounds__(256) rdg_zero_rows_dev_kernel(uint4* __restric
 extern "C" {
 
 int rdg_abi_version(void) { return RDG_ABI_VERSION; }
+int rdg_pose_fork_prepare(void) { return rdg_pose_fork_event_ready(); }
 size_t rdg_settings_bytes(void) { return sizeof(RdgRasterSettings); }
 const char* rdg_last_error(void) { return g_err; }
 
@@ -336,6 +340,7 @@ int rdg_preprocess_backward(const RdgRasterSettings* s_host, const float* means3
     const size_t grow_bytes = rdg_align_up((size_t)(d.P > 0 ? d.P : 1) * RDG_GROW * 4, 256);
     float* posebuf = (float*)((char*)grad_ws + grow_bytes);
     rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
+    rdg_set_pose_aux((hipStream_t)s_host->aux_stream);
     int rc = rdg_launch_preprocess_bwd(d, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                        viewmatrix, projmatrix, radii, geom_ws, (const float*)grad_ws, posebuf,
                                        dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales,
@@ -376,6 +381,7 @@ static int rdg_pre_bwd_adam(const RdgRasterSettings* s_host, const float* means3
     ad.eps = eps;
     ad.head_len = head_len;
     rdg_stage_begin(RDG_STAGE_PREPROCESS_BWD, st);
+    rdg_set_pose_aux((hipStream_t)s_host->aux_stream);
     int rc = rdg_launch_preprocess_bwd(d, means3D, shs, nullptr, opacities, scales, rotations, nullptr, viewmatrix,
                                        projmatrix, radii, geom_ws, (const float*)grad_ws, posebuf, dL_dmeans3D,
                                        dL_dmeans2D, nullptr, nullptr, dL_dopacities, dL_dscales, dL_drotations, nullptr,

@@ -535,6 +535,20 @@ rdg_pose_finalize_kernel(const float* __restrict__ view, const float* __restrict
     for (int c = 0; c < 16; ++c) dview[c] = g[c];
 }
 
+// RdgRasterSettings.aux_stream of the call in flight on this thread (set by the C-ABI wrapper right before the launch, consumed
+// by it: one shot), and the event the fork goes through (one per thread, created on first use -- rdg_pose_fork_prepare() lets a
+// caller do that outside a stream capture).
+static thread_local hipStream_t g_pose_aux = nullptr;
+static thread_local hipEvent_t g_pose_fork_ev = nullptr;
+void rdg_set_pose_aux(hipStream_t s) { g_pose_aux = s; }
+int rdg_pose_fork_event_ready() {
+    if (!g_pose_fork_ev && hipEventCreateWithFlags(&g_pose_fork_ev, hipEventDisableTiming) != hipSuccess) {
+        g_pose_fork_ev = nullptr;
+        return rdg_set_error("pose fork: hipEventCreate failed");
+    }
+    return 0;
+}
+
 int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float* shs, const float* colors,
                               const float* opac, const float* scales, const float* rots, const float* cov3D,
                               const float* view, const float* proj, const int32_t* radii, const void* geom_ws,
@@ -552,8 +566,18 @@ int rdg_launch_preprocess_bwd(const RdgDev& d, const float* means3D, const float
     // second-level rows live behind the per-workgroup rows (rdg_grad_bytes reserves them)
     float* part = (float*)((char*)posebuf + rdg_align_up((size_t)(nblk > 0 ? nblk : 1) * RDG_POSE_N * 4, 256));
     const int rows = d.P > 0 ? nblk : 0;
-    hipLaunchKernelGGL(rdg_pose_partial_kernel, dim3(RDG_POSE_L2), dim3(256), 0, s, posebuf, rows, part);
-    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(64), 0, s, view, part, RDG_POSE_L2, dview);
+    hipStream_t ps = s;
+    hipStream_t aux = g_pose_aux;
+    g_pose_aux = nullptr;
+    if (aux && aux != s) {
+        // fork: the pose chain behind an event on `s`, on the caller's second stream (a graph branch under capture)
+        if (rdg_pose_fork_event_ready()) return -1;
+        if (hipEventRecord(g_pose_fork_ev, s) != hipSuccess || hipStreamWaitEvent(aux, g_pose_fork_ev, 0) != hipSuccess)
+            return rdg_set_error("pose fork: event record / wait failed");
+        ps = aux;
+    }
+    hipLaunchKernelGGL(rdg_pose_partial_kernel, dim3(RDG_POSE_L2), dim3(256), 0, ps, posebuf, rows, part);
+    hipLaunchKernelGGL(rdg_pose_finalize_kernel, dim3(1), dim3(64), 0, ps, view, part, RDG_POSE_L2, dview);
     return rdg_check_hip(hipGetLastError(), "preprocess_bwd launch");
 }
 

@@ -14,6 +14,7 @@ from __future__ import annotations
 from typing import Dict, Optional
 
 import torch
+from contextlib import nullcontext as _nullcontext
 
 from . import _lib
 
@@ -205,7 +206,11 @@ class _PoseView(torch.autograd.Function):
         else:
             d_q = torch.empty_like(q)
             d_t = torch.empty_like(t)
-        with torch.cuda.device(q.device):
+        # graph capture (trainstep.GraphedStep): the kernel joins the pose-gradient chain on the rasterizer state's second stream
+        # (sinks["aux"] = the RasterState; everything it touches is persistent: the state's dL/dviewmatrix buffer, the sinks)
+        st_ = None if sinks is None else sinks.get("aux")
+        on_aux = st_ is not None and st_.graph_capture and st_.aux_stream is not None and g.data_ptr() == st_.pose_grad.data_ptr()
+        with torch.cuda.device(q.device), (torch.cuda.stream(st_.aux_stream) if on_aux else _nullcontext()):
             if ctx.step_scalars is not None:
                 _lib.check(L.rdg_pose_view_backward_dev(T, _lib.ptr(ctx.step_scalars), _lib.ptr(q), _lib.ptr(t),
                                                         _lib.ptr(g), _lib.ptr(d_q), _lib.ptr(d_t), _lib.stream_ptr()),

@@ -103,6 +103,13 @@ class RasterState:
         self.nren_max = None          # optional device int32[1]: sticky maximum of D (RdgRasterSettings.num_rendered_max)
         self.nren_max_key = None      # ... folded into by forwards of THIS (P, H, W) only (None: by every forward)
         self.det_ws = None            # deterministic mode: the per-instance row workspace, kept across steps
+        # graph capture only (trainstep.GraphedStep): a second stream the pose-gradient chain of backward is forked onto
+        # (RdgRasterSettings.aux_stream: a graph branch next to the deformation / MLP backward), the persistent [4,4] buffer
+        # dL/dviewmatrix is written to (it is read on that stream after the backward's own tensors are gone) and the gradient
+        # workspaces kept alive until the owner has joined the streams
+        self.aux_stream = None
+        self.pose_grad = None
+        self.keep_alive = []
         self.lock = threading.RLock()
 
     def mode(self, name: str) -> bool:
@@ -471,6 +478,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_ro = torch.empty_like(ro) if ro is not None else None
             d_cov = torch.empty_like(cov) if cov is not None else None
             d_vm = torch.empty(4, 4, **f32)
+            ctx.cs.aux_stream = None
+            st_ = ctx.state
+            if st_.graph_capture and st_.aux_stream is not None and st_.pose_grad is not None and not ctx.deterministic:
+                ctx.cs.aux_stream = st_.aux_stream.cuda_stream
+                d_vm = st_.pose_grad
+                st_.keep_alive.append(gws)
             fused = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs_adam")
             if fused is not None:
                 # optimizer in backward for the SH features: dL/dshs never leaves the kernel's LDS tile; the kernel

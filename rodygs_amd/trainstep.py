@@ -504,6 +504,10 @@ class DynamicScene:
         if self._grad_one is None or self._grad_one.device != loss.device:
             self._grad_one = torch.ones((), dtype=torch.float32, device=loss.device)
         loss.backward(self._grad_one)
+        st_ = self.raster_state
+        if st_.graph_capture and st_.aux_stream is not None:
+            # the pose-gradient chain ran as a branch of the graph (RasterState.aux_stream): join before the optimiser reads it
+            torch.cuda.current_stream(self.device).wait_stream(st_.aux_stream)
         if after is not None:
             loss = loss.detach() + after()
         # (densification statistics, when tracked: updated inside backward by the per-Gaussian kernel, see render())
@@ -598,6 +602,16 @@ class GraphedStep:
         if ds.full_losses and step % ds.rigidity[1] == 0:
             step += 1
         self.next_step = step
+        # RDG_GRAPH_BRANCHES=1 (opt-in, A/B switch): the pose-gradient chain (two reduction launches + the pose backward) as an
+        # independent branch of the captured step next to the deformation / MLP backward -- forked inside the library onto a second
+        # stream (RdgRasterSettings.aux_stream), joined before the optimiser.  Built in round 5 and measured as a LOSS: 0.626 ms
+        # against 0.597 ms per replayed step at 100 k points (profiles/r05_experiments.txt 6) -- the fork / join nodes of the
+        # hipGraph cost more than the 14 us the branch hides.  Off by default; not for the deterministic mode's two-pass backward.
+        if os.environ.get("RDG_GRAPH_BRANCHES", "0") == "1" and not st.mode("deterministic"):
+            _lib.check(_lib.lib().rdg_pose_fork_prepare(), "rdg_pose_fork_prepare")
+            st.aux_stream = torch.cuda.Stream(device=dev)
+            st.pose_grad = torch.empty(4, 4, dtype=torch.float32, device=dev)
+            ds.pose_sinks["aux"] = st
         torch.cuda.synchronize(dev)
         mark("setup_and_eager_warmup")
         counts = (ds.fp.step_count, ds.sp.step_count)
@@ -610,6 +624,7 @@ class GraphedStep:
                 self.loss = ds.train_step(step, 0, 1, self.perm)       # recorded, not executed
         finally:
             st.graph_capture = False
+            st.keep_alive.clear()
         mark("capture_and_instantiate")
         ds.fp.step_count, ds.sp.step_count = counts                    # capture advanced the host counters only
         self._nren, self._key, self._cap = st.last_nren
@@ -711,6 +726,8 @@ class GraphedStep:
         torch.cuda.current_stream(self.ds.device).synchronize()
         GraphedStep._RING_CACHE[str(self.ds.device)] = self.ring
         self.ds._graph_inputs = None
+        self.ds.pose_sinks.pop("aux", None)
+        self.ds.raster_state.aux_stream = self.ds.raster_state.pose_grad = None
         self.ds.raster_state.nren_max = None
         self.ds.raster_state.nren_max_key = None
         self.ds.fp.__dict__.pop("_adam_graph_layout", None)

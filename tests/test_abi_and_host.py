@@ -48,8 +48,9 @@ def _lib_mod():
 def test_c_struct_matches_header():
     import ctypes
     from rodygs_amd._lib import RdgRasterSettings
-    # 18 int32 / float fields, two pointers, the three statistics pointers + (rows, reserved), the sticky-count pointer
-    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 16 + 24 + 8 + 8
+    # 18 int32 / float fields, two pointers, the three statistics pointers + (rows, reserved), the sticky-count pointer, the
+    # auxiliary stream of the backward's pose chain
+    assert ctypes.sizeof(RdgRasterSettings) == 18 * 4 + 16 + 24 + 8 + 8 + 8
     assert ctypes.sizeof(_lib_mod().RdgStepScalars) == 128 == 4 * _lib_mod().STEP_SCALARS_FLOATS
     assert RdgRasterSettings.densify_grad_accum.offset == 88 and RdgRasterSettings.num_rendered_max.offset == 120
     from rodygs_amd import _lib

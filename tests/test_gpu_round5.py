@@ -371,3 +371,37 @@ def test_reference_iteration_keeps_the_stale_gradient_semantics():
     for it in range(1, 12):
         l1 = [float(x) for x in ri.iteration(it, list(range(T)))]
     assert all(np.isfinite(l0 + l1))
+
+
+def test_graph_branches_switch_gives_the_same_step(monkeypatch):
+    """RDG_GRAPH_BRANCHES=1 (opt-in; measured as a loss, profiles/r05_experiments.txt 6): the pose-gradient chain of backward forked
+    onto RdgRasterSettings.aux_stream as a branch of the captured graph.  The replayed steps must be the eager steps: the
+    parameters of the pose / MLP bucket and of the Gaussians after four steps agree to float-atomic noise, the pose gradient of
+    the last step to 1e-5."""
+    from rodygs_amd.trainstep import DynamicScene, GraphedStep
+    sc = O.synthetic_scene(15000, 320, 240, 3, seed=5)
+    tgt = O.synthetic_scene(4000, 320, 240, 3, seed=6)
+    frames = list(range(6))
+
+    def scene():
+        ds = DynamicScene(sc, num_frames=6, device=DEV)
+        ds.make_ground_truth(tgt, frames)
+        for s_ in range(3):
+            ds.train_step(s_, perm=frames)
+        return ds
+    a, b = scene(), scene()
+    for s_ in range(3, 7):
+        a.train_step(s_, perm=frames)
+    monkeypatch.setenv("RDG_GRAPH_BRANCHES", "1")
+    gs = GraphedStep(b, frames, warmup=1, first_step=3)
+    assert b.raster_state.aux_stream is not None and b.pose_sinks.get("aux") is b.raster_state
+    while gs.next_step < 7:
+        gs.step()
+    gs.check()
+    torch.cuda.synchronize()
+    rel_ok(b.sp["cam_q"].grad, a.sp["cam_q"].grad, tol=1e-5, what="pose gradient (rotation) of the last replayed step")
+    rel_ok(b.sp["cam_t"].grad, a.sp["cam_t"].grad, tol=1e-5, what="pose gradient (translation)")
+    rel_ok(b.sp.flat, a.sp.flat, tol=1e-5, what="MLP + pose parameters after four steps")
+    rel_ok(b.fp["xyz"], a.fp["xyz"], tol=1e-5, what="positions after four steps")
+    gs.close()
+    assert b.raster_state.aux_stream is None and "aux" not in b.pose_sinks
