@@ -61,6 +61,7 @@ DETERMINISTIC = os.environ.get("RDG_DETERMINISTIC", "0") == "1"
 # graph between replays.
 GRAPH_CAPTURE = False
 
+HINT_DECAY = 0.98                 # deferred mode: how fast the capacity hint follows lighter frames down (per checked frame)
 DEFERRED_OVERFLOW_CHECK = False   # opt-in (see poll_overflow); the default reads D once per forward, like upstream
 
 
@@ -152,7 +153,10 @@ class RasterState:
                 self.pinned_free.append(host)
                 if n >= _INSTANCE_LIMIT:
                     raise RuntimeError(_too_many(key))
-                self.capacity_hint[key] = max(n, int(self.capacity_hint.get(key, 0) * 0.9))
+                # a slowly decaying maximum (2 % per checked frame): consecutive frames of a training run can be far apart on
+                # the camera path, and a hint that followed every light frame down (10 % per frame until round 5) was outgrown by
+                # the next heavy one -- 52 frames rendered empty in a 2 500-step loop once the frames differed by more than 25 %
+                self.capacity_hint[key] = max(n, int(self.capacity_hint.get(key, 0) * HINT_DECAY))
                 self.note_largest_tile(key, int(host[1]), n)
                 if n > cap:
                     self.capacity_hint[key] = n

@@ -356,9 +356,10 @@ class DynamicScene:
         """densify_and_prune over the flat bucket, then re-point everything that referred to the old buffers
         (gradient sinks live in the new bucket, birth indices follow the Gaussians, exchange object rebuilt).
         The rasterizer's frame-to-frame memory is carried across the row surgery: the capacity of the binning workspace
-        scaled by P' / P (+ 10 %), the binning / split-compositing hints as they stand -- the first forward of the new cloud
-        then needs no read-back of its instance count (a capacity that turns out too small is found by the usual overflow
-        check).  ``timings``: per-phase wall times (ms) of this call, synchronising at every phase boundary (diagnosis)."""
+        scaled by P' / P (+ 25 %: clones and split children are drawn from the Gaussians with the largest screen-space gradient,
+        the instance count grows faster than the cloud -- a 2 500-step loop outgrew + 10 % after 18 densifications), the binning /
+        split-compositing hints as they stand -- the first forward of the new cloud then needs no read-back of its instance
+        count (a capacity that turns out too small is found by the usual overflow check).  ``timings``: per-phase wall times (ms) of this call, synchronising at every phase boundary (diagnosis)."""
         from .densify import FlatPool, _Phase, allreduce_stats_, densify_and_prune
         if self.stats is None:
             raise RuntimeError("call track_densification() first")
@@ -383,7 +384,7 @@ class DynamicScene:
         with st.lock:
             if old in st.capacity_hint and new != old:
                 st.capacity_hint[new] = max(int(st.capacity_hint.get(new, 0)),
-                                            int(st.capacity_hint[old] * (self.P / max(P_old, 1)) * 1.1) + 4096)
+                                            int(st.capacity_hint[old] * (self.P / max(P_old, 1)) * 1.25) + 4096)
                 for table in (st.bin_hint, st.split_hint):
                     if old in table:
                         table[new] = table[old]
@@ -709,7 +710,7 @@ class GraphedStep:
         if n >= rasterizer._INSTANCE_LIMIT:
             raise RuntimeError(rasterizer._too_many(self._key))
         with st.lock:
-            st.capacity_hint[self._key] = max(n, int(st.capacity_hint.get(self._key, 0) * 0.9))
+            st.capacity_hint[self._key] = max(n, int(st.capacity_hint.get(self._key, 0) * 0.9))   # (n = max over the replays)
         if n > self._cap:
             raise rasterizer.RasterizerCapacityOverflow(
                 f"a replayed frame needed {n} instances, the graph was captured with {self._cap}: that frame was "

@@ -25,6 +25,7 @@ python3 scripts/trace_one_step.py $O/kt > $O/${T}_one_step.txt 2>&1
 # the train LOOP (densify_and_prune every 100 steps), eager / per-phase profile / graph re-captured per densification, and the
 # reference's iteration (static + dynamic sub-steps over the two-segment cloud)
 python3 bench.py --loop 600 > $O/${T}_loop_bench.json 2>/dev/null
+python3 bench.py --loop 2500 > $O/${T}_loop_long_bench.json 2>/dev/null
 python3 bench.py --loop 600 --loop-profile > $O/${T}_loop_profile.json 2>/dev/null
 python3 bench.py --loop 600 --graph > $O/${T}_loop_graph_bench.json 2>/dev/null
 python3 bench.py --loop 600 --points 100000 > $O/${T}_loop_100k_bench.json 2>/dev/null
