@@ -94,6 +94,7 @@ class RasterState:
         self.deterministic, self.force_radix, self.force_bucket = deterministic, force_radix, force_bucket
         self.deferred_overflow_check, self.render_normal = deferred_overflow_check, render_normal
         self.capacity_hint = {}       # (P, H, W) -> last num_rendered
+        self.d_high = {}              # (P, H, W) -> slowly decaying maximum of num_rendered over the checked frames (HINT_DECAY)
         self.bin_hint = {}            # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
         self.split_hint = {}          # (P, H, W) -> 1 while it calls for the split compositing path
         self.pending = []             # (stream, pinned int32[2], key, capacity, device pair) of forwards not yet checked
@@ -120,6 +121,11 @@ class RasterState:
             return bool(v)
         return bool({"deterministic": DETERMINISTIC, "force_radix": _FORCE_RADIX, "force_bucket": _FORCE_BUCKET,
                      "deferred_overflow_check": DEFERRED_OVERFLOW_CHECK, "render_normal": RENDER_NORMAL}[name])
+
+    def note_instances(self, key, n: int) -> None:
+        """Fold a frame's instance count into the slowly decaying maximum a graph owner sizes its fixed capacity with (consecutive
+        frames of a training run can be far apart on the camera path: the LAST frame says little about the next hundred)."""
+        self.d_high[key] = max(int(n), int(self.d_high.get(key, 0) * HINT_DECAY))
 
     def pinned_slot(self) -> torch.Tensor:
         return self.pinned_free.pop() if self.pinned_free else torch.empty(2, dtype=torch.int32).pin_memory()
@@ -157,6 +163,7 @@ class RasterState:
                 # the camera path, and a hint that followed every light frame down (10 % per frame until round 5) was outgrown by
                 # the next heavy one -- 52 frames rendered empty in a 2 500-step loop once the frames differed by more than 25 %
                 self.capacity_hint[key] = max(n, int(self.capacity_hint.get(key, 0) * HINT_DECAY))
+                self.note_instances(key, n)
                 self.note_largest_tile(key, int(host[1]), n)
                 if n > cap:
                     self.capacity_hint[key] = n
@@ -420,6 +427,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     raise RuntimeError(_too_many(key))
                 with state.lock:
                     state.capacity_hint[key] = n
+                    state.note_instances(key, n)
                     state.note_largest_tile(key, largest, n)
                 if n <= cap:
                     break

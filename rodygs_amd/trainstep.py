@@ -385,11 +385,13 @@ class DynamicScene:
             if old in st.capacity_hint and new != old:
                 st.capacity_hint[new] = max(int(st.capacity_hint.get(new, 0)),
                                             int(st.capacity_hint[old] * (self.P / max(P_old, 1)) * 1.25) + 4096)
+                st.d_high[new] = max(int(st.d_high.get(new, 0)), st.capacity_hint[new],
+                                     int(st.d_high.get(old, 0) * (self.P / max(P_old, 1)) * 1.25))
                 for table in (st.bin_hint, st.split_hint):
                     if old in table:
                         table[new] = table[old]
                 # the old cloud's entries are dead weight from here on
-                for table in (st.capacity_hint, st.bin_hint, st.split_hint):
+                for table in (st.capacity_hint, st.d_high, st.bin_hint, st.split_hint):
                     table.pop(old, None)
         ph.mark("re_hint")
         return {"P": self.P, "cloned": res.n_clone, "split": res.n_split, "pruned": res.n_pruned,
@@ -616,6 +618,12 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         mark("setup_and_eager_warmup")
         counts = (ds.fp.step_count, ds.sp.step_count)
+        # the captured capacity is fixed for every replay: size it with the recent MAXIMUM of the instance count (and what a
+        # densification carried over), not with the one frame the warm-up step happened to render -- frames of a run differ
+        # by 25 % and more (a 2 500-step loop with a re-capture every 100 steps outgrew a capacity taken from the last frame)
+        with st.lock:
+            key_ = (ds.P, ds.H, ds.W)
+            st.capacity_hint[key_] = max(int(st.capacity_hint.get(key_, 0)), int(st.d_high.get(key_, 0)))
         self.graph = torch.cuda.CUDAGraph()
         st.graph_capture = True
         try:
