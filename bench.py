@@ -1019,7 +1019,18 @@ def main():
                 res["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": torch.get_num_threads(),
                                        "host": {"cpu_count": n_cpu, "cpu_model": model},
                                        "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(res))
+    # The JSON line is the LAST line on stdout: RCCL writes its version banner through C stdio, which sits in a buffer until the
+    # process exits when stdout is a pipe -- after Python's print.  Every rank flushes C stdio, the ranks meet, then rank 0 prints.
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
