@@ -73,6 +73,12 @@ class OracleSettings:
     debug: bool = False
     enable_cov_grad: bool = True
     enable_sh_grad: bool = True
+    # Not a field of the reference's settings: which (tile, Gaussian) instances the per-Gaussian stage hands to the binning
+    # stage -- RdgRasterSettings.cull of the C-ABI.  False = the reference algorithm's 3-sigma square (the key stream the
+    # north_star's bit-exact bar names); True (the product's default) = that square intersected with the tiles holding a
+    # pixel centre inside the box of the splat's alpha >= 1/255 ellipse (`_tight_rect`).  Images, final_T and gradients are
+    # identical either way (tests/test_oracle_cull.py proves it on the CPU: the dropped instances blend nowhere).
+    cull: bool = True
 
 
 class _SteMin(torch.autograd.Function):
@@ -145,6 +151,60 @@ def covariance3d(scales: torch.Tensor, scale_modifier: float, rotations: torch.T
 def f32(x: float) -> float:
     """Round a python double to float32 (the value the C-ABI receives as a `float` argument)."""
     return float(np.float32(x))
+
+
+def _ln_f32(x: np.ndarray) -> np.ndarray:
+    """ln of positive normal float32 numbers from +, -, *, / and bit operations only, in the order of
+    rdg_ln_exact_ops (csrc/rdg_preprocess_fwd.hip): the same bits on both sides."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    e = (u >> np.uint32(23)).astype(np.int32) - np.int32(127)
+    m = ((u & np.uint32(0x007fffff)) | np.uint32(0x3f800000)).view(np.float32)
+    big = m > np.float32(1.41421354)
+    m = np.where(big, m * np.float32(0.5), m)
+    e = np.where(big, e + 1, e)
+    s = (m - np.float32(1.0)) / (m + np.float32(1.0))
+    s2 = s * s
+    p = np.float32(0.111111111) * s2 + np.float32(0.142857143)
+    p = p * s2 + np.float32(0.2)
+    p = p * s2 + np.float32(0.333333333)
+    p = p * s2 + np.float32(1.0)
+    return (np.float32(2.0) * s) * p + e.astype(np.float32) * np.float32(0.693147181)
+
+
+def _tight_rect(px, py, conic_a, conic_b, inv_cyy, opacity, rect, gx, gy):
+    """RdgRasterSettings.cull = 1, restated (rdg_splat_rect, csrc/rdg_preprocess_fwd.hip; float32: operation for
+    operation): the reference rectangle intersected with the tiles that hold a pixel centre inside the axis-aligned box of the
+    splat's alpha >= 1/255 ellipse.  The quadratic form the compositing evaluates is Q = a (dx + beta dy)^2 + dy^2 / cov_yy;
+    a pixel blends only where Q <= 2 ln(255 opacity); over dx Q >= dy^2 / cov_yy, over dy Q >= dx^2 / cov_xx, cov_xx =
+    c_eff cov_yy / a with c_eff = b^2 / a + 1 / cov_yy.  The bound carries a margin (0.02 in the log, 1e-3 relative).
+    numpy arrays in, (x0, y0, x1, y1) int64 arrays out; a splat that cannot reach 1/255 gets an empty rectangle."""
+    x0, y0, x1, y1 = [np.array(r, dtype=np.int64) for r in rect]
+    f32 = px.dtype == np.float32
+    one, two = px.dtype.type(1.0), px.dtype.type(2.0)
+    with np.errstate(all="ignore"):
+        t255 = px.dtype.type(255.0) * opacity
+        dead = ~(t255 >= px.dtype.type(0.99))
+        tl = np.where(dead, one, t255)
+        ln = _ln_f32(tl) if f32 else np.log(tl)
+        r2 = (two * (ln + px.dtype.type(0.02))) * px.dtype.type(1.001)
+        cyy = one / inv_cyy
+        c_eff = (conic_b * conic_b) / conic_a + inv_cyy
+        cxx = (c_eff * cyy) / conic_a
+        hx, hy = np.sqrt(r2 * cxx), np.sqrt(r2 * cyy)
+        # fmaxf / fminf return the other operand for a NaN: a NaN extent keeps the reference rectangle
+        lox = np.fmax(np.ceil(px - hx), px.dtype.type(0.0)); hix = np.fmin(np.floor(px + hx), px.dtype.type(gx * TILE - 1))
+        loy = np.fmax(np.ceil(py - hy), px.dtype.type(0.0)); hiy = np.fmin(np.floor(py + hy), px.dtype.type(gy * TILE - 1))
+        empty = dead | (hix < lox) | (hiy < loy)
+        i = lambda v: np.nan_to_num(v, nan=0.0, posinf=2.0e9, neginf=-2.0e9).astype(np.int64)
+        tx0, tx1 = i(lox) >> 4, (i(hix) >> 4) + 1
+        ty0, ty1 = i(loy) >> 4, (i(hiy) >> 4) + 1
+    nx0, nx1 = np.maximum(x0, tx0), np.minimum(x1, tx1)
+    ny0, ny1 = np.maximum(y0, ty0), np.minimum(y1, ty1)
+    nx1, ny1 = np.maximum(nx1, nx0), np.maximum(ny1, ny0)
+    nx1 = np.where(empty, nx0, nx1)
+    ny1 = np.where(empty, ny0, ny1)
+    return nx0, ny0, nx1, ny1
 
 
 def preprocess(means3D, means2D, opacities, viewmatrix, settings: OracleSettings, shs=None, colors_precomp=None,
@@ -247,7 +307,15 @@ def preprocess(means3D, means2D, opacities, viewmatrix, settings: OracleSettings
         tiles = (rmaxx - rminx) * (rmaxy - rminy)
         valid = valid & (tiles > 0)
         tiles = torch.where(valid, tiles, torch.zeros_like(tiles))
+        # visibility (radii > 0, /root/reference/src/trainer/renderer.py:111) is the reference rule's, whatever is binned
         radii = torch.where(valid, radius_f.to(torch.int64), torch.zeros_like(tiles)).to(torch.int32)
+        if getattr(settings, "cull", False):
+            inv_cyy = (torch.ones_like(cc) / cc).detach()
+            t = _tight_rect(pxd.numpy(), pyd.numpy(), conic_a.detach().numpy(), conic_b.detach().numpy(), inv_cyy.numpy(),
+                            opacities.detach().reshape(P).to(dt).numpy(),
+                            (rminx.numpy(), rminy.numpy(), rmaxx.numpy(), rmaxy.numpy()), gx, gy)
+            rminx, rminy, rmaxx, rmaxy = [torch.from_numpy(np.ascontiguousarray(v)) for v in t]
+            tiles = torch.where(valid, (rmaxx - rminx) * (rmaxy - rminy), torch.zeros_like(tiles))
 
     # colour
     if colors_precomp is not None:

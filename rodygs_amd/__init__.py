@@ -7,8 +7,8 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rast
 from .knn import distCUDA2  # noqa: F401
 from .deform import (MLPBasisNetwork, TimestepEmbedder, MLPMotionBasis, gaussian_deformation,  # noqa: F401
                      DeformationField)
-from .render import render  # noqa: F401
+from .render import render, render_model  # noqa: F401
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "distCUDA2",
            "MLPBasisNetwork", "TimestepEmbedder", "MLPMotionBasis", "gaussian_deformation", "DeformationField",
-           "render"]
+           "render", "render_model"]

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RDG_LIB_PATH: load another build of the same ABI (A/B runs of kernel variants on one GPU box)
 LIB_PATH = os.environ.get("RDG_LIB_PATH") or os.path.join(_HERE, "csrc", "librodygs_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 _lock = threading.Lock()
@@ -26,7 +26,7 @@ class RdgRasterSettings(C.Structure):
         ("bin_mode", C.c_int32), ("num_rendered_stats", C.c_int32), ("list_hints", C.c_int32),
         ("grad_rows_zeroed", C.c_int32), ("densify_row0", C.c_int32), ("zero_grad_ws", C.c_void_p),
         ("num_rendered_host", C.c_void_p), ("densify_grad_accum", C.c_void_p), ("densify_denom", C.c_void_p),
-        ("densify_max_radii", C.c_void_p), ("densify_rows", C.c_int32), ("reserved1", C.c_int32),
+        ("densify_max_radii", C.c_void_p), ("densify_rows", C.c_int32), ("cull", C.c_int32),
         ("num_rendered_max", C.c_void_p), ("aux_stream", C.c_void_p),
     ]
 

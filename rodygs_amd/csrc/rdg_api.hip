@@ -117,6 +117,7 @@ static int rdg_make_dev(const RdgRasterSettings* s, RdgDev* d) {
     d->smod = s->scale_modifier;
     d->prefiltered = s->prefiltered; d->cov_grad = s->enable_cov_grad; d->sh_grad = s->enable_sh_grad;
     d->render_normal = s->render_normal;
+    d->cull = s->cull ? 1 : 0;
     d->bin_mode = s->bin_mode; d->nren_stats = s->num_rendered_stats; d->list_hints = s->list_hints;
     d->grad_rows_zeroed = s->grad_rows_zeroed; d->zero_grad_ws = s->zero_grad_ws;
     d->nren_host = s->num_rendered_stats ? s->num_rendered_host : nullptr;

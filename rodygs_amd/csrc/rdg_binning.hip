@@ -16,18 +16,11 @@
 // Gaussian by binary search in the block's LDS offsets -> perfectly coalesced 8-B key / 4-B value stores
 // regardless of how skewed tiles_touched is.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rdg_rect_dup(float px, float py, int radius, int gx, int gy, int& x0, int& y0,
-                                             int& x1, int& y1) {
-    float r = (float)radius;
-    x0 = min(gx, max(0, (int)((px - r) / (float)RDG_TILE)));
-    y0 = min(gy, max(0, (int)((py - r) / (float)RDG_TILE)));
-    x1 = min(gx, max(0, (int)((((px + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
-    y1 = min(gy, max(0, (int)((((py + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
-}
-
+// every kernel below takes a Gaussian's tile rectangle, depth bits and tile count from the per-Gaussian `rectd` words the
+// per-Gaussian stage wrote (rdg_splat_rect, rdg_preprocess_fwd.hip): one coalesced 16-B load, and ONE definition of the
+// rectangle for the reference rule and the tight one (RdgRasterSettings.cull)
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_duplicate_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
-                     const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
+rdg_duplicate_kernel(int P, int gx, int gy, const uint4* __restrict__ rectd,
                      const uint32_t* __restrict__ block_sums, uint64_t* __restrict__ keys,
                      uint32_t* __restrict__ vals, long long capacity, const int32_t* __restrict__ num_rendered) {
     if ((long long)(*num_rendered) > capacity) return;
@@ -39,14 +32,12 @@ rdg_duplicate_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
     const int i = blockIdx.x * RDG_PRE_BLOCK + tid;
     uint32_t t = 0;
     if (i < P) {
-        t = tiles_touched[i];
+        const uint4 rd = rectd[i];
+        t = rd.w;
         if (t > 0) {
-            const float4 q0 = rec[i].q0;
-            const float4 q1 = rec[i].q1;
-            int x0, y0, x1, y1;
-            rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
-            sX0[tid] = (uint16_t)x0; sY0[tid] = (uint16_t)y0; sW[tid] = (uint16_t)(x1 - x0);
-            sDepth[tid] = __float_as_uint(q1.z);
+            sX0[tid] = (uint16_t)(rd.x & 0xffffu); sY0[tid] = (uint16_t)(rd.x >> 16);
+            sW[tid] = (uint16_t)((rd.y & 0xffffu) - (rd.x & 0xffffu));
+            sDepth[tid] = rd.z;
         }
     }
     const uint32_t inc = rdg_wave_scan_incl(t);
@@ -152,8 +143,7 @@ __device__ __forceinline__ uint32_t rdg_zidx(uint32_t x, uint32_t y) {
 #endif
 template <int MODE>  // 0 = count, 1 = scatter
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restrict__ rec,
-                       const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
+rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict__ rectd,
                        const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_cnt,
                        const uint2* __restrict__ ranges, uint32_t* __restrict__ rank_buf,
                        uint64_t* __restrict__ comp, long long capacity, const int32_t* __restrict__ num_rendered,
@@ -179,14 +169,9 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const RdgRec* __restric
     const int i = blockIdx.x * RDG_PRE_BLOCK + tid;
     uint32_t t = 0, xy0 = 0, wd0 = 1, dep = 0;
     if (i < P) {
-        t = tiles_touched[i];
-        if (t > 0) {
-            const float4 q0 = rec[i].q0;
-            int x0, y0, x1, y1;
-            rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
-            xy0 = (uint32_t)x0 | ((uint32_t)y0 << 16); wd0 = (uint32_t)(x1 - x0);
-            if (MODE == 1) dep = __float_as_uint(rec[i].q1.z);
-        }
+        const uint4 rd = rectd[i];
+        t = rd.w;
+        if (t > 0) { xy0 = rd.x; wd0 = (rd.y & 0xffffu) - (rd.x & 0xffffu); dep = rd.z; }
     }
     const uint32_t inc = rdg_wave_scan_incl(t);
     const uint32_t lane = tid & 63, w = tid >> 6;
@@ -923,12 +908,13 @@ rdg_tile_max_kernel(int n_tiles, const uint2* __restrict__ ranges, long long cap
 // depth key of every Gaussian (its view-space depth's bits: positive floats order like their bits; Gaussians that touch no
 // tile go last), value = its index; n_p[0] = P for the sort
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_depth_keys_kernel(int P, const RdgRec* __restrict__ rec, const uint32_t* __restrict__ tiles_touched,
+rdg_depth_keys_kernel(int P, const uint4* __restrict__ rectd,
                       uint32_t* __restrict__ dkey, uint32_t* __restrict__ dval, int32_t* __restrict__ n_p) {
     const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
     if (i == 0) n_p[0] = P;
     if (i >= P) return;
-    dkey[i] = tiles_touched[i] > 0 ? __float_as_uint(rec[i].q1.z) : 0xFFFFFFFFu;
+    const uint4 rd = rectd[i];
+    dkey[i] = rd.w > 0 ? rd.z : 0xFFFFFFFFu;
     dval[i] = (uint32_t)i;
 }
 
@@ -966,8 +952,7 @@ __global__ void __launch_bounds__(1024) rdg_scan_u32_kernel(uint32_t* __restrict
 // Gaussian's tiles row by row; slots dealt round-robin to the threads of a block (coalesced stores however skewed the
 // footprints are)
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_duplicate_sorted_kernel(int P, int gx, int gy, const uint32_t* __restrict__ perm, const RdgRec* __restrict__ rec,
-                            const uint32_t* __restrict__ tiles_touched, const int32_t* __restrict__ radii,
+rdg_duplicate_sorted_kernel(int P, int gx, int gy, const uint32_t* __restrict__ perm, const uint4* __restrict__ rectd,
                             const uint32_t* __restrict__ psum, uint32_t* __restrict__ tkey, uint32_t* __restrict__ vals,
                             long long capacity, const int32_t* __restrict__ num_rendered) {
     if ((long long)(*num_rendered) > capacity) return;
@@ -980,12 +965,11 @@ rdg_duplicate_sorted_kernel(int P, int gx, int gy, const uint32_t* __restrict__ 
     if (j < P) {
         const uint32_t i = perm[j];
         sId[tid] = i;
-        t = tiles_touched[i];
+        const uint4 rd = rectd[i];
+        t = rd.w;
         if (t > 0) {
-            const float4 q0 = rec[i].q0;
-            int x0, y0, x1, y1;
-            rdg_rect_dup(q0.x, q0.y, radii[i], gx, gy, x0, y0, x1, y1);
-            sX0[tid] = (uint16_t)x0; sY0[tid] = (uint16_t)y0; sW[tid] = (uint16_t)(x1 - x0);
+            sX0[tid] = (uint16_t)(rd.x & 0xffffu); sY0[tid] = (uint16_t)(rd.x >> 16);
+            sW[tid] = (uint16_t)((rd.y & 0xffffu) - (rd.x & 0xffffu));
         }
     }
     const uint32_t inc = rdg_wave_scan_incl(t);
@@ -1070,7 +1054,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
             // emission-order (key, value) stream for the parity tests: the radix path's duplicate kernel
             uint32_t* vscr = (npass & 1) ? vals_a : vals_b;
             hipLaunchKernelGGL(rdg_duplicate_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
-                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                               (const uint4*)(g + G.rectd),
                                (const uint32_t*)(g + G.block_sums), keys_out, vscr, (long long)capacity, num_rendered);
             hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_out, vscr, keys_unsorted_copy,
                                vals_unsorted_copy, (long long)capacity, num_rendered);
@@ -1091,7 +1075,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         }
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
-                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                               (const uint4*)(g + G.rectd),
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered, (uint4*)nullptr, 0ll);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
@@ -1100,7 +1084,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                            (uint2*)(hv + HL.chunks), HL.max_chunk_items, d.nren_host);
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
-                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                               (const uint4*)(g + G.rectd),
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered, (uint4*)(b + B.hit),
                                (long long)(rdg_hit_bytes(capacity, n_tiles) / 16));
@@ -1138,7 +1122,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
     if ((keys_unsorted_copy || vals_unsorted_copy) && d.P > 0) {
         // emission-order (key, value) stream of the reference algorithm, for the parity tests only
         hipLaunchKernelGGL(rdg_duplicate_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
-                           (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii,
+                           (const uint4*)(g + G.rectd),
                            (const uint32_t*)(g + G.block_sums), keys_b, vals_b, (long long)capacity, num_rendered);
         hipLaunchKernelGGL(rdg_copy_pairs_kernel, dim3(1024), dim3(256), 0, s, keys_b, vals_b, keys_unsorted_copy,
                            vals_unsorted_copy, (long long)capacity, num_rendered);
@@ -1155,8 +1139,8 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
             int32_t* n_p = (int32_t*)(q + 4 * Pp + rdg_align_up((size_t)(nblk + 1) * 4, 256));   // [0] = P, [1] = scratch
             if ((size_t)((char*)(n_p + 2) - q) > (size_t)capacity * 8)
                 return rdg_set_error("radix binning: capacity %lld too small for %d Gaussians", (long long)capacity, d.P);
-            hipLaunchKernelGGL(rdg_depth_keys_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, (const RdgRec*)(g + G.rec),
-                               (const uint32_t*)(g + G.tiles_touched), dk_a, dv_a, n_p);
+            hipLaunchKernelGGL(rdg_depth_keys_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P,
+                               (const uint4*)(g + G.rectd), dk_a, dv_a, n_p);
             int in_b = 0;
             int rc = rdg_launch_radix_sort<uint32_t>(dk_a, dk_b, dv_a, dv_b, (int64_t)d.P, n_p, 0, 32, b + B.sort_tmp, &in_b, s);
             if (rc) return rc;
@@ -1165,7 +1149,7 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
                                (const uint32_t*)(g + G.tiles_touched), psum);
             hipLaunchKernelGGL(rdg_scan_u32_kernel, dim3(1), dim3(1024), 0, s, psum, nblk);
             hipLaunchKernelGGL(rdg_duplicate_sorted_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, perm,
-                               (const RdgRec*)(g + G.rec), (const uint32_t*)(g + G.tiles_touched), radii, psum, tkey_a,
+                               (const uint4*)(g + G.rectd), psum, tkey_a,
                                vals_a, (long long)capacity, num_rendered);
         }
     }

@@ -43,6 +43,9 @@ struct RdgGeomLayout {
     size_t tiles_touched;  // uint32[P]
     size_t clamped;        // uint8[P]  (bit c set = channel c clamped at 0)
     size_t block_sums;     // uint32[nblk+1]  (exclusive-scanned in place; [nblk] = total)
+    size_t rectd;          // uint4[P]: (x0 | y0 << 16, x1 | y1 << 16, view-space depth bits, tiles touched) -- the tile
+                           // rectangle [x0, x1) x [y0, y1) the binning stage expands (rdg_splat_rect: the ONE place it is
+                           // formed), next to the two other words that stage needs: one coalesced 16-B load per Gaussian
     size_t total;
 };
 static inline RdgGeomLayout rdg_geom_layout(int32_t P) {
@@ -54,6 +57,7 @@ static inline RdgGeomLayout rdg_geom_layout(int32_t P) {
     L.tiles_touched = o;  o = rdg_align_up(o + Pp * 4, 256);
     L.clamped = o;        o = rdg_align_up(o + Pp, 256);
     L.block_sums = o;     o = rdg_align_up(o + (nblk + 1) * 4, 256);
+    L.rectd = o;          o = rdg_align_up(o + Pp * 16, 256);
     L.total = o;
     return L;
 }
@@ -211,6 +215,7 @@ struct RdgDev {
     float tanx, tany, fx, fy, smod;
     int32_t prefiltered, cov_grad, sh_grad, render_normal;
     int32_t bin_mode, nren_stats;
+    int32_t cull;              // RdgRasterSettings.cull: 0 = the reference's tile rectangles, 1 = tight rectangles
     int32_t list_hints;        // RdgRasterSettings.list_hints: bit 0 = split compositing path for lists > RDG_SPLIT_MIN
     int32_t tile_cnt_zeroed;   // internal: the per-tile counters were cleared by the per-Gaussian stage's scan kernel
     int32_t grad_rows_zeroed;  // RdgRasterSettings.grad_rows_zeroed (backward)

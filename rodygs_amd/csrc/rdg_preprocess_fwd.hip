@@ -26,6 +26,69 @@ __device__ __forceinline__ void rdg_rect(float px, float py, int radius, int gx,
     y1 = min(gy, max(0, (int)((((py + r) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
 }
 
+// ln(x) for a positive normal float from +, -, *, / and bit operations ONLY, in a fixed order (this file is built without
+// FMA contraction): the oracle restates it operation for operation (oracle/rasterizer_oracle.py::_ln_f32), so the tight
+// rectangles -- hence the culled key stream -- are bit-exact against it, which no library logarithm would be.
+// x = m 2^e with m in [0.707, 1.414]; ln m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172: five terms, 1e-9 absolute.
+__device__ __forceinline__ float rdg_ln_exact_ops(float x) {
+    const uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    const float s = (m - 1.0f) / (m + 1.0f);
+    const float s2 = s * s;
+    float p = 0.111111111f * s2 + 0.142857143f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.333333333f;
+    p = p * s2 + 1.0f;
+    return (2.0f * s) * p + (float)e * 0.693147181f;
+}
+
+// The tile rectangle [x0, x1) x [y0, y1) of a splat, from its RECORD alone (so that a rank which received the record over the
+// wire forms the same rectangle bit for bit: rdg_geom_from_records) -- the one place of the library that forms it; every later
+// stage reads it from the per-Gaussian `rectd` array.
+//   cull = 0: the reference's rule -- the square of half-width `radius` = ceil(3 sqrt(lambda_max)) around the pixel centre.
+//             This is what the exported (tile | depth) key stream is held to bit for bit (rdg_bin_forward, the oracle).
+//   cull = 1: that rectangle INTERSECTED with the tiles that hold a pixel centre inside the axis-aligned box of the splat's
+//             "alpha >= 1/255" ellipse.  A pixel blends the splat only where opacity * exp(-Q / 2) >= 1/255 (and Q >= 0), Q the
+//             quadratic form the compositing kernels evaluate, Q = a (dx + beta dy)^2 + dy^2 / cov2D_yy: i.e. Q <= r2 =
+//             2 ln(255 opacity).  Over all dx the form is >= dy^2 / cov_yy, over all dy it is >= dx^2 / cov_xx with cov_xx =
+//             c_eff cov_yy / a (c_eff = b^2 / a + 1 / cov_yy, the third conic entry as the staged form has it), so the ellipse
+//             lies in |dx| <= sqrt(r2 cov_xx), |dy| <= sqrt(r2 cov_yy).  r2 carries the margin of rdg_quadrant_bits (0.02 in the
+//             log + 1e-3 relative: orders of magnitude above the rounding of these few operations), so no tile with a blending
+//             pixel is ever dropped: image, final_T and every gradient are those of the reference rectangle; only the
+//             instances that could not blend anywhere in their tile never enter the lists.  The reference's 3-sigma square is
+//             a circle's box around an ellipse that is often thin, and often ends well inside 3 sigma (r2 < 9 for every
+//             opacity below 0.35): on the bench frame 27 % of the reference's (tile, Gaussian) instances (32 % at 100 k points)
+//             go, of the 32 % (41 %) an exact per-tile test could remove.  A splat that cannot reach 1/255 anywhere
+//             (255 opacity < 1) keeps its radius (the reference's visibility) and gets no tile.
+__device__ __forceinline__ void rdg_splat_rect(const float4 q0, const float4 q1, const float inv_cyy, int gx, int gy, int cull,
+                                               int& x0, int& y0, int& x1, int& y1) {
+    rdg_rect(q0.x, q0.y, __float_as_int(q1.w), gx, gy, x0, y0, x1, y1);
+    if (!cull) return;
+    const float a = q0.z, b = q0.w, o = q1.y;
+    const float t255 = 255.0f * o;
+    if (!(t255 >= 0.99f)) { x1 = x0; y1 = y0; return; }      // never reaches 1/255 (a NaN opacity is dropped too)
+    const float r2 = (2.0f * (rdg_ln_exact_ops(t255) + 0.02f)) * 1.001f;
+    const float cyy = 1.0f / inv_cyy;
+    const float c_eff = (b * b) / a + inv_cyy;
+    const float cxx = (c_eff * cyy) / a;
+    const float hx = sqrtf(r2 * cxx), hy = sqrtf(r2 * cyy);
+    // pixel columns / rows with a centre inside the box: ceil(p - h) .. floor(p + h), clamped to the tile grid's pixels.
+    // Written so that a NaN extent keeps the reference rectangle (fmaxf / fminf return the other operand).
+    const float lox = fmaxf(ceilf(q0.x - hx), 0.0f), hix = fminf(floorf(q0.x + hx), (float)(gx * RDG_TILE - 1));
+    const float loy = fmaxf(ceilf(q0.y - hy), 0.0f), hiy = fminf(floorf(q0.y + hy), (float)(gy * RDG_TILE - 1));
+    if (hix < lox || hiy < loy) { x1 = x0; y1 = y0; return; }  // no pixel centre inside the box
+    x0 = max(x0, (int)lox >> 4); x1 = min(x1, ((int)hix >> 4) + 1);
+    y0 = max(y0, (int)loy >> 4); y1 = min(y1, ((int)hiy >> 4) + 1);
+    if (x1 < x0) x1 = x0;
+    if (y1 < y0) y1 = y0;
+}
+__device__ __forceinline__ uint4 rdg_pack_rectd(int x0, int y0, int x1, int y1, float depth, uint32_t tiles) {
+    if (tiles == 0u) return make_uint4(0u, 0u, 0u, 0u);
+    return make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)x1 | ((uint32_t)y1 << 16), __float_as_uint(depth), tiles);
+}
+
 template <bool MULTI>
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
 rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const float* __restrict__ proj,
@@ -35,7 +98,7 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                           const float* __restrict__ cov3Dp, RdgRec* __restrict__ rec_b,
                           uint32_t* __restrict__ tiles_touched_b, uint8_t* __restrict__ clampedm_b,
                           uint32_t* __restrict__ block_sums_b, int32_t* __restrict__ radii_b, int nviews_arg,
-                          int vstride_arg, int blk0_arg) {
+                          int vstride_arg, int blk0_arg, uint4* __restrict__ rectd_b) {
     const int nviews = MULTI ? nviews_arg : 1, vstride = MULTI ? vstride_arg : 0;   // MULTI = false: the single-camera kernel
     // row-range launches of the multi-camera kernel (chunked owner stage, pipelined with the exchange): workgroup
     // blockIdx.x works on rows [(blk0 + blockIdx.x) * RDG_PRE_BLOCK, ...) and d.P is the END row of the range
@@ -65,6 +128,7 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
     uint8_t* __restrict__ clampedm = clampedm_b + vo;
     int32_t* __restrict__ radii = radii_b + vo;
     uint32_t* __restrict__ block_sums = block_sums_b + vo / RDG_PRE_BLOCK;
+    uint4* __restrict__ rectd = rectd_b + vo;
     float V[16], Pm[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = view[k]; Pm[k] = proj[k]; }
@@ -72,6 +136,7 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
     if (i < d.P) {
         int radius_out = 0;
         uint8_t cl = 0;
+        uint4 rd = make_uint4(0u, 0u, 0u, 0u);
         RdgRec R;
         R.q0 = make_float4(0.f, 0.f, 0.f, 0.f);
         R.q1 = R.q0; R.q2 = R.q0; R.q3 = R.q0;
@@ -157,11 +222,18 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                 const int radius = (int)ceilf(3.0f * sqrtf(lam));
                 const float px = ((ndc_x + 1.0f) * (float)d.W - 1.0f) * 0.5f;
                 const float py = ((ndc_y + 1.0f) * (float)d.H - 1.0f) * 0.5f;
+                // record fields the rectangle is formed from (rdg_splat_rect reads nothing else)
+                const float4 rq0 = make_float4(px, py, cc * det_inv, -cb * det_inv);
+                const float4 rq1 = make_float4(ca * det_inv, opac[i], vz, __int_as_float(radius));
+                const float inv_cyy = 1.0f / cc;
                 int x0, y0, x1, y1;
                 rdg_rect(px, py, radius, d.gx, d.gy, x0, y0, x1, y1);
                 const int area = (x1 - x0) * (y1 - y0);
                 if (area > 0) {
-                    my_tiles = (uint32_t)area;
+                    // visible by the reference's rule (radius > 0: renderer.py:111); the binning stage may see fewer tiles
+                    if (d.cull) rdg_splat_rect(rq0, rq1, inv_cyy, d.gx, d.gy, 1, x0, y0, x1, y1);
+                    my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+                    rd = rdg_pack_rectd(x0, y0, x1, y1, vz, my_tiles);
                     radius_out = radius;
                     float cr, cg, cbl;
                     if (colors) {
@@ -209,18 +281,19 @@ rdg_preprocess_fwd_kernel(RdgDev d, const float* __restrict__ view_b, const floa
                         if (res[2] < 0.f) cl |= 4;
                         cr = fmaxf(res[0], 0.f); cg = fmaxf(res[1], 0.f); cbl = fmaxf(res[2], 0.f);
                     }
-                    R.q0 = make_float4(px, py, cc * det_inv, -cb * det_inv);
+                    R.q0 = rq0;
                     // q1.w carries the pixel radius: a record is then self-contained (another rank can bin it, rdg_geom_from_records)
-                    R.q1 = make_float4(ca * det_inv, opac[i], vz, __int_as_float(radius));
+                    R.q1 = rq1;
                     // q2.w = 1 / cov2D_yy = conic_c - conic_b^2 / conic_a without that difference's cancellation: the second
                     // coefficient of the completed square the compositing kernels evaluate (rdg_stage_conic)
-                    R.q2 = make_float4(cr, cg, cbl, 1.0f / cc);
+                    R.q2 = make_float4(cr, cg, cbl, inv_cyy);
                     R.q3 = make_float4(nx, ny, nz, 0.f);
                 }
             }
         }
         rec[i] = R;
         tiles_touched[i] = my_tiles;
+        rectd[i] = rd;
         clampedm[i] = cl;
         radii[i] = radius_out;
     }
@@ -293,26 +366,32 @@ __global__ void __launch_bounds__(1024) rdg_scan_block_sums_kernel(uint32_t* __r
 // Gaussian-sharded frame-DP: the records of this camera arrived from the ranks that own the Gaussians; rebuild what
 // the binning stage reads besides them (tile counts, radii, per-block sums) from the record itself.
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
-rdg_geom_from_records_kernel(int P, int gx, int gy, const RdgRec* __restrict__ rec,
+rdg_geom_from_records_kernel(int P, int gx, int gy, int cull, const RdgRec* __restrict__ rec,
                              uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums,
-                             int32_t* __restrict__ radii) {
+                             int32_t* __restrict__ radii, uint4* __restrict__ rectd) {
     const int i = blockIdx.x * RDG_PRE_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
     if (i < P) {
-        const float4 q0 = rec[i].q0;
-        const int radius = __float_as_int(rec[i].q1.w);
+        const float4 q0 = rec[i].q0, q1 = rec[i].q1;
+        const int radius = __float_as_int(q1.w);
+        uint4 rd = make_uint4(0u, 0u, 0u, 0u);
+        bool seen = false;
         // The per-tile sort compares (depth bits << 32 | id) composites as IEEE doubles (v_min_f64 / v_max_f64,
         // rdg_binning.hip rdg_cx): valid only for depth bits of a positive finite float.  This stage's own records
         // satisfy it by the near cull (vz > RDG_NEAR_CULL, which a NaN fails); records that arrived from another rank
         // are checked here -- anything else is dropped (tiles_touched = 0), never sorted.
-        const uint32_t dbits = __float_as_uint(rec[i].q1.z);
+        const uint32_t dbits = __float_as_uint(q1.z);
         if (radius > 0 && dbits > 0u && dbits < 0x7f800000u) {
             int x0, y0, x1, y1;
             rdg_rect(q0.x, q0.y, radius, gx, gy, x0, y0, x1, y1);
+            seen = (x1 - x0) * (y1 - y0) > 0;
+            if (seen && cull) rdg_splat_rect(q0, q1, rec[i].q2.w, gx, gy, 1, x0, y0, x1, y1);
             my_tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+            rd = rdg_pack_rectd(x0, y0, x1, y1, q1.z, my_tiles);
         }
         tiles_touched[i] = my_tiles;
-        radii[i] = my_tiles ? radius : 0;
+        rectd[i] = rd;
+        radii[i] = seen ? radius : 0;
     }
     __shared__ uint32_t wsum[RDG_PRE_BLOCK / RDG_WAVE];
     uint32_t inc = rdg_wave_scan_incl(my_tiles);
@@ -329,8 +408,9 @@ int rdg_launch_geom_from_records(const RdgDev& d, void* geom_ws, int32_t* radii,
     const int nblk = (d.P + RDG_PRE_BLOCK - 1) / RDG_PRE_BLOCK;
     uint32_t* block_sums = (uint32_t*)(g + L.block_sums);
     if (d.P > 0)
-        hipLaunchKernelGGL(rdg_geom_from_records_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy,
-                           (const RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), block_sums, radii);
+        hipLaunchKernelGGL(rdg_geom_from_records_kernel, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, d.cull,
+                           (const RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), block_sums, radii,
+                           (uint4*)(g + L.rectd));
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
                        num_rendered, (uint32_t*)nullptr, 0, d.nren_max);
     return rdg_check_hip(hipGetLastError(), "geom_from_records launch");
@@ -347,7 +427,8 @@ int rdg_launch_preprocess_fwd(const RdgDev& d, const float* means3D, const float
     if (d.P > 0) {
         hipLaunchKernelGGL(rdg_preprocess_fwd_kernel<false>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, view, proj, means3D,
                            shs, colors, opac, scales, rots, cov3D, (RdgRec*)(g + L.rec),
-                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0, 0);
+                           (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped), block_sums, radii, 1, 0, 0,
+                           (uint4*)(g + L.rectd));
     }
     hipLaunchKernelGGL(rdg_scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, d.P > 0 ? nblk : 0,
                        num_rendered, zero_buf, (int)zero_words, d.nren_max);
@@ -371,6 +452,7 @@ int rdg_launch_preprocess_fwd_views(const RdgDev& d_in, int32_t nviews, int32_t 
         hipLaunchKernelGGL(rdg_preprocess_fwd_kernel<true>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d, views, proj, means3D,
                            shs, (const float*)nullptr, opac, scales, rots, (const float*)nullptr,
                            (RdgRec*)(g + L.rec), (uint32_t*)(g + L.tiles_touched), (uint8_t*)(g + L.clamped),
-                           (uint32_t*)(g + L.block_sums), radii, nviews, stride, row0 / RDG_PRE_BLOCK);
+                           (uint32_t*)(g + L.block_sums), radii, nviews, stride, row0 / RDG_PRE_BLOCK,
+                           (uint4*)(g + L.rectd));
     return rdg_check_hip(hipGetLastError(), "preprocess_fwd views launch");
 }

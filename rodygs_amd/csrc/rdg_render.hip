@@ -60,8 +60,12 @@ __device__ __forceinline__ float rdg_edge_min(float a, float b2, float c, float 
     const float vs = __builtin_amdgcn_fmed3f(-0.5f * t * inv_c, v0, v1);
     return fmaf(fmaf(c, vs, t), vs, a * ue * ue);
 }
-__device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const float4 q1, float X0, float Y0) {
-    const float a = q0.z, b = q0.w, c = q1.x, o = q1.y;
+__device__ __forceinline__ uint32_t rdg_quadrant_bits(const float4 q0, const float4 q1, const float inv_cyy, float X0, float Y0) {
+    // c as the compositing kernels' completed square has it (rdg_stage_conic: a (dx + beta dy)^2 + dy^2 / cov2D_yy, i.e.
+    // c = b^2 / a + 1 / cov2D_yy), not the record's float32 conic_c: on a needle the two differ along the long axis by
+    // eps a c / det (5e-3 at 300 : 1), which the margin below was never meant to cover
+    const float a = q0.z, b = q0.w, o = q1.y;
+    const float c = (b * b) / a + inv_cyy;
     const float t255 = 255.0f * o;
     if (!(t255 >= 0.99f)) return 0u;  // alpha can never reach 1/255 (margin below); written so that a NaN opacity is dropped too
     const float det = a * c - b * b;
@@ -237,7 +241,7 @@ rdg_fwd_composite(const int k_begin, const int k_end, const uint2 range, const f
             *(float2*)&sQ1[tid] = make_float2(cs.gam, q1.y);
             sQ2[tid] = make_float4(q2.x, q2.y, q2.z, q1.z);
             if (NORMAL) sQ3[tid] = p->q3;
-            qbits = rdg_quadrant_bits(q0, q1, X0, Y0);
+            qbits = rdg_quadrant_bits(q0, q1, q2.w, X0, Y0);
             over_cap = q1.y > RDG_ALPHA_CAP;
         }
 #pragma unroll
@@ -838,7 +842,7 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                   const RdgRec* __restrict__ rec, const unsigned long long* __restrict__ hit, float4* sQ0, float4* sQ1,
                   float4* sQ2, float4* sQ3, unsigned long long (*sMask)[4], unsigned long long* sCap, float (*ring)[16][RDG_RING_Q],
                   const float flush_scale, const int flush_off, float* __restrict__ gdst, float& T, float& behind,
-                  int& ring_n, const uint32_t* __restrict__ det_off, const int gx, const int gy, const int tx, const int ty) {
+                  int& ring_n, const uint32_t* __restrict__ det_off, const uint4* __restrict__ rectd, const int tx, const int ty) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int rounds = (k_top - k_lo + RDG_BATCH - 1) / RDG_BATCH;
@@ -869,12 +873,10 @@ rdg_bwd_composite(const int k_lo, const int k_top, const uint2 range, const int 
                     if (DET) {
                         // deterministic mode: the row of this (tile, Gaussian) instance in Gaussian-major order -- the
                         // Gaussian's first instance (det_off, exclusive scan of tiles_touched) + the tile's ordinal inside
-                        // the Gaussian's rectangle (the rectangle rule of the binning stage, restated on the record): the
+                        // the Gaussian's rectangle (the rectangle the binning stage expanded, `rectd`): the
                         // reduction then reads a Gaussian's rows one after the other, no search
-                        const float r_ = (float)__float_as_int(q1.w);
-                        const int x0 = min(gx, max(0, (int)((q0.x - r_) / (float)RDG_TILE)));
-                        const int y0 = min(gy, max(0, (int)((q0.y - r_) / (float)RDG_TILE)));
-                        const int x1 = min(gx, max(0, (int)((((q0.x + r_) + (float)RDG_TILE) - 1.0f) / (float)RDG_TILE)));
+                        const uint4 rd = rectd[id];
+                        const int x0 = (int)(rd.x & 0xffffu), y0 = (int)(rd.x >> 16), x1 = (int)(rd.y & 0xffffu);
                         row = det_off[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
                     }
                     sQ2[tid] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(row));
@@ -930,7 +932,8 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
                       const float* __restrict__ g_depth, const float* __restrict__ g_alpha,
                       const float* __restrict__ g_normal, float* __restrict__ grow, const unsigned long long* __restrict__ hitbits, int split_min,
                       const uint32_t* __restrict__ sp_header, const uint4* __restrict__ sp_work,
-                      const float* __restrict__ seg_pix, const uint32_t* __restrict__ det_off, int gy) {
+                      const float* __restrict__ seg_pix, const uint32_t* __restrict__ det_off,
+                      const uint4* __restrict__ rectd) {
     __shared__ float4 sQ0[RDG_BATCH], sQ1[RDG_BATCH], sQ2[RDG_BATCH];   // sQ2.w = the Gaussian's row index (bits)
     __shared__ float4 sQ3[HAS_NORMAL ? RDG_BATCH : 1];                  // normals, only with a normal gradient
     __shared__ float sRing[4][RDG_RING][16][RDG_RING_Q];   // per wave: [entry][quad][slot] partial sums
@@ -1020,7 +1023,7 @@ rdg_render_bwd_kernel(int W, int H, int gx, int n_tiles, const float* __restrict
         rdg_bwd_composite<HAS_DEPTH, DET, HAS_NORMAL>(k_lo, k_top, range, m0, m1, m2, m3, last_contributor, pixx, pixy, dLp0,
                                                       dLp1, dLp2, dLd, dLn0, dLn1, dLn2, point_list, rec, hit, sQ0, sQ1, sQ2,
                                                       sQ3, sMask, sCap, sRing[wv], flush_scale, flush_off, gdst, T, behind,
-                                                      ring_n, det_off, gx, gy, tx, ty);
+                                                      ring_n, det_off, rectd, tx, ty);
         rdg_ring_flush<HAS_DEPTH, DET>(sRing[wv], ring_n, lane, flush_scale, flush_off, gdst);
     }
 }
@@ -1107,7 +1110,7 @@ int rdg_launch_render_bwd(const RdgDev& d, const float* bg, const void* geom_ws,
                        (const float*)(im + I.final_T), (const uint32_t*)(im + I.n_contrib), g_color, g_depth,      \
                        g_alpha, g_normal, DST, (const unsigned long long*)(b + B.hit), split_min,                  \
                        (const uint32_t*)(sp + SL.header), (const uint4*)(sp + SL.work), (const float*)(sp + SL.seg_pix), \
-                       (const uint32_t*)det_off, d.gy)
+                       (const uint32_t*)det_off, (const uint4*)((const char*)geom_ws + G.rectd))
 #define RDG_BWD_LAUNCH(DEPTH, DET, SEG, GRID, DST)                                                                 \
     do { if (g_normal) RDG_BWD_LAUNCH4(DEPTH, DET, SEG, true, GRID, DST); else RDG_BWD_LAUNCH4(DEPTH, DET, SEG, false, GRID, DST); } while (0)
     if (det) {

@@ -55,6 +55,13 @@ _FORCE_BUCKET = os.environ.get("RDG_BIN_MODE", "") == "bucket"
 # atomics (rdg_composite_backward_det) -- two runs give the same bits; ~2x the compositing backward (1.3x the train step) and 256 B per instance.
 DETERMINISTIC = os.environ.get("RDG_DETERMINISTIC", "0") == "1"
 
+# Tight tile rectangles (RdgRasterSettings.cull; RDG_CULL=0 in the environment or RasterState(cull=False) = the reference's
+# 3-sigma squares): the per-Gaussian stage hands the binning stage only the tiles that hold a pixel centre inside the box of
+# the splat's alpha >= 1/255 ellipse -- 27-32 % fewer (tile, Gaussian) instances on the benchmark frames, same image, same
+# gradients, same radii; every tile list a subsequence of the reference's.  The stage entry points the bit-exact key-stream
+# tests drive (rdg_preprocess_forward + rdg_bin_forward) take the switch from their settings struct like everything else.
+CULL = os.environ.get("RDG_CULL", "1") != "0"
+
 # hipGraph capture (rodygs_amd.trainstep.GraphedStep sets RasterState.graph_capture around capture; the module flag is the
 # same switch for every state): the forward touches nothing on the host -- capacity and binning mode come from the hints
 # of the warm-up steps, the instance count stays on the device (last_num_rendered()) and is checked by the owner of the
@@ -85,14 +92,16 @@ class RasterState:
 
     def __init__(self, deterministic: Optional[bool] = None, force_radix: Optional[bool] = None,
                  force_bucket: Optional[bool] = None, deferred_overflow_check: Optional[bool] = None,
-                 render_normal: Optional[bool] = None):
-        """The four mode switches ride on the state (two trainers in one process can differ in them): ``deterministic``
+                 render_normal: Optional[bool] = None, cull: Optional[bool] = None):
+        """The mode switches ride on the state (two trainers in one process can differ in them): ``deterministic``
         (compositing backward without float atomics), ``force_radix`` / ``force_bucket`` (binning algorithm on every frame),
-        ``deferred_overflow_check`` (no host wait for the instance count), ``render_normal`` (composite the normal channels).
+        ``deferred_overflow_check`` (no host wait for the instance count), ``render_normal`` (composite the normal channels),
+        ``cull`` (tight tile rectangles: see CULL).
         None = follow the module attribute of that name (DETERMINISTIC, _FORCE_RADIX, _FORCE_BUCKET, DEFERRED_OVERFLOW_CHECK,
-        RENDER_NORMAL) as it stands when a forward runs -- the process-wide default, initialised from the environment."""
+        RENDER_NORMAL, CULL) as it stands when a forward runs -- the process-wide default, initialised from the environment."""
         self.deterministic, self.force_radix, self.force_bucket = deterministic, force_radix, force_bucket
         self.deferred_overflow_check, self.render_normal = deferred_overflow_check, render_normal
+        self.cull = cull
         self.capacity_hint = {}       # (P, H, W) -> last num_rendered
         self.d_high = {}              # (P, H, W) -> slowly decaying maximum of num_rendered over the checked frames (HINT_DECAY)
         self.bin_hint = {}            # (P, H, W) -> 1 while the largest tile list of the last frame calls for the radix path
@@ -120,7 +129,8 @@ class RasterState:
         if v is not None:
             return bool(v)
         return bool({"deterministic": DETERMINISTIC, "force_radix": _FORCE_RADIX, "force_bucket": _FORCE_BUCKET,
-                     "deferred_overflow_check": DEFERRED_OVERFLOW_CHECK, "render_normal": RENDER_NORMAL}[name])
+                     "deferred_overflow_check": DEFERRED_OVERFLOW_CHECK, "render_normal": RENDER_NORMAL,
+                     "cull": CULL}[name])
 
     def note_instances(self, key, n: int) -> None:
         """Fold a frame's instance count into the slowly decaying maximum a graph owner sizes its fixed capacity with (consecutive
@@ -230,6 +240,7 @@ def _c_settings(rs: GaussianRasterizationSettings, P: int, M: int, state: Option
     s.bin_mode = 1 if state.mode("force_radix") else 0
     s.num_rendered_stats = 0
     s.list_hints = 0
+    s.cull = int(state.mode("cull"))
     return s
 
 
@@ -426,7 +437,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 if n >= _INSTANCE_LIMIT:
                     raise RuntimeError(_too_many(key))
                 with state.lock:
-                    state.capacity_hint[key] = n
+                    # an owner that checks only now and then (GraphedStep.check, the deferred mode) may have left a HIGHER
+                    # record of this shape: keep it, decayed like everywhere else, instead of following this one frame down
+                    checked = (state.nren_max is not None and state.nren_max_key in (None, key)) or bool(state.pending)
+                    state.capacity_hint[key] = max(n, int(state.capacity_hint.get(key, 0) * HINT_DECAY)) if checked else n
                     state.note_instances(key, n)
                     state.note_largest_tile(key, largest, n)
                 if n <= cap:

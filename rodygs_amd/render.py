@@ -44,3 +44,31 @@ def render(xyz, active_sh_degree, opacity, scaling, rotation, features, viewpoin
     out = dict(zip(_IMAGE_KEYS, images))
     out.update(viewspace_points=mean2d_sink, visibility_filter=radii > 0, radii=radii, extra=extra)
     return out
+
+
+def render_model(model, viewpoint_camera, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+                 enable_sh_grad=False, enable_cov_grad=False, translation=0.0, rotation=0.0,
+                 raster_state: Optional[RasterState] = None, **kwargs):
+    """The MODEL variant of the glue -- ``StaticRoDyGS.render`` (/root/reference/src/model/rodygs_static.py:184-296), the one
+    ``PoseOptimizer`` (src/evaluator/eval.py:407-412) and ``ThreeDGSTrainer.train_iteration``
+    (src/trainer/rodygs_static.py:375-381) call: the cloud comes from the model's getters (``get_xyz``, ``get_opacity``,
+    ``get_scaling``, ``get_rotation``, ``get_features``, ``active_sh_degree``, ``isotropic``), ``translation`` is added to the
+    means and ``rotation`` to the (activated) quaternions -- the latter only for an anisotropic model, as the reference
+    does (:247-249) --, both default to the number 0.0, and both are handed back under the two extra keys ``translation`` and
+    ``rotation`` of the result (:294-295).  ``viewspace_points`` is the reference's non-leaf ``zeros + 0`` with its gradient
+    retained (:204-216): ``.grad`` holds dL/dmean2D after backward.  Unknown keyword arguments are accepted and ignored, as
+    the reference's ``**kwargs`` does; ``raster_state`` is outside the reference surface."""
+    xyz = model.get_xyz
+    settings = camera_settings(viewpoint_camera, bg_color, model.active_sh_degree, scaling_modifier,
+                               cov_gate=enable_sh_grad, sh_gate=enable_cov_grad)
+    mean2d_sink = torch.zeros_like(xyz, requires_grad=True) + 0
+    mean2d_sink.retain_grad()
+    quats = model.get_rotation if getattr(model, "isotropic", False) else model.get_rotation + rotation
+    colour = {"colors_precomp": override_color} if override_color is not None else {"shs": model.get_features}
+    *images, radii, extra = GaussianRasterizer(settings, state=raster_state)(
+        means3D=xyz + translation, means2D=mean2d_sink, opacities=model.get_opacity, scales=model.get_scaling,
+        rotations=quats, viewmatrix=viewpoint_camera.world_view_transform.t(), **colour)
+    out = dict(zip(_IMAGE_KEYS, images))
+    out.update(viewspace_points=mean2d_sink, visibility_filter=radii > 0, radii=radii, extra=extra,
+               translation=translation, rotation=rotation)
+    return out

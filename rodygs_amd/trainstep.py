@@ -718,7 +718,12 @@ class GraphedStep:
         if n >= rasterizer._INSTANCE_LIMIT:
             raise RuntimeError(rasterizer._too_many(self._key))
         with st.lock:
-            st.capacity_hint[self._key] = max(n, int(st.capacity_hint.get(self._key, 0) * 0.9))   # (n = max over the replays)
+            # the replayed maximum feeds BOTH records the next capture sizes itself with: the hint (a slowly decaying maximum,
+            # the rule of every other path) and d_high -- the new GraphedStep's eager warm-up forward takes its capacity from
+            # the hint, and without d_high having seen the overflowing count the re-captured graph could come out too small
+            # again whenever no densification sits between check() and the re-capture
+            st.capacity_hint[self._key] = max(n, int(st.capacity_hint.get(self._key, 0) * rasterizer.HINT_DECAY))
+            st.note_instances(self._key, n)
         if n > self._cap:
             raise rasterizer.RasterizerCapacityOverflow(
                 f"a replayed frame needed {n} instances, the graph was captured with {self._cap}: that frame was "

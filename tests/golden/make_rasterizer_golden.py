@@ -13,7 +13,9 @@ shows up against committed numbers.  Two scenes:
           pose, coloured background, SH degree 1 -- the long-list paths of binning and compositing.
 Stored per scene: every input, and radii, tiles_touched, D, unsorted / sorted keys + values, tile ranges,
 n_contrib, final_T, colour / depth / normal / alpha, and the gradient of `fixture_loss` w.r.t. every input
-including viewmatrix and means2D.  Arrays only (no source text)."""
+including viewmatrix and means2D -- all under the REFERENCE's tile-rectangle rule (OracleSettings.cull = False) --, plus
+(`cull_*`, round 6) the integers that change under the tight rectangles of RdgRasterSettings.cull = 1: tiles_touched, D,
+sorted keys / values, ranges and n_contrib (a list position).  Arrays only (no source text)."""
 import math
 import os
 import sys
@@ -27,6 +29,8 @@ if ROOT not in sys.path:
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 INPUTS = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
+CULL_KEYS = ("tiles_touched", "num_rendered", "keys_unsorted", "vals_unsorted", "keys_sorted", "vals_sorted", "ranges",
+             "n_contrib")
 
 
 def fixture_weights(H, W):
@@ -63,13 +67,13 @@ def scenes():
     return {"c1": (c1, 0, (0.0, 0.0, 0.0)), "skewed": (sk, 1, (0.1, 0.2, 0.3))}
 
 
-def run_oracle(inp, deg, bg, H, W, tanx, tany, proj):
+def run_oracle(inp, deg, bg, H, W, tanx, tany, proj, cull=False):
     """inp: dict of float32 CPU tensors.  Returns (arrays dict) of everything the fixture stores."""
     from oracle import rasterizer_oracle as O
     ins = {k: inp[k].clone().requires_grad_(True) for k in INPUTS}
     P = ins["means3D"].shape[0]
     m2 = torch.zeros(P, 3, requires_grad=True)
-    st = O.OracleSettings(H, W, tanx, tany, torch.tensor(bg), 1.0, proj, deg)
+    st = O.OracleSettings(H, W, tanx, tany, torch.tensor(bg), 1.0, proj, deg, cull=cull)
     color, depth, normal, alpha, radii, aux = O.rasterize(ins["means3D"], m2, ins["opacities"], ins["viewmatrix"], st,
                                                           shs=ins["shs"], scales=ins["scales"], rotations=ins["rotations"])
     fixture_loss(color, depth, alpha).backward()
@@ -94,6 +98,8 @@ def main():
                      in_tanfovy=np.float64(sc["tanfovy"]), in_W=np.int64(sc["W"]), in_H=np.int64(sc["H"]),
                      in_sh_degree=np.int64(deg), in_bg=np.asarray(bg, dtype=np.float32))
         store.update(out)
+        culled = run_oracle(inp, deg, bg, sc["H"], sc["W"], sc["tanfovx"], sc["tanfovy"], sc["projmatrix"], cull=True)
+        store.update({"cull_" + k: culled[k] for k in CULL_KEYS})
         path = os.path.join(OUT, f"rasterizer_golden_{name}.npz")
         np.savez_compressed(path, **store)
         r = out["ranges"].astype(np.int64)

@@ -16,9 +16,11 @@ def make_settings(sc, sh_degree, bg=None, dev="cuda", cov_grad=True, sh_grad=Tru
         debug=False, enable_cov_grad=cov_grad, enable_sh_grad=sh_grad)
 
 
-def run_stages(sc, sh_degree, dev="cuda", capacity=None, bin_mode=None):
+def run_stages(sc, sh_degree, dev="cuda", capacity=None, bin_mode=None, cull=None):
     """preprocess -> export -> bin (with copies) on the GPU; returns numpy views of every intermediate.
-    bin_mode: 0 = bucket binning, 1 = LSD radix sort (RdgRasterSettings.bin_mode); None = the default of the settings."""
+    bin_mode: 0 = bucket binning, 1 = LSD radix sort (RdgRasterSettings.bin_mode); None = the default of the settings.
+    cull: RdgRasterSettings.cull -- False = the reference's tile rectangles (the north_star's key stream), True = the tight
+    ones; None = the product's default (rasterizer.CULL)."""
     L = _lib.lib()
     rs = make_settings(sc, sh_degree, dev=dev)
     m3 = sc["means3D"].to(dev).contiguous()
@@ -27,6 +29,8 @@ def run_stages(sc, sh_degree, dev="cuda", capacity=None, bin_mode=None):
     cs = _c_settings(rs, P, shs.shape[1])
     if bin_mode is not None:
         cs.bin_mode = int(bin_mode)
+    if cull is not None:
+        cs.cull = int(bool(cull))
     H, W = sc["H"], sc["W"]
     n_tiles = ((W + 15) // 16) * ((H + 15) // 16)
     u8 = dict(dtype=torch.uint8, device=dev)

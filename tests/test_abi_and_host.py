@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
         assert hasattr(raw, n), f"{n} declared in include/rodygs_hip.h but not exported"
     # and the ctypes binding table covers the whole header
     assert set(names) == set(_lib.EXPORTED_SYMBOLS)
-    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 6
+    assert hip_lib.rdg_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_workspace_sizes(hip_lib):
@@ -579,3 +579,30 @@ def test_flat_params_laid_out_in_given_storage():
     import pytest as _pt
     with _pt.raises(ValueError):
         FlatParams(spec, "cpu", storage=FlatStorage(n - 1, "cpu"))
+
+
+def test_the_binding_documented_in_integration_md_matches_the_library(hip_lib):
+    """INTEGRATION.md shows the ctypes binding a RoDyGS maintainer would write.  A maintainer who copies it must get THE
+    struct of the library: the snippet is extracted from the document and EXECUTED up to its `def forward` -- its two guards
+    (rdg_abi_version, rdg_settings_bytes) run against the built library -- and its field table is compared with the
+    package's own mirror name by name, type by type.  (Round 5's snippet ended one field short: the backward would have read
+    `aux_stream` past the end of the caller's struct.)"""
+    import ctypes
+    import re
+    from rodygs_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    snippet = next(b for b in blocks if "class RdgRasterSettings(C.Structure)" in b)
+    head = snippet.split("def forward(")[0]
+    assert "rdg_settings_bytes" in head and "rdg_abi_version" in head, "the snippet must call the header's two guards"
+    os.environ["RDG_LIB_PATH"] = _lib.LIB_PATH
+    ns = {}
+    exec(compile(head, "INTEGRATION.md", "exec"), ns)         # raises if a guard fails
+    doc = ns["RdgRasterSettings"]
+    assert ctypes.sizeof(doc) == ctypes.sizeof(_lib.RdgRasterSettings) == hip_lib.rdg_settings_bytes()
+    assert [(n, t) for n, t in doc._fields_] == [(n, t) for n, t in _lib.RdgRasterSettings._fields_]
+    for (n, _t) in doc._fields_:
+        assert getattr(doc, n).offset == getattr(_lib.RdgRasterSettings, n).offset, n
+    # and the forward of the snippet names arguments in the header's order: 1 struct + 12 pointers + capacity + 8 pointers
+    assert "[C.c_void_p] * 12 + [C.c_int64] + [C.c_void_p] * 8" in snippet

@@ -254,7 +254,7 @@ def test_oracle_reproduces_the_committed_rasterizer_fixture(scene):
     spec.loader.exec_module(M)
     g = load(f"rasterizer_golden_{scene}.npz")
     inp, c = raster_fixture_inputs(g)
-    out = M.run_oracle(inp, c["deg"], c["bg"], c["H"], c["W"], c["tanx"], c["tany"], c["proj"])
+    out = M.run_oracle(inp, c["deg"], c["bg"], c["H"], c["W"], c["tanx"], c["tany"], c["proj"], cull=False)
     assert int(out["num_rendered"]) == int(g["num_rendered"])
     for k in RASTER_INT:
         assert np.array_equal(out[k], g[k]), k
@@ -262,6 +262,16 @@ def test_oracle_reproduces_the_committed_rasterizer_fixture(scene):
         scale = np.abs(g[k]).max() + 1e-30
         assert np.abs(out[k] - g[k]).max() <= 2e-5 * scale, (k, np.abs(out[k] - g[k]).max() / scale)
     assert (out["n_contrib"] != g["n_contrib"]).mean() <= 2e-5
+    # the tight rectangles (RdgRasterSettings.cull = 1): their integers are frozen too; every float is the SAME fixture's
+    cul = M.run_oracle(inp, c["deg"], c["bg"], c["H"], c["W"], c["tanx"], c["tany"], c["proj"], cull=True)
+    assert int(cul["num_rendered"]) == int(g["cull_num_rendered"]) < int(g["num_rendered"])
+    assert np.array_equal(cul["radii"], g["radii"])
+    for k in ("tiles_touched", "keys_unsorted", "vals_unsorted", "keys_sorted", "vals_sorted", "ranges"):
+        assert np.array_equal(cul[k], g["cull_" + k]), k
+    for k in RASTER_IMG + RASTER_GRAD:
+        scale = np.abs(g[k]).max() + 1e-30
+        assert np.abs(cul[k] - g[k]).max() <= 2e-5 * scale, ("cull", k, np.abs(cul[k] - g[k]).max() / scale)
+    assert (cul["n_contrib"] != g["cull_n_contrib"]).mean() <= 2e-5
     if scene == "skewed":                           # the fixture really exercises what it is there for
         r = g["ranges"].astype(np.int64)
         n = np.sort(r[:, 1] - r[:, 0])
