@@ -62,7 +62,8 @@ def render_model(model, viewpoint_camera, bg_color: torch.Tensor, scaling_modifi
     settings = camera_settings(viewpoint_camera, bg_color, model.active_sh_degree, scaling_modifier,
                                cov_gate=enable_sh_grad, sh_gate=enable_cov_grad)
     mean2d_sink = torch.zeros_like(xyz, requires_grad=True) + 0
-    mean2d_sink.retain_grad()
+    if mean2d_sink.requires_grad:          # (not under torch.no_grad(): the reference wraps the call in try / except)
+        mean2d_sink.retain_grad()
     quats = model.get_rotation if getattr(model, "isotropic", False) else model.get_rotation + rotation
     colour = {"colors_precomp": override_color} if override_color is not None else {"shs": model.get_features}
     *images, radii, extra = GaussianRasterizer(settings, state=raster_state)(

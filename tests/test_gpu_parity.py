@@ -25,7 +25,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 OUTLIER_FRAC = 2e-5
-OUTLIER_CAP = 2e-2
+OUTLIER_CAP = 2e-2          # small scenes (check_pair): ONE flipped pixel is a visible share of a 777-Gaussian column
+FULL_FRAME_CAP = 5e-3       # whole frames (full_frame_report): what a witnessed flip may move, column scales of 10^5 Gaussians
 DEV = "cuda"
 NAMES = ("means3D", "shs", "opacities", "scales", "rotations", "viewmatrix")
 
@@ -905,12 +906,14 @@ def test_full_size_sampled_tiles_against_oracle(P, W, H, n_sample):
     rel_ok(hm2.grad, om2.grad, outliers=OUTLIER_FRAC, what="sampled tiles d_means2D", flips=flips)
 
 
-def _full_frame_pair(P, W, H, seed=5):
+def _full_frame_pair(P, W, H, seed=5, variant="uniform", sc=None):
     """run_pair on a BASELINE-size frame with an UNRESTRICTED loss (random weights on every pixel of colour, depth and
-    alpha), packed for oracle.parity.full_frame_report."""
+    alpha), packed for oracle.parity.full_frame_report.  sc: the rasterizer inputs to use instead of the section-8d generator's."""
     from rodygs_amd import rasterizer
-    sc = O.synthetic_scene(P, W, H, 3, seed=777)
-    sc["viewmatrix"] = orbit_view(4.0, -2.0, (0.3, -0.2, 0.5))
+    if sc is None:
+        sc = O.synthetic_scene(P, W, H, 3, seed=777, variant=variant)
+        sc["viewmatrix"] = orbit_view(4.0, -2.0, (0.3, -0.2, 0.5))
+    P = sc["means3D"].shape[0]
     # the oracle's tensors are a few hundred KB each: beyond ~16 threads torch's intra-op fork / join costs more than it buys
     # (bench.py's CPU leg: 1 M / 1080p in 15 s on 16 threads of the 256-core box, 100 s on all of them)
     threads = torch.get_num_threads()
@@ -934,7 +937,8 @@ def _full_frame_pair(P, W, H, seed=5):
                                    (1000000, 1920, 1080),       # configs[2..3]: the frame the headline is quoted on
                                    (4000000, 3840, 2160)])      # configs[4]: the largest size, all 32 400 tiles
 def test_full_frame_parity(P, W, H):
-    """EVERY tile of the frame: the oracle composites all 8 160 tiles forward and backward (seconds on the host), the loss
+    """(the section-8d generator's untrained `uniform` cloud; the hard regimes: test_full_frame_parity_hard_regimes)
+    EVERY tile of the frame: the oracle composites all 8 160 tiles forward and backward (seconds on the host), the loss
     is unrestricted, and every pixel of colour / depth / normal / alpha / final_T, n_contrib, radii, D and every entry of every
     gradient (incl. viewmatrix and means2D) is held to 1e-4 of its column -- no outlier fraction.  The only entries that
     may miss the bar (and then must stay below 2e-2) are the ones a WITNESSED decision flip explains: the flipped pixels
@@ -942,7 +946,7 @@ def test_full_frame_parity(P, W, H):
     (oracle.parity.full_frame_report).  The flips themselves are bounded: at most 2e-5 of the pixels."""
     from oracle.parity import full_frame_report
     hip, orc, binning, gx = _full_frame_pair(P, W, H)
-    rep = full_frame_report(hip, orc, binning["vals_sorted"], binning["ranges"], gx, tol=TOL, cap=OUTLIER_CAP)
+    rep = full_frame_report(hip, orc, binning["vals_sorted"], binning["ranges"], gx, tol=TOL, cap=FULL_FRAME_CAP)
     assert rep["ok"], rep
     assert rep["witnessed_flips"] <= OUTLIER_FRAC * H * W, rep
     assert rep["n_contrib_mismatch_off_flips"] == 0

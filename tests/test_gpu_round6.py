@@ -138,3 +138,110 @@ def test_torch_free_c_caller_of_the_abi_reproduces_the_committed_fixture(tmp_pat
             want = g["grad_" + name]
             got = np.fromfile(d / f"out_d_{name}.bin", dtype=np.float32).reshape(want.shape)
             TP.rel_ok(got, want, outliers=TP.OUTLIER_FRAC, what=f"C caller d_{name} (cull {cull})", flips=flips)
+
+
+# ---- full-frame parity in the numerically hard regimes, at the headline size -----------------------------------------------
+
+def _report(hip, orc, binning, gx):
+    from oracle.parity import full_frame_report
+    TP = _tp()
+    return full_frame_report(hip, orc, binning["vals_sorted"], binning["ranges"], gx, tol=TP.TOL, cap=TP.FULL_FRAME_CAP)
+
+
+@pytest.mark.parametrize("variant", ["dense", "sheets"])
+def test_full_frame_parity_hard_regimes(variant):
+    """test_full_frame_parity's rule (every pixel, every gradient entry, 1e-4 per column, no outlier fraction; misses only where
+    a witnessed flip explains them, 5e-3 there) at 1 M Gaussians / 1080p on the two scenes the section-8d generator never
+    enters: `dense` (three times the projected sigma: 12 M instances after the tight rectangles, ~1 500 per tile -- the radix
+    binning the per-frame rule picks, lists deep enough for the split compositing path on the heaviest tiles) and `sheets`
+    (surface-like: opacities 0.6-0.99 on eight depth sheets, every pixel saturates within the first sheets -- early stops
+    everywhere, n_contrib far below the list length)."""
+    TP = _tp()
+    P, W, H = 1000000, 1920, 1080
+    hip, orc, binning, gx = TP._full_frame_pair(P, W, H, variant=variant)
+    rep = _report(hip, orc, binning, gx)
+    assert rep["ok"], rep
+    # deep lists: more decisions per pixel sit on a discontinuity than on the uniform frame (2e-5 there)
+    assert rep["witnessed_flips"] <= 1e-4 * H * W, rep
+    assert rep["n_contrib_mismatch_off_flips"] == 0
+    r = binning["ranges"].astype(np.int64)
+    mean_list = float((r[:, 1] - r[:, 0]).mean())
+    assert mean_list > (900 if variant == "dense" else 500), mean_list            # the regime the test is there for
+
+
+def test_full_frame_parity_on_a_trained_densified_cloud():
+    """The same rule on a cloud the train LOOP produced: 1 M Gaussians at 1080p, 300 steps of the product's train step with
+    densify_and_prune after every 100 (the reference's cadence, bench.py --loop) -- clones and split children (anisotropic,
+    shrunk, overlapping their parents), opacities and scales moved by Adam, a refined pose --, then the rasterizer inputs of one
+    frame as they stand (bench.capture_bench_frame) through the HIP path and the oracle."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from rodygs_amd import rasterizer
+    from rodygs_amd.trainstep import DynamicScene
+    TP = _tp()
+    P, W, H = 1000000, 1920, 1080
+    sc = O.synthetic_scene(P, W, H, 3, seed=777)
+    tgt = O.synthetic_scene(P // 4, W, H, 3, seed=778)
+    frames = [0, 6, 12, 19, 25, 31, 38, 44]
+    ds = DynamicScene(sc, num_frames=50, device=DEV, spatial_order=True)
+    ds.make_ground_truth(tgt, frames)
+    ds.track_densification()
+    step = 0
+    keep = rasterizer.DEFERRED_OVERFLOW_CHECK
+    try:
+        for seg in range(3):
+            for _ in range(100):
+                ds.train_step(step, perm=frames)
+                step += 1
+                rasterizer.DEFERRED_OVERFLOW_CHECK = True
+            g_mean = (ds.stats.xyz_gradient_accum / ds.stats.denom.clamp_min(1)).reshape(-1)
+            info = ds.densify(max_grad=torch.quantile(g_mean, 0.97), min_opacity=0.005, want_decisions=False)
+            assert info["cloned"] + info["split"] > 0
+        ds.raster_state.poll_overflow(block=True)
+    finally:
+        rasterizer.DEFERRED_OVERFLOW_CHECK = keep
+    assert ds.P > 1.05 * P
+    fr, _gt = bench.capture_bench_frame(ds, frames[3])
+    del ds
+    torch.cuda.empty_cache()
+    hip, orc, binning, gx = TP._full_frame_pair(fr["means3D"].shape[0], W, H, sc=fr)
+    rep = _report(hip, orc, binning, gx)
+    assert rep["ok"], rep
+    assert rep["witnessed_flips"] <= 1e-4 * H * W, rep
+    assert rep["n_contrib_mismatch_off_flips"] == 0
+
+
+# ---- the randomised sweep under FROZEN rules ---------------------------------------------------------------------------------
+# What a miss of the per-column bar may be taken to, and in how many cases of a sweep, is fixed HERE: the hash covers the
+# arbiters (tests/resolution.py), the comparison rules (oracle/parity.py, rel_ok / check_pair / run_pair), the case generators
+# and the case runner.  Editing any of them changes the hash: this constant has to be edited in the same commit, where the
+# diff shows it.  (Rounds 4-5 ran these sweeps from a script, and round 5 corrected two rules AFTER seeing two cases fail
+# under them; a sweep inside the driver's test run, on seeds no earlier round looked at, is what polices that.)
+SWEEP_RULES_HASH = "f8d2927394e949d6"
+SWEEP_SEEDS = {"regular": 610000, "aniso": 620000}
+SWEEP_CASES = int(os.environ.get("RDG_SWEEP_TEST_CASES", "300"))
+# most cases a class may hold in a profile's sweep (of SWEEP_CASES = 300; scaled for other counts); "fail": never
+SWEEP_LIMITS = {"regular": {"flip": 6, "f64": 3, "geom": 2, "f32": 2, "f32s": 1, "cond": 1},
+                "aniso": {"flip": 9, "f64": 9, "geom": 6, "f32": 6, "f32s": 3, "cond": 3}}
+
+
+@pytest.mark.parametrize("profile", ["regular", "aniso"])
+def test_randomised_sweep_under_frozen_rules(profile):
+    """300 random small scenes per profile (sizes 1 ... 5 000 Gaussians, ragged images, every SH degree, random pose / background /
+    gates / scale modifier; `aniso`: pancakes and needles 10-300x thinner than long) through the HIP path and the oracle:
+    NO case may FAIL, and each arbiter class may explain only a handful (SWEEP_LIMITS)."""
+    import sweep_run
+    assert sweep_run.rules_hash() == SWEEP_RULES_HASH, "the sweep's rules were edited: update SWEEP_RULES_HASH in the same commit"
+    counts, lines = {}, []
+    for c in range(SWEEP_CASES):
+        verdict, tag, txt = sweep_run.run_case("aniso" if profile == "aniso" else "", SWEEP_SEEDS[profile], c)
+        counts[verdict] = counts.get(verdict, 0) + 1
+        if verdict != "ok":
+            lines.append(f"{verdict}: {tag} || {txt[:600]}")
+    print(f"sweep {profile}: {counts}")
+    for ln in lines:
+        print(ln)
+    assert counts.get("fail", 0) == 0, "\n".join(ln for ln in lines if ln.startswith("fail"))
+    scale = max(1.0, SWEEP_CASES / 300.0)
+    for cls, lim in SWEEP_LIMITS[profile].items():
+        assert counts.get(cls, 0) <= math.ceil(lim * scale), (cls, counts, lines)

@@ -125,3 +125,17 @@ def test_bench_cpu_leg_feeds_the_oracle_the_frames_own_bits_and_its_result_passe
     assert "skipped" in bench._parity(None, o2, gt) and "skipped" in bench._parity(o1h, None, gt)
     n, model = bench._host_cpu()
     assert n == os.cpu_count()
+
+
+def test_the_frozen_sweep_rules_hash_is_current():
+    """tests/test_gpu_round6.py::test_randomised_sweep_under_frozen_rules holds a hash of everything that decides a sweep
+    verdict; checked here on the CPU as well, so that an edited rule without the edited constant fails before any GPU run."""
+    import importlib
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    sweep_run = importlib.import_module("sweep_run")
+    src = open(os.path.join(here, "test_gpu_round6.py")).read()
+    assert f'SWEEP_RULES_HASH = "{sweep_run.rules_hash()}"' in src
