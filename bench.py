@@ -764,6 +764,57 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def live_pmc(P, W, H, scene, timeout_s=120.0):
+    """Hardware counters of THIS run's box and build: three child runs of a short bench under `rocprofv3 --pmc ...` --
+    FETCH_SIZE, WRITE_SIZE (separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes for the HBM bytes; FETCH_SIZE
+    doubled per its gfx950 note) and one pass of the SQ instruction counters -- counters only, no trace domain next to them; the
+    program after `--` is python3 itself (no shell, no env wrapper).  Parsed like scripts/pmc_hbm_traffic.py / pmc_summary.py.
+    Returns (tables, note): tables = {counter: {kernel (template arguments stripped): (mean per launch, launches)}} or None."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found on this box"
+    env = dict(os.environ, TMPDIR="/tmp")
+    tables = {}
+    tmp = tempfile.mkdtemp(prefix="rdg_pmc_", dir="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE")):
+            d = os.path.join(tmp, counters[0])
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "4", "--warmup", "2", "--settle", "4", "--points", str(P), "--width", str(W), "--height", str(H),
+                   "--scene", scene, "--no-cpu-baseline", "--no-sub-records"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=env)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {' '.join(counters)} pass failed (exit {r.returncode}): {(r.stderr or '')[-200:]}"
+            tot = {c: collections.defaultdict(lambda: [0.0, 0]) for c in counters}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] not in tot:
+                        continue
+                    k = re.sub(r"<.*>", "", row["Kernel_Name"].split("(")[0].replace("void ", "")).strip()
+                    a = tot[row["Counter_Name"]][k]
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
+            for c in counters:
+                tables[c] = {k: (v[0] / v[1], v[1]) for k, v in tot[c].items() if v[1] and k.startswith("rdg_")}
+        if "rdg_render_bwd_kernel" not in tables.get("FETCH_SIZE", {}):
+            return None, "the PMC passes ran but hold no rdg_render_bwd_kernel rows"
+        return tables, (f"LIVE: rocprofv3 --pmc child passes of this run (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_INSTS_SALU "
+                        f"GRBM_GUI_ACTIVE; {tables['FETCH_SIZE']['rdg_render_bwd_kernel'][1]} launches of the dominant kernel, "
+                        f"{time.perf_counter() - t0:.0f} s); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; gfx950 correction)")
+    except Exception as e:                                    # noqa: BLE001
+        return None, f"live PMC passes failed: {type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _child_json(argv, timeout_s, script="bench.py"):
     """Run `python <script> argv...` as a CHILD process (never exec: this process has initialised the GPU) and return the last
     JSON line of its stdout, or {"error": ...}.  Sub-records must never take the headline down with them."""
@@ -908,6 +959,8 @@ def main():
     ap.add_argument("--no-sub-records", action="store_true",
                     help="skip the compact loop / reference-iteration / 100 k graph / PSNR-delta records the default N = 1 headline run "
                          "appends (sub_records: child runs after the timed region)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes the default N = 1 headline run takes roofline.traffic from")
     ap.add_argument("--preflight", action="store_true",
                     help="print devices, peer access, RCCL version and the wire bytes of both frame-DP formulations, and exit")
     ap.add_argument("--no-normal", action="store_true",
@@ -1182,6 +1235,33 @@ def main():
                     res["psnr_delta_db"] = pd["drift_db"]          # BASELINE.json metric: "... PSNR delta vs ref"
             except Exception as e:                            # noqa: BLE001
                 res["sub_records"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if default_run and not args.no_live_pmc:
+            # roofline.traffic and the VALU-issue figures from the counters of THIS box and THIS build (the committed
+            # profiles/ files stay the fallback, labelled as such)
+            tables, note = live_pmc(P, W, H, args.scene)
+            if tables is not None:
+                def hbm(k):
+                    return 2 * tables["FETCH_SIZE"].get(k, (0.0, 0))[0] * 1024 + tables["WRITE_SIZE"].get(k, (0.0, 0))[0] * 1024
+                live = hbm("rdg_render_bwd_kernel")
+                res["roofline"]["traffic"], res["roofline"]["traffic_source"] = live, note
+                res["roofline"]["traffic_over_algorithmic"] = live / alg_bytes
+                res["hbm_traffic_per_kernel_live"] = {k: hbm(k) for k in sorted(set(tables["FETCH_SIZE"]) | set(tables["WRITE_SIZE"]))}
+                lv = {"issue_classes_cycles_per_inst": VALU_ISSUE_CLASSES, "source": note}
+                for stage, k in (("render_fwd", "rdg_render_fwd_kernel"), ("render_bwd", "rdg_render_bwd_kernel")):
+                    try:
+                        insts, salu = tables["SQ_INSTS_VALU"][k][0], tables["SQ_INSTS_SALU"][k][0]
+                        cycles = tables["GRBM_GUI_ACTIVE"][k][0] / 8.0       # counted per XCD (8 of them)
+                        cpi = cycles * N_SIMD / insts
+                        lv[stage] = {"valu_wave_insts_per_launch": insts, "salu_wave_insts_per_launch": salu,
+                                     "kernel_cycles": cycles, "cycles_per_valu_inst_per_simd": cpi,
+                                     "frac_of_issue_ceiling": VALU_ISSUE_CLASSES["f32 mul/add/fma/mov with VGPR sources"] / cpi}
+                    except (KeyError, ZeroDivisionError):
+                        pass
+                if "render_bwd" in lv:
+                    res["render_valu_issue"] = lv
+                    res["roofline"]["second_roofline"] = {"bound": "valu_issue", **lv["render_bwd"], "source": note}
+            else:
+                res["roofline"]["traffic_live_note"] = note
     # The JSON line is the LAST line on stdout: RCCL writes its version banner through C stdio, which sits in a buffer until the
     # process exits when stdout is a pipe -- after Python's print.  Every rank flushes C stdio, the ranks meet, then rank 0 prints.
     import ctypes

@@ -1869,12 +1869,13 @@ def test_pose_view_matrix_matches_reference_camera():
         rel_ok(qg.grad, qc.grad, tol=1e-5, what="d_quat"); rel_ok(tg.grad, tc.grad, tol=1e-5, what="d_trans")
 
 
-@pytest.mark.parametrize("NR", [1, 37, 101, 300])
-def test_mfma_mlp_matches_torch(NR):
-    """rdg_mlp_forward/backward (v_mfma_f32_16x16x4_f32) vs the torch expression of the same network."""
+@pytest.mark.parametrize("NR,width", [(1, 128), (16, 128), (37, 128), (101, 128), (300, 128), (33, 64), (20, 40), (50, 32)])
+def test_mfma_mlp_matches_torch(NR, width):
+    """rdg_mlp_forward/backward (v_mfma_f32_16x16x4_f32) vs the torch expression of the same network, at several batch sizes and
+    widths (whole MFMA tiles and ragged ones)."""
     from rodygs_amd import deform
     g = torch.Generator().manual_seed(NR)
-    net = deform.MLPBasisNetwork(128, 16, 26, False).to(DEV)
+    net = deform.MLPBasisNetwork(width, 16, 26, False).to(DEV)
     with torch.no_grad():
         for p in net.parameters():
             p.copy_((torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.1)).to(DEV))
