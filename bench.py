@@ -694,12 +694,16 @@ def run_reference_iteration(args, dev):
     on the dynamic cloud alone.  --points Gaussians are split evenly between the two clouds, so every sub-step renders --points
     Gaussians.  value = iterations / s (one iteration = two optimiser steps, two renders)."""
     import gc
+    from rodygs_amd.refiter import FusedReferenceIteration, GraphedIteration
     from rodygs_amd.synthetic import synthetic_scene
     from rodygs_amd.trainstep import ReferenceIteration
     P, W, H = args.points, args.width, args.height
     ps = P // 2
-    ri = ReferenceIteration(synthetic_scene(ps, W, H, 3, seed=777, variant=args.scene),
-                            synthetic_scene(P - ps, W, H, 3, seed=778, variant=args.scene), num_frames=args.frames, device=dev)
+    # "reference": the fused bookkeeping (refiter.FusedReferenceIteration: same semantics, tested against the other);
+    # "reference-v1": the reference-shaped class (autograd accumulation, f_dc / f_rest split, clears)
+    cls = ReferenceIteration if args.iteration == "reference-v1" else FusedReferenceIteration
+    ri = cls(synthetic_scene(ps, W, H, 3, seed=777, variant=args.scene),
+             synthetic_scene(P - ps, W, H, 3, seed=778, variant=args.scene), num_frames=args.frames, device=dev)
     n_gt = min(args.gt_frames, args.frames)
     perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
     perm = [perm[j] for j in _spread_order(len(perm))]
@@ -714,13 +718,29 @@ def run_reference_iteration(args, dev):
     for _ in range(args.settle // 2):
         ri.iteration(it, perm)
         it += 1
+    graphed = None
+    if args.graph:
+        if cls is ReferenceIteration:
+            raise SystemExit("--graph with --iteration reference-v1: only the fused iteration can be captured")
+        ri.raster_state.deferred_overflow_check = False
+        ri.raster_state.poll_overflow(block=True)
+        graphed = GraphedIteration(ri, perm, first_iteration=it, warmup=2)
+        it = graphed.next_iteration
+        for _ in range(5):
+            graphed.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = ri.iteration(it, perm)
-        it += 1
+        if graphed is not None:
+            loss = graphed.step()
+        else:
+            loss = ri.iteration(it, perm)
+            it += 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if graphed is not None:
+        graphed.check()
+        graphed.close()
     ri.raster_state.poll_overflow(block=True)
     ri.raster_state.deferred_overflow_check = None
     gc.unfreeze()
@@ -733,6 +753,10 @@ def run_reference_iteration(args, dev):
                                    f"synthetic video: the reference's iteration (not a BASELINE config: its metric is per step on "
                                    f"the dynamic cloud)", "points": P, "width": W, "height": H, "scene": args.scene,
                        "sub_steps_per_iteration": 2, "gaussians_rendered_per_sub_step": P,
+                       "bookkeeping": ("reference-shaped (autograd accumulation into .grad, f_dc / f_rest split, zero_grad)"
+                                       if cls is ReferenceIteration else
+                                       "fused (two gradient buffers written in turn, Adam on their sum, one feature tensor)"),
+                       "graph_replay": graphed is not None,
                        "stale_gradient_semantics": "kept (a sub-step's backward accumulates in both clouds; only its own "
                                                    "trainer steps and clears)", "densify_stats": True,
                        "deferred_overflow_check": True},
@@ -837,7 +861,9 @@ def sub_records(budget_s=150.0):
     """What DESIGN.md section 5 claims beside the headline, measured in THE SAME driver run: each a short
     child run of this file's own modes, outside the headline's timed region, reduced to a few numbers.
       loop                : 300 steps with the reference's densification cadence (every 100): sustained / steady fps, overflows;
-      reference_iteration : the iteration a RoDyGS user runs (static + dynamic sub-step), at 0.5 M + 0.5 M and 0.1 M + 0.1 M;
+      reference_iteration : the iteration a RoDyGS user runs (static + dynamic sub-step), at 0.5 M + 0.5 M and 0.1 M + 0.1 M
+                            (refiter.FusedReferenceIteration; the 0.1 M form also as one replayed hipGraph; the reference-shaped
+                            bookkeeping of trainstep.ReferenceIteration next to it);
       graph_100k          : the reference's real cloud size, eager step against the replayed hipGraph;
       psnr_delta          : the teacher-forced protocol of scripts/psnr_delta.py, 100 steps with a densification at 20 k points /
                             320x240 (the 100 k / 1080p form takes 410 s of oracle: profiles/r03_psnr_teacher_forced_100k_1080p.json)."""
@@ -860,14 +886,17 @@ def sub_records(budget_s=150.0):
     else:
         out["loop"] = lp
     ri = {}
-    for name, pts in (("0.5M+0.5M", 1000000), ("0.1M+0.1M", 200000)):
+    for name, pts, mode, extra in (("0.5M+0.5M", 1000000, "reference", []), ("0.1M+0.1M", 200000, "reference", []),
+                                   ("0.1M+0.1M graph", 200000, "reference", ["--graph"]),
+                                   ("0.5M+0.5M reference-shaped bookkeeping", 1000000, "reference-v1", [])):
         if left() < 15:
             ri[name] = {"error": "sub-record budget spent"}
             continue
-        r = _child_json(["--iteration", "reference", "--points", pts, "--steps", "40", "--settle", "20", "--warmup", "3"],
+        r = _child_json(["--iteration", mode, "--points", pts, "--steps", "40", "--settle", "20", "--warmup", "3"] + extra,
                         max(15.0, min(60.0, left())))
         ri[name] = ({"iterations_per_s": r["value"], "ms_per_iteration": r["ms_per_step"], "ms_per_sub_step": r["ms_per_sub_step"],
-                     "graph_replay": r["config"].get("graph_replay", False), "seconds": r["_seconds"]} if "error" not in r else r)
+                     "bookkeeping": r["config"].get("bookkeeping"), "graph_replay": r["config"].get("graph_replay", False),
+                     "seconds": r["_seconds"]} if "error" not in r else r)
     out["reference_iteration"] = ri
     g = {}
     for name, extra in (("eager", []), ("graph", ["--graph"])):
@@ -991,7 +1020,7 @@ def main():
     ap.add_argument("--loop-profile", nargs="?", const="sync", default=None, choices=["sync", "host"],
                     help="--loop: per-phase times of every densification; 'sync' (default) synchronises the device at every "
                          "phase boundary, 'host' records host time only (where the host blocks)")
-    ap.add_argument("--iteration", choices=["step", "reference"], default="step",
+    ap.add_argument("--iteration", choices=["step", "reference", "reference-v1"], default="step",
                     help="'reference': time the reference's ITERATION -- static sub-step + dynamic sub-step over the "
                          "two-segment cloud with its stale-gradient semantics (run_reference_iteration) -- instead of the step")
     ap.add_argument("--dp-mode", choices=["both", "allreduce", "shard"], default=os.environ.get("RDG_DP_MODE", "both"),
@@ -1040,7 +1069,7 @@ def main():
     P, W, H = args.points, args.width, args.height
     scene = synthetic_scene(P, W, H, 3, seed=777, variant=args.scene)
     target = synthetic_scene(max(P // 4, 1000), W, H, 3, seed=1234, variant=args.scene)
-    if args.iteration == "reference":
+    if args.iteration in ("reference", "reference-v1"):
         if world != 1:
             raise SystemExit("--iteration reference is a single-GPU measurement")
         print(json.dumps(run_reference_iteration(args, dev)))

@@ -532,6 +532,11 @@ typedef struct RdgAdamSeg {
     float* exp_avg_sq;
     float lr_head, lr_tail; /* lr of the first head_len floats of every row / of the rest */
     int32_t row_len, head_len;   /* row_len <= 1: uniform lr_head                          */
+    const float* grad2;     /* optional second gradient buffer: the step uses grad + grad2 (ABI 7).  The reference's iteration
+                             * leaves a sub-step's gradient in the OTHER trainer's parameters until that trainer steps
+                             * (/root/reference/src/trainer/rodygs.py:157-179, 364-369): with two gradient buffers written in
+                             * turn -- every backward kernel OVERWRITES its buffer -- the stale part and the fresh part meet
+                             * here, and nothing is ever accumulated or cleared.  NULL: grad alone.                          */
 } RdgAdamSeg;
 int rdg_adam_step_multi(int32_t nseg, const RdgAdamSeg* segs_host, double beta1, double beta2, float eps, int32_t step,
                         void* stream);

@@ -34,7 +34,7 @@ class RdgRasterSettings(C.Structure):
 class RdgAdamSeg(C.Structure):
     _fields_ = [("n", C.c_int64), ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p),
                 ("exp_avg_sq", C.c_void_p), ("lr_head", C.c_float), ("lr_tail", C.c_float), ("row_len", C.c_int32),
-                ("head_len", C.c_int32)]
+                ("head_len", C.c_int32), ("grad2", C.c_void_p)]
 
 
 class RdgStepScalars(C.Structure):

@@ -903,11 +903,15 @@ template <int VAR>
 __device__ __forceinline__ void
 rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                  float* __restrict__ v, float step_head, float step_tail, int row_len, int head_len, float b1, float b2, float omb1, float omb2,
-                 float eps, float bc2_sqrt) {
+                 float eps, float bc2_sqrt, const float* __restrict__ g2 = nullptr) {
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
         float4 pp = rdg_ld4<VAR>(p, i);
-        const float4 gg = rdg_ld4<VAR>(g, i);
+        float4 gg = rdg_ld4<VAR>(g, i);
+        if (g2) {      // RdgAdamSeg.grad2: the gradient is the sum of two buffers (one float add per element, as AccumulateGrad's)
+            const float4 hh = rdg_ld4<VAR>(g2, i);
+            gg.x += hh.x; gg.y += hh.y; gg.z += hh.z; gg.w += hh.w;
+        }
         float4 mm = rdg_ld4<VAR>(m, i);
         float4 vv = rdg_ld4<VAR>(v, i);
         float s0 = step_tail, s1 = step_tail, s2 = step_tail, s3 = step_tail;
@@ -932,7 +936,7 @@ rdg_adam_segment(long long n, float* __restrict__ p, const float* __restrict__ g
     if (i < n) {
         const float st = (row_len > 1) ? ((int)(i % row_len) < head_len ? step_head : step_tail) : step_head;
         float pi = p[i], mi = m[i], vi = v[i];
-        rdg_adam_elem(pi, g[i], mi, vi, st, b1, b2, omb1, omb2, eps, bc2_sqrt);
+        rdg_adam_elem(pi, g2 ? g[i] + g2[i] : g[i], mi, vi, st, b1, b2, omb1, omb2, eps, bc2_sqrt);
         m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
@@ -957,7 +961,7 @@ rdg_adam_multi_kernel(RdgAdamSegs segs, float inv_bc1, float b1, float b2, float
         if (dev->lr_from_table) { lr_head = dev->seg_lr_head[blockIdx.y]; lr_tail = dev->seg_lr_tail[blockIdx.y]; }
     }
     rdg_adam_segment<VAR>(sg.n, sg.param, sg.grad, sg.exp_avg, sg.exp_avg_sq, lr_head * inv_bc1, lr_tail * inv_bc1,
-                     sg.row_len, sg.head_len, b1, b2, omb1, omb2, eps, bc2_sqrt);
+                     sg.row_len, sg.head_len, b1, b2, omb1, omb2, eps, bc2_sqrt, sg.grad2);
 }
 
 extern "C" {

@@ -245,3 +245,116 @@ def test_randomised_sweep_under_frozen_rules(profile):
     scale = max(1.0, SWEEP_CASES / 300.0)
     for cls, lim in SWEEP_LIMITS[profile].items():
         assert counts.get(cls, 0) <= math.ceil(lim * scale), (cls, counts, lines)
+
+
+# ---- the reference's iteration, fused bookkeeping (rodygs_amd/refiter.py) -------------------------------------------------------
+
+def _ri_pair(Ps=3000, Pd=4000, W=208, H=144, T=6):
+    from rodygs_amd.refiter import FusedReferenceIteration
+    from rodygs_amd.trainstep import ReferenceIteration
+    ri = ReferenceIteration(O.synthetic_scene(Ps, W, H, 3, seed=3), O.synthetic_scene(Pd, W, H, 3, seed=4), num_frames=T,
+                            device=DEV, spatial_order=True)
+    ri.make_ground_truth(O.synthetic_scene(2000, W, H, 3, seed=5), range(T))
+    return ri, FusedReferenceIteration.from_reference(ri)
+
+
+def test_fused_reference_iteration_equals_the_reference_shaped_one():
+    """``refiter.FusedReferenceIteration`` (two gradient buffers written in turn, Adam on their sum, one feature tensor for both
+    clouds, nothing accumulated or cleared) against ``trainstep.ReferenceIteration`` (the reference's own shape, itself tested
+    against the framework-op flow): after EVERY sub-step of three iterations the gradient each trainer is about to step on
+    (buffer A + buffer B over its rows = the reference's accumulated ``.grad``, i.e. the stale deposit of the previous sub-step
+    plus this one's) and the parameters after its step agree to 1e-6, with the deterministic backward (no float atomics).
+    After each step the fused object takes the other's parameters and moments exactly (``load_state_from``): the deformation
+    network's gradient is the residue of a cancellation (below), so the two networks part by a float32 ulp per step, and a run of
+    several iterations would otherwise compare two different frames -- the gradient BUFFERS, which carry the semantics under
+    test from one sub-step to the next, stay each object's own."""
+    TP = _tp()
+    from rodygs_amd import rasterizer
+    keep = rasterizer.DETERMINISTIC
+    rasterizer.DETERMINISTIC = True
+    try:
+        ri, fr = _ri_pair()
+        perm = list(range(6))
+        names = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity")
+        # The MLP is held at its OUTPUT, the gradient of the motion bases [T + 1, 16, 7]: its rows sum to zero and the MLP's
+        # parameter gradients are what is left of that cancellation (1e-5 of the rows' size: a 4e-7 difference between two float32
+        # reductions of dB -- the two classes reduce it in different kernels -- reads 1e-2 on them; test_gpu_round5's note).
+        # Accumulated over a static + dynamic sub-step like the parameters' gradients.
+        fr.keep_bases_grad = True
+        real_props = ri.properties
+
+        def props_keep(frame):
+            out = real_props(frame)
+            ri._last_allb.retain_grad()
+            return out
+        ri.properties = props_keep
+        acc = {}
+        for it in range(3):
+            fs, fd = fr.frames_of(it, perm)
+            for frame, which in ((fs, "static"), (fd, "dynamic")):
+                l1 = ri.forward_backward(frame, which)
+                l2 = fr.forward_backward(frame, which)
+                assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
+                f1 = ri.fp_s if which == "static" else ri.fp_d
+                g2 = fr.effective_grad(which)
+                for k in names + (("motion_coeff",) if which == "dynamic" else ()):
+                    # (a pixel decision may flip between the two: the fused getter and deformation + activation round the dynamic
+                    # Gaussians' positions differently in the last bit -- a handful of rows then differ by that pixel's share)
+                    TP.rel_ok(g2[k], f1[k].grad, tol=1e-6, outliers=3e-3, cap=5e-3, what=f"it {it} {which}: the gradient {k} steps on")
+                if which == "static":
+                    acc = {"ri": ri._last_allb.grad.clone(), "fr": fr._last_allb.grad.clone()}
+                else:
+                    acc = {"ri": acc["ri"] + ri._last_allb.grad, "fr": acc["fr"] + fr._last_allb.grad}
+                TP.rel_ok(acc["fr"], acc["ri"], tol=1e-4, outliers=1e-2, cap=5e-3, what=f"it {it} {which}: gradient of the motion bases")
+                if which == "dynamic":
+                    # the network's parameter gradients: same sign and size (residue of a cancellation: see above)
+                    gm = fr.grad_mlp[0] + fr.grad_mlp[1]
+                    g1 = torch.cat([ri.sp_mlp[n].grad.reshape(-1) for n in fr.sp_mlp.names])
+                    g2_ = torch.cat([fr.sp_mlp.segment(gm, n) for n in fr.sp_mlp.names])
+                    assert float((g1 - g2_).norm() / g1.norm()) < 0.1
+                else:
+                    for k in ("cam_q", "cam_t"):
+                        TP.rel_ok(fr.sp_cam[k].grad, ri.sp_cam[k].grad, tol=1e-3, what=f"it {it} d_{k}")
+                ri.step(which)
+                fr.step(which)
+                for cloud, f in (("static", ri.fp_s), ("dynamic", ri.fp_d)):
+                    p2 = fr.params(cloud)
+                    for k in names + (("motion_coeff",) if cloud == "dynamic" else ()):
+                        TP.rel_ok(p2[k], f[k], tol=1e-6, outliers=3e-3, cap=5e-3, what=f"it {it} after the {which} step: {cloud} {k}")
+                # (the network's parameters are not compared: Adam with eps 1e-15 turns the residue gradients above into steps of
+                #  the learning rate's size whose sign is noise; its moments and values are re-synchronised here like the rest)
+                fr.load_state_from(ri)
+        # the statistics of each sub-step's own slice
+        for c in ("static", "dynamic"):
+            assert torch.equal(fr.stats[c].denom, ri.stats[c].denom) and float(fr.stats[c].denom.sum()) > 0
+            TP.rel_ok(fr.stats[c].xyz_gradient_accum, ri.stats[c].xyz_gradient_accum, tol=1e-5, outliers=3e-3, cap=5e-3,
+                      what=c + " statistics")
+    finally:
+        rasterizer.DETERMINISTIC = keep
+
+
+def test_graphed_iteration_replays_the_eager_iteration_bit_for_bit():
+    """``refiter.GraphedIteration``: the whole iteration (both sub-steps) as one captured hipGraph; with the deterministic
+    backward the replayed iterations leave the SAME BITS in every parameter as eager iterations from the same state."""
+    from rodygs_amd import rasterizer
+    from rodygs_amd.refiter import FusedReferenceIteration, GraphedIteration
+    keep = rasterizer.DETERMINISTIC
+    rasterizer.DETERMINISTIC = True
+    try:
+        ri, fa = _ri_pair()
+        fb = FusedReferenceIteration.from_reference(ri)
+        perm = list(range(6))
+        n_eager_first, n_replay = 2, 5            # GraphedIteration's warm-up runs 2 eager iterations itself
+        for it in range(n_eager_first + n_replay):
+            fa.iteration(it, perm)
+        g = GraphedIteration(fb, perm, first_iteration=0, warmup=n_eager_first)
+        for _ in range(n_replay):
+            g.step()
+        g.check()
+        g.close()
+        torch.cuda.synchronize()
+        assert fb.steps == fa.steps
+        assert torch.equal(fa.fp.flat, fb.fp.flat) and torch.equal(fa.fp.exp_avg_sq, fb.fp.exp_avg_sq)
+        assert torch.equal(fa.sp_mlp.flat, fb.sp_mlp.flat) and torch.equal(fa.sp_cam.flat, fb.sp_cam.flat)
+    finally:
+        rasterizer.DETERMINISTIC = keep
