@@ -40,13 +40,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-SQ_FILE = "r05_pmc_sq_counters.json"     # rocprofv3 --pmc SQ_* pass of this bench command (scripts/pmc_summary.py)
+SQ_FILE = "r06_pmc_sq_counters.json"     # rocprofv3 --pmc SQ_* pass of this bench command (scripts/pmc_summary.py)
 N_SIMD = 1024                            # 256 CUs x 4 SIMDs
 # measured issue cost of a wave64 VALU instruction with every SIMD saturated (scripts/valu_probe.hip,
 # profiles/r02_valu_issue_cost.txt), in cycles per instruction and SIMD
 VALU_ISSUE_CLASSES = {"f32 mul/add/fma/mov with VGPR sources": 2.3, "every other VALU instruction": 4.2,
                       "transcendental": 8.4}
-PMC_FILE = "r05_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
+PMC_FILE = "r06_pmc_hbm_traffic.json"   # rocprofv3 --pmc passes of this bench command (scripts/pmc_hbm_traffic.py)
 
 
 def kernel_source_hash(files=("rdg_render.hip", "rdg_common.h")):
@@ -631,11 +631,15 @@ def run_loop(args, dev, scene, target):
             step += 1
         t1 = sync()
         if graphed is not None:
-            graphed.check()
-            step = graphed.next_step
-            graphed.close()
-            graphed = None
-            ds.raster_state.deferred_overflow_check = True
+            try:
+                graphed.check()
+            except rasterizer.RasterizerCapacityOverflow:
+                overflows += 1           # counted like the eager path's; the next segment re-captures with the raised hint
+            finally:
+                step = graphed.next_step
+                graphed.close()
+                graphed = None
+                ds.raster_state.deferred_overflow_check = True
         try:
             ds.raster_state.poll_overflow(block=True)
         except rasterizer.RasterizerCapacityOverflow:

@@ -304,7 +304,11 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         prune_own, prune_child = low, low
         if max_screen_size:                                                              # max_radii2D was just zeroed
             prune_own = low | (max_s > 0.1 * extent)
-            prune_child = low | (max_s / (0.8 * N) > 0.1 * extent)
+            # the children's world size as the reference tests it: get_scaling of the STORED rows, exp(log(s * 1 / (0.8 N))) with
+            # the float32 reciprocal rdg_split_children multiplies by (rodygs_static.py:201-203, 292-296) -- max_s / (0.8 N) can
+            # sit one ulp on the other side of 0.1 * extent, and the general path (decisions=) tests the stored rows
+            inv_shrink = torch.tensor(1.0, dtype=torch.float32, device=dev) / (torch.tensor(0.8, dtype=torch.float32, device=dev) * N)
+            prune_child = low | (torch.exp(torch.log(max_s * inv_shrink)) > 0.1 * extent)
         keep0 = ~split_mask & ~prune_own
         keepc = clone_mask & ~prune_own
         keeps = split_mask & ~prune_child

@@ -363,6 +363,11 @@ class DynamicScene:
         from .densify import FlatPool, _Phase, allreduce_stats_, densify_and_prune
         if self.stats is None:
             raise RuntimeError("call track_densification() first")
+        if self._graph_inputs is not None:
+            # the buffers this call hands back to the pool become the gather target of the NEXT densification: a captured graph
+            # that still replays into them would train on -- and overwrite -- live parameters of a later cloud, silently
+            raise RuntimeError("DynamicScene.densify(): a GraphedStep of this scene is still open; close() it first (its "
+                               "graph holds the addresses of the buffers that are about to be recycled)")
         allreduce_stats_(self.stats)
         P_old = self.P
         if getattr(self, "_fp_pool", None) is None:
@@ -375,6 +380,9 @@ class DynamicScene:
         ph = _Phase(timings, self.device)
         self.fp, self.stats, self.time_ind = res.fp, res.stats, res.per_point["time_ind"].contiguous()
         self._fp_pool.give_back(old_fp)          # (stream-ordered: the gathers that read it are queued before any re-use)
+        # the old bucket's storage is the pool's again: whoever still holds `old_fp` must not find live-looking views in it
+        old_fp.flat = old_fp.flat_grad = old_fp.exp_avg = old_fp.exp_avg_sq = None
+        old_fp.params = {}
         del old_fp
         self.P = self.fp.shapes["xyz"][0]
         self.m2 = torch.zeros(self.P, 3, device=self.device, requires_grad=True)

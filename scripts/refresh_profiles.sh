@@ -7,7 +7,7 @@ set -u
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 R=$PWD
-T=${1:-r05}
+T=${1:-r06}
 O=$R/gpurun_out/prof_$T
 mkdir -p $O
 # the PMC passes first: bench.py reads profiles/${T}_pmc_*.json (stamped with the hash of the kernel sources) for `roofline.traffic`
@@ -32,6 +32,17 @@ python3 bench.py --loop 600 --points 100000 > $O/${T}_loop_100k_bench.json 2>/de
 python3 bench.py --loop 600 --points 100000 --graph > $O/${T}_loop_100k_graph_bench.json 2>/dev/null
 python3 bench.py --iteration reference > $O/${T}_reference_iteration_bench.json 2>/dev/null
 python3 bench.py --iteration reference --points 200000 > $O/${T}_reference_iteration_200k_bench.json 2>/dev/null
+python3 bench.py --iteration reference --points 200000 --graph > $O/${T}_reference_iteration_200k_graph_bench.json 2>/dev/null
+python3 bench.py --iteration reference-v1 > $O/${T}_reference_iteration_v1_bench.json 2>/dev/null
+python3 bench.py --iteration reference-v1 --points 200000 > $O/${T}_reference_iteration_v1_200k_bench.json 2>/dev/null
+# the tight tile rectangles against the reference's (RdgRasterSettings.cull), alternating on this box
+for i in 1 2; do
+  RDG_CULL=1 python3 bench.py --steps 60 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=b['stage_ms']; print('cull 1', 'step %.4f ms' % b['ms_per_step'], 'D', b['config']['D'], 'D_composited', b['config']['D_composited'], 'binning %.1f us' % (1e3*(s['scan_dup']+s['sort']+s['ranges'])), 'render_fwd %.1f' % (1e3*s['render_fwd']), 'render_bwd %.1f' % (1e3*s['render_bwd']))"
+  RDG_CULL=0 python3 bench.py --steps 60 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; b=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=b['stage_ms']; print('cull 0', 'step %.4f ms' % b['ms_per_step'], 'D', b['config']['D'], 'D_composited', b['config']['D_composited'], 'binning %.1f us' % (1e3*(s['scan_dup']+s['sort']+s['ranges'])), 'render_fwd %.1f' % (1e3*s['render_fwd']), 'render_bwd %.1f' % (1e3*s['render_bwd']))"
+done > $O/${T}_cull_ab.txt
+# the randomised sweeps on seeds of their own (the -m gpu test runs 300 + 300 on 610000 / 620000 under frozen rules)
+python3 scripts/parity_sweep.py 1500 630000 > $O/${T}_parity_sweep_regular.txt 2>&1
+RDG_SWEEP_PROFILE=aniso python3 scripts/parity_sweep.py 1500 640000 > $O/${T}_parity_sweep_aniso.txt 2>&1
 # the two scenes the survey's generator never enters (not the headline): bench line + kernel table each
 for SC in sheets dense; do
   python3 bench.py --scene $SC --no-cpu-baseline > $O/${T}_scene_${SC}_bench.json 2>/dev/null
