@@ -349,7 +349,8 @@ def test_committed_bench_line_honours_the_contract():
     import json
     prof = os.path.join(os.path.dirname(__file__), "..", "profiles")
     newest = os.path.exists(os.path.join(prof, "r05_bench.json"))       # (the byte accounting of the deformation changed in round 5)
-    d = json.load(open(os.path.join(prof, "r05_bench.json" if newest else "r03_bench.json")))
+    r6 = os.path.exists(os.path.join(prof, "r06_bench.json"))           # (round 6: D / D_composited, sub-records, live counters)
+    d = json.load(open(os.path.join(prof, "r06_bench.json" if r6 else "r05_bench.json" if newest else "r03_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -386,6 +387,21 @@ def test_committed_bench_line_honours_the_contract():
             assert pc["ok"] and pc["radii_equal"] and pc["D_equal"] and not pc["violations"], (name, pc)
             assert max(pc["image_max_rel"].values()) <= 1e-4 and max(pc["grad_max_rel_per_tensor"].values()) <= 1e-4
         assert d["cpu_baseline"]["host"]["cpu_count"] >= d["cpu_baseline"]["cores"] and d["cpu_baseline"]["host"]["cpu_model"]
+    if r6:
+        # the instances the reference's rectangles hold against the ones this build bins and composites
+        assert cfg["tight_tile_rectangles"] and cfg["D_composited"] == cfg["num_rendered_D"] < 0.8 * cfg["D"]
+        for name in ("bench_frame", "c2"):
+            assert d["parity_check"][name]["cap"] == 5e-3
+        # roofline.traffic from THIS run's counters, not a replayed file
+        assert d["roofline"]["traffic_source"].startswith("LIVE") and d["roofline"]["traffic"] > d["roofline"]["algorithmic_bytes_per_launch"]
+        assert d["render_valu_issue"]["source"].startswith("LIVE") and 0.3 < d["render_valu_issue"]["render_bwd"]["frac_of_issue_ceiling"] <= 1.0
+        # what DESIGN.md section 5 claims next to the step, in the same line
+        sr = d["sub_records"]
+        assert sr["loop"]["capacity_overflows"] == 0 and sr["loop"]["sustained_over_steady"] >= 0.95 and sr["loop"]["steps"] >= 300
+        assert sr["reference_iteration"]["0.5M+0.5M"]["ms_per_sub_step"] <= 1.75
+        assert sr["reference_iteration"]["0.1M+0.1M"]["ms_per_sub_step"] <= 0.85
+        assert sr["graph_100k"]["graph"]["ms_per_step"] > 0 and sr["psnr_delta"]["within_gate"]
+        assert abs(d["psnr_delta_db"]) <= 0.05
 
 
 def test_bench_accounting_follows_the_algorithm_that_runs():
