@@ -51,7 +51,7 @@ def column_stats(a, b, tol=1e-4):
             "columns": int(A.shape[0]), "entries_per_column": int(A.shape[1]), "nan": bool(torch.isnan(a).any())}
 
 
-def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=5e-3, loss_kink=None):
+def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=5e-3, loss_kink=None, pixel_cap=2e-2):
     """Every pixel and every gradient entry of a WHOLE frame, HIP against the oracle, with the witness rule taken down to
     the Gaussian: an entry may miss ``tol`` (and then must stay below ``cap``) only if
       * it is a pixel with a witnessed decision flip (flip_mask), or
@@ -60,9 +60,13 @@ def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=5e-3,
         whose weight at that pixel changed with it.
     Everything else -- all other pixels, all other Gaussians' rows, the pose gradient -- is held to ``tol`` of its column's
     largest oracle entry with no allowance at all.
-    ``cap`` = 5e-3 (round 6; 2e-2 before): a flipped decision moves a pixel by one splat's alpha * T * colour with alpha at the
-    1/255 floor (3.9e-3 of the channel's scale at most), and a whole frame's gradient columns by less: the worst entry measured on
-    a flip candidate over the rounds' frames is 2.0e-3 -- a 1 % systematic error on those rows would no longer pass.
+    ``cap`` = 5e-3 (round 6; 2e-2 before) bounds the GRADIENT rows of the flip candidates: the worst entry measured on a candidate
+    over the rounds' frames is 2.7e-3 -- a 1 % systematic error on those rows no longer passes.  ``pixel_cap`` = 2e-2 bounds the
+    flipped PIXELS themselves: such a pixel moves by one splat's alpha * T * feature with alpha at the 1/255 floor, and the feature
+    can be several times the image's scale -- the per-Gaussian normal is a column of R built from the RAW quaternion (norm |q|^2:
+    a trained cloud's activated + deformed quaternions are not unit), so one splat with |n| = 2.5 moves a flipped pixel of the
+    normal image by 1e-2 of the channel's maximum (the first version of the round-6 rule held pixels to 5e-3 as well: the trained-
+    cloud test then failed in 5 of 58 runs, every time `normal: 5.7e-3 ... 9.8e-3 on a flipped pixel`, never a gradient).
     loss_kink: optional bool [H,W] -- pixels where the LOSS the gradients come from is witnessed on two sides of a kink of its
     own (an L1 term: sign(hip - gt) != sign(oracle - gt) in some channel, i.e. the two images, equal to 1e-6, straddle the
     ground truth): dL/dpixel differs there by the whole L1 weight although the images agree.  The Gaussians in such a
@@ -102,7 +106,7 @@ def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=5e-3,
         n = int(max(int(nc_h[y, x]), int(nc_o[y, x])))
         cand[np.asarray(vals_sorted[s:min(e, s + n)]).astype(np.int64)] = True
     cand_t = torch.from_numpy(cand)
-    rep = {"tol": tol, "cap": cap, "pixels": H * W, "witnessed_flips": n_flip, "loss_kink_pixels": n_kink,
+    rep = {"tol": tol, "cap": cap, "pixel_cap": pixel_cap, "pixels": H * W, "witnessed_flips": n_flip, "loss_kink_pixels": n_kink,
            "flip_candidate_gaussians": int(cand.sum()),
            "radii_equal": radii_equal, "D_equal": D_equal, "image_max_rel": {}, "image_max_rel_on_flipped_pixels": {},
            "grad_max_rel_per_tensor": {}, "grad_max_rel_on_flip_candidates": {}}
@@ -127,8 +131,8 @@ def full_frame_report(hip, orc, vals_sorted, ranges, grid_x, tol=1e-4, cap=5e-3,
         rep["image_max_rel_on_flipped_pixels"][name] = flipped
         if nan or not clean <= tol:
             viol.append(f"{name}: {clean:.3e} on a pixel without a witnessed flip ({int((rel[:, ~fmf] > tol).sum())} entries)")
-        if not flipped <= cap:
-            viol.append(f"{name}: {flipped:.3e} on a flipped pixel (cap {cap:g})")
+        if not flipped <= pixel_cap:
+            viol.append(f"{name}: {flipped:.3e} on a flipped pixel (cap {pixel_cap:g})")
     mism = int(((nc_h.to(torch.int64) != nc_o.to(torch.int64)) & ~fm).sum())     # zero by construction of flip_mask
     rep["n_contrib_mismatch_off_flips"] = mism
     for name, go in orc["grads"].items():

@@ -947,7 +947,7 @@ def test_full_frame_parity(P, W, H):
     from oracle.parity import full_frame_report
     hip, orc, binning, gx = _full_frame_pair(P, W, H)
     rep = full_frame_report(hip, orc, binning["vals_sorted"], binning["ranges"], gx, tol=TOL, cap=FULL_FRAME_CAP)
-    assert rep["ok"], rep
+    assert rep["ok"], (rep["violations"], rep["witnessed_flips"], rep["flip_candidate_gaussians"])
     assert rep["witnessed_flips"] <= OUTLIER_FRAC * H * W, rep
     assert rep["n_contrib_mismatch_off_flips"] == 0
     assert float(hip["grads"]["means2D"][:, 2].abs().max()) == 0.0
