@@ -554,12 +554,29 @@ def run_loop(args, dev, scene, target):
     P, W, H = args.points, args.width, args.height
     spatial_order = os.environ.get("RDG_SPATIAL_ORDER", "1") != "0"
     ds = DynamicScene(scene, num_frames=args.frames, sh_degree=3, device=dev, seed=777, spatial_order=spatial_order)
-    ds.track_densification()
+    fixed = args.fixed_capacity > 1.0
+    if fixed:
+        ds.fix_capacity(args.fixed_capacity)
+    else:
+        ds.track_densification()
     n_gt = min(args.gt_frames, args.frames)
     perm = sorted(set(int(round(i * args.frames / n_gt)) % args.frames for i in range(n_gt)))
     perm = [perm[j] for j in _spread_order(len(perm))]
     ds.make_ground_truth(target, perm)
     ds.raster_state.deferred_overflow_check = False
+    regrown = 0
+
+    def densify_now(tm=None):
+        # one densify_and_prune with the loop's threshold rule; fixed capacity: in place, growing the buffers when the dead rows run out
+        nonlocal regrown
+        if not fixed:
+            return ds.densify(max_grad=threshold(), min_opacity=0.005, percent_dense=0.01, want_decisions=False, timings=tm)
+        thr = args.densify_grad_threshold if args.densify_grad_threshold > 0 else ds.live_gradient_quantile(args.densify_quantile)
+        info = ds.densify_inplace(max_grad=thr, min_opacity=0.005, percent_dense=0.01)
+        if info is None:
+            regrown += 1
+            raise RuntimeError("fixed capacity exhausted")
+        return info
     step = 0
     for _ in range(args.warmup):
         ds.train_step(step, 0, 1, perm)
@@ -581,7 +598,7 @@ def run_loop(args, dev, scene, target):
     # The first densification of a process pays for the lazy initialisation of ~40 framework kernels (180 ms): like the first
     # train steps it belongs to the warm-up.  One real densification on the statistics of the steps so far, untimed, then the
     # statistics start afresh and a few more untimed steps settle the new cloud; the P trajectory below starts from its result.
-    warm = ds.densify(max_grad=threshold(), min_opacity=0.005, percent_dense=0.01, want_decisions=False)
+    warm = densify_now()
     for _ in range(min(args.settle, 20)):
         ds.train_step(step, 0, 1, perm)
         step += 1
@@ -601,7 +618,7 @@ def run_loop(args, dev, scene, target):
     while done < K:
         n = min(interval, K - done)
         t_cap = 0.0
-        if args.graph:
+        if args.graph and graphed is None:
             t0 = sync()
             ds.raster_state.deferred_overflow_check = False
             ds.raster_state.poll_overflow(block=True)
@@ -631,21 +648,24 @@ def run_loop(args, dev, scene, target):
             step += 1
         t1 = sync()
         if graphed is not None:
+            keep_graph = fixed             # fixed capacity: the captured step survives the densification that follows
             try:
                 graphed.check()
             except rasterizer.RasterizerCapacityOverflow:
                 overflows += 1           # counted like the eager path's; the next segment re-captures with the raised hint
+                keep_graph = False
             finally:
                 step = graphed.next_step
-                graphed.close()
-                graphed = None
-                ds.raster_state.deferred_overflow_check = True
+                if not keep_graph:
+                    graphed.close()
+                    graphed = None
+                    ds.raster_state.deferred_overflow_check = True
         try:
             ds.raster_state.poll_overflow(block=True)
         except rasterizer.RasterizerCapacityOverflow:
             overflows += 1
         n_head = min(head, n) - eager_done
-        segments.append({"P": ds.P, "steps": n, "graph_capture_ms": t_cap, "graph_capture_phases_ms": cap_tm,
+        segments.append({"P": ds.P_live if fixed else ds.P, "rows": ds.P, "steps": n, "graph_capture_ms": t_cap, "graph_capture_phases_ms": cap_tm,
                          "ms_per_step_first_20": ((t_head or t1) - t0) * 1e3 / max(n_head, 1),
                          "ms_per_step_settled": ((t1 - t_head) * 1e3 / (n - head)) if (t_head is not None and n > head) else None})
         done += n
@@ -653,15 +673,16 @@ def run_loop(args, dev, scene, target):
             t0 = sync()
             tm = ({"_nosync": True} if args.loop_profile == "host" else {}) if args.loop_profile else None
             t_q = time.perf_counter()
-            thr = threshold()
-            p0 = ds.P
+            p0 = ds.P_live if fixed else ds.P
             if tm is not None:
                 tm["threshold_host"] = (time.perf_counter() - t_q) * 1e3
-            info = ds.densify(max_grad=thr, min_opacity=0.005, percent_dense=0.01, want_decisions=False, timings=tm)
+            info = densify_now(tm)
             t1 = sync()
             densifies.append({"after_step": done, "ms": (t1 - t0) * 1e3, "P_before": p0, "P_after": info["P"],
                               "cloned": info["cloned"], "split": info["split"], "pruned": info["pruned"], "phases_ms": tm})
     t_end = sync()
+    if graphed is not None:
+        graphed.close()
     ds.raster_state.deferred_overflow_check = False
     gc.unfreeze()
     total = t_end - t_begin
@@ -677,6 +698,10 @@ def run_loop(args, dev, scene, target):
             "config": {"workload": workload_label(P, W, H, args.frames, False, 1, args.scene) + f", train loop with "
                        f"densification every {interval} steps", "points": P, "width": W, "height": H, "scene": args.scene,
                        "graph_replay": bool(args.graph), "densify_interval": interval,
+                       # > 0: the cloud lives in buffers of a fixed number of rows (dead rows + in-place densification); with
+                       # --graph the step is captured once for the whole loop
+                       "fixed_capacity": args.fixed_capacity if fixed else 0.0, "rows": ds.P if fixed else None,
+                       "graph_captures": sum(1 for sg in segments if sg["graph_capture_ms"] > 0),
                        "points_after_warmup_densification": int(warm["P"]),
                        "densify_threshold": (args.densify_grad_threshold if args.densify_grad_threshold > 0 else
                                              f"{args.densify_quantile} quantile of the mean screen-space gradient"),
@@ -1017,6 +1042,10 @@ def main():
                     help="N = 1: time K steps of the train LOOP with a densify_and_prune every --densify-interval steps "
                          "(run_loop) instead of the steady-state step; prints one JSON line with the `loop` table")
     ap.add_argument("--densify-interval", type=int, default=100)
+    ap.add_argument("--fixed-capacity", type=float, default=0.0,
+                    help="--loop: keep the cloud in buffers of (this factor) x P rows for good (DynamicScene.fix_capacity: dead rows, "
+                         "densify_and_prune in place) -- with --graph the step is then captured ONCE and keeps replaying across the "
+                         "densifications (nothing it refers to moves or changes size); 0 = off")
     ap.add_argument("--densify-quantile", type=float, default=0.97)
     ap.add_argument("--densify-grad-threshold", type=float, default=0.0,
                     help="> 0: the reference's absolute threshold on the mean screen-space gradient (its configs: 0.0002) "

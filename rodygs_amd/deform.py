@@ -260,6 +260,28 @@ def invalidate_birth_order_cache() -> None:
     _ORDER_CACHE.clear()
 
 
+def refresh_birth_order_inplace(time_ind: torch.Tensor, n_births: int) -> None:
+    """``time_ind`` was modified IN PLACE (a fixed-capacity densification): recompute the sorted order and write it into the SAME
+    (order, inverse, seg_start) tensors the cache holds for it -- a captured graph reads them by address --, and re-key the entry
+    to the tensor's new version.  Creates the entry if there is none."""
+    old_key = next((k for k in _ORDER_CACHE if len(k) == 5 and k[0] == time_ind.data_ptr() and k[2] == time_ind.shape[0]
+                    and k[4] == int(n_births)), None)
+    if old_key is None:
+        _birth_order(time_ind, n_births)
+        return
+    order_t, inv_t, seg_t, _ = _ORDER_CACHE.pop(old_key)
+    order = torch.argsort(time_ind, stable=True)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=order.device)
+    order_t.copy_(order.to(torch.int32))
+    inv_t.copy_(inv.to(torch.int32))
+    if seg_t is not None:
+        seg = torch.searchsorted(time_ind[order].contiguous(), torch.arange(n_births + 1, device=order.device, dtype=time_ind.dtype))
+        seg_t.copy_(seg.to(torch.int32))
+    key = (time_ind.data_ptr(), time_ind._version, time_ind.shape[0], str(time_ind.device), int(n_births))
+    _ORDER_CACHE[key] = (order_t, inv_t, seg_t, time_ind)
+
+
 def _identity_order(P: int, dev) -> torch.Tensor:
     key = ("id", P, str(dev))
     o = _ORDER_CACHE.get(key)

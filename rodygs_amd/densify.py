@@ -388,3 +388,112 @@ def reset_opacity_(fp: FlatParams, name: str = "opacity", max_opacity: float = 0
         _lib.check(_lib.lib().rdg_reset_opacity(n, float(max_opacity), fp.flat.data_ptr() + 4 * o,
                                                 fp.exp_avg.data_ptr() + 4 * o, fp.exp_avg_sq.data_ptr() + 4 * o,
                                                 _lib.stream_ptr()), "rdg_reset_opacity")
+
+
+# ---- fixed capacity: densify and prune IN PLACE (round 6) ---------------------------------------------------------------------------
+# A captured hipGraph holds the address and the launch dimensions of every buffer of the step; densify_and_prune above changes
+# both (P changes, the rows move to the other buffer set), so a graph had to be re-captured at every densification -- which costs
+# more than the graph saves in the 100 steps between two of them.  The alternative built here: the cloud lives in buffers of a
+# FIXED number of rows; rows that hold no Gaussian are "dead" -- parked far behind every camera (culled by the near plane: no
+# tile, radius 0, no gradient, no statistics), motion coefficients and Adam moments zero (a zero gradient on zero moments is a
+# zero update: they stay where they are).  Densification then is row surgery in place: pruned Gaussians and split parents die,
+# clones and split children are written into dead rows.  Nothing a captured graph refers to moves or changes size.
+DEAD_XYZ = (0.0, 0.0, -1.0e6)
+DEAD_OPACITY_LOGIT = -20.0
+
+
+def dead_row_template(fp: FlatParams, rows: torch.Tensor) -> None:
+    """Park ``rows`` (int64 indices): position behind every camera, opacity logit -20, unit quaternion, log-scale of 1e-3, zero
+    features and motion coefficients, zero Adam moments."""
+    with torch.no_grad():
+        for k in fp.names:
+            p = fp[k].detach()
+            if k == "xyz":
+                p[rows] = torch.tensor(DEAD_XYZ, dtype=torch.float32, device=p.device)
+            elif k == "opacity":
+                p[rows] = DEAD_OPACITY_LOGIT
+            elif k == "scaling":
+                p[rows] = -6.9
+            elif k == "rotation":
+                p[rows] = torch.tensor((1.0, 0.0, 0.0, 0.0), dtype=torch.float32, device=p.device)
+            else:
+                p[rows] = 0.0
+            o, n = fp.offsets[k]
+            for buf in (fp.exp_avg, fp.exp_avg_sq):
+                buf[o:o + n].view(fp.shapes[k])[rows] = 0.0
+
+
+def densify_and_prune_inplace(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, torch.Tensor], dead: torch.Tensor,
+                              max_grad, min_opacity: float, extent: float, max_screen_size, percent_dense: float = 0.01,
+                              N: int = 2, z: Optional[torch.Tensor] = None):
+    """``densify_and_prune`` (same decisions: rodygs_static.py:170-319, the fast path's masks above) on a cloud of FIXED capacity,
+    in place.  ``dead`` [rows] bool marks the rows that hold no Gaussian and is updated in place; ``per_point`` tensors are
+    updated in place; ``stats`` is zeroed.  The set of live Gaussians after the call -- values, moments, per-point data -- is the
+    one ``densify_and_prune`` produces (a -m gpu test compares the two as multisets); their ROW ORDER is not: new Gaussians land
+    wherever a row is free.  Returns a dict (cloned, split, pruned, live) or None when the free rows do not suffice (nothing has
+    been touched then: the caller grows the capacity)."""
+    if not fp.flat.is_cuda:
+        raise RuntimeError("rodygs_amd.densify_and_prune_inplace: buffers must be on the GPU (no CPU fallback exists)")
+    dev = fp.flat.device
+    with torch.no_grad(), torch.cuda.device(dev):
+        live = ~dead
+        grads = stats.xyz_gradient_accum / stats.denom
+        grads[grads.isnan()] = 0.0
+        max_s = torch.exp(fp["scaling"].detach()).max(dim=1).values
+        small = max_s <= percent_dense * extent
+        clone_mask = (torch.norm(grads, dim=-1) >= max_grad) & small & live
+        split_mask = (grads.squeeze(-1) >= max_grad) & ~small & live
+        low = torch.sigmoid(fp["opacity"].detach().reshape(-1)) < min_opacity
+        prune_own, prune_child = low, low
+        if max_screen_size:
+            inv_shrink = torch.tensor(1.0, dtype=torch.float32, device=dev) / (torch.tensor(0.8, dtype=torch.float32, device=dev) * N)
+            prune_own = low | (max_s > 0.1 * extent)
+            prune_child = low | (torch.exp(torch.log(max_s * inv_shrink)) > 0.1 * extent)
+        kill = live & (split_mask | prune_own)             # split parents are replaced by their children; pruned originals go
+        keepc = clone_mask & ~prune_own                     # (a pruned original's clone is pruned with it: same opacity, same scale)
+        keeps = split_mask & ~prune_child
+        free = dead | kill
+        counts = torch.stack([keepc.sum(), keeps.sum(), free.sum(), kill.sum(), split_mask.sum(), clone_mask.sum()])
+        kc, ks, n_free, n_kill, n_sel, n_clone = (int(v) for v in counts.tolist())            # the ONE read-back
+        n_new = kc + ks * N
+        if n_new > n_free:
+            return None
+        srcc, srcs = _compact(keepc, kc), _compact(keeps, ks)
+        src = torch.cat([srcc, srcs.repeat(N)])                                                 # clones, then children in repeat order
+        dst = _compact(free, n_free)[:n_new]
+        child_xyz = child_sc = None
+        if ks:
+            if z is None:
+                z = torch.randn(n_sel * N, 3, device=dev)
+            rank = torch.cumsum(split_mask, 0) - 1
+            child_no = torch.cat([rank[srcs] + r * n_sel for r in range(N)])
+            zz = z.to(device=dev, dtype=torch.float32)[child_no].contiguous()
+            parents = src[kc:].contiguous()
+            child_xyz = torch.empty(ks * N, 3, dtype=torch.float32, device=dev)
+            child_sc = torch.empty(ks * N, 3, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().rdg_split_children(ks * N, N, _lib.ptr(parents), _lib.ptr(fp["xyz"].detach()),
+                                                     _lib.ptr(fp["scaling"].detach()), _lib.ptr(fp["rotation"].detach()),
+                                                     _lib.ptr(zz), _lib.ptr(child_xyz), _lib.ptr(child_sc),
+                                                     _lib.stream_ptr()), "rdg_split_children")
+        # read every source row BEFORE any row is rewritten (a split parent's row may be the very slot its child lands in)
+        taken = {k: fp[k].detach()[src] for k in fp.names}
+        taken_pp = {k: v[src] for k, v in per_point.items()}
+        if ks:
+            taken["xyz"][kc:] = child_xyz
+            taken["scaling"][kc:] = child_sc
+        kill_rows = _compact(kill, n_kill)
+        dead_row_template(fp, kill_rows)
+        for k in fp.names:
+            fp[k].detach()[dst] = taken[k]
+            o, n = fp.offsets[k]
+            for buf in (fp.exp_avg, fp.exp_avg_sq):                   # new Gaussians start with zero moments
+                buf[o:o + n].view(fp.shapes[k])[dst] = 0.0
+        for k, v in per_point.items():
+            v[dst] = taken_pp[k]
+        dead |= kill
+        dead[dst] = False
+        stats.xyz_gradient_accum.zero_(); stats.denom.zero_(); stats.max_radii2D.zero_()
+        n_live = int(dead.numel()) - (n_free - n_new)
+    # "pruned" as densify_and_prune counts it: the reference's prune mask names the split parents too (rodygs_static.py:205-209)
+    return {"cloned": n_clone, "split": n_sel, "pruned": n_kill + (n_clone - kc) + (n_sel - ks) * N, "live": n_live,
+            "free_rows": n_free - n_new}

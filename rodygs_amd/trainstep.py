@@ -350,6 +350,73 @@ class DynamicScene:
             self._fp_pool.spare = FlatStorage(self.fp.storage.capacity, self.device)
             self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
 
+    # ---- fixed capacity: a cloud whose buffers never move or change size (graph replay across densifications) -------------
+    def fix_capacity(self, headroom: float = 1.15) -> None:
+        """Move the cloud into buffers of ``ceil(P * headroom)`` rows (rounded up to 256) and keep them for good: the rows beyond
+        the live Gaussians are DEAD (``densify.dead_row_template``: parked behind every camera, zero motion coefficients and
+        moments -- culled by the near plane, no gradient, no statistics, a zero Adam update), and ``densify_inplace`` turns dead
+        rows into clones / split children and pruned Gaussians into dead rows.  ``self.P`` becomes the CAPACITY -- what every launch
+        dimension and every tensor shape of the step is made of --, ``self.P_live`` counts the Gaussians.  Addresses, shapes and
+        launch dimensions then survive a densification, so a ``GraphedStep`` captured once keeps replaying across it.  The price:
+        the per-Gaussian kernels also walk the dead rows (``headroom`` - 1 of their time while the cloud is young)."""
+        from .densify import DensifyStats, dead_row_template
+        from .deform import invalidate_birth_order_cache
+        if self._graph_inputs is not None:
+            raise RuntimeError("fix_capacity(): close the open GraphedStep first")
+        dev, P = self.device, self.P
+        cap = ((int(math.ceil(P * float(headroom))) + 255) // 256) * 256
+        old = self.fp
+        spec = {k: ((cap,) + tuple(old.shapes[k][1:]), old.lr[k]) for k in old.names}
+        fp = FlatParams(spec, dev)
+        with torch.no_grad():
+            for k in old.names:
+                oo, on = old.offsets[k]
+                no, _ = fp.offsets[k]
+                for dst, src in ((fp.flat, old.flat), (fp.exp_avg, old.exp_avg), (fp.exp_avg_sq, old.exp_avg_sq)):
+                    dst[no:no + on].copy_(src[oo:oo + on])
+        fp.step_count = old.step_count
+        self.dead = torch.zeros(cap, dtype=torch.bool, device=dev)
+        self.dead[P:] = True
+        dead_row_template(fp, torch.arange(P, cap, device=dev))
+        ti = torch.zeros(cap, dtype=self.time_ind.dtype, device=dev)
+        ti[:P] = self.time_ind
+        self.fp, self.time_ind, self.P, self.P_live = fp, ti, cap, P
+        invalidate_birth_order_cache()
+        self.m2 = torch.zeros(cap, 3, device=dev, requires_grad=True)
+        self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
+        self.stats = DensifyStats.zeros(cap, dev)
+        self._fp_pool = None
+
+    def live_gradient_quantile(self, q: float) -> torch.Tensor:
+        """The ``q`` quantile of the mean screen-space gradient over the LIVE Gaussians (a 0-dim device tensor: no read-back)."""
+        g_mean = (self.stats.xyz_gradient_accum / self.stats.denom.clamp_min(1)).reshape(-1)
+        if getattr(self, "dead", None) is None:
+            return torch.quantile(g_mean, q)
+        # dead rows carry 0 and the live count is known on the host: the q quantile of the live values is the
+        # (dead + q * live) / rows quantile of all of them up to the position of the zeros, which sort first
+        rows, live = self.P, self.P_live
+        return torch.quantile(g_mean, min(1.0, ((rows - live) + q * live) / rows))
+
+    def densify_inplace(self, max_grad=0.0002, min_opacity: float = 0.005, extent: Optional[float] = None, max_screen_size=None,
+                        percent_dense: float = 0.01, z: Optional[torch.Tensor] = None):
+        """``densify()`` on a cloud of fixed capacity (``fix_capacity``): same decisions, row surgery in place; may be called
+        while a ``GraphedStep`` of this scene is open -- nothing the graph refers to moves.  Returns the info dict, or None when
+        the dead rows do not suffice (the caller closes its graph, calls ``fix_capacity`` again and re-captures)."""
+        from .deform import refresh_birth_order_inplace
+        from .densify import allreduce_stats_, densify_and_prune_inplace
+        if getattr(self, "dead", None) is None:
+            raise RuntimeError("call fix_capacity() first")
+        allreduce_stats_(self.stats)
+        info = densify_and_prune_inplace(self.fp, self.stats, {"time_ind": self.time_ind}, self.dead, max_grad, min_opacity,
+                                         extent if extent is not None else self.spatial_lr_scale, max_screen_size, percent_dense,
+                                         z=z)
+        if info is None:
+            return None
+        self.P_live = info["live"]
+        refresh_birth_order_inplace(self.time_ind, self.T)      # the sorted order the dB reduction reads: same tensors, new content
+        info["P"] = self.P_live
+        return info
+
     def densify(self, max_grad=0.0002, min_opacity: float = 0.005, extent: Optional[float] = None,
                 max_screen_size=None, percent_dense: float = 0.01, z: Optional[torch.Tensor] = None,
                 decisions=None, want_decisions: bool = True, timings: Optional[dict] = None) -> dict:

@@ -366,3 +366,128 @@ def test_graphed_iteration_replays_the_eager_iteration_bit_for_bit():
         assert torch.equal(fa.sp_mlp.flat, fb.sp_mlp.flat) and torch.equal(fa.sp_cam.flat, fb.sp_cam.flat)
     finally:
         rasterizer.DETERMINISTIC = keep
+
+
+# ---- fixed capacity: densification in place, one graph for the whole loop ------------------------------------------------------
+
+def _small_loop_scene(fixed=None, seed=5):
+    from rodygs_amd.trainstep import DynamicScene
+    sc = O.synthetic_scene(20000, 320, 240, 3, seed=seed)
+    tgt = O.synthetic_scene(5000, 320, 240, 3, seed=seed + 1)
+    frames = list(range(8))
+    ds = DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True)
+    ds.make_ground_truth(tgt, frames)
+    if fixed:
+        ds.fix_capacity(fixed)
+    else:
+        ds.track_densification()
+    return ds, frames
+
+
+def test_inplace_densification_makes_the_same_gaussians_as_the_row_rebuilding_one():
+    """``densify_and_prune_inplace`` (fixed capacity: pruned Gaussians and split parents become dead rows, clones and children are
+    written into dead rows) against ``densify_and_prune`` (rebuilds every buffer) on THE SAME state -- a fixed-capacity scene after
+    20 train steps, its live rows compacted for the row-rebuilding call, the same split draws: the two clouds are the same MULTISET of
+    Gaussians, bit for bit in every parameter, both Adam moments and the birth index; dead rows stay parked and inert."""
+    from rodygs_amd.densify import DensifyStats, densify_and_prune
+    from rodygs_amd.dp import FlatParams
+    ds, frames = _small_loop_scene(fixed=1.25)
+    assert ds.P > ds.P_live and int(ds.dead.sum()) == ds.P - ds.P_live
+    for step in range(20):
+        ds.train_step(step, perm=frames)
+    fp = ds.fp
+    live = (~ds.dead).nonzero().squeeze(1)
+    # dead rows: never visible, no gradient, no statistics, nothing moved
+    assert float(ds.stats.denom[ds.dead].sum()) == 0.0 and float(fp.exp_avg_sq[fp.offsets["xyz"][0]:][:ds.P * 3].view(-1, 3)[ds.dead].abs().sum()) == 0.0
+    assert torch.equal(fp["xyz"].detach()[ds.dead][0].cpu(), torch.tensor([0.0, 0.0, -1.0e6]))
+    thr = ds.live_gradient_quantile(0.9)
+    # (1) the row-rebuilding form on the compacted live rows
+    spec = {k: ((live.numel(),) + tuple(fp.shapes[k][1:]), fp.lr[k]) for k in fp.names}
+    cp = FlatParams(spec, DEV)
+    with torch.no_grad():
+        for k in fp.names:
+            o, n = cp.offsets[k]
+            fo, fn = fp.offsets[k]
+            for dst, src in ((cp.flat, fp.flat), (cp.exp_avg, fp.exp_avg), (cp.exp_avg_sq, fp.exp_avg_sq)):
+                dst[o:o + n].view(cp.shapes[k]).copy_(src[fo:fo + fn].view(fp.shapes[k])[live])
+    st = DensifyStats(ds.stats.xyz_gradient_accum[live].clone(), ds.stats.denom[live].clone(), ds.stats.max_radii2D[live].clone())
+    z = torch.randn(4 * live.numel(), 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    ref = densify_and_prune(cp, st, {"time_ind": ds.time_ind[live].clone()}, thr, 0.01, ds.spatial_lr_scale, 20, z=z)
+    # (2) in place
+    info = ds.densify_inplace(max_grad=thr, min_opacity=0.01, max_screen_size=20, z=z)
+    assert info is not None and info["cloned"] == ref.n_clone and info["split"] == ref.n_split and info["pruned"] == ref.n_pruned
+    assert info["cloned"] + info["split"] > 20 and info["live"] == ref.fp.shapes["xyz"][0] == int((~ds.dead).sum())
+
+    def table(f, rows, ti):
+        cols = []
+        for k in f.names:
+            o, n = f.offsets[k]
+            for buf in (f.flat, f.exp_avg, f.exp_avg_sq):
+                cols.append(buf[o:o + n].view(f.shapes[k][0], -1)[rows])
+        m = torch.cat(cols + [ti[rows].to(torch.float32).unsqueeze(1)], dim=1).cpu().numpy()
+        return m[np.lexsort(m.T[::-1])]
+    a = table(ds.fp, (~ds.dead).nonzero().squeeze(1), ds.time_ind)
+    b = table(ref.fp, torch.arange(ref.fp.shapes["xyz"][0], device=DEV), ref.per_point["time_ind"])
+    assert a.shape == b.shape and np.array_equal(a, b)
+    assert float(ds.stats.denom.sum()) == 0.0
+    # the cloud still trains, the dead rows still do nothing
+    l0 = float(ds.train_step(20, perm=frames))
+    for step in range(21, 40):
+        l1 = float(ds.train_step(step, perm=frames))
+    assert np.isfinite(l1) and l1 < l0 * 1.05
+    assert float(ds.stats.denom[ds.dead].sum()) == 0.0
+
+
+def test_one_captured_graph_replays_across_inplace_densifications():
+    """Fixed capacity + ``GraphedStep``: the step is captured ONCE and keeps replaying while ``densify_inplace`` turns rows over
+    underneath it (nothing the graph refers to moves or changes size; the birth-order tensors are refreshed in place).  With the
+    deterministic backward the replayed loop leaves the SAME BITS in every buffer as the eager loop with the same
+    densifications."""
+    from rodygs_amd import rasterizer
+    from rodygs_amd.trainstep import GraphedStep
+    keep = rasterizer.DETERMINISTIC
+    rasterizer.DETERMINISTIC = True
+    try:
+        runs = []
+        for graph in (False, True):
+            ds, frames = _small_loop_scene(fixed=1.5)
+            step, traj = 0, [ds.P_live]
+            gs = None
+            if graph:
+                gs = GraphedStep(ds, frames, warmup=2, first_step=0)
+                step = gs.next_step
+            else:
+                for _ in range(2):
+                    ds.train_step(step, perm=frames)
+                    step += 1
+            for seg in range(3):
+                for _ in range(10):
+                    if gs is not None:
+                        gs.step()
+                    else:
+                        ds.train_step(step, perm=frames)
+                    step += 1
+                if gs is not None:
+                    gs.check()
+                info = ds.densify_inplace(max_grad=ds.live_gradient_quantile(0.95), min_opacity=0.01,
+                                          z=torch.randn(4 * ds.P, 3, generator=torch.Generator().manual_seed(seg)).to(DEV))
+                assert info is not None and info["cloned"] + info["split"] > 0
+                traj.append(ds.P_live)
+            for _ in range(6):
+                if gs is not None:
+                    gs.step()
+                else:
+                    ds.train_step(step, perm=frames)
+                step += 1
+            if gs is not None:
+                gs.check()
+                gs.close()
+            torch.cuda.synchronize()
+            runs.append((ds, traj))
+        (a, ta), (b, tb) = runs
+        assert ta == tb and ta[-1] > ta[0]
+        assert torch.equal(a.dead, b.dead) and torch.equal(a.time_ind, b.time_ind)
+        assert torch.equal(a.fp.flat, b.fp.flat) and torch.equal(a.fp.exp_avg_sq, b.fp.exp_avg_sq)
+        assert torch.equal(a.sp.flat, b.sp.flat)
+    finally:
+        rasterizer.DETERMINISTIC = keep
