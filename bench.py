@@ -565,6 +565,7 @@ def run_loop(args, dev, scene, target):
     ds.make_ground_truth(target, perm)
     ds.raster_state.deferred_overflow_check = False
     regrown = 0
+    graphed = None
 
     def densify_now(tm=None):
         # one densify_and_prune with the loop's threshold rule; fixed capacity: in place, growing the buffers when the dead rows run out
@@ -574,8 +575,23 @@ def run_loop(args, dev, scene, target):
         thr = args.densify_grad_threshold if args.densify_grad_threshold > 0 else ds.live_gradient_quantile(args.densify_quantile)
         info = ds.densify_inplace(max_grad=thr, min_opacity=0.005, percent_dense=0.01)
         if info is None:
+            # the dead rows do not suffice: the live rows move into larger buffers (the captured graph, if any, goes: its
+            # addresses are the old buffers'), and the densification is repeated there
+            nonlocal graphed
             regrown += 1
-            raise RuntimeError("fixed capacity exhausted")
+            if graphed is not None:
+                graphed.close()
+                graphed = None
+            stats = ds.stats
+            live = (~ds.dead).nonzero().squeeze(1)
+            ds.fix_capacity(args.fixed_capacity)
+            for a, b in ((ds.stats.xyz_gradient_accum, stats.xyz_gradient_accum), (ds.stats.denom, stats.denom),
+                         (ds.stats.max_radii2D, stats.max_radii2D)):
+                a[:live.numel()] = b.index_select(0, live)
+            thr = args.densify_grad_threshold if args.densify_grad_threshold > 0 else ds.live_gradient_quantile(args.densify_quantile)
+            info = ds.densify_inplace(max_grad=thr, min_opacity=0.005, percent_dense=0.01)
+            if info is None:
+                raise RuntimeError("fixed capacity exhausted right after growing it: --fixed-capacity is too small for one densification")
         return info
     step = 0
     for _ in range(args.warmup):
@@ -701,7 +717,7 @@ def run_loop(args, dev, scene, target):
                        # > 0: the cloud lives in buffers of a fixed number of rows (dead rows + in-place densification); with
                        # --graph the step is captured once for the whole loop
                        "fixed_capacity": args.fixed_capacity if fixed else 0.0, "rows": ds.P if fixed else None,
-                       "graph_captures": sum(1 for sg in segments if sg["graph_capture_ms"] > 0),
+                       "graph_captures": sum(1 for sg in segments if sg["graph_capture_ms"] > 0), "capacity_regrown": regrown,
                        "points_after_warmup_densification": int(warm["P"]),
                        "densify_threshold": (args.densify_grad_threshold if args.densify_grad_threshold > 0 else
                                              f"{args.densify_quantile} quantile of the mean screen-space gradient"),

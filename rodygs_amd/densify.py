@@ -476,20 +476,26 @@ def densify_and_prune_inplace(fp: FlatParams, stats: DensifyStats, per_point: Di
                                                      _lib.ptr(zz), _lib.ptr(child_xyz), _lib.ptr(child_sc),
                                                      _lib.stream_ptr()), "rdg_split_children")
         # read every source row BEFORE any row is rewritten (a split parent's row may be the very slot its child lands in)
-        taken = {k: fp[k].detach()[src] for k in fp.names}
-        taken_pp = {k: v[src] for k, v in per_point.items()}
+        taken = {k: fp[k].detach().index_select(0, src) for k in fp.names}
+        taken_pp = {k: v.index_select(0, src) for k, v in per_point.items()}
         if ks:
             taken["xyz"][kc:] = child_xyz
             taken["scaling"][kc:] = child_sc
+        # rows that die: parked behind every camera, zero moments in every segment (the rows new Gaussians land in are dead rows
+        # or rows that die right here: their moments are zero either way, which is what a new Gaussian starts with)
         kill_rows = _compact(kill, n_kill)
-        dead_row_template(fp, kill_rows)
+        fp["xyz"].detach().index_copy_(0, kill_rows, torch.tensor(DEAD_XYZ, dtype=torch.float32, device=dev).expand(n_kill, 3).contiguous())
+        fp["opacity"].detach().index_fill_(0, kill_rows, DEAD_OPACITY_LOGIT)
         for k in fp.names:
-            fp[k].detach()[dst] = taken[k]
             o, n = fp.offsets[k]
-            for buf in (fp.exp_avg, fp.exp_avg_sq):                   # new Gaussians start with zero moments
-                buf[o:o + n].view(fp.shapes[k])[dst] = 0.0
+            rows_ = fp.shapes[k][0]
+            if k not in ("xyz", "opacity", "scaling", "rotation"):
+                fp[k].detach().view(rows_, -1).index_fill_(0, kill_rows, 0.0)      # features, motion coefficients
+            for buf in (fp.exp_avg, fp.exp_avg_sq):
+                buf[o:o + n].view(rows_, -1).index_fill_(0, kill_rows, 0.0)
+            fp[k].detach().index_copy_(0, dst, taken[k])
         for k, v in per_point.items():
-            v[dst] = taken_pp[k]
+            v.index_copy_(0, dst, taken_pp[k])
         dead |= kill
         dead[dst] = False
         stats.xyz_gradient_accum.zero_(); stats.denom.zero_(); stats.max_radii2D.zero_()

@@ -363,24 +363,36 @@ class DynamicScene:
         from .deform import invalidate_birth_order_cache
         if self._graph_inputs is not None:
             raise RuntimeError("fix_capacity(): close the open GraphedStep first")
-        dev, P = self.device, self.P
-        cap = ((int(math.ceil(P * float(headroom))) + 255) // 256) * 256
+        dev = self.device
         old = self.fp
+        # called again on a cloud that already has dead rows (its capacity ran out): the live rows move up, in order
+        live = None if getattr(self, "dead", None) is None else (~self.dead).nonzero().squeeze(1)
+        P = self.P if live is None else int(live.numel())
+        cap = ((int(math.ceil(P * float(headroom))) + 255) // 256) * 256
         spec = {k: ((cap,) + tuple(old.shapes[k][1:]), old.lr[k]) for k in old.names}
         fp = FlatParams(spec, dev)
         with torch.no_grad():
             for k in old.names:
                 oo, on = old.offsets[k]
                 no, _ = fp.offsets[k]
+                rl = on // old.shapes[k][0]
                 for dst, src in ((fp.flat, old.flat), (fp.exp_avg, old.exp_avg), (fp.exp_avg_sq, old.exp_avg_sq)):
-                    dst[no:no + on].copy_(src[oo:oo + on])
+                    rows = src[oo:oo + on].view(old.shapes[k][0], rl)
+                    dst[no:no + P * rl].view(P, rl).copy_(rows if live is None else rows.index_select(0, live))
         fp.step_count = old.step_count
         self.dead = torch.zeros(cap, dtype=torch.bool, device=dev)
         self.dead[P:] = True
         dead_row_template(fp, torch.arange(P, cap, device=dev))
         ti = torch.zeros(cap, dtype=self.time_ind.dtype, device=dev)
-        ti[:P] = self.time_ind
+        ti[:P] = self.time_ind if live is None else self.time_ind.index_select(0, live)
+        old_key = (self.P, self.H, self.W)
         self.fp, self.time_ind, self.P, self.P_live = fp, ti, cap, P
+        # the rasterizer's frame-to-frame memory is keyed by the row count: carried over (same Gaussians, a few more dead rows)
+        st = self.raster_state
+        with st.lock:
+            for tbl in (st.capacity_hint, st.d_high, st.bin_hint, st.split_hint):
+                if old_key in tbl and old_key != (cap, self.H, self.W):
+                    tbl[(cap, self.H, self.W)] = tbl.pop(old_key)
         invalidate_birth_order_cache()
         self.m2 = torch.zeros(cap, 3, device=dev, requires_grad=True)
         self.sync = BucketedAllReduce(self.fp, [self.sp.flat_grad])
@@ -699,6 +711,10 @@ class GraphedStep:
         with st.lock:
             key_ = (ds.P, ds.H, ds.W)
             st.capacity_hint[key_] = max(int(st.capacity_hint.get(key_, 0)), int(st.d_high.get(key_, 0)))
+            if getattr(ds, "dead", None) is not None:
+                # fixed capacity: this graph is meant to outlive densifications -- the instance count can grow with the cloud
+                # until every dead row is a Gaussian (and a little faster: new Gaussians sit where the gradient is large)
+                st.capacity_hint[key_] = int(st.capacity_hint[key_] * 1.1 * ds.P / max(int(ds.P_live), 1))
         self.graph = torch.cuda.CUDAGraph()
         st.graph_capture = True
         try:

@@ -30,6 +30,15 @@ python3 bench.py --loop 600 --loop-profile > $O/${T}_loop_profile.json 2>/dev/nu
 python3 bench.py --loop 600 --graph > $O/${T}_loop_graph_bench.json 2>/dev/null
 python3 bench.py --loop 600 --points 100000 > $O/${T}_loop_100k_bench.json 2>/dev/null
 python3 bench.py --loop 600 --points 100000 --graph > $O/${T}_loop_100k_graph_bench.json 2>/dev/null
+# fixed capacity (dead rows, densification in place): eager, and ONE captured graph for the whole loop (re-captured only when the
+# capacity itself is outgrown: the 2 500-step runs double the cloud)
+python3 bench.py --loop 600 --fixed-capacity 1.2 > $O/${T}_loop_fixed_bench.json 2>/dev/null
+python3 bench.py --loop 600 --fixed-capacity 1.2 --graph > $O/${T}_loop_fixed_graph_bench.json 2>/dev/null
+python3 bench.py --loop 2500 --fixed-capacity 1.3 --graph > $O/${T}_loop_fixed_graph_long_bench.json 2>/dev/null
+python3 bench.py --loop 600 --points 100000 --fixed-capacity 1.2 > $O/${T}_loop_100k_fixed_bench.json 2>/dev/null
+python3 bench.py --loop 600 --points 100000 --fixed-capacity 1.2 --graph > $O/${T}_loop_100k_fixed_graph_bench.json 2>/dev/null
+python3 bench.py --loop 2500 --points 100000 --fixed-capacity 1.3 --graph > $O/${T}_loop_100k_fixed_graph_long_bench.json 2>/dev/null
+python3 bench.py --loop 2500 --points 100000 > $O/${T}_loop_100k_long_bench.json 2>/dev/null
 python3 bench.py --iteration reference > $O/${T}_reference_iteration_bench.json 2>/dev/null
 python3 bench.py --iteration reference --points 200000 > $O/${T}_reference_iteration_200k_bench.json 2>/dev/null
 python3 bench.py --iteration reference --points 200000 --graph > $O/${T}_reference_iteration_200k_graph_bench.json 2>/dev/null
