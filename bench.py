@@ -902,10 +902,12 @@ def _child_json(argv, timeout_s, script="bench.py"):
         return {"error": f"{type(e).__name__}: {e}"[:300], "seconds": time.perf_counter() - t0}
 
 
-def sub_records(budget_s=150.0):
+def sub_records(budget_s=170.0):
     """What DESIGN.md section 5 claims beside the headline, measured in THE SAME driver run: each a short
     child run of this file's own modes, outside the headline's timed region, reduced to a few numbers.
       loop                : 300 steps with the reference's densification cadence (every 100): sustained / steady fps, overflows;
+      loop_100k           : the same loop at the reference's real cloud size, eager and as ONE captured graph over a cloud of fixed
+                            capacity (DynamicScene.fix_capacity: dead rows, densification in place);
       reference_iteration : the iteration a RoDyGS user runs (static + dynamic sub-step), at 0.5 M + 0.5 M and 0.1 M + 0.1 M
                             (refiter.FusedReferenceIteration; the 0.1 M form also as one replayed hipGraph; the reference-shaped
                             bookkeeping of trainstep.ReferenceIteration next to it);
@@ -930,6 +932,18 @@ def sub_records(budget_s=150.0):
                        "P_trajectory": L["P_trajectory"], "densify_ms_mean": L["densify_ms_mean"], "seconds": lp["_seconds"]}
     else:
         out["loop"] = lp
+    # the reference's real cloud size in the loop: eager against ONE captured graph over a cloud of fixed capacity
+    l100 = {}
+    for name, extra in (("eager", []), ("one_graph_fixed_capacity", ["--graph", "--fixed-capacity", "1.2"])):
+        if left() < 12:
+            l100[name] = {"error": "sub-record budget spent"}
+            continue
+        r = _child_json(["--loop", "300", "--points", "100000", "--densify-interval", "100", "--settle", "20", "--warmup", "3"] + extra,
+                        max(12.0, min(45.0, left())))
+        l100[name] = ({"sustained_fps": r["loop"]["sustained_fps"], "sustained_over_steady": r["loop"]["sustained_over_steady"],
+                       "capacity_overflows": r["loop"]["capacity_overflows"], "graph_captures": r["config"].get("graph_captures"),
+                       "seconds": r["_seconds"]} if "error" not in r else r)
+    out["loop_100k"] = l100
     ri = {}
     for name, pts, mode, extra in (("0.5M+0.5M", 1000000, "reference", []), ("0.1M+0.1M", 200000, "reference", []),
                                    ("0.1M+0.1M graph", 200000, "reference", ["--graph"]),

@@ -622,3 +622,40 @@ def test_the_binding_documented_in_integration_md_matches_the_library(hip_lib):
         assert getattr(doc, n).offset == getattr(_lib.RdgRasterSettings, n).offset, n
     # and the forward of the snippet names arguments in the header's order: 1 struct + 12 pointers + capacity + 8 pointers
     assert "[C.c_void_p] * 12 + [C.c_int64] + [C.c_void_p] * 8" in snippet
+
+
+def test_birth_order_refresh_in_place_keeps_the_tensors_a_graph_knows():
+    """deform.refresh_birth_order_inplace: after the birth indices were modified IN PLACE (a fixed-capacity densification) the
+    sorted order, its inverse and the segment starts are recomputed INTO the tensors the cache already holds (a captured graph
+    reads them by address), and the cache answers for the tensor's new version."""
+    from rodygs_amd import deform
+    deform.invalidate_birth_order_cache()
+    ti = torch.tensor([3, 0, 2, 0, 1, 3, 2], dtype=torch.int64)
+    order, inv, seg = deform._birth_order(ti, 4)
+    ptrs = (order.data_ptr(), inv.data_ptr(), seg.data_ptr())
+    assert ti[order.long()].tolist() == sorted(ti.tolist()) and seg.tolist() == [0, 2, 3, 5, 7]
+    ti[1], ti[5] = 3, 0                                     # in place: same address, new version
+    deform.refresh_birth_order_inplace(ti, 4)
+    o2, i2, s2 = deform._birth_order(ti, 4)                 # a cache hit on the new version ...
+    assert (o2.data_ptr(), i2.data_ptr(), s2.data_ptr()) == ptrs      # ... and the very tensors of before
+    assert ti[o2.long()].tolist() == sorted(ti.tolist()) and s2.tolist() == [0, 2, 3, 5, 7]
+    assert torch.equal(i2[o2.long()].long(), torch.arange(7))
+    deform.invalidate_birth_order_cache()
+
+
+def test_bench_preflight_reports_and_refuses_without_devices():
+    """`bench.py --gpus N --preflight`: one JSON line with the devices, the peer-access matrix, RCCL and the wire bytes of both
+    frame-DP formulations; exit 2 when fewer than N devices are visible (this box shows none)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--preflight"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, r.stderr[-500:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["preflight"] and d["gpus_requested"] == 8 and d["devices_visible"] == 0 and d["ok"] is False and "why" in d
+    w = d["wire_bytes_per_step_at_1M"]
+    assert w["allreduce"]["all_reduce_payload_bytes"] == 1000000 * 75 * 4 + (68656 + 700) * 4
+    assert w["shard"]["all_to_all_payload_bytes"] < w["allreduce"]["all_reduce_payload_bytes"]

@@ -491,3 +491,62 @@ def test_one_captured_graph_replays_across_inplace_densifications():
         assert torch.equal(a.sp.flat, b.sp.flat)
     finally:
         rasterizer.DETERMINISTIC = keep
+
+
+def test_extreme_needles_lose_no_blending_pixel_to_the_culls():
+    """Both culls -- the tight tile rectangle of the per-Gaussian stage and the per-quadrant ellipse test of the compositing
+    kernels -- bound the SAME quadratic form the blend test evaluates (a (dx + beta dy)^2 + dy^2 / cov2D_yy: the third conic entry
+    from the staged values, not the record's float32 conic_c, which is off by eps a c / det along a needle's long axis).  A cloud of
+    footprints 300-1500 pixels long and 1-3 wide (a c / det up to 1e5):
+      * the image with the tight rectangles is the image with the reference's rectangles BIT FOR BIT (forward is deterministic):
+        no instance that blends anywhere was dropped;
+      * against the oracle composited in FLOAT64 on that very form (float32 per-Gaussian geometry, conic_c := b^2 / a + 1 / cov2D_yy)
+        no more than a handful of pixels differ by a boundary splat's worth (alpha T colour >= 4e-3 T) -- a quadrant cull too tight
+        at the ends of the long axes would lose a run of boundary pixels per needle.  (Against the float32 oracle's naive exponent
+        the same image differs in 59 pixels: that is the float32 conic, `geom` in tests/resolution.py, not a cull.)"""
+    TP = _tp()
+    import hip_stages as HS
+    from rodygs_amd import GaussianRasterizer
+    from rodygs_amd.rasterizer import RasterState
+    W, H, P = 640, 480, 300
+    sc = O.synthetic_scene(P, W, H, 3, seed=41)
+    g = torch.Generator().manual_seed(7)
+    s = sc["scales"].clone()
+    long_axis = torch.randint(0, 3, (P,), generator=g)
+    s[:] = s.mean() * 0.004 * (1.0 + torch.rand(P, 3, generator=g))                  # 0.5-1 pixel thick before the dilation
+    s[torch.arange(P), long_axis] = s.mean() * 250.0 * (1.0 + 4.0 * torch.rand(P, generator=g))
+    sc["scales"] = s
+    sc["opacities"] = 0.02 + 0.9 * torch.rand(P, 1, generator=g)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+
+    def hip(cull):
+        with torch.no_grad():
+            return GaussianRasterizer(HS.make_settings(sc, 3, bg=bg), state=RasterState(cull=cull))(
+                means3D=sc["means3D"].to(DEV), means2D=torch.zeros(P, 3, device=DEV), shs=sc["shs"].to(DEV),
+                opacities=sc["opacities"].to(DEV), scales=sc["scales"].to(DEV), rotations=sc["rotations"].to(DEV),
+                viewmatrix=sc["viewmatrix"].to(DEV))
+    tight, ref = hip(True), hip(False)
+    for i in range(5):
+        assert torch.equal(tight[i], ref[i]), f"output {i} differs between the tight and the reference rectangles"
+    # the float64 oracle at the float32 geometry, on the quadratic form the kernels evaluate
+    st = O.OracleSettings(H, W, sc["tanfovx"], sc["tanfovy"], bg, 1.0, sc["projmatrix"], 3, cull=False)
+    with torch.no_grad():
+        geom = O.preprocess(sc["means3D"], torch.zeros(P, 3), sc["opacities"], sc["viewmatrix"], st, shs=sc["shs"],
+                            scales=sc["scales"], rotations=sc["rotations"])
+        binning = O.bin_and_sort(geom)
+        cov = geom["cov2D"].double()
+        ratio = (cov[:, 0] * cov[:, 2]) / (cov[:, 0] * cov[:, 2] - cov[:, 1] ** 2).clamp_min(1e-300)
+        assert int(((geom["radii"] > 0) & (ratio > 1e3)).sum()) > 50, "the scene is there for footprints with a c / det above 1e3"
+        g64 = dict(geom)
+        for k in ("px", "py", "opacity", "rgb", "depth", "normal"):
+            g64[k] = geom[k].double()
+        con = geom["conic"].double()
+        inv_cyy = (torch.ones_like(geom["cov2D"][:, 2]) / geom["cov2D"][:, 2]).double()        # the record's float32 1 / cov2D_yy
+        con[:, 2] = con[:, 1] ** 2 / con[:, 0] + inv_cyy
+        g64["conic"] = con
+        img = O.render_tiles(g64, binning, bg.double(), H, W)
+    assert torch.equal(tight[4].cpu(), geom["radii"])
+    diff = (tight[0].cpu().double() - img["color"]).abs().amax(dim=0)
+    n_off = int((diff > 1e-3).sum())
+    assert n_off <= 12, (n_off, float(diff.max()))
+    assert float(img["alpha"].mean()) > 0.05                                         # the needles do cover the image
