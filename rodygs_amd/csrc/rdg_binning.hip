@@ -144,6 +144,9 @@ __device__ __forceinline__ uint32_t rdg_zidx(uint32_t x, uint32_t y) {
 template <int MODE>  // 0 = count, 1 = scatter
 __global__ void __launch_bounds__(RDG_PRE_BLOCK)
 rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict__ rectd,
+#ifdef RDG_ABL_EXACT_CULL   // measurement build (scripts/build_variant.sh): the exact ellipse-vs-tile test per INSTANCE in the count pass
+                       const RdgRec* __restrict__ rec_abl,
+#endif
                        const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ tile_cnt,
                        const uint2* __restrict__ ranges, uint32_t* __restrict__ rank_buf,
                        uint64_t* __restrict__ comp, long long capacity, const int32_t* __restrict__ num_rendered,
@@ -173,6 +176,17 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict
         t = rd.w;
         if (t > 0) { xy0 = rd.x; wd0 = (rd.y & 0xffffu) - (rd.x & 0xffffu); dep = rd.z; }
     }
+#ifdef RDG_ABL_EXACT_CULL
+    // per-Gaussian constants of the quadratic form the compositing kernels evaluate (rdg_quadrant_bits): Q <= r2 somewhere
+    // in the tile's rectangle of pixel centres, or the instance gets no slot in its tile's list
+    float e_px = 0.f, e_py = 0.f, e_a = 1.f, e_b2 = 0.f, e_c = 1.f, e_r2 = -1.f;
+    if (MODE == 0 && i < P && t > 0) {
+        const float4 q0 = rec_abl[i].q0, q1 = rec_abl[i].q1;
+        const float icyy = rec_abl[i].q2.w;
+        e_px = q0.x; e_py = q0.y; e_a = q0.z; e_b2 = 2.0f * q0.w; e_c = (q0.w * q0.w) / q0.z + icyy;
+        e_r2 = 2.0f * (__logf(255.0f * q1.y) + 0.02f) * 1.001f;
+    }
+#endif
     const uint32_t inc = rdg_wave_scan_incl(t);
     const uint32_t lane = tid & 63, w = tid >> 6;
     const uint32_t excl = inc - t;
@@ -198,6 +212,11 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict
     constexpr int U = RDG_BUCKET_PIPE;
     for (uint32_t k0 = 0; k0 < total; k0 += RDG_WAVE * U) {
         bool act[U];
+#ifdef RDG_ABL_EXACT_CULL
+        bool dead_slot[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dead_slot[u] = false;
+#endif
         uint32_t kk[U], tx[U], ty[U], own_lane[U], odep[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -218,6 +237,27 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict
             const uint32_t j = act[u] ? kk[u] - oex : 0u;
             const uint32_t ry = j / wd, rx = j - ry * wd;
             tx[u] = (oxy & 0xffffu) + rx; ty[u] = (oxy >> 16) + ry;
+#ifdef RDG_ABL_EXACT_CULL
+            if (MODE == 0) {
+                const float opx = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e_px)));
+                const float opy = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e_py)));
+                const float oa = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e_a)));
+                const float ob2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e_b2)));
+                const float oc = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e_c)));
+                const float or2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, e_r2)));
+                const float u1 = opx - (float)(tx[u] * RDG_TILE), u0 = u1 - 15.0f;
+                const float v1 = opy - (float)(ty[u] * RDG_TILE), v0 = v1 - 15.0f;
+                const bool inside = u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f;
+                auto edge = [](float a_, float b2_, float c_, float ue, float w0, float w1) {
+                    const float tt = b2_ * ue;
+                    const float vs = __builtin_amdgcn_fmed3f(-0.5f * tt / c_, w0, w1);
+                    return fmaf(fmaf(c_, vs, tt), vs, a_ * ue * ue);
+                };
+                const float m = fminf(fminf(edge(oa, ob2, oc, u0, v0, v1), edge(oa, ob2, oc, u1, v0, v1)),
+                                      fminf(edge(oc, ob2, oa, v0, u0, u1), edge(oc, ob2, oa, v1, u0, u1)));
+                dead_slot[u] = act[u] && !(inside || !(m > or2));
+            }
+#endif
         }
         if (MODE == 0) {
             uint32_t below[U], base[U];
@@ -225,6 +265,11 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint32_t z = rdg_zidx(tx[u], ty[u]);
+#ifdef RDG_ABL_EXACT_CULL
+                const bool slot_in = act[u];
+                if (dead_slot[u]) act[u] = false;            // no slot in the tile's list ...
+                if (slot_in && dead_slot[u]) rank_buf[first + kk[u]] = 0xffffffffu;   // ... and the scatter pass skips it
+#endif
                 unsigned long long m = __ballot(act[u]);
                 for (int bit = 0; bit < zbits; ++bit) {
                     const bool bset = (z >> bit) & 1u;
@@ -248,6 +293,9 @@ rdg_tile_bucket_kernel(int P, int gx, int gy, int zbits, const uint4* __restrict
             for (int u = 0; u < U; ++u) {
                 st[u] = 0u; rk[u] = 0u;
                 if (act[u]) { st[u] = ranges[ty[u] * (uint32_t)gx + tx[u]].x; rk[u] = rank_buf[first + kk[u]]; }
+#ifdef RDG_ABL_EXACT_CULL
+                if (rk[u] == 0xffffffffu) act[u] = false;
+#endif
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -1076,6 +1124,9 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<0>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const uint4*)(g + G.rectd),
+#ifdef RDG_ABL_EXACT_CULL
+                               (const RdgRec*)(g + G.rec),
+#endif
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered, (uint4*)nullptr, 0ll);
         hipLaunchKernelGGL(rdg_tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, d.gx, tile_cnt, ranges, tile_fill,
@@ -1085,6 +1136,9 @@ int rdg_launch_bin(const RdgDev& d, const void* geom_ws, const int32_t* radii, v
         if (d.P > 0)
             hipLaunchKernelGGL(rdg_tile_bucket_kernel<1>, dim3(nblk), dim3(RDG_PRE_BLOCK), 0, s, d.P, d.gx, d.gy, zbits,
                                (const uint4*)(g + G.rectd),
+#ifdef RDG_ABL_EXACT_CULL
+                               (const RdgRec*)(g + G.rec),
+#endif
                                (const uint32_t*)(g + G.block_sums), tile_cnt, ranges, rank_buf, comp,
                                (long long)capacity, num_rendered, (uint4*)(b + B.hit),
                                (long long)(rdg_hit_bytes(capacity, n_tiles) / 16));
