@@ -99,6 +99,8 @@ def test_torch_free_c_caller_of_the_abi_reproduces_the_committed_fixture(tmp_pat
     TP = _tp()
     from rodygs_amd import _lib
     exe = os.path.join(ROOT, "tests", "abi_caller")
+    if not os.path.exists(exe):          # (built by `make -C rodygs_amd/csrc`, i.e. by __graft_entry__.build(); a bare checkout: here)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "rodygs_amd", "csrc"), "abi_caller"], check=True, capture_output=True)
     assert os.path.exists(exe), "tests/abi_caller is not built (make -C rodygs_amd/csrc abi_caller)"
     spec = importlib.util.spec_from_file_location("mrg", os.path.join(ROOT, "tests", "golden", "make_rasterizer_golden.py"))
     M = importlib.util.module_from_spec(spec)
