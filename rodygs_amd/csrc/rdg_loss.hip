@@ -25,6 +25,28 @@
 
 struct RdgWin { float w[11]; };
 
+// Both kernels are VALU-issue bound (not HBM-bound: profiles/r06_experiments.txt), and a third of the issue slots went to
+// address arithmetic: 64-bit address chains per load / store and a division by 42 per halo element.  So: uniform base
+// pointer (SGPRs) + one unsigned 32-bit BYTE offset per access (the global_load saddr form; the launchers refuse images
+// of 2^30 pixels or more), and a walk over the halo tile that advances (row, column) without dividing.
+__device__ __forceinline__ float rdg_ldg(const float* base, unsigned byte_off) {
+    return *(const float*)((const char*)base + byte_off);
+}
+__device__ __forceinline__ void rdg_stg(float* base, unsigned byte_off, float v) {
+    *(float*)((char*)base + byte_off) = v;
+}
+// The halo tile is loaded by 6 x 42 = 252 threads, thread (hr0, hc) taking the rows hr0 + 6 it, it = 0..6 (7 x 6 = 42
+// rows exactly): the column test is made once, a row costs one compare and one add, and the LDS offsets are immediates.
+#define RDG_HALO_RPI (256 / LWX)
+static_assert(RDG_HALO_RPI * RDG_LOSS_NL == LWY, "the halo walk covers the tile with no remainder");
+#define RDG_HALO_WALK(hc, hact, colok, gy, g, lo)                                        \
+    const int hr0_ = tid / LWX, hc = tid - hr0_ * LWX;                                   \
+    const bool hact = tid < RDG_HALO_RPI * LWX;                                          \
+    const bool colok = hact && (unsigned)(ox + hc - LH) < (unsigned)Wd;                  \
+    int gy = oy + hr0_ - LH;                                                             \
+    unsigned g = (unsigned)(gy * Wd + ox + hc - LH) * 4u;                                \
+    const int lo = hr0_ * (LWX + 1) + hc;
+
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so every XCD gets a
 // contiguous band of tiles: the 5-pixel halos a tile shares with its neighbours are then L2 hits instead of a second
 // trip to memory (PMC: the backward kernel fetched 2.8x its algorithmic bytes with the plain 3-D grid).
@@ -86,21 +108,26 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
         // the whole halo tile in ONE round of loads per thread (7 elements x 2 images in flight before the first LDS
         // store): with three workgroups per CU the load phase, not the filters, set this kernel's time
         float xv[RDG_LOSS_NL], yv[RDG_LOSS_NL];
+        RDG_HALO_WALK(hc, hact, colok, gy, g, lo)
+        const unsigned gstep = (unsigned)(RDG_HALO_RPI * Wd) * 4u;
 #pragma unroll
         for (int it = 0; it < RDG_LOSS_NL; ++it) {
-            const int idx = tid + 256 * it;
-            const int r = idx / LWX, cc = idx - r * LWX;
-            const int gy = oy + r - LH, gx = ox + cc - LH;
             xv[it] = 0.f; yv[it] = 0.f;
-            if (idx < LWY * LWX && gy >= 0 && gy < H && gx >= 0 && gx < Wd) {
-                xv[it] = X[(size_t)gy * Wd + gx]; yv[it] = Y[(size_t)gy * Wd + gx];
+#ifdef RDG_ABL_LOSS_NOLOAD     // measurement build: no global loads of the halo tile
+            if (H == -1) {
+#else
+            if (colok && (unsigned)gy < (unsigned)H) {
+#endif
+                xv[it] = rdg_ldg(X, g); yv[it] = rdg_ldg(Y, g);
             }
+            gy += RDG_HALO_RPI; g += gstep;
         }
+        if (hact) {
 #pragma unroll
-        for (int it = 0; it < RDG_LOSS_NL; ++it) {
-            const int idx = tid + 256 * it;
-            const int r = idx / LWX, cc = idx - r * LWX;
-            if (idx < LWY * LWX) { sx[r][cc] = xv[it]; sy[r][cc] = yv[it]; }
+            for (int it = 0; it < RDG_LOSS_NL; ++it) {
+                (&sx[0][0])[lo + it * RDG_HALO_RPI * (LWX + 1)] = xv[it];
+                (&sy[0][0])[lo + it * RDG_HALO_RPI * (LWX + 1)] = yv[it];
+            }
         }
     }
     __syncthreads();
@@ -121,14 +148,17 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
             float xs[RB + 10], ys[RB + 10];
 #pragma unroll
             for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
+            // the three products once per element (not once per tap): an output then costs 5 multiply-adds per tap
+            float xx[RB + 10], yy[RB + 10], xy[RB + 10];
+#pragma unroll
+            for (int k = 0; k < RB + 10; ++k) { xx[k] = xs[k] * xs[k]; yy[k] = ys[k] * ys[k]; xy[k] = xs[k] * ys[k]; }
 #pragma unroll
             for (int o = 0; o < RB; ++o) {
                 float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
-                    const float xv = xs[o + k], yv = ys[o + k];
-                    const float wx = w[k] * xv, wy = w[k] * yv;
-                    h0 += wx; h1 += wy; h2 += wx * xv; h3 += wy * yv; h4 += wx * yv;
+                    h0 += w[k] * xs[o + k]; h1 += w[k] * ys[o + k]; h2 += w[k] * xx[o + k]; h3 += w[k] * yy[o + k];
+                    h4 += w[k] * xy[o + k];
                 }
                 sh4[0][r][c0 + o] = h0; sh4[1][r][c0 + o] = h1; sh4[2][r][c0 + o] = h2; sh4[3][r][c0 + o] = h3;
                 h4reg[hi][o] = h4;
@@ -165,6 +195,9 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
         }
     }
     const size_t stride = (size_t)C * hw;  // maps layout: [3 maps][C][H][W]
+    float* M0 = maps + c * hw;
+    float* M1 = M0 + stride;
+    float* M2 = M1 + stride;
 #pragma unroll
     for (int o = 0; o < RB; ++o) {
         const int py = oy + ty0 + o;
@@ -174,15 +207,18 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
             const float mu1s = m1 * m1, mu2s = m2 * m2, mu12 = m1 * m2;
             const float s1 = e11[o] - mu1s, s2 = e22[o] - mu2s, s12 = e12[o] - mu12;
             const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
-            const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
+            // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten instructions each, eight of them per thread):
+            // B1, B2 >= C1, C2 > 0, and the parity bar of the loss is 1e-4
+            const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
             const float m = A1 * A2 * iB1 * iB2;
             const float dmu1 = 2.f * m2 * (A2 - A1) * iB1 * iB2 - 2.f * m1 * m * (iB1 - iB2);
             const float de11 = -m * iB2;
             const float de12 = 2.f * A1 * iB1 * iB2;
-            const size_t p = (size_t)py * Wd + px;
-            maps[c * hw + p] = dmu1;
-            maps[stride + c * hw + p] = de11;
-            maps[2 * stride + c * hw + p] = de12;
+            const unsigned p = (unsigned)(py * Wd + px) * 4u;
+#ifdef RDG_ABL_LOSS_NOSTORE    // measurement build: the three maps are not stored
+            if (m == 123.456f)
+#endif
+            { rdg_stg(M0, p, dmu1); rdg_stg(M1, p, de11); rdg_stg(M2, p, de12); }
             ms += m;
             l1 += l1v[o];
         }
@@ -231,24 +267,26 @@ rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
     RDG_LOSS_WEIGHTS(w, win)
     const size_t hw = (size_t)H * Wd;
     const size_t stride = (size_t)C * hw;
+    const float* M0 = maps + c * hw;
+    const float* M1 = M0 + stride;
+    const float* M2 = M1 + stride;
     {
         float a[RDG_LOSS_NL], b[RDG_LOSS_NL], d[RDG_LOSS_NL];
+        RDG_HALO_WALK(hc, hact, colok, gy, g, lo)
+        const unsigned gstep = (unsigned)(RDG_HALO_RPI * Wd) * 4u;
 #pragma unroll
         for (int it = 0; it < RDG_LOSS_NL; ++it) {
-            const int idx = tid + 256 * it;
-            const int r = idx / LWX, cc = idx - r * LWX;
-            const int gy = oy + r - LH, gx = ox + cc - LH;
             a[it] = 0.f; b[it] = 0.f; d[it] = 0.f;
-            if (idx < LWY * LWX && gy >= 0 && gy < H && gx >= 0 && gx < Wd) {
-                const size_t p = c * hw + (size_t)gy * Wd + gx;
-                a[it] = maps[p]; b[it] = maps[stride + p]; d[it] = maps[2 * stride + p];
-            }
+            if (colok && (unsigned)gy < (unsigned)H) { a[it] = rdg_ldg(M0, g); b[it] = rdg_ldg(M1, g); d[it] = rdg_ldg(M2, g); }
+            gy += RDG_HALO_RPI; g += gstep;
         }
+        if (hact) {
 #pragma unroll
-        for (int it = 0; it < RDG_LOSS_NL; ++it) {
-            const int idx = tid + 256 * it;
-            const int r = idx / LWX, cc = idx - r * LWX;
-            if (idx < LWY * LWX) { sa[0][r][cc] = a[it]; sa[1][r][cc] = b[it]; sa[2][r][cc] = d[it]; }
+            for (int it = 0; it < RDG_LOSS_NL; ++it) {
+                (&sa[0][0][0])[lo + it * RDG_HALO_RPI * (LWX + 1)] = a[it];
+                (&sa[1][0][0])[lo + it * RDG_HALO_RPI * (LWX + 1)] = b[it];
+                (&sa[2][0][0])[lo + it * RDG_HALO_RPI * (LWX + 1)] = d[it];
+            }
         }
     }
     __syncthreads();
@@ -298,15 +336,18 @@ rdg_loss_bwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
     const float go = grad_loss ? grad_loss[0] : 1.0f;
     const float gs = -lambda * inv_n * go;           // d loss / d ssim_map(q)
     const float gl = (1.0f - lambda) * inv_n * go;   // d loss / d |x - y|
+    const float* X = img + c * hw;
+    const float* Y = gt + c * hw;
+    float* DX = d_img + c * hw;
 #pragma unroll
     for (int o = 0; o < RB; ++o) {
         const int py = oy + ty0 + o;
         if (py < H && px < Wd) {
-            const size_t p = c * hw + (size_t)py * Wd + px;
-            const float x = img[p], y = gt[p];
+            const unsigned p = (unsigned)(py * Wd + px) * 4u;
+            const float x = rdg_ldg(X, p), y = rdg_ldg(Y, p);
             const float d = x - y;
             const float sgn = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f);
-            d_img[p] = gs * (u0[o] + 2.0f * x * u1[o] + y * u2[o]) + gl * sgn;
+            rdg_stg(DX, p, gs * (u0[o] + 2.0f * x * u1[o] + y * u2[o]) + gl * sgn);
         }
     }
 }
@@ -320,14 +361,17 @@ size_t rdg_loss_ws_bytes(int32_t C, int32_t H, int32_t W) {
 
 int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float lambda,
                                  void* ws, float* loss3, void* stream) {
-    if (C <= 0 || H <= 0 || W <= 0) return rdg_set_error("loss: bad image size");
+    if (C <= 0 || H <= 0 || W <= 0 || (size_t)H * W >= ((size_t)1 << 30)) return rdg_set_error("loss: bad image size");
     hipStream_t st = (hipStream_t)stream;
     float* maps = (float*)ws;
     float* sums = (float*)((char*)ws + (size_t)3 * C * H * W * 4);
     rdg_stage_begin(RDG_STAGE_LOSS_FWD, st);
     const RdgWin win = rdg_make_window();
     const int n_tiles = ((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * C;
-    hipLaunchKernelGGL(rdg_loss_fwd_kernel, dim3(((n_tiles + 7) / 8) * 8), dim3(256), 0, st, H, W, C, win, img, gt, maps,
+#ifndef RDG_ABL_LOSS_LDSPAD     // measurement builds: extra (unused) dynamic LDS bytes, i.e. fewer workgroups per CU
+#define RDG_ABL_LOSS_LDSPAD 0
+#endif
+    hipLaunchKernelGGL(rdg_loss_fwd_kernel, dim3(((n_tiles + 7) / 8) * 8), dim3(256), RDG_ABL_LOSS_LDSPAD, st, H, W, C, win, img, gt, maps,
                        sums);
     hipLaunchKernelGGL(rdg_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, n_tiles,
                        1.0f / ((float)C * H * W), lambda, loss3);
@@ -337,7 +381,7 @@ int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* i
 
 int rdg_photometric_loss_backward(int32_t C, int32_t H, int32_t W, const float* img, const float* gt, float lambda,
                                   const void* ws, const float* grad_loss, float* d_img, void* stream) {
-    if (C <= 0 || H <= 0 || W <= 0) return rdg_set_error("loss: bad image size");
+    if (C <= 0 || H <= 0 || W <= 0 || (size_t)H * W >= ((size_t)1 << 30)) return rdg_set_error("loss: bad image size");
     hipStream_t st = (hipStream_t)stream;
     const RdgWin win = rdg_make_window();
     const int n_tiles = ((W + LTX - 1) / LTX) * ((H + LTY - 1) / LTY) * C;

@@ -12,7 +12,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed -I../../include"
 case "$2" in
   rdg_preprocess_fwd|rdg_binning) MODE="-ffp-contract=off" ;;
-  rdg_render) MODE="-ffp-contract=fast -fno-slp-vectorize" ;;
+  rdg_render|rdg_loss) MODE="-ffp-contract=fast -fno-slp-vectorize" ;;
   *) MODE="-ffp-contract=fast" ;;
 esac
 $HIPCC $COMMON $MODE $3 -c $2.hip -o variants/$1.$2.o
