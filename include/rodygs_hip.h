@@ -410,6 +410,12 @@ int rdg_gather_rows(int64_t n_new, int32_t row_len, const int64_t* idx, const fl
  * scaling_out[i] = log(exp(scaling[p]) / (0.8 N)); z[n,3] are standard-normal draws supplied by the caller.        */
 int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float* xyz, const float* scaling,
                        const float* rotation, const float* z, float* xyz_out, float* scaling_out, void* stream);
+/* rank[i] = (number of non-zero bytes in mask[0..i]) - 1, int64 [n]: the position of row i in the selection `mask` -- what
+ * the reference's boolean indexing (xyz[selected_pts_mask], rodygs_static.py:176-215, utils.py:40-63) computes inside the
+ * framework; with the selection's size known, idx[rank[i]] = i over the set rows is the compacted row list.  n < 2^32;
+ * ws: rdg_mask_rank_ws_bytes(n).                                                                                       */
+size_t rdg_mask_rank_ws_bytes(int64_t n);
+int rdg_mask_rank(int64_t n, const uint8_t* mask, int64_t* rank, void* ws, void* stream);
 
 /* The per-iteration densification statistics as a stand-alone launch, for a caller that follows the reference's flow
  * (viewspace_point_tensor.grad and radii in hand after loss.backward(), /root/reference/src/trainer/rodygs.py:316-341,

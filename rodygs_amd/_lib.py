@@ -101,6 +101,8 @@ _SIGS = {
     "rdg_dist2_knn3": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "rdg_gather_rows": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 4),
     "rdg_split_children": (C.c_int, [C.c_int64, C.c_int32] + [_vp] * 8),
+    "rdg_mask_rank_ws_bytes": (C.c_size_t, [C.c_int64]),
+    "rdg_mask_rank": (C.c_int, [C.c_int64, _vp, _vp, _vp, _vp]),
     "rdg_densify_stats": (C.c_int, [C.c_int64, C.c_int64] + [_vp] * 6),
     "rdg_reset_opacity": (C.c_int, [C.c_int64, C.c_float, _vp, _vp, _vp, _vp]),
     "rdg_morton_codes": (C.c_int, [C.c_int64, _vp, _vp, C.c_int32, _vp, _vp]),

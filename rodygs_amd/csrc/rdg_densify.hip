@@ -98,6 +98,76 @@ rdg_morton_codes_kernel(long long n, const float* __restrict__ xyz, const float*
     codes[i] = (long long)(rdg_spread3(q[0]) | (rdg_spread3(q[1]) << 1) | (rdg_spread3(q[2]) << 2));
 }
 
+// ---- rank of the set entries of a byte mask: rank[i] = (number of non-zero mask bytes in [0, i]) - 1 ---------------------
+// What densify.py needs to compact a selection with its size already known on the host (the row lists of clone / split /
+// prune, the free-row list of the in-place form) -- the one place the product path still went through the framework's
+// scan.  Three launches: per-block counts (4096 entries per 256-thread block), a one-workgroup exclusive scan of the
+// block counts, the in-block ranks.
+#define RDG_RANK_PER_THREAD 16
+#define RDG_RANK_BLOCK (256 * RDG_RANK_PER_THREAD)
+
+__device__ __forceinline__ uint32_t rdg_mask_bits16(const uint8_t* __restrict__ mask, long long i0, long long n) {
+    uint32_t bits = 0;
+    if (i0 + RDG_RANK_PER_THREAD <= n && ((((uintptr_t)mask) + (uintptr_t)i0) & 15) == 0) {
+        const uint4 v = *(const uint4*)(mask + i0);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bits |= (((wds[k] >> (8 * b)) & 0xffu) != 0u ? 1u : 0u) << (4 * k + b);
+    } else {
+        for (int k = 0; k < RDG_RANK_PER_THREAD; ++k)
+            if (i0 + k < n && mask[i0 + k] != 0) bits |= 1u << k;
+    }
+    return bits;
+}
+
+__global__ void __launch_bounds__(256)
+rdg_mask_block_count_kernel(long long n, const uint8_t* __restrict__ mask, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t wsum[4];
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * RDG_RANK_PER_THREAD;
+    const uint32_t c = i0 < n ? (uint32_t)__popc(rdg_mask_bits16(mask, i0, n)) : 0u;
+    const uint32_t inc = rdg_wave_scan_incl(c);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// exclusive scan of v[0..n) in place by one workgroup (a run of ceil(n / 1024) block counts per thread)
+__global__ void __launch_bounds__(1024) rdg_mask_scan_blocks_kernel(uint32_t* __restrict__ v, int n) {
+    __shared__ uint32_t wtot[16];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (n + 1023) / 1024;
+    const int t0 = min(n, (int)threadIdx.x * per), t1 = min(n, t0 + per);
+    uint32_t mine = 0;
+    for (int c = t0; c < t1; ++c) mine += v[c];
+    const uint32_t inc = rdg_wave_scan_incl(mine);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - mine;
+    for (uint32_t k = 0; k < w; ++k) run += wtot[k];
+    for (int c = t0; c < t1; ++c) { const uint32_t x = v[c]; v[c] = run; run += x; }
+}
+
+__global__ void __launch_bounds__(256)
+rdg_mask_rank_kernel(long long n, const uint8_t* __restrict__ mask, const uint32_t* __restrict__ bsum,
+                     long long* __restrict__ rank) {
+    __shared__ uint32_t wsum[4];
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * RDG_RANK_PER_THREAD;
+    const uint32_t bits = i0 < n ? rdg_mask_bits16(mask, i0, n) : 0u;
+    const uint32_t c = (uint32_t)__popc(bits);
+    const uint32_t inc = rdg_wave_scan_incl(c);
+    const uint32_t w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = bsum[blockIdx.x] + inc - c;
+    for (uint32_t k = 0; k < w; ++k) before += wsum[k];
+    if (i0 >= n) return;
+    const int cnt = (int)min((long long)RDG_RANK_PER_THREAD, n - i0);
+    for (int k = 0; k < cnt; ++k)
+        rank[i0 + k] = (long long)before + (long long)__popc(bits & ((2u << k) - 1u)) - 1;
+}
+
 int rdg_launch_densify_stats(long long n, long long row0, const float* dmeans2D, const int32_t* radii, float* accum,
                              float* denom, float* maxr, hipStream_t s) {
     hipLaunchKernelGGL(rdg_densify_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, row0, dmeans2D,
@@ -142,6 +212,24 @@ int rdg_split_children(int64_t n, int32_t N, const int64_t* parent, const float*
                        (long long)n, (const long long*)parent, 1.0f / (0.8f * (float)N), xyz, scaling, rotation, z,
                        xyz_out, scaling_out);
     return rdg_check_hip(hipGetLastError(), "split_children launch");
+}
+
+size_t rdg_mask_rank_ws_bytes(int64_t n) {
+    return (size_t)((n + RDG_RANK_BLOCK - 1) / RDG_RANK_BLOCK + 1) * 4 + 256;
+}
+
+int rdg_mask_rank(int64_t n, const uint8_t* mask, int64_t* rank, void* ws, void* stream) {
+    if (n <= 0) return 0;
+    if (!mask || !rank || !ws) return rdg_set_error("mask_rank: NULL buffer");
+    if (n >= ((int64_t)1 << 32)) return rdg_set_error("mask_rank: n must be below 2^32");
+    const long long nblk = (n + RDG_RANK_BLOCK - 1) / RDG_RANK_BLOCK;
+    uint32_t* bsum = (uint32_t*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rdg_mask_block_count_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (long long)n, mask, bsum);
+    hipLaunchKernelGGL(rdg_mask_scan_blocks_kernel, dim3(1), dim3(1024), 0, st, bsum, (int)nblk);
+    hipLaunchKernelGGL(rdg_mask_rank_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (long long)n, mask, bsum,
+                       (long long*)rank);
+    return rdg_check_hip(hipGetLastError(), "mask_rank launch");
 }
 
 }  // extern "C"

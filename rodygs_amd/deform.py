@@ -243,7 +243,7 @@ def _birth_order(time_ind: torch.Tensor, n_births: int = 0):
     if o is None:
         if len(_ORDER_CACHE) > 8:
             _ORDER_CACHE.clear()
-        order = torch.argsort(time_ind, stable=True)
+        order = _stable_order(time_ind, n_births)
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
         seg = None
@@ -254,6 +254,16 @@ def _birth_order(time_ind: torch.Tensor, n_births: int = 0):
         o = (order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous(), seg, time_ind)
         _ORDER_CACHE[key] = o
     return o[:3]
+
+
+def _stable_order(time_ind: torch.Tensor, n_births: int) -> torch.Tensor:
+    """Stable ascending order of the birth indices (int64 [P]): on the GPU the library's LSD radix sort over the bits the
+    indices have (rdg_sort_pairs; the product path does not go through the framework's sort), the framework's on the CPU."""
+    if time_ind.is_cuda and 0 < time_ind.numel() < 2 ** 31:
+        from .rigidity import _sort_by_key
+        hi = int(n_births) if n_births > 0 else int(time_ind.max()) + 1
+        return _sort_by_key(time_ind, max(1, int(hi).bit_length()))[1]
+    return torch.argsort(time_ind, stable=True)
 
 
 def invalidate_birth_order_cache() -> None:
@@ -270,7 +280,7 @@ def refresh_birth_order_inplace(time_ind: torch.Tensor, n_births: int) -> None:
         _birth_order(time_ind, n_births)
         return
     order_t, inv_t, seg_t, _ = _ORDER_CACHE.pop(old_key)
-    order = torch.argsort(time_ind, stable=True)
+    order = _stable_order(time_ind, n_births)
     inv = torch.empty_like(order)
     inv[order] = torch.arange(order.numel(), device=order.device)
     order_t.copy_(order.to(torch.int32))

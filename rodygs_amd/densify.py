@@ -248,11 +248,29 @@ class _Phase:
         self.last = now
 
 
+def mask_rank(mask: torch.Tensor) -> torch.Tensor:
+    """int64 [P]: rank[i] = (number of set entries of the bool mask in [0, i]) - 1, the position of row i in the selection
+    (what ``torch.cumsum(mask, 0) - 1`` returns).  GPU masks go through the library's scan (rdg_mask_rank), not the framework's."""
+    if not mask.is_cuda:
+        return torch.cumsum(mask, 0) - 1
+    m = mask.detach().contiguous()
+    m = m.view(torch.uint8) if m.dtype == torch.bool else (m != 0).view(torch.uint8)
+    n = m.numel()
+    rank = torch.empty(n, dtype=torch.int64, device=m.device)
+    if n == 0:
+        return rank
+    L = _lib.lib()
+    with torch.cuda.device(m.device):
+        ws = torch.empty(L.rdg_mask_rank_ws_bytes(n), dtype=torch.uint8, device=m.device)
+        _lib.check(L.rdg_mask_rank(n, _lib.ptr(m), _lib.ptr(rank), _lib.ptr(ws), _lib.stream_ptr()), "rdg_mask_rank")
+    return rank
+
+
 def _compact(mask: torch.Tensor, n: int) -> torch.Tensor:
     """Indices of the True entries of ``mask`` in ascending order, their number ``n`` already known on the host: no read-back
     (a boolean-mask index or ``nonzero`` waits for the count it has to size its result with)."""
     P = mask.numel()
-    pos = torch.cumsum(mask, 0) - 1
+    pos = mask_rank(mask)
     out = torch.empty(n + 1, dtype=torch.int64, device=mask.device)
     out.scatter_(0, torch.where(mask, pos, torch.full_like(pos, n)), torch.arange(P, device=mask.device))
     return out[:n]
@@ -328,7 +346,7 @@ def densify_and_prune(fp: FlatParams, stats: DensifyStats, per_point: Dict[str, 
         if n_child_kept:
             if z is None:
                 z = torch.randn(n_child, 3, device=dev)
-            rank = torch.cumsum(split_mask, 0) - 1                                       # position in the split selection
+            rank = mask_rank(split_mask)                                                 # position in the split selection
             child_no = torch.cat([rank[srcs] + r * n_sel for r in range(N)])
             zz = z.to(device=dev, dtype=torch.float32)[child_no].contiguous()
             parents = src[first:].contiguous()
@@ -465,7 +483,7 @@ def densify_and_prune_inplace(fp: FlatParams, stats: DensifyStats, per_point: Di
         if ks:
             if z is None:
                 z = torch.randn(n_sel * N, 3, device=dev)
-            rank = torch.cumsum(split_mask, 0) - 1
+            rank = mask_rank(split_mask)
             child_no = torch.cat([rank[srcs] + r * n_sel for r in range(N)])
             zz = z.to(device=dev, dtype=torch.float32)[child_no].contiguous()
             parents = src[kc:].contiguous()

@@ -552,3 +552,32 @@ def test_extreme_needles_lose_no_blending_pixel_to_the_culls():
     n_off = int((diff > 1e-3).sum())
     assert n_off <= 12, (n_off, float(diff.max()))
     assert float(img["alpha"].mean()) > 0.05                                         # the needles do cover the image
+
+
+# ---- the product path's last framework scan / sort: library ops, the framework's as the checker ----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 70001, 1_000_003, 5_000_000])
+def test_mask_rank_equals_the_framework_scan(n):
+    from rodygs_amd.densify import mask_rank, _compact
+    g = torch.Generator().manual_seed(n)
+    for density in (0.0, 0.03, 0.5, 1.0):
+        mask = (torch.rand(n + 5, generator=g) < density).to(DEV)
+        for m in (mask[:n], mask[3:3 + n], mask[5:]):                  # aligned and unaligned starts (a view's storage offset)
+            want = torch.cumsum(m, 0) - 1
+            got = mask_rank(m)
+            assert got.dtype == torch.int64 and torch.equal(got, want), (n, density)
+            k = int(m.sum())
+            assert torch.equal(_compact(m, k), m.nonzero().squeeze(1))
+
+
+@pytest.mark.gpu
+def test_birth_order_comes_from_the_library_sort_and_equals_the_stable_framework_sort():
+    from rodygs_amd import deform
+    g = torch.Generator().manual_seed(5)
+    for P, nb in ((1, 1), (1000, 7), (300_001, 101), (1_000_000, 300)):
+        t = torch.randint(0, nb, (P,), generator=g).to(DEV)
+        want = torch.argsort(t, stable=True)
+        got = deform._stable_order(t, nb)
+        assert got.dtype == torch.int64 and torch.equal(got, want)
+        got0 = deform._stable_order(t, 0)                               # number of births not given: taken from the data
+        assert torch.equal(got0, want)
