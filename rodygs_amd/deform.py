@@ -445,6 +445,11 @@ class _DynamicGetter(torch.autograd.Function):
                        "rdg_dyn_getter_backward")
         ret = [None if k in sinks and sinks[k] is not None else out[k] for k in ("xyz", "scaling", "rotation", "opacity")]
         d_c = None if sinks.get("coeff") is not None else out["coeff"]
+        after = sinks.get("after_rows")
+        if after is not None:
+            # every per-Gaussian gradient of the step is in its sink now; what is left of backward is the MLP's (d_bases).
+            # The owner may start on the rows here (trainstep: their Adam launch on a second stream, next to the MLP backward)
+            after()
         return ret[0], ret[1], ret[2], ret[3], d_c, None, d_bases, None, None
 
 

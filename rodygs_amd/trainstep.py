@@ -137,7 +137,26 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
                "rdg_adam_step_multi")
 
 
+def _low_priority_stream(device):
+    """A stream of the LOWEST priority the device offers (hipStreamCreateWithPriority through the HIP runtime torch has loaded,
+    wrapped as an ExternalStream; never destroyed: one per scene).  The framework's own pool only hands out streams of the
+    default priority or higher, and the work put here -- an HBM-bound launch that fills every CU -- must yield to the chain of
+    small dependent launches on the caller's stream, not starve it."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    with torch.cuda.device(device):
+        if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+            return torch.cuda.Stream(device=device)
+        h = ctypes.c_void_p()
+        prio = int(os.environ.get("RDG_SIDE_STREAM_PRIORITY", str(least.value)))
+        if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, prio) != 0 or not h.value:   # 1 = hipStreamNonBlocking
+            return torch.cuda.Stream(device=device)
+    return torch.cuda.ExternalStream(h.value, device=device)
+
+
 _FUSE_SH_ADAM = os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0"
+_EARLY_ROWS_ADAM = os.environ.get("RDG_EARLY_ROWS_ADAM", "1") != "0"   # the rows' Adam launch next to the MLP backward (eager step)
 _PLAIN_FULL_FAST = os.environ.get("RDG_PLAIN_FULL_FAST", "1") != "0"   # 0: every full-loss step on the general path
 
 _MLP_SINK_ORDER = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias", "timenet.4.weight",
@@ -262,6 +281,9 @@ class DynamicScene:
         self.fuse_sh_adam = False
         self._graph_inputs = None    # GraphedStep: (time-embedding rows, ground truth, RdgStepScalars, depth ground truth) at fixed addresses
         self._grad_one = None
+        self._rows_adam_hook = None  # set for one backward by train_step: _step_rows_early (the rows' Adam next to the MLP backward)
+        self._rows_stepped = False
+        self._side_stream = None
         self._plain_full = False     # full_losses on a step without rigidity: the photometric step's fused kernels
         if full_losses:
             from .depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
@@ -289,6 +311,8 @@ class DynamicScene:
             # deformation + activations in ONE kernel each way; all five parameter gradients go straight to the bucket
             sinks = {k: fp[k].grad for k in ("xyz", "scaling", "rotation", "opacity")}
             sinks["coeff"] = fp["motion_coeff"].grad
+            if self._rows_adam_hook is not None:
+                sinks["after_rows"] = self._rows_adam_hook
             xyz, scaling, rot, opacity = dynamic_gaussians(fp["xyz"], fp["scaling"], fp["rotation"], fp["opacity"],
                                                            fp["motion_coeff"], self.time_ind, allb,
                                                            self.spatial_lr_scale, grad_sinks=sinks)
@@ -572,10 +596,26 @@ class DynamicScene:
             return reg.detach()
         return loss, after
 
+    def _step_rows_early(self) -> None:
+        """Called from inside backward (deform._DynamicGetter.backward, ``after_rows``) once every per-Gaussian gradient is in the
+        bucket: the Adam launch of the per-Gaussian rows (0.13 ms at 1 M, HBM-bound) goes to a second stream and runs NEXT TO the
+        rest of backward -- the MLP's products, a chain of small latency-bound launches (0.045 ms) that touches neither the rows
+        nor their gradients.  train_step() steps the MLP + pose bucket afterwards and joins the streams.  Same launches, same
+        arithmetic, same bits as the one-launch form (RDG_EARLY_ROWS_ADAM=0)."""
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = _low_priority_stream(self.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fused_adam_(self.fp, names=[k for k in self.fp.names if k != "features"])
+        self._rows_stepped = True
+
     def train_step(self, step: int, rank: int = 0, world: int = 1, perm=None) -> torch.Tensor:
         perm = perm if perm is not None else list(self.gt.keys())
         frame = frame_for(step, rank, world, perm)
         after = None
+        self._rows_adam_hook, self._rows_stepped = None, False
         if self.full_losses and step % self.rigidity[1] != 0 and _PLAIN_FULL_FAST:
             fuse = world == 1 and _FUSE_SH_ADAM
             loss, after = self._full_loss_plain(frame, fuse)
@@ -584,6 +624,8 @@ class DynamicScene:
         else:
             # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
             self.fuse_sh_adam = fuse = world == 1 and _FUSE_SH_ADAM
+            if fuse and _EARLY_ROWS_ADAM and self._graph_inputs is None and not self.raster_state.graph_capture:
+                self._rows_adam_hook = self._step_rows_early
             try:
                 out, _ = self.render(frame)
             finally:
@@ -594,6 +636,7 @@ class DynamicScene:
         if self._grad_one is None or self._grad_one.device != loss.device:
             self._grad_one = torch.ones((), dtype=torch.float32, device=loss.device)
         loss.backward(self._grad_one)
+        self._rows_adam_hook = None
         st_ = self.raster_state
         if st_.graph_capture and st_.aux_stream is not None:
             # the pose-gradient chain ran as a branch of the graph (RasterState.aux_stream): join before the optimiser reads it
@@ -611,6 +654,12 @@ class DynamicScene:
                 else:
                     fused_adam_(self.fp, row_lr=self.row_lr, names=names, advance=first)
                 first = False
+        elif self._rows_stepped:
+            # the per-Gaussian rows are being stepped on the second stream (_step_rows_early): the small MLP + pose bucket here,
+            # then the two streams meet -- the next forward reads both
+            self._rows_stepped = False
+            fused_adam_(self.fp, names=(), extra=(self.sp,), advance=False)
+            torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
         elif (not self.full_losses or after is not None) and fuse:
             # the SH features were stepped inside backward; everything else in the usual single launch
             fused_adam_(self.fp, names=[k for k in self.fp.names if k != "features"], extra=(self.sp,),

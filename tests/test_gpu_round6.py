@@ -581,3 +581,37 @@ def test_birth_order_comes_from_the_library_sort_and_equals_the_stable_framework
         assert got.dtype == torch.int64 and torch.equal(got, want)
         got0 = deform._stable_order(t, 0)                               # number of births not given: taken from the data
         assert torch.equal(got0, want)
+
+
+def test_rows_adam_next_to_the_mlp_backward_is_the_same_step_bit_for_bit():
+    """trainstep.DynamicScene._step_rows_early: the per-Gaussian rows' Adam launch on a second (lowest-priority) stream, started from
+    inside backward once the rows' gradients are in the bucket, next to the MLP's backward -- against the one-launch form
+    (RDG_EARLY_ROWS_ADAM=0).  Deterministic backward mode (float atomics otherwise decide the last bit of the gradients): twelve
+    steps over all frames, every parameter, both moments, the MLP + pose bucket and the losses identical to the last bit; the second
+    stream exists only in the early form and is joined (a synchronize() finds nothing left to do that changes a value)."""
+    import rodygs_amd.trainstep as TS
+    from rodygs_amd.rasterizer import RasterState
+    saved = TS._EARLY_ROWS_ADAM
+    res = {}
+    try:
+        for early in (False, True):
+            TS._EARLY_ROWS_ADAM = early
+            sc = O.synthetic_scene(20000, 320, 240, 3, seed=5)
+            tgt = O.synthetic_scene(5000, 320, 240, 3, seed=6)
+            ds = TS.DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True)
+            ds.raster_state = RasterState(deterministic=True)
+            ds.make_ground_truth(tgt, list(range(8)))
+            losses = [float(ds.train_step(s, perm=list(range(8)))) for s in range(12)]
+            before = {k: t.clone() for k, t in (("flat", ds.fp.flat), ("m", ds.fp.exp_avg), ("v", ds.fp.exp_avg_sq),
+                                                ("sp", ds.sp.flat), ("spm", ds.sp.exp_avg))}
+            torch.cuda.synchronize()
+            for k, t in (("flat", ds.fp.flat), ("m", ds.fp.exp_avg), ("v", ds.fp.exp_avg_sq), ("sp", ds.sp.flat), ("spm", ds.sp.exp_avg)):
+                assert torch.equal(before[k], t), k
+            assert (ds._side_stream is not None) == early
+            assert ds.fp.step_count == 12 and ds.sp.step_count == 12
+            res[early] = (losses, {k: v.cpu() for k, v in before.items()})
+    finally:
+        TS._EARLY_ROWS_ADAM = saved
+    assert res[False][0] == res[True][0]
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
