@@ -209,8 +209,13 @@ class _PoseView(torch.autograd.Function):
         # graph capture (trainstep.GraphedStep): the kernel joins the pose-gradient chain on the rasterizer state's second stream
         # (sinks["aux"] = the RasterState; everything it touches is persistent: the state's dL/dviewmatrix buffer, the sinks)
         st_ = None if sinks is None else sinks.get("aux")
-        on_aux = st_ is not None and st_.graph_capture and st_.aux_stream is not None and g.data_ptr() == st_.pose_grad.data_ptr()
-        with torch.cuda.device(q.device), (torch.cuda.stream(st_.aux_stream) if on_aux else _nullcontext()):
+        aux = None
+        if st_ is not None:
+            if st_.graph_capture and st_.aux_stream is not None and g.data_ptr() == st_.pose_grad.data_ptr():
+                aux = st_.aux_stream
+            elif st_.pose_fork_eager is not None and g.data_ptr() == st_.pose_fork_eager[1].data_ptr():
+                aux = st_.pose_fork_eager[0]          # the eager step's fork: same chain, same stream, no graph
+        with torch.cuda.device(q.device), (torch.cuda.stream(aux) if aux is not None else _nullcontext()):
             if ctx.step_scalars is not None:
                 _lib.check(L.rdg_pose_view_backward_dev(T, _lib.ptr(ctx.step_scalars), _lib.ptr(q), _lib.ptr(t),
                                                         _lib.ptr(g), _lib.ptr(d_q), _lib.ptr(d_t), _lib.stream_ptr()),

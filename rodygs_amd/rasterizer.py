@@ -120,6 +120,7 @@ class RasterState:
         # workspaces kept alive until the owner has joined the streams
         self.aux_stream = None
         self.pose_grad = None
+        self.pose_fork_eager = None   # (stream, [4,4] buffer): the same fork for ONE eager step, set and cleared by its owner
         self.keep_alive = []
         self.lock = threading.RLock()
 
@@ -510,6 +511,13 @@ class _RasterizeGaussians(torch.autograd.Function):
                 ctx.cs.aux_stream = st_.aux_stream.cuda_stream
                 d_vm = st_.pose_grad
                 st_.keep_alive.append(gws)
+            elif (st_.pose_fork_eager is not None and not st_.graph_capture and not GRAPH_CAPTURE and not ctx.deterministic
+                  and gws is not None):
+                # the eager step's fork (trainstep.DynamicScene.train_step): same branch, no graph -- the allocator must know
+                # that the gradient workspace is read on the second stream after this function returns
+                aux_, d_vm = st_.pose_fork_eager
+                ctx.cs.aux_stream = aux_.cuda_stream
+                gws.record_stream(aux_)
             fused = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs_adam")
             if fused is not None:
                 # optimizer in backward for the SH features: dL/dshs never leaves the kernel's LDS tile; the kernel

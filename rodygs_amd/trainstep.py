@@ -157,6 +157,7 @@ def _low_priority_stream(device):
 
 _FUSE_SH_ADAM = os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0"
 _EARLY_ROWS_ADAM = os.environ.get("RDG_EARLY_ROWS_ADAM", "1") != "0"   # the rows' Adam launch next to the MLP backward (eager step)
+_EAGER_POSE_FORK = os.environ.get("RDG_EAGER_POSE_FORK", "1") != "0"   # the pose-gradient chain as a branch of the eager step
 _PLAIN_FULL_FAST = os.environ.get("RDG_PLAIN_FULL_FAST", "1") != "0"   # 0: every full-loss step on the general path
 
 _MLP_SINK_ORDER = ("timenet.0.weight", "timenet.0.bias", "timenet.2.weight", "timenet.2.bias", "timenet.4.weight",
@@ -284,6 +285,7 @@ class DynamicScene:
         self._rows_adam_hook = None  # set for one backward by train_step: _step_rows_early (the rows' Adam next to the MLP backward)
         self._rows_stepped = False
         self._side_stream = None
+        self._pose_fork = None       # (stream, dL/dviewmatrix buffer) of the eager step's pose-chain branch
         self._plain_full = False     # full_losses on a step without rigidity: the photometric step's fused kernels
         if full_losses:
             from .depth_losses import GlobalPearsonDepthLoss, LocalPearsonDepthLoss
@@ -616,6 +618,7 @@ class DynamicScene:
         frame = frame_for(step, rank, world, perm)
         after = None
         self._rows_adam_hook, self._rows_stepped = None, False
+        self.raster_state.pose_fork_eager = None
         if self.full_losses and step % self.rigidity[1] != 0 and _PLAIN_FULL_FAST:
             fuse = world == 1 and _FUSE_SH_ADAM
             loss, after = self._full_loss_plain(frame, fuse)
@@ -624,8 +627,17 @@ class DynamicScene:
         else:
             # every segment of both flat gradient buckets is OVERWRITTEN by a backward kernel: nothing to zero
             self.fuse_sh_adam = fuse = world == 1 and _FUSE_SH_ADAM
-            if fuse and _EARLY_ROWS_ADAM and self._graph_inputs is None and not self.raster_state.graph_capture:
+            eager = self._graph_inputs is None and not self.raster_state.graph_capture
+            if fuse and _EARLY_ROWS_ADAM and eager:
                 self._rows_adam_hook = self._step_rows_early
+            if fuse and _EAGER_POSE_FORK and eager and self.pose_sinks is not None:
+                # the pose-gradient chain (two reductions + the pose backward, three small dependent launches between the
+                # per-Gaussian backward and the getter's) as a branch on a second stream; joined before the pose Adam
+                if self._pose_fork is None:
+                    self._pose_fork = (torch.cuda.Stream(device=self.device),
+                                       torch.empty(4, 4, dtype=torch.float32, device=self.device))
+                self.raster_state.pose_fork_eager = self._pose_fork
+                self.pose_sinks["aux"] = self.raster_state
             try:
                 out, _ = self.render(frame)
             finally:
@@ -638,6 +650,9 @@ class DynamicScene:
         loss.backward(self._grad_one)
         self._rows_adam_hook = None
         st_ = self.raster_state
+        if st_.pose_fork_eager is not None:
+            torch.cuda.current_stream(self.device).wait_stream(st_.pose_fork_eager[0])
+            st_.pose_fork_eager = None
         if st_.graph_capture and st_.aux_stream is not None:
             # the pose-gradient chain ran as a branch of the graph (RasterState.aux_stream): join before the optimiser reads it
             torch.cuda.current_stream(self.device).wait_stream(st_.aux_stream)

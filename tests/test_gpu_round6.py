@@ -615,3 +615,38 @@ def test_rows_adam_next_to_the_mlp_backward_is_the_same_step_bit_for_bit():
     assert res[False][0] == res[True][0]
     for k in res[False][1]:
         assert torch.equal(res[False][1][k], res[True][1][k]), k
+
+
+def test_eager_pose_chain_branch_gives_the_same_pose_gradient():
+    """RasterState.pose_fork_eager (set per step by DynamicScene.train_step): the pose-gradient chain of the eager step on a second
+    stream.  The chain itself is deterministic (fixed-order sums of the per-Gaussian rows); the rows come from float atomics, so the
+    two forms are compared like two runs of the same form: the camera gradients of one step to 1e-5 of their largest entry, and the
+    camera parameters after eight steps; the gradient is not zero and the parameters move."""
+    import rodygs_amd.trainstep as TS
+    saved = TS._EAGER_POSE_FORK
+    res = {}
+    try:
+        for fork in (False, True):
+            TS._EAGER_POSE_FORK = fork
+            sc = O.synthetic_scene(20000, 320, 240, 3, seed=5)
+            tgt = O.synthetic_scene(5000, 320, 240, 3, seed=6)
+            ds = TS.DynamicScene(sc, num_frames=8, device=DEV, spatial_order=True)
+            ds.make_ground_truth(tgt, list(range(8)))
+            q0, t0 = ds.sp["cam_q"].detach().clone(), ds.sp["cam_t"].detach().clone()
+            ds.train_step(0, perm=list(range(8)))
+            torch.cuda.synchronize()
+            g1 = (ds.sp["cam_q"].grad.clone(), ds.sp["cam_t"].grad.clone())
+            for s in range(1, 8):
+                ds.train_step(s, perm=list(range(8)))
+            torch.cuda.synchronize()
+            assert (ds._pose_fork is not None) == fork and ds.raster_state.pose_fork_eager is None
+            res[fork] = (g1, ds.sp["cam_q"].detach().clone(), ds.sp["cam_t"].detach().clone(), q0, t0)
+    finally:
+        TS._EAGER_POSE_FORK = saved
+    (ga, qa, ta, q0, t0), (gb, qb, tb, _, _) = res[False], res[True]
+    for a, b in zip(ga, gb):
+        assert float(a.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    assert float((qa - q0).abs().max()) > 0 and float((ta - t0).abs().max()) > 0
+    assert float((qa - qb).abs().max()) <= 2e-3 * float((qa - q0).abs().max())
+    assert float((ta - tb).abs().max()) <= 2e-3 * float((ta - t0).abs().max())
