@@ -530,7 +530,8 @@ def test_bench_gpus_flag_is_never_silently_ignored():
     """bench.py --gpus N (CPU side of the launcher logic): without a launcher and without N visible devices the command
     refuses (exit 2) instead of running one GPU and printing n_gpus = 1; under a launcher whose WORLD_SIZE disagrees with
     --gpus it refuses too; with RDG_ONE_DEVICE=1 it really starts N child ranks (which, on this GPU-less box, stop at
-    "needs a GPU" -- the parent hands their failure on)."""
+    "needs a GPU" -- the parent hands their failure on; the launcher ends the other rank as soon as the first one has failed, so
+    how many of them got to print the message is a race: at least one, through the launcher)."""
     import subprocess
     import sys
     root = os.path.join(os.path.dirname(__file__), "..")
@@ -543,7 +544,7 @@ def test_bench_gpus_flag_is_never_silently_ignored():
     r = run(["--gpus", "4", "--steps", "1"], dict(env, WORLD_SIZE="2", RANK="0"))
     assert r.returncode != 0 and "they must agree" in r.stderr
     r = run(["--gpus", "2", "--steps", "1"], dict(env, RDG_ONE_DEVICE="1", RDG_DIST_BACKEND="gloo"))
-    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-2000:]
+    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 1 and "local_rank" in r.stderr, r.stderr[-2000:]
 
 
 def test_mode_switches_ride_on_the_raster_state():
