@@ -6,7 +6,7 @@
 // The reference runs five 121-tap depth-wise convolutions forward and their transposes backward through the
 // framework's conv library (3.6 ms per step at 1080p on MI355X, more than the whole rasterizer).  Here:
 //   forward : one pass per 32x32 tile -- the 42x42 halo tile of x and y goes to LDS once, the five windowed
-//             moments are produced separably (11 + 11 taps, register-blocked 4 outputs per work item so that an
+//             moments (x, y, x^2 + y^2, xy: four maps) are produced separably (11 + 11 taps, register-blocked 4 outputs per work item so that an
 //             output costs ~27 LDS reads instead of ~90) from LDS, and the kernel stores, per pixel, the three
 //             partial derivatives dm/dmu1, dm/dE[x^2], dm/dE[xy] of the SSIM map; |x-y| and the map are block-
 //             reduced into two floats.
@@ -89,13 +89,11 @@ static RdgWin rdg_make_window() {
 __global__ void __launch_bounds__(256, 4)
 rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
                     float* __restrict__ maps, float* __restrict__ sums) {
-    // 35.1 KB instead of 41.4 KB -- four workgroups per CU instead of three (the phases of a workgroup are separated by
-    // barriers; other workgroups fill the gaps): the fifth filtered map reuses the halo tile of x, its horizontal results
-    // waiting in registers until every thread has read its inputs
+    // FOUR filtered maps, not five: the SSIM map and the three derivatives the backward needs (d/dmu1, d/dE[x^2], d/dE[xy]: the
+    // ground truth gets no gradient) contain E[x^2] and E[y^2] only through sigma1^2 + sigma2^2, so x^2 + y^2 is filtered as ONE
+    // map.  35.1 KB of LDS: four workgroups per CU (the phases of a workgroup are separated by barriers; others fill the gaps)
     __shared__ float sx[LWY][LWX + 1], sy[LWY][LWX + 1];
     __shared__ float sh4[4][LWY][LTX];
-    float (*sh5)[LTX] = (float (*)[LTX])&sx[0][0];
-    static_assert(LWY * LTX <= LWY * (LWX + 1), "the fifth map must fit the halo tile it reuses");
     __shared__ float sred[2][4];
     const int tid = threadIdx.x;
     int ox, oy, c; size_t bid;
@@ -139,7 +137,6 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
 #pragma unroll
     for (int o = 0; o < RB; ++o) l1v[o] = fabsf(sx[ty0 + o + LH][tx + LH] - sy[ty0 + o + LH][tx + LH]);
     // horizontal pass: LWY rows x (LTX / RB) groups of RB outputs
-    float h4reg[RDG_LOSS_HITEMS][RB];
 #pragma unroll
     for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
         const int item = tid + 256 * hi;
@@ -148,50 +145,35 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
             float xs[RB + 10], ys[RB + 10];
 #pragma unroll
             for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
-            // the three products once per element (not once per tap): an output then costs 5 multiply-adds per tap
-            float xx[RB + 10], yy[RB + 10], xy[RB + 10];
+            // the products once per element (not once per tap): an output then costs 4 multiply-adds per tap
+            float ss[RB + 10], xy[RB + 10];
 #pragma unroll
-            for (int k = 0; k < RB + 10; ++k) { xx[k] = xs[k] * xs[k]; yy[k] = ys[k] * ys[k]; xy[k] = xs[k] * ys[k]; }
+            for (int k = 0; k < RB + 10; ++k) { ss[k] = xs[k] * xs[k] + ys[k] * ys[k]; xy[k] = xs[k] * ys[k]; }
 #pragma unroll
             for (int o = 0; o < RB; ++o) {
-                float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f, h4 = 0.f;
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
-                    h0 += w[k] * xs[o + k]; h1 += w[k] * ys[o + k]; h2 += w[k] * xx[o + k]; h3 += w[k] * yy[o + k];
-                    h4 += w[k] * xy[o + k];
+                    h0 += w[k] * xs[o + k]; h1 += w[k] * ys[o + k]; h2 += w[k] * ss[o + k]; h3 += w[k] * xy[o + k];
                 }
                 sh4[0][r][c0 + o] = h0; sh4[1][r][c0 + o] = h1; sh4[2][r][c0 + o] = h2; sh4[3][r][c0 + o] = h3;
-                h4reg[hi][o] = h4;
             }
         }
         asm volatile("" ::: "memory");      // one work item's reads at a time (the second item's 28 loads hoisted: +28 registers)
     }
     __syncthreads();
-#pragma unroll
-    for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
-        const int item = tid + 256 * hi;
-        if (item < LWY * (LTX / RB)) {
-            const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
-#pragma unroll
-            for (int o = 0; o < RB; ++o) sh5[r][c0 + o] = h4reg[hi][o];
-        }
-    }
-    __syncthreads();
     float l1 = 0.f, ms = 0.f;
-    float mu1[RB], mu2[RB], e11[RB], e22[RB], e12[RB];
+    float mu1[RB], mu2[RB], ess[RB], e12[RB];
 #pragma unroll
-    for (int o = 0; o < RB; ++o) { mu1[o] = 0.f; mu2[o] = 0.f; e11[o] = 0.f; e22[o] = 0.f; e12[o] = 0.f; }
+    for (int o = 0; o < RB; ++o) { mu1[o] = 0.f; mu2[o] = 0.f; ess[o] = 0.f; e12[o] = 0.f; }
 #pragma unroll
     for (int rr = 0; rr < RB + 10; ++rr) {
-        const float a0 = sh4[0][ty0 + rr][tx], a1 = sh4[1][ty0 + rr][tx], a2 = sh4[2][ty0 + rr][tx],
-                    a3 = sh4[3][ty0 + rr][tx], a4 = sh5[ty0 + rr][tx];
-        if ((rr & 1) == 1) asm volatile("" ::: "memory");   // ten row reads in flight, not seventy (registers: occupancy 4)
+        const float a0 = sh4[0][ty0 + rr][tx], a1 = sh4[1][ty0 + rr][tx], a2 = sh4[2][ty0 + rr][tx], a3 = sh4[3][ty0 + rr][tx];
+        if ((rr & 1) == 1) asm volatile("" ::: "memory");   // eight row reads in flight, not fifty-six (registers: occupancy 4)
 #pragma unroll
         for (int o = 0; o < RB; ++o) {
             const int k = rr - o;
-            if (k >= 0 && k < 11) {
-                mu1[o] += w[k] * a0; mu2[o] += w[k] * a1; e11[o] += w[k] * a2; e22[o] += w[k] * a3; e12[o] += w[k] * a4;
-            }
+            if (k >= 0 && k < 11) { mu1[o] += w[k] * a0; mu2[o] += w[k] * a1; ess[o] += w[k] * a2; e12[o] += w[k] * a3; }
         }
     }
     const size_t stride = (size_t)C * hw;  // maps layout: [3 maps][C][H][W]
@@ -205,8 +187,9 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
             const float C1 = 0.0001f, C2 = 0.0009f;
             const float m1 = mu1[o], m2 = mu2[o];
             const float mu1s = m1 * m1, mu2s = m2 * m2, mu12 = m1 * m2;
-            const float s1 = e11[o] - mu1s, s2 = e22[o] - mu2s, s12 = e12[o] - mu12;
-            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s1 + s2 + C2;
+            const float s12 = e12[o] - mu12;
+            const float B1 = mu1s + mu2s + C1;
+            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B2 = (ess[o] - B1) + (C1 + C2);   // sigma1^2 + sigma2^2 + C2
             // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten instructions each, eight of them per thread):
             // B1, B2 >= C1, C2 > 0, and the parity bar of the loss is 1e-4
             const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);

@@ -1,3 +1,3 @@
-for v in "" loss_rotate "" loss_rotate; do
-  if [ -z "$v" ]; then python scripts/probes/loss_probe.py | sed "s/^/regular      /"; else RDG_LIB_PATH=$PWD/rodygs_amd/csrc/variants/$v.so python scripts/probes/loss_probe.py | sed "s/^/$v /"; fi
-done
+python scripts/probes/loss_probe.py
+python scripts/probes/loss_probe.py
+python -m pytest tests -m gpu -x -q -k "loss or ssim or photometric or psnr" 2>&1 | tail -3
