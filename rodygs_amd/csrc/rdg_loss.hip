@@ -85,6 +85,25 @@ static RdgWin rdg_make_window() {
 
 #define RDG_LOSS_HITEMS ((LWY * (LTX / RB) + 255) / 256)   // horizontal-pass work items per thread (2)
 
+// Tiles per workgroup of the forward kernel: a workgroup takes RDG_LOSS_NT consecutive tiles of its XCD band and issues the global
+// loads of the next tile's halo (14 registers) before it filters the current one, so only the first tile of a workgroup waits
+// for memory.
+#ifndef RDG_LOSS_NT
+#define RDG_LOSS_NT 2
+#endif
+
+__device__ __forceinline__ bool rdg_loss_tile_nt(int gx, int gy, int C, int rep, int& ox, int& oy, int& c, size_t& bid) {
+    const int n = gx * gy * C, per = (n + 7) >> 3;
+    const int j = (int)(blockIdx.x >> 3) * RDG_LOSS_NT + rep;
+    const int t = (int)(blockIdx.x & 7) * per + j;
+    if (j >= per || t >= n) return false;
+    c = t / (gx * gy);
+    const int r = t - c * gx * gy;
+    oy = (r / gx) * LTY; ox = (r - (r / gx) * gx) * LTX;
+    bid = (size_t)t;
+    return true;
+}
+
 // four waves per SIMD (<= 128 registers): with the 35 KB of LDS that is four workgroups per CU
 __global__ void __launch_bounds__(256, 4)
 rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ img, const float* __restrict__ gt,
@@ -96,30 +115,39 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
     __shared__ float sh4[4][LWY][LTX];
     __shared__ float sred[2][4];
     const int tid = threadIdx.x;
+    const int gxt = (Wd + LTX - 1) / LTX, gyt = (H + LTY - 1) / LTY;
     int ox, oy, c; size_t bid;
-    if (!rdg_loss_tile((Wd + LTX - 1) / LTX, (H + LTY - 1) / LTY, C, ox, oy, c, bid)) return;
+    if (!rdg_loss_tile_nt(gxt, gyt, C, 0, ox, oy, c, bid)) return;
     RDG_LOSS_WEIGHTS(w, win)
     const size_t hw = (size_t)H * Wd;
-    const float* X = img + c * hw;
-    const float* Y = gt + c * hw;
-    {
-        // the whole halo tile in ONE round of loads per thread (7 elements x 2 images in flight before the first LDS
-        // store): with three workgroups per CU the load phase, not the filters, set this kernel's time
-        float xv[RDG_LOSS_NL], yv[RDG_LOSS_NL];
-        RDG_HALO_WALK(hc, hact, colok, gy, g, lo)
-        const unsigned gstep = (unsigned)(RDG_HALO_RPI * Wd) * 4u;
-#pragma unroll
-        for (int it = 0; it < RDG_LOSS_NL; ++it) {
-            xv[it] = 0.f; yv[it] = 0.f;
-#ifdef RDG_ABL_LOSS_NOLOAD     // measurement build: no global loads of the halo tile
-            if (H == -1) {
-#else
-            if (colok && (unsigned)gy < (unsigned)H) {
-#endif
-                xv[it] = rdg_ldg(X, g); yv[it] = rdg_ldg(Y, g);
-            }
-            gy += RDG_HALO_RPI; g += gstep;
-        }
+    const size_t stride = (size_t)C * hw;  // maps layout: [3 maps][C][H][W]
+    // this thread's element of the halo walk (6 x 42 threads, 7 rows each) and of the vertical pass (column tx, RB rows from ty0)
+    const int hr0 = tid / LWX, hc = tid - hr0 * LWX;
+    const bool hact = tid < RDG_HALO_RPI * LWX;
+    const int lo = hr0 * (LWX + 1) + hc;
+    const unsigned gstep = (unsigned)(RDG_HALO_RPI * Wd) * 4u;
+    const int tx = tid % LTX, ty0 = (tid / LTX) * RB;
+    // the whole halo tile in ONE round of loads per thread (7 elements x 2 images in flight before the first LDS store)
+    float xv[RDG_LOSS_NL], yv[RDG_LOSS_NL];
+#define RDG_LOSS_ISSUE_LOADS(ox_, oy_, c_)                                                               \
+    {                                                                                                    \
+        const float* X_ = img + (c_) * hw;                                                               \
+        const float* Y_ = gt + (c_) * hw;                                                                \
+        const bool colok_ = hact && (unsigned)((ox_) + hc - LH) < (unsigned)Wd;                          \
+        int gy_ = (oy_) + hr0 - LH;                                                                      \
+        unsigned g_ = (unsigned)(gy_ * Wd + (ox_) + hc - LH) * 4u;                                       \
+        _Pragma("unroll") for (int it = 0; it < RDG_LOSS_NL; ++it) {                                     \
+            xv[it] = 0.f; yv[it] = 0.f;                                                                  \
+            if (colok_ && (unsigned)gy_ < (unsigned)H) { xv[it] = rdg_ldg(X_, g_); yv[it] = rdg_ldg(Y_, g_); } \
+            gy_ += RDG_HALO_RPI; g_ += gstep;                                                            \
+        }                                                                                                \
+    }
+    RDG_LOSS_ISSUE_LOADS(ox, oy, c)
+#pragma unroll 1
+    for (int rep = 0; rep < RDG_LOSS_NT; ++rep) {
+        // the barrier in front of these stores also ends the previous tile's vertical pass (it reads sh4, which the horizontal
+        // pass below overwrites); sx / sy were last read before the previous tile's second barrier
+        if (rep > 0) __syncthreads();
         if (hact) {
 #pragma unroll
             for (int it = 0; it < RDG_LOSS_NL; ++it) {
@@ -127,94 +155,93 @@ rdg_loss_fwd_kernel(int H, int Wd, int C, RdgWin win, const float* __restrict__ 
                 (&sy[0][0])[lo + it * RDG_HALO_RPI * (LWX + 1)] = yv[it];
             }
         }
-    }
-    __syncthreads();
-    // vertical-pass coordinates: thread = column tx, RB rows starting at ty0; its |x - y| terms are taken now, while the
-    // halo tile of x is still in LDS
-    const int tx = tid % LTX, ty0 = (tid / LTX) * RB;
-    const int px = ox + tx;
-    float l1v[RB];
+        __syncthreads();
+        // the next tile's halo: in flight while this one is filtered
+        int nox = 0, noy = 0, nc = 0; size_t nbid = 0;
+        const bool more = rep + 1 < RDG_LOSS_NT && rdg_loss_tile_nt(gxt, gyt, C, rep + 1, nox, noy, nc, nbid);
+        if (more) RDG_LOSS_ISSUE_LOADS(nox, noy, nc)
+        const int px = ox + tx;
+        // the |x - y| terms of the thread's pixels are taken now, while the halo tile of x is still in LDS
+        float l1v[RB];
 #pragma unroll
-    for (int o = 0; o < RB; ++o) l1v[o] = fabsf(sx[ty0 + o + LH][tx + LH] - sy[ty0 + o + LH][tx + LH]);
-    // horizontal pass: LWY rows x (LTX / RB) groups of RB outputs
+        for (int o = 0; o < RB; ++o) l1v[o] = fabsf(sx[ty0 + o + LH][tx + LH] - sy[ty0 + o + LH][tx + LH]);
+        // horizontal pass: LWY rows x (LTX / RB) groups of RB outputs
 #pragma unroll
-    for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
-        const int item = tid + 256 * hi;
-        if (item < LWY * (LTX / RB)) {
-            const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
-            float xs[RB + 10], ys[RB + 10];
+        for (int hi = 0; hi < RDG_LOSS_HITEMS; ++hi) {
+            const int item = tid + 256 * hi;
+            if (item < LWY * (LTX / RB)) {
+                const int r = item / (LTX / RB), c0 = (item - r * (LTX / RB)) * RB;
+                float xs[RB + 10], ys[RB + 10];
 #pragma unroll
-            for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
-            // the products once per element (not once per tap): an output then costs 4 multiply-adds per tap
-            float ss[RB + 10], xy[RB + 10];
+                for (int k = 0; k < RB + 10; ++k) { xs[k] = sx[r][c0 + k]; ys[k] = sy[r][c0 + k]; }
+                // the products once per element (not once per tap): an output then costs 4 multiply-adds per tap
+                float ss[RB + 10], xy[RB + 10];
 #pragma unroll
-            for (int k = 0; k < RB + 10; ++k) { ss[k] = xs[k] * xs[k] + ys[k] * ys[k]; xy[k] = xs[k] * ys[k]; }
+                for (int k = 0; k < RB + 10; ++k) { ss[k] = xs[k] * xs[k] + ys[k] * ys[k]; xy[k] = xs[k] * ys[k]; }
+#pragma unroll
+                for (int o = 0; o < RB; ++o) {
+                    float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 11; ++k) {
+                        h0 += w[k] * xs[o + k]; h1 += w[k] * ys[o + k]; h2 += w[k] * ss[o + k]; h3 += w[k] * xy[o + k];
+                    }
+                    sh4[0][r][c0 + o] = h0; sh4[1][r][c0 + o] = h1; sh4[2][r][c0 + o] = h2; sh4[3][r][c0 + o] = h3;
+                }
+            }
+            asm volatile("" ::: "memory");      // one work item's reads at a time (the second item's 28 loads hoisted: +28 registers)
+        }
+        __syncthreads();
+        float l1 = 0.f, ms = 0.f;
+        float mu1[RB], mu2[RB], ess[RB], e12[RB];
+#pragma unroll
+        for (int o = 0; o < RB; ++o) { mu1[o] = 0.f; mu2[o] = 0.f; ess[o] = 0.f; e12[o] = 0.f; }
+#pragma unroll
+        for (int rr = 0; rr < RB + 10; ++rr) {
+            const float a0 = sh4[0][ty0 + rr][tx], a1 = sh4[1][ty0 + rr][tx], a2 = sh4[2][ty0 + rr][tx], a3 = sh4[3][ty0 + rr][tx];
+            if ((rr & 1) == 1) asm volatile("" ::: "memory");   // eight row reads in flight, not fifty-six (registers: occupancy 4)
 #pragma unroll
             for (int o = 0; o < RB; ++o) {
-                float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    h0 += w[k] * xs[o + k]; h1 += w[k] * ys[o + k]; h2 += w[k] * ss[o + k]; h3 += w[k] * xy[o + k];
-                }
-                sh4[0][r][c0 + o] = h0; sh4[1][r][c0 + o] = h1; sh4[2][r][c0 + o] = h2; sh4[3][r][c0 + o] = h3;
+                const int k = rr - o;
+                if (k >= 0 && k < 11) { mu1[o] += w[k] * a0; mu2[o] += w[k] * a1; ess[o] += w[k] * a2; e12[o] += w[k] * a3; }
             }
         }
-        asm volatile("" ::: "memory");      // one work item's reads at a time (the second item's 28 loads hoisted: +28 registers)
-    }
-    __syncthreads();
-    float l1 = 0.f, ms = 0.f;
-    float mu1[RB], mu2[RB], ess[RB], e12[RB];
-#pragma unroll
-    for (int o = 0; o < RB; ++o) { mu1[o] = 0.f; mu2[o] = 0.f; ess[o] = 0.f; e12[o] = 0.f; }
-#pragma unroll
-    for (int rr = 0; rr < RB + 10; ++rr) {
-        const float a0 = sh4[0][ty0 + rr][tx], a1 = sh4[1][ty0 + rr][tx], a2 = sh4[2][ty0 + rr][tx], a3 = sh4[3][ty0 + rr][tx];
-        if ((rr & 1) == 1) asm volatile("" ::: "memory");   // eight row reads in flight, not fifty-six (registers: occupancy 4)
+        float* M0 = maps + c * hw;
+        float* M1 = M0 + stride;
+        float* M2 = M1 + stride;
 #pragma unroll
         for (int o = 0; o < RB; ++o) {
-            const int k = rr - o;
-            if (k >= 0 && k < 11) { mu1[o] += w[k] * a0; mu2[o] += w[k] * a1; ess[o] += w[k] * a2; e12[o] += w[k] * a3; }
+            const int py = oy + ty0 + o;
+            if (py < H && px < Wd) {
+                const float C1 = 0.0001f, C2 = 0.0009f;
+                const float m1 = mu1[o], m2 = mu2[o];
+                const float mu1s = m1 * m1, mu2s = m2 * m2, mu12 = m1 * m2;
+                const float s12 = e12[o] - mu12;
+                const float B1 = mu1s + mu2s + C1;
+                const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B2 = (ess[o] - B1) + (C1 + C2);   // sigma1^2 + sigma2^2 + C2
+                // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten instructions each, eight of them per thread):
+                // B1, B2 >= C1, C2 > 0, and the parity bar of the loss is 1e-4
+                const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
+                const float m = A1 * A2 * iB1 * iB2;
+                const float dmu1 = 2.f * m2 * (A2 - A1) * iB1 * iB2 - 2.f * m1 * m * (iB1 - iB2);
+                const float de11 = -m * iB2;
+                const float de12 = 2.f * A1 * iB1 * iB2;
+                const unsigned p = (unsigned)(py * Wd + px) * 4u;
+                rdg_stg(M0, p, dmu1); rdg_stg(M1, p, de11); rdg_stg(M2, p, de12);
+                ms += m;
+                l1 += l1v[o];
+            }
         }
+        l1 = rdg_wave_sum_to63(l1);
+        ms = rdg_wave_sum_to63(ms);
+        if ((tid & 63) == 63) { sred[0][tid >> 6] = l1; sred[1][tid >> 6] = ms; }
+        __syncthreads();
+        // one partial pair per TILE, summed in fixed order by the finalize kernel: 24 k workgroups adding into the
+        // same two floats ran at the contended-atomic rate (0.3 ms of a 0.33 ms kernel) and were not deterministic
+        if (tid < 2) sums[2 * bid + tid] = (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]);
+        if (!more) break;
+        ox = nox; oy = noy; c = nc; bid = nbid;
     }
-    const size_t stride = (size_t)C * hw;  // maps layout: [3 maps][C][H][W]
-    float* M0 = maps + c * hw;
-    float* M1 = M0 + stride;
-    float* M2 = M1 + stride;
-#pragma unroll
-    for (int o = 0; o < RB; ++o) {
-        const int py = oy + ty0 + o;
-        if (py < H && px < Wd) {
-            const float C1 = 0.0001f, C2 = 0.0009f;
-            const float m1 = mu1[o], m2 = mu2[o];
-            const float mu1s = m1 * m1, mu2s = m2 * m2, mu12 = m1 * m2;
-            const float s12 = e12[o] - mu12;
-            const float B1 = mu1s + mu2s + C1;
-            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B2 = (ess[o] - B1) + (C1 + C2);   // sigma1^2 + sigma2^2 + C2
-            // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (ten instructions each, eight of them per thread):
-            // B1, B2 >= C1, C2 > 0, and the parity bar of the loss is 1e-4
-            const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
-            const float m = A1 * A2 * iB1 * iB2;
-            const float dmu1 = 2.f * m2 * (A2 - A1) * iB1 * iB2 - 2.f * m1 * m * (iB1 - iB2);
-            const float de11 = -m * iB2;
-            const float de12 = 2.f * A1 * iB1 * iB2;
-            const unsigned p = (unsigned)(py * Wd + px) * 4u;
-#ifdef RDG_ABL_LOSS_NOSTORE    // measurement build: the three maps are not stored
-            if (m == 123.456f)
-#endif
-            { rdg_stg(M0, p, dmu1); rdg_stg(M1, p, de11); rdg_stg(M2, p, de12); }
-            ms += m;
-            l1 += l1v[o];
-        }
-    }
-    l1 = rdg_wave_sum_to63(l1);
-    ms = rdg_wave_sum_to63(ms);
-    if ((tid & 63) == 63) { sred[0][tid >> 6] = l1; sred[1][tid >> 6] = ms; }
-    __syncthreads();
-    // one partial pair per workgroup, summed in fixed order by the finalize kernel: 24 k workgroups adding into the
-    // same two floats ran at the contended-atomic rate (0.3 ms of a 0.33 ms kernel) and were not deterministic
-    if (tid < 2) {
-        sums[2 * bid + tid] = (sred[tid][0] + sred[tid][1]) + (sred[tid][2] + sred[tid][3]);
-    }
+#undef RDG_LOSS_ISSUE_LOADS
 }
 
 __global__ void __launch_bounds__(1024)
@@ -354,8 +381,9 @@ int rdg_photometric_loss_forward(int32_t C, int32_t H, int32_t W, const float* i
 #ifndef RDG_ABL_LOSS_LDSPAD     // measurement builds: extra (unused) dynamic LDS bytes, i.e. fewer workgroups per CU
 #define RDG_ABL_LOSS_LDSPAD 0
 #endif
-    hipLaunchKernelGGL(rdg_loss_fwd_kernel, dim3(((n_tiles + 7) / 8) * 8), dim3(256), RDG_ABL_LOSS_LDSPAD, st, H, W, C, win, img, gt, maps,
-                       sums);
+    const int per_band = (n_tiles + 7) / 8;      // tiles per XCD band; RDG_LOSS_NT consecutive ones per workgroup
+    hipLaunchKernelGGL(rdg_loss_fwd_kernel, dim3(((per_band + RDG_LOSS_NT - 1) / RDG_LOSS_NT) * 8), dim3(256), RDG_ABL_LOSS_LDSPAD, st,
+                       H, W, C, win, img, gt, maps, sums);
     hipLaunchKernelGGL(rdg_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, n_tiles,
                        1.0f / ((float)C * H * W), lambda, loss3);
     rdg_stage_end(RDG_STAGE_LOSS_FWD, st);
