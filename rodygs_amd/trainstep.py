@@ -137,22 +137,36 @@ def fused_adam_(fp: FlatParams, lr_scale: float = 1.0, betas=(0.9, 0.999), eps=1
                "rdg_adam_step_multi")
 
 
+_LOW_PRIORITY_STREAMS: dict = {}
+
+
 def _low_priority_stream(device):
     """A stream of the LOWEST priority the device offers (hipStreamCreateWithPriority through the HIP runtime torch has loaded,
-    wrapped as an ExternalStream; never destroyed: one per scene).  The framework's own pool only hands out streams of the
-    default priority or higher, and the work put here -- an HBM-bound launch that fills every CU -- must yield to the chain of
-    small dependent launches on the caller's stream, not starve it."""
+    wrapped as an ExternalStream; ONE per device and process, shared by every scene and never destroyed).  The framework's own
+    pool only hands out streams of the default priority or higher, and the work put here -- an HBM-bound launch that fills every
+    CU -- must yield to the chain of small dependent launches on the caller's stream, not starve it."""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-    with torch.cuda.device(device):
-        if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
-            return torch.cuda.Stream(device=device)
-        h = ctypes.c_void_p()
-        prio = int(os.environ.get("RDG_SIDE_STREAM_PRIORITY", str(least.value)))
-        if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, prio) != 0 or not h.value:   # 1 = hipStreamNonBlocking
-            return torch.cuda.Stream(device=device)
-    return torch.cuda.ExternalStream(h.value, device=device)
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _LOW_PRIORITY_STREAMS.get(idx)
+    if st is not None:
+        return st
+    st = None
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(idx):
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0:
+                h = ctypes.c_void_p()
+                prio = int(os.environ.get("RDG_SIDE_STREAM_PRIORITY", str(least.value)))
+                if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, prio) == 0 and h.value:   # 1 = hipStreamNonBlocking
+                    st = torch.cuda.ExternalStream(h.value, device=idx)
+    except OSError:
+        st = None
+    if st is None:
+        st = torch.cuda.Stream(device=idx)      # the runtime would not give one: a pool stream of the default priority
+    _LOW_PRIORITY_STREAMS[idx] = st
+    return st
 
 
 _FUSE_SH_ADAM = os.environ.get("RDG_FUSE_SH_ADAM", "1") != "0"
