@@ -620,8 +620,10 @@ def test_rows_adam_next_to_the_mlp_backward_is_the_same_step_bit_for_bit():
 def test_eager_pose_chain_branch_gives_the_same_pose_gradient():
     """RasterState.pose_fork_eager (set per step by DynamicScene.train_step): the pose-gradient chain of the eager step on a second
     stream.  The chain itself is deterministic (fixed-order sums of the per-Gaussian rows); the rows come from float atomics, so the
-    two forms are compared like two runs of the same form: the camera gradients of one step to 1e-5 of their largest entry, and the
-    camera parameters after eight steps; the gradient is not zero and the parameters move."""
+    two forms are compared like two runs of the same form: the camera gradients of one step to 1e-5 of their largest entry; after
+    eight steps the losses agree to 1e-3 and the camera parameters have moved in both.  (The parameters themselves are NOT compared:
+    Adam's first update of an entry is -lr * sign(g), so a component whose gradient is rounding noise of the atomics moves by
+    +lr in one run and -lr in the other -- the first version of this test compared them and failed in one run of three.)"""
     import rodygs_amd.trainstep as TS
     saved = TS._EAGER_POSE_FORK
     res = {}
@@ -636,17 +638,16 @@ def test_eager_pose_chain_branch_gives_the_same_pose_gradient():
             ds.train_step(0, perm=list(range(8)))
             torch.cuda.synchronize()
             g1 = (ds.sp["cam_q"].grad.clone(), ds.sp["cam_t"].grad.clone())
-            for s in range(1, 8):
-                ds.train_step(s, perm=list(range(8)))
+            losses = [float(ds.train_step(s, perm=list(range(8)))) for s in range(1, 8)]
             torch.cuda.synchronize()
             assert (ds._pose_fork is not None) == fork and ds.raster_state.pose_fork_eager is None
-            res[fork] = (g1, ds.sp["cam_q"].detach().clone(), ds.sp["cam_t"].detach().clone(), q0, t0)
+            res[fork] = (g1, ds.sp["cam_q"].detach().clone(), ds.sp["cam_t"].detach().clone(), q0, t0, losses)
     finally:
         TS._EAGER_POSE_FORK = saved
-    (ga, qa, ta, q0, t0), (gb, qb, tb, _, _) = res[False], res[True]
+    (ga, qa, ta, q0, t0, la), (gb, qb, tb, _, _, lb) = res[False], res[True]
     for a, b in zip(ga, gb):
         assert float(a.abs().max()) > 0
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
-    assert float((qa - q0).abs().max()) > 0 and float((ta - t0).abs().max()) > 0
-    assert float((qa - qb).abs().max()) <= 2e-3 * float((qa - q0).abs().max())
-    assert float((ta - tb).abs().max()) <= 2e-3 * float((ta - t0).abs().max())
+    for q, t in ((qa, ta), (qb, tb)):
+        assert float((q - q0).abs().max()) > 0 and float((t - t0).abs().max()) > 0
+    assert all(abs(x - y) <= 1e-3 * abs(x) for x, y in zip(la, lb)), (la, lb)
