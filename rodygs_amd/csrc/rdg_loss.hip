@@ -5,14 +5,15 @@
 //
 // The reference runs five 121-tap depth-wise convolutions forward and their transposes backward through the
 // framework's conv library (3.6 ms per step at 1080p on MI355X, more than the whole rasterizer).  Here:
-//   forward : one pass per 32x32 tile -- the 42x42 halo tile of x and y goes to LDS once, the five windowed
-//             moments (x, y, x^2 + y^2, xy: four maps) are produced separably (11 + 11 taps, register-blocked 4 outputs per work item so that an
-//             output costs ~27 LDS reads instead of ~90) from LDS, and the kernel stores, per pixel, the three
-//             partial derivatives dm/dmu1, dm/dE[x^2], dm/dE[xy] of the SSIM map; |x-y| and the map are block-
-//             reduced into two floats.
+//   forward : one pass per 32x32 tile -- the 42x42 halo tile of x and y goes to LDS once, the windowed moments
+//             (FOUR maps: x, y, x^2 + y^2, xy -- E[x^2] and E[y^2] are only needed as a sum) are produced separably
+//             (11 + 11 taps, register-blocked 4 outputs per work item so that an output costs ~22 LDS reads instead
+//             of ~90) from LDS, and the kernel stores, per pixel, the three partial derivatives dm/dmu1, dm/dE[x^2],
+//             dm/dE[xy] of the SSIM map; |x-y| and the map are block-reduced into two floats per tile.
 //   backward: dL/dx(p) = g * (conv(dm/dmu1) + 2 x(p) conv(dm/dE11) + y(p) conv(dm/dE12))(p) + L1 term, i.e. the
 //             same separable filter over the three stored maps (the window is symmetric).
-// HBM-bound: forward reads 2 and writes 3 images, backward reads 5 and writes 1.
+// Forward reads 2 and writes 3 images, backward reads 5 and writes 1; the backward runs at 4.9 TB/s, the forward is bound by
+// VALU issue (round 6: profiles/r06_experiments.txt 3).
 #include "rdg_common.h"
 #include <math.h>
 
