@@ -518,6 +518,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 aux_, d_vm = st_.pose_fork_eager
                 ctx.cs.aux_stream = aux_.cuda_stream
                 gws.record_stream(aux_)
+                vm.record_stream(aux_)        # rdg_pose_finalize reads the view matrix there; this node's saved tensors die with it
             fused = None if ctx.grad_sinks is None else ctx.grad_sinks.get("shs_adam")
             if fused is not None:
                 # optimizer in backward for the SH features: dL/dshs never leaves the kernel's LDS tile; the kernel
