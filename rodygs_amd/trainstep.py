@@ -153,7 +153,18 @@ def _low_priority_stream(device):
         return st
     st = None
     try:
-        hip = ctypes.CDLL("libamdhip64.so")
+        # the HIP runtime THIS process already runs on (torch's; a stream made by another copy of the runtime would be a foreign
+        # handle): the mapped file, by path -- the loader hands back the loaded instance for it
+        path = "libamdhip64.so"
+        try:
+            with open("/proc/self/maps") as maps:
+                for line in maps:
+                    if "libamdhip64.so" in line:
+                        path = line.split(None, 5)[-1].strip()
+                        break
+        except OSError:
+            pass
+        hip = ctypes.CDLL(path)
         least, greatest = ctypes.c_int(0), ctypes.c_int(0)
         with torch.cuda.device(idx):
             if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0:
