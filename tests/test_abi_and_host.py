@@ -660,3 +660,25 @@ def test_bench_preflight_reports_and_refuses_without_devices():
     w = d["wire_bytes_per_step_at_1M"]
     assert w["allreduce"]["all_reduce_payload_bytes"] == 1000000 * 75 * 4 + (68656 + 700) * 4
     assert w["shard"]["all_to_all_payload_bytes"] < w["allreduce"]["all_reduce_payload_bytes"]
+
+
+def test_selection_rank_and_birth_order_host_branches():
+    """densify.mask_rank / _compact and deform._stable_order on CPU tensors (the branches the CPU suite can run; the library ops
+    behind the GPU branches are compared with these in tests/test_gpu_round6.py): rank = position of a row in its selection,
+    compacted list = ascending indices of the set rows, birth order = the stable sort."""
+    import torch
+    from rodygs_amd import deform
+    from rodygs_amd.densify import _compact, mask_rank
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 17, 4097):
+        for density in (0.0, 0.3, 1.0):
+            m = torch.rand(n, generator=g) < density
+            r = mask_rank(m)
+            assert r.dtype == torch.int64 and torch.equal(r, torch.cumsum(m, 0) - 1)
+            k = int(m.sum())
+            idx = _compact(m, k)
+            assert torch.equal(idx, m.nonzero().squeeze(1))
+            assert k == 0 or torch.equal(r[idx], torch.arange(k))
+    t = torch.randint(0, 7, (1000,), generator=g)
+    o = deform._stable_order(t, 7)
+    assert torch.equal(t[o], torch.sort(t, stable=True).values) and torch.equal(o, torch.argsort(t, stable=True))
